@@ -1,0 +1,180 @@
+"""Scenario specs for the batched mUAV_TA environment.
+
+The registry keys/values restate the *data* of the reference's case table
+(experiments/paper_scenarios.py:59-106,107-125,241-266) so that a spec dict taken from the
+reference's ``CASE_SPECS`` and one taken from here are interchangeable; the ``*_x2`` / ``*24`` /
+``*64`` entries are the scaled perf configs fixed in SURVEY.md §8(d) (configs 2b, 4b, 5).
+``WPS_ENV_FLAGS`` mirrors experiments/paper_scenarios.py:344-366 after the two mask overrides the
+evaluation harness applies (experiments/wps_eval.py:92-97).
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Dict
+
+_WPS_HARD = {
+    "agents": {"F1": 2, "F2": 2, "R1": 2, "R2": 2},
+    "tasks": {"Att": 3, "Rec": 5, "Hold": 0},
+    "fail_rate": 0.08,
+    "threats_list": [("T1", 5), ("T2", 4)],
+    "arrival_rate": 0.12,
+    "sense_radius": 120.0,
+    "threat_delay": 15,
+    "hard_windows": True,
+    "window_length": 25,
+    "burst_mode": True,
+    "burst_size": 3,
+    "miss_penalty": 30.0,
+    "on_time_bonus": 12.0,
+}
+
+_WPS_BURST = {
+    "agents": {"F1": 2, "F2": 2, "R1": 2, "R2": 2},
+    "tasks": {"Att": 2, "Rec": 4, "Hold": 0},
+    "fail_rate": 0.1,
+    "threats_list": [("T1", 6), ("T2", 4)],
+    "arrival_rate": 0.15,
+    "sense_radius": 150.0,
+    "threat_delay": 12,
+    "hard_windows": True,
+    "window_length": 20,
+    "burst_mode": True,
+    "burst_size": 4,
+    "miss_penalty": 35.0,
+    "on_time_bonus": 15.0,
+}
+
+_WPS_ATTN = {
+    "agents": {"F1": 4, "F2": 2, "R1": 4, "R2": 2},
+    "tasks": {"Att": 4, "Rec": 8, "Hold": 0},
+    "fail_rate": 0.08,
+    "threats_list": [("T1", 8), ("T2", 6)],
+    "arrival_rate": 0.18,
+    "sense_radius": 90.0,
+    "threat_delay": 18,
+    "hard_windows": True,
+    "window_length": 22,
+    "burst_mode": True,
+    "burst_size": 4,
+    "miss_penalty": 30.0,
+    "on_time_bonus": 12.0,
+    "dual_region_bursts": True,
+    "share_knowledge": False,
+}
+
+_WPS_ESCORT = {
+    "agents": {"F1": 5, "F2": 3, "R1": 4, "R2": 2},
+    "tasks": {"Att": 2, "Rec": 6, "Hold": 0},
+    "fail_rate": 0.03,
+    "threats_list": [("T1", 4), ("T2", 6)],
+    "arrival_rate": 0.15,
+    "sense_radius": 100.0,
+    "threat_delay": 15,
+    "hard_windows": True,
+    "window_length": 28,
+    "burst_mode": True,
+    "burst_size": 3,
+    "miss_penalty": 30.0,
+    "on_time_bonus": 12.0,
+    "dual_region_bursts": True,
+    "share_knowledge": False,
+    "commit_horizon": 20,
+    "reassign_penalty": 2.0,
+    "escort_enabled": True,
+    "escort_radius": 70.0,
+    "escort_requirement": 1.2,
+    "escort_intercept_radius": 100.0,
+    "mutual_support_radius": 80.0,
+    "escort_agent_types": ("F1", "F2"),
+}
+
+
+def _derive(base: Dict[str, Any], **over) -> Dict[str, Any]:
+    s = copy.deepcopy(base)
+    s.update(over)
+    return s
+
+
+CASE_SPECS: Dict[str, Dict[str, Any]] = {
+    "D2_popup_threats": {
+        "agents": {"F1": 2, "F2": 2, "R1": 2, "R2": 2},
+        "tasks": {"Att": 4, "Rec": 8, "Hold": 0},
+        "fail_rate": 0.0,
+        "threats_list": [("T1", 3), ("T2", 2)],
+        "arrival_rate": 0.0,
+    },
+    "WPS_easy": {
+        "agents": {"F1": 2, "F2": 2, "R1": 2, "R2": 2},
+        "tasks": {"Att": 4, "Rec": 6, "Hold": 0},
+        "fail_rate": 0.05,
+        "threats_list": [("T1", 4), ("T2", 3)],
+        "arrival_rate": 0.08,
+        "sense_radius": 250.0,
+        "threat_delay": 8,
+        "hard_windows": True,
+        "window_length": 40,
+        "burst_mode": False,
+        "burst_size": 2,
+        "miss_penalty": 25.0,
+        "on_time_bonus": 10.0,
+    },
+    "WPS_hard": _WPS_HARD,
+    "WPS_burst": _WPS_BURST,
+    "WPS_attn": _WPS_ATTN,
+    "WPS_attn_AWACS": _derive(_WPS_ATTN, sense_radius=0.0, threat_delay=0, share_knowledge=True),
+    "WPS_escort": _WPS_ESCORT,
+    # --- scaled perf configs -------------------------------------------------
+    "WPS_hard_x2": _derive(
+        _WPS_HARD,
+        agents={"F1": 4, "F2": 4, "R1": 4, "R2": 4},
+        tasks={"Att": 4, "Rec": 8, "Hold": 0},
+        threats_list=[("T1", 6), ("T2", 5)],
+    ),
+    "WPS_escort24": _derive(
+        _WPS_ESCORT,
+        agents={"F1": 9, "F2": 5, "R1": 6, "R2": 4},
+        tasks={"Att": 4, "Rec": 10, "Hold": 0},
+        threats_list=[("T1", 7), ("T2", 10)],
+    ),
+    "WPS_burst64": _derive(
+        _WPS_BURST,
+        agents={"F1": 16, "F2": 16, "R1": 16, "R2": 16},
+        tasks={"Att": 16, "Rec": 32, "Hold": 0},
+        threats_list=[("T1", 24), ("T2", 16)],
+    ),
+}
+
+# Flag preset the WPS / escort harnesses run with (masks off, full 150-step horizon).
+WPS_ENV_FLAGS: Dict[str, Any] = {
+    "early_terminate": False,
+    "capability_mask": False,
+    "saturate_mask": False,
+    "include_time_windows": True,
+    "dynamic_idle_penalty": 0.05,
+    "reward_weights": {
+        "action": 0.0,
+        "distance": 1.0,
+        "quality": 1.0,
+        "s_quality": 1.0,
+        "time": 0.0,
+        "alloc": 0.0,
+        "time_penaulty": 0.0,
+        "step": 0.0,
+    },
+    "multiple_tasks_per_agent": True,
+    "max_time_steps": 150,
+}
+
+# (agent tile, task-slot tile, threat capacity) used for each benchmark configuration.
+TILES = {
+    "WPS_easy": (16, 32, 16),
+    "WPS_hard": (16, 32, 16),
+    "WPS_burst": (16, 32, 16),
+    "WPS_attn": (16, 48, 16),
+    "WPS_attn_AWACS": (16, 48, 16),
+    "D2_popup_threats": (16, 32, 16),
+    "WPS_hard_x2": (16, 32, 16),
+    "WPS_escort": (24, 48, 24),
+    "WPS_escort24": (24, 48, 24),
+    "WPS_burst64": (64, 128, 48),
+}

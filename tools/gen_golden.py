@@ -1,0 +1,371 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING the reference (this container only).
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+
+The reference is imported from /root/reference through ``tools/refshim.py``; its episode loop
+(experiments/wps_eval.py:112-133,272-275 == experiments/escort_eval.py:137-148,204) is re-driven
+here so every step can be snapshotted.  Output = data only (inputs + expected outputs):
+
+  trace_<case>_s<seed>.npz   per-step state digest, actions, events, open-list order, every LSAP
+                             call (cost,row,col), observations, final 30-key metrics
+  metrics_<case>.npz         final metrics for seeds 0..N-1 (rows) x 30 keys (cols)
+  lsap_cases.npz             scipy.optimize.linear_sum_assignment known answers (tie-heavy, masked)
+  mt_kat.npz                 CPython random.Random known answers
+  numpy_kat.npz              np.linalg.norm / np.sum bit patterns the env relies on
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import refshim  # noqa: E402
+
+refshim.install()
+
+from experiments.paper_eval import _events, _open_tasks, make_config  # noqa: E402
+from mUAV_TA.DroneEnv import MultiUAVEnv  # noqa: E402
+import TaskAllocation.OptimizationBased.HungarianAllocator as HA  # noqa: E402
+from scipy.optimize import linear_sum_assignment  # noqa: E402
+
+from muavta_amd.scenarios import CASE_SPECS, WPS_ENV_FLAGS  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+EVENT_CODE = {"Reset_Allocation": 0, "New_Threat": 1, "Agent_Fail": 2, "Escort_Created": 3, "Escort_Retired": 4}
+METRIC_KEYS = [
+    "F_time", "F_distance", "F_quality", "F_Reward", "S_WPS", "S_ESC", "Losses", "Kills", "makespan",
+    "total_distance", "n_reallocations", "n_task_switches", "n_arrivals", "n_tasks_final", "n_reached",
+    "n_missed_windows", "n_on_time", "n_windowed_tasks", "on_time_rate", "reserve_idle_fraction",
+    "escort_coverage_rate", "protected_rec_completed", "recon_losses", "escort_losses",
+    "threats_intercepted", "mutual_support_engagements", "protection_breaches", "escort_requests",
+    "escort_completed", "escort_failed",
+]
+SCALARS = [
+    "F_Reward", "total_distance", "n_on_time", "n_missed_windows", "n_windowed_tasks", "n_task_switches",
+    "n_reallocations", "n_arrivals", "_idle_reserve_steps", "conclusion_time", "escort_requests",
+    "escort_completed", "escort_failed", "escort_required_steps", "escort_covered_steps",
+    "protection_breaches", "threats_intercepted", "recon_losses", "escort_losses",
+    "mutual_support_engagements", "protected_rec_completed",
+]
+QCAP = 12
+
+
+def make_env(case):
+    spec = CASE_SPECS[case]
+    flags = dict(WPS_ENV_FLAGS)
+    cfg = make_config(spec, flags)
+    cfg.multiple_tasks_per_agent = True
+    return MultiUAVEnv(cfg)
+
+
+class LsapTap:
+    """Wraps the module attribute the allocator calls (HungarianAllocator.py:9,181)."""
+
+    def __init__(self):
+        self.calls = []
+        self.step = 0
+
+    def __call__(self, cost):
+        r, c = linear_sum_assignment(cost)
+        self.calls.append((self.step, np.array(cost, dtype=np.float64), np.array(r), np.array(c)))
+        return r, c
+
+
+def run_episode(case, seed, interval, full):
+    env = make_env(case)
+    tap = LsapTap()
+    HA.linear_sum_assignment = tap
+    try:
+        obs, info = env.reset(seed=seed)
+        hung = HA.HungarianAllocator(replan_interval=interval, max_coord=env.max_coord)
+        A = env.n_agents
+        recs = []
+        ev_rows, act_rows, open_ptr, open_ids = [], [], [0], []
+        done = {a: False for a in env.agents}
+        trunc = {a: False for a in env.agents}
+        rewards = [0.0]
+        obs_rows = []
+
+        def snap():
+            recs.append(snapshot(env))
+            if full:
+                obs_rows.append(snapshot_obs(env))
+            for t in env.last_tasks_info:
+                open_ids.append(t.id)
+            open_ptr.append(len(open_ids))
+
+        snap()
+        latest = None
+        while not all(done.values()) and not all(trunc.values()):
+            events = _events(info)
+            tap.step = env.time_steps
+            result = hung.allocate_tasks(
+                env.get_live_agents(), _open_tasks(env), time_step=env.time_steps, events=events,
+                agent_known_ids=env.agent_visibility_map(),
+            )
+            actions = {}
+            for name, task in result:
+                if env.last_tasks_info and task in env.last_tasks_info and name not in actions:
+                    actions[name] = env.last_tasks_info.index(task)
+                    act_rows.append((env.time_steps, env.agent_by_name[name].id, task.id, actions[name]))
+            obs, reward, done, trunc, info = env.step(actions)
+            for ev in info["events"]:
+                ev_rows.append((env.time_steps, EVENT_CODE[ev[0]], int(ev[1])))
+            rewards.append(float(next(iter(reward.values()))))
+            snap()
+            if "metrics" in info:
+                latest = info["metrics"]
+    finally:
+        HA.linear_sum_assignment = linear_sum_assignment
+    metrics = np.array([float(latest[k]) for k in METRIC_KEYS], dtype=np.float64)
+    assert list(latest.keys()) == METRIC_KEYS
+    out = {"metrics": metrics, "n_replans": np.int64(hung.n_replans), "n_agents": np.int64(A),
+           "interval": np.int64(interval), "seed": np.int64(seed)}
+    if not full:
+        return out
+    out.update(stack(recs, env))
+    out["reward"] = np.array(rewards)
+    out["events"] = np.array(ev_rows, dtype=np.int64).reshape(-1, 3)
+    out["actions"] = np.array(act_rows, dtype=np.int64).reshape(-1, 4)
+    out["open_ptr"] = np.array(open_ptr, dtype=np.int64)
+    out["open_ids"] = np.array(open_ids, dtype=np.int64)
+    out["lsap_step"] = np.array([c[0] for c in tap.calls], dtype=np.int64)
+    out["lsap_shape"] = np.array([c[1].shape for c in tap.calls], dtype=np.int64).reshape(-1, 2)
+    out["lsap_cost"] = np.concatenate([c[1].ravel() for c in tap.calls]) if tap.calls else np.zeros(0)
+    out["lsap_row"] = np.concatenate([c[2] for c in tap.calls]) if tap.calls else np.zeros(0, np.int64)
+    out["lsap_col"] = np.concatenate([c[3] for c in tap.calls]) if tap.calls else np.zeros(0, np.int64)
+    out["obs_tasks"] = np.stack([o[0] for o in obs_rows])
+    out["obs_legal"] = np.packbits(np.stack([o[1] for o in obs_rows]), axis=-1)
+    out["obs_flags"] = np.stack([o[2] for o in obs_rows])
+    out["obs_agent"] = np.stack([o[3] for o in obs_rows])
+    out["agent_type"] = np.array([a.typeIdx for a in env.agents_obj], dtype=np.int64)
+    out["agent_name_idx"] = np.array([env.possible_agents.index(a.name) for a in env.agents_obj], dtype=np.int64)
+    out["fail_event"] = np.array([a.fail_event for a in env.agents_obj], dtype=np.int64)
+    out["max_tasks"] = np.int64(env.max_tasks)
+    return out
+
+
+def snapshot(env):
+    A = env.n_agents
+    d = {}
+    d["pos"] = np.array([[float(a.position[0]), float(a.position[1])] for a in env.agents_obj])
+    d["state"] = np.array([a.state for a in env.agents_obj], dtype=np.int8)
+    d["head"] = np.array([a.tasks[0].id if a.tasks else -1 for a in env.agents_obj], dtype=np.int32)
+    q = -np.ones((A, QCAP), dtype=np.int32)
+    for i, a in enumerate(env.agents_obj):
+        assert len(a.tasks) <= QCAP
+        for k, t in enumerate(a.tasks):
+            q[i, k] = t.id
+    d["queue"] = q
+    d["nft"] = np.array([float(a.next_free_time) for a in env.agents_obj])
+    d["nfp"] = np.array([[float(a.next_free_position[0]), float(a.next_free_position[1])] for a in env.agents_obj])
+    d["caps"] = np.array([a.currentCap2Task for a in env.agents_obj], dtype=np.float64)
+    d["attack_cap"] = np.array([a.attackCap for a in env.agents_obj], dtype=np.int32)
+    d["task_start"] = np.array([a.task_start for a in env.agents_obj], dtype=np.int32)
+    d["re_eval"] = np.array([a.re_eval for a in env.agents_obj], dtype=np.int8)
+    d["last_task"] = np.array([-1 if a.last_task is None else a.last_task.id for a in env.agents_obj], dtype=np.int32)
+    d["agent_dist"] = np.array(env.agent_distances, dtype=np.float64)
+    d["tasks"] = [
+        (t.id, int(t.status), float(t.position[0]), float(t.position[1]), t.currentReqs.copy(), t.allocatedReqs.copy(),
+         t.doneReqs.copy(), float(t.initTime), float(t.doneTime), len(t.allocationDetails),
+         t.typeIdx, -1 if getattr(t, "hard_deadline", None) is None else int(t.hard_deadline),
+         int(t.created_at), int(t.required_agents or 0), 1 if t.kind == "Escort" else 0)
+        for t in env.tasks
+    ]
+    d["known"] = [sorted(env.agent_known_tasks[a.name]) for a in env.agents_obj]
+    d["threats"] = [
+        (th.id, int(th.status), float(th.position[0]), float(th.position[1]),
+         -1 if th.target_agent is None else th.target_agent.id, int(th.attackCap), th.relative_task.id)
+        for th in env.threats
+    ]
+    d["scalars"] = np.array([float(getattr(env, k)) for k in SCALARS] + [float(env._pending_reset), float(len(env.reached_tasks)),
+                                                                       float(len(env.pending_reveals))])
+    return d
+
+
+def snapshot_obs(env):
+    """Numeric view of the observation dicts (DroneEnv.py:365-415,468-492)."""
+    T = env.max_tasks
+    first = env.observations[env.agents_obj[0].name]
+    ti = np.zeros((T, 21), dtype=np.float32)
+    for j, info in enumerate(first["tasks_info"]):
+        if info.get("status", -1) == -1 and "id" not in info:
+            ti[j, 3] = -1.0
+            continue
+        ti[j, 0] = info["id"]
+        ti[j, 1:3] = info["position"]
+        ti[j, 3] = info["status"]
+        ti[j, 4:10] = info["current_reqs"]
+        ti[j, 10:16] = info["alloc_reqs"]
+        ti[j, 16] = info.get("init_time", 0.0)
+        ti[j, 17] = info.get("end_time", 0.0)
+        ti[j, 18] = info.get("type_idx", 0.0)
+        ti[j, 19] = info.get("unmet", 0.0)
+        ti[j, 20] = info.get("age", 0.0)
+    legal = np.zeros((env.n_agents, T), dtype=bool)
+    ag = np.zeros((env.n_agents, 9), dtype=np.float32)
+    for i, a in enumerate(env.agents_obj):
+        o = env.observations[a.name]
+        legal[i] = o["legal_mask"]
+        ag[i, 0:2] = o["agent_position"]
+        ag[i, 2:8] = o["agent_caps"]
+        ag[i, 8] = o["alloc_task"]
+    return ti, legal, np.array(first["event_flags"], dtype=np.float32), ag
+
+
+def stack(recs, env):
+    S = len(recs)
+    NT = max(t.id for t in env.tasks) + 1
+    H = env._next_threat_id
+    A = env.n_agents
+    out = {}
+    for k in ("pos", "state", "head", "queue", "nft", "nfp", "caps", "attack_cap", "task_start", "re_eval",
+              "last_task", "agent_dist", "scalars"):
+        out[k] = np.stack([r[k] for r in recs])
+    t_status = np.full((S, NT), -9, dtype=np.int8)
+    t_pos = np.zeros((S, NT, 2))
+    t_cur = np.zeros((S, NT, 6))
+    t_alloc = np.zeros((S, NT, 6))
+    t_done = np.zeros((S, NT, 6))
+    t_init = np.zeros((S, NT))
+    t_dtime = np.zeros((S, NT))
+    t_ndet = np.zeros((S, NT), dtype=np.int16)
+    t_static = np.full((NT, 5), -9, dtype=np.int32)  # type, deadline, created, required, escort
+    known = np.zeros((S, A, NT), dtype=bool)
+    h_status = np.full((S, H), -9, dtype=np.int8)
+    h_pos = np.zeros((S, H, 2))
+    h_tgt = np.full((S, H), -9, dtype=np.int32)
+    h_acap = np.zeros((S, H), dtype=np.int32)
+    h_task = np.full((H,), -1, dtype=np.int32)
+    for s, r in enumerate(recs):
+        for (tid, st, x, y, cur, al, dn, it, dt, nd, ty, dl, cr, rq, es) in r["tasks"]:
+            t_status[s, tid] = st
+            t_pos[s, tid] = (x, y)
+            t_cur[s, tid] = cur
+            t_alloc[s, tid] = al
+            t_done[s, tid] = dn
+            t_init[s, tid] = it
+            t_dtime[s, tid] = dt
+            t_ndet[s, tid] = nd
+            t_static[tid] = (ty, dl, cr, rq, es)
+        for i, ids in enumerate(r["known"]):
+            known[s, i, ids] = True
+        for (hid, st, x, y, tg, ac, rt) in r["threats"]:
+            h_status[s, hid] = st
+            h_pos[s, hid] = (x, y)
+            h_tgt[s, hid] = tg
+            h_acap[s, hid] = ac
+            h_task[hid] = rt
+    out.update(t_status=t_status, t_pos=t_pos, t_cur=t_cur, t_alloc=t_alloc, t_done=t_done, t_init=t_init,
+               t_donetime=t_dtime, t_ndet=t_ndet, t_static=t_static, known=np.packbits(known, axis=-1),
+               n_task_ids=np.int64(NT), h_status=h_status, h_pos=h_pos, h_target=h_tgt, h_acap=h_acap, h_task=h_task)
+    return out
+
+
+def gen_lsap_cases(rng):
+    costs, shapes, rows, cols = [], [], [], []
+    for k in range(400):
+        nr, nc = int(rng.integers(1, 25)), int(rng.integers(1, 41))
+        mode = k % 5
+        if mode == 0:
+            c = rng.uniform(-2, 2, (nr, nc))
+        elif mode == 1:
+            c = rng.integers(0, 4, (nr, nc)).astype(np.float64)  # tie-heavy
+        elif mode == 2:
+            c = rng.uniform(-1, 1, (nr, nc))
+            c[rng.random((nr, nc)) < 0.5] = 1e6  # masked like the allocator
+        elif mode == 3:
+            c = np.full((nr, nc), 1e6)
+            c[rng.random((nr, nc)) < 0.15] = -0.5
+        else:
+            c = np.round(rng.uniform(-1, 1, (nr, nc)), 1)
+        r, cc = linear_sum_assignment(c)
+        costs.append(c.ravel()); shapes.append((nr, nc)); rows.append(r); cols.append(cc)
+    return dict(cost=np.concatenate(costs), shape=np.array(shapes, dtype=np.int64),
+                row=np.concatenate(rows).astype(np.int64), col=np.concatenate(cols).astype(np.int64))
+
+
+def gen_mt_kat():
+    out = {}
+    seeds = [0, 1, 2, 7, 12345, 2**32 - 1, 2**32, 2**40 + 17, 2**63 - 1, 6364136223846793005]
+    out["seeds"] = np.array(seeds, dtype=np.uint64)
+    rnd, bits64, ri, unif, rb, shuf = [], [], [], [], [], []
+    for s in seeds:
+        r = random.Random(s)
+        rnd.append([r.random() for _ in range(8)])
+        bits64.append([r.randint(0, sys.maxsize) for _ in range(4)])
+        ri.append([r.randint(1, 150) for _ in range(8)] + [r.randint(120, 1080) for _ in range(4)])
+        unif.append([r.uniform(3.5, 1196.25) for _ in range(4)])
+        rb.append([r.choice([0, 1]) for _ in range(8)] + [r.choice([0, 1, 2]) for _ in range(8)])
+        x = list(range(16)); r.shuffle(x); shuf.append(x)
+        # run past one 624-word block
+        for _ in range(700):
+            r.random()
+        rnd[-1].append(r.random())
+    out.update(random=np.array(rnd), randint63=np.array(bits64, dtype=np.uint64), randint=np.array(ri, dtype=np.int64),
+               uniform=np.array(unif), choice=np.array(rb, dtype=np.int64), shuffle16=np.array(shuf, dtype=np.int64))
+    return out
+
+
+def gen_numpy_kat(rng):
+    v = rng.uniform(-1200, 1200, (512, 2))
+    n1 = np.array([np.linalg.norm(x) for x in v])
+    n2 = np.linalg.norm(v, axis=1)
+    sums = {}
+    for n in (4, 8, 14, 16, 24, 40, 64):
+        d = rng.uniform(0, 30, (64, n))
+        sums[f"sum{n}_in"] = d
+        sums[f"sum{n}_out"] = np.array([np.sum(r) for r in d])
+    return dict(vec=v, norm_1d=n1, norm_axis1=n2, **sums)
+
+
+TRACE_PLAN = [
+    # case, interval, seeds with full per-step traces, number of metric-only seeds
+    ("WPS_easy", 20, (0, 1, 2), 24),
+    ("WPS_hard", 20, (0, 1, 2), 48),
+    ("WPS_burst", 20, (0,), 24),
+    ("WPS_attn", 20, (0, 1), 24),
+    ("WPS_attn_AWACS", 20, (0,), 16),
+    ("D2_popup_threats", 20, (0,), 8),
+    ("WPS_hard_x2", 20, (0, 1), 48),
+    ("WPS_escort", 12, (0, 1), 24),
+    ("WPS_escort24", 12, (0,), 16),
+    ("WPS_burst64", 20, (0,), 8),
+]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20261003)
+    np.savez_compressed(os.path.join(OUT, "lsap_cases.npz"), **gen_lsap_cases(rng))
+    np.savez_compressed(os.path.join(OUT, "mt_kat.npz"), **gen_mt_kat())
+    np.savez_compressed(os.path.join(OUT, "numpy_kat.npz"), **gen_numpy_kat(rng))
+    only = sys.argv[1:]
+    for case, interval, full_seeds, n_metric in TRACE_PLAN:
+        if only and case not in only:
+            continue
+        for s in full_seeds:
+            tr = run_episode(case, s, interval, full=True)
+            path = os.path.join(OUT, f"trace_{case}_s{s}.npz")
+            np.savez_compressed(path, **tr)
+            print(path, os.path.getsize(path) // 1024, "KiB", "S_WPS", tr["metrics"][4])
+        rows, reps = [], []
+        for s in range(n_metric):
+            r = run_episode(case, s, interval, full=False)
+            rows.append(r["metrics"]); reps.append(int(r["n_replans"]))
+        np.savez_compressed(os.path.join(OUT, f"metrics_{case}.npz"), metrics=np.stack(rows),
+                            n_replans=np.array(reps, dtype=np.int64), interval=np.int64(interval),
+                            keys=np.array(METRIC_KEYS))
+        print("metrics", case, np.stack(rows)[:, 4].mean())
+
+
+if __name__ == "__main__":
+    main()
