@@ -1,0 +1,233 @@
+/*
+ * muavta.h — C ABI of the MI355X-native batched mUAV_TA environment.
+ *
+ * Drop-in boundary for ONE path of andrekuros/Multi-UAV-TA-gym-env: batched reset/step of
+ * mUAV_TA.MultiUAVEnv plus the Local-/Coalition-Hungarian allocator that drives it in the WPS and
+ * escort evaluation loops.  The reference has no FFI for this path (it is a Python class plus one
+ * PyO3 helper), so every entry point cites the reference interface it replaces; the ctypes binding a
+ * maintainer would add is shown in INTEGRATION.md.  All functions return 0 on success and a negative
+ * MUAVTA_E_* code on failure; muavta_last_error() gives the message.  Plain pointers and sizes only.
+ *
+ * Host buffers passed in are copied before the call returns; `dst` buffers are host memory filled
+ * synchronously.  One handle owns one HIP stream on one device; calls on a handle must be
+ * serialized by the caller (the reference env is single-threaded and non-reentrant too).
+ */
+#ifndef MUAVTA_H
+#define MUAVTA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUAVTA_ABI_VERSION 1
+
+/* UAV / threat type indices = mUAV_TA/MultiDroneEnvData.py:15 (UavTypes order). */
+enum { MUAVTA_R1 = 0, MUAVTA_R2 = 1, MUAVTA_E1 = 2, MUAVTA_F1 = 3, MUAVTA_F2 = 4, MUAVTA_T1 = 5, MUAVTA_T2 = 6 };
+/* Task type indices = mUAV_TA/MultiDroneEnvData.py:18 (TaskTypes order). */
+enum { MUAVTA_HOLD = 0, MUAVTA_REC = 1, MUAVTA_ATT = 2, MUAVTA_DEF = 3, MUAVTA_INT = 4, MUAVTA_DET = 5 };
+/* Event tags pushed on MultiUAVEnv.event_list (mUAV_TA/DroneEnv.py:976-977,1639-1640,1914-1915,1950). */
+enum { MUAVTA_EV_RESET_ALLOCATION = 0, MUAVTA_EV_NEW_THREAT = 1, MUAVTA_EV_AGENT_FAIL = 2,
+       MUAVTA_EV_ESCORT_CREATED = 3, MUAVTA_EV_ESCORT_RETIRED = 4 };
+
+enum {
+  MUAVTA_OK = 0,
+  MUAVTA_E_ARG = -1,        /* bad argument / unsupported configuration */
+  MUAVTA_E_NO_DEVICE = -2,  /* no HIP device: this library has no CPU fallback */
+  MUAVTA_E_HIP = -3,        /* HIP runtime error */
+  MUAVTA_E_CAPACITY = -4,   /* an env overflowed a tile (task slots / queue / events / pending) */
+  MUAVTA_E_STATE = -5       /* call order violated (e.g. step before reset) */
+};
+
+#define MUAVTA_MAX_GROUPS 8
+#define MUAVTA_N_METRICS 30
+#define MUAVTA_N_REWARD_WEIGHTS 8
+
+/*
+ * Configuration: mUAV_TA/MultiDroneEnvUtils.py:5-105 (agentEnvOptions) as read by
+ * MultiUAVEnv.__init__ (mUAV_TA/DroneEnv.py:73-243), already coerced the way __init__ coerces it
+ * (`x or default`).  Dict-valued options keep their insertion ORDER, which the reference's reset
+ * depends on (agent naming/creation order DroneEnv.py:124-127,603-612; task creation :641-667).
+ */
+typedef struct MuavtaParams {
+  int32_t abi_version;                       /* MUAVTA_ABI_VERSION */
+  int32_t n_agent_groups;                    /* config.agents: (type, count) in dict order */
+  int32_t agent_type[MUAVTA_MAX_GROUPS];
+  int32_t agent_count[MUAVTA_MAX_GROUPS];
+  int32_t n_task_groups;                     /* config.tasks: (type, count) in dict order */
+  int32_t task_type[MUAVTA_MAX_GROUPS];
+  int32_t task_count[MUAVTA_MAX_GROUPS];
+  int32_t n_threat_groups;                   /* config.threats_list: (type, count) */
+  int32_t threat_type[MUAVTA_MAX_GROUPS];
+  int32_t threat_count[MUAVTA_MAX_GROUPS];
+  int32_t max_time_steps;
+  int32_t multiple_tasks_per_agent;
+  int32_t early_terminate;
+  int32_t capability_mask;
+  int32_t saturate_mask;
+  int32_t include_time_windows;
+  int32_t threat_delay;
+  int32_t hard_windows;
+  int32_t window_length;
+  int32_t burst_mode;
+  int32_t burst_size;
+  int32_t dual_region_bursts;
+  int32_t share_knowledge;
+  int32_t commit_horizon;
+  int32_t escort_enabled;
+  uint32_t escort_agent_type_mask;           /* bit t set <=> UAV type t in escort_agent_types */
+  int32_t num_obstacles;                     /* <= 8; drawn per env at reset from the rndObsGen stream (DroneEnv.py:579-583) */
+  double simulation_frame_rate;
+  double fail_rate;
+  double reward_weights[MUAVTA_N_REWARD_WEIGHTS]; /* action, distance, quality, s_quality, time, alloc, time_penaulty, step */
+  double arrival_rate;
+  double dynamic_idle_penalty;
+  double sense_radius;
+  double miss_penalty;
+  double on_time_bonus;
+  double reassign_penalty;
+  double escort_radius;
+  double escort_requirement;
+  double escort_intercept_radius;
+  double mutual_support_radius;
+  /* Tile (capacity) of one env instance in device memory; 0 = derive a default. */
+  int32_t tile_agents;   /* >= n_agents; 16 / 24 / 64 in BASELINE configs */
+  int32_t tile_tasks;    /* live task slots (open + retired-but-referenced); 32 / 48 / 128 */
+  int32_t tile_threats;  /* >= sum(threat_count) */
+  int32_t random_init_pos; /* config.random_init_pos (DroneEnv.py:607) */
+} MuavtaParams;
+
+/* Geometry the caller needs to size its buffers. */
+typedef struct MuavtaDims {
+  int32_t n_envs, n_agents, tile_agents, tile_tasks, tile_threats;
+  int32_t max_tasks;      /* observation pad length = n_tasks + 28 (DroneEnv.py:145-147) */
+  int32_t obs_task_width; /* 21 floats per task row */
+  int32_t obs_agent_width;/* 9 floats per agent row */
+  int32_t queue_cap, event_cap, action_cap;
+  int64_t state_bytes;    /* bytes of one env's device state blob */
+} MuavtaDims;
+
+/* State fields readable with muavta_get (row-major, leading dim n_envs). */
+typedef enum MuavtaField {
+  MUAVTA_F_AGENT_POS = 0,      /* f64 [N, A, 2]      UAV.position                         */
+  MUAVTA_F_AGENT_STATE,        /* i32 [N, A]         UAV.state                            */
+  MUAVTA_F_AGENT_HEAD,         /* i32 [N, A]         UAV.tasks[0].id                      */
+  MUAVTA_F_AGENT_QUEUE,        /* i32 [N, A, Q]      UAV.tasks ids, -1 padded             */
+  MUAVTA_F_AGENT_NFT,          /* f64 [N, A]         UAV.next_free_time                   */
+  MUAVTA_F_AGENT_NFP,          /* f64 [N, A, 2]      UAV.next_free_position               */
+  MUAVTA_F_AGENT_CAPS,         /* f64 [N, A, 6]      UAV.currentCap2Task                  */
+  MUAVTA_F_AGENT_ATTACK_CAP,   /* i32 [N, A]         UAV.attackCap                        */
+  MUAVTA_F_AGENT_TYPE,         /* i32 [N, A]         UAV.typeIdx                          */
+  MUAVTA_F_AGENT_NAME_IDX,     /* i32 [N, A]         index of UAV.name in possible_agents */
+  MUAVTA_F_AGENT_DIST,         /* f64 [N, A]         env.agent_distances                  */
+  MUAVTA_F_TASK_ID,            /* i32 [N, T]         Task.id of slot (-1 = free slot)     */
+  MUAVTA_F_TASK_STATUS,        /* i32 [N, T]                                              */
+  MUAVTA_F_TASK_POS,           /* f64 [N, T, 2]                                           */
+  MUAVTA_F_TASK_CUR,           /* f64 [N, T, 6]      Task.currentReqs                     */
+  MUAVTA_F_TASK_ALLOC,         /* f64 [N, T, 6]      Task.allocatedReqs                   */
+  MUAVTA_F_TASK_DONE,          /* f64 [N, T, 6]      Task.doneReqs                        */
+  MUAVTA_F_TASK_META,          /* i32 [N, T, 8]      type, deadline(-1 none), created_at, required_agents, escort, n_alloc, protected_agent(-1), eligible_mask */
+  MUAVTA_F_TASK_TIMES,         /* f64 [N, T, 2]      initTime, doneTime                   */
+  MUAVTA_F_KNOWN,              /* u32 [N, A, ceil(T/32)]  bit s of row a: agent a knows the task in slot s */
+  MUAVTA_F_THREAT_POS,         /* f64 [N, H, 2]                                           */
+  MUAVTA_F_THREAT_META,        /* i32 [N, H, 6]      status(-9 not spawned), target agent, mission target, attackCap, task id, type */
+  MUAVTA_F_SCALARS,            /* f64 [N, 24]        see MUAVTA_S_* below                 */
+  MUAVTA_F_OPEN_IDS,           /* i32 [N, T]         env.last_tasks_info ids in order, -1 padded */
+  MUAVTA_F_EVENTS,             /* i32 [N, E, 2]      events drained by the last step (infos['events']), tag -1 padded */
+  MUAVTA_F_ERROR,              /* i32 [N]            0 or a MUAVTA_E_CAPACITY detail code */
+  MUAVTA_F_COUNT_
+} MuavtaField;
+
+/* Columns of MUAVTA_F_SCALARS. */
+enum {
+  MUAVTA_S_TIME_STEPS = 0, MUAVTA_S_REWARD, MUAVTA_S_F_REWARD, MUAVTA_S_TOTAL_DISTANCE, MUAVTA_S_N_ON_TIME,
+  MUAVTA_S_N_MISSED, MUAVTA_S_N_WINDOWED, MUAVTA_S_N_SWITCHES, MUAVTA_S_N_REALLOC, MUAVTA_S_N_ARRIVALS,
+  MUAVTA_S_IDLE_RESERVE, MUAVTA_S_CONCLUSION_TIME, MUAVTA_S_ESCORT_REQUESTS, MUAVTA_S_ESCORT_COMPLETED,
+  MUAVTA_S_ESCORT_FAILED, MUAVTA_S_ESCORT_REQUIRED_STEPS, MUAVTA_S_ESCORT_COVERED_STEPS,
+  MUAVTA_S_PROTECTION_BREACHES, MUAVTA_S_THREATS_INTERCEPTED, MUAVTA_S_RECON_LOSSES, MUAVTA_S_ESCORT_LOSSES,
+  MUAVTA_S_MUTUAL_SUPPORT, MUAVTA_S_PROTECTED_REC, MUAVTA_S_N_REPLANS, MUAVTA_N_SCALARS
+};
+
+typedef struct MuavtaEnv MuavtaEnv; /* opaque */
+
+/* MultiUAVEnv(config) for n_envs independent instances on HIP device `device` (DroneEnv.py:73-323).
+ * Fails with MUAVTA_E_NO_DEVICE when no GPU is present. */
+int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, MuavtaEnv** out);
+int muavta_destroy(MuavtaEnv* env);
+const char* muavta_last_error(const MuavtaEnv* env); /* env may be NULL: last create() error */
+int muavta_dims(const MuavtaEnv* env, MuavtaDims* out);
+
+/* env.reset(seed=seeds[i]) for every instance (DroneEnv.py:522-762). */
+int muavta_reset(MuavtaEnv* env, const uint64_t* seeds);
+
+/* env.step(actions) (DroneEnv.py:774-1206).  Actions are the ORDERED (agent, index) items of the
+ * reference's actions dict: act_agent[i, k] = UAV.id (position in agents_obj) or -1 to end the
+ * list, act_index[i, k] = index into env.last_tasks_info (the open list returned by the previous
+ * observation).  Leading dims are [n_envs, action_cap]. */
+int muavta_step(MuavtaEnv* env, const int32_t* act_agent, const int32_t* act_index);
+
+/* HungarianAllocator.allocate_tasks(get_live_agents(), _open_tasks(env), time_steps, events,
+ * agent_known_ids=agent_visibility_map()) + _apply_assign  (HungarianAllocator.py:72-208,
+ * experiments/wps_eval.py:55-61,123-133).  Writes the actions the harness would pass to step, in
+ * muavta_step's layout (host buffers, may be NULL to only stage them on the device for
+ * muavta_step_staged).  use_visibility=0 gives Global-Hungarian.  The allocator state
+ * (last_plan_step, n_replans) lives in the handle and is cleared by muavta_reset. */
+int muavta_allocate(MuavtaEnv* env, int32_t replan_interval, int32_t use_visibility,
+                    int32_t* act_agent, int32_t* act_index);
+int muavta_step_staged(MuavtaEnv* env); /* step with the actions muavta_allocate left on the device */
+
+/* The measured path: reset(seeds) followed by n_steps x (allocate -> step) fused in ONE kernel
+ * launch, state resident in LDS (run_wps_episode / run_escort_episode with Local-/Coalition-
+ * Hungarian, experiments/wps_eval.py:76-291, experiments/escort_eval.py:86-226).  seeds == NULL
+ * continues from the current state without a reset.  write_obs != 0 also writes the batched
+ * observation tensors after every step, as env.step does. */
+int muavta_rollout(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps, int32_t replan_interval,
+                   int32_t use_visibility, int32_t write_obs);
+
+/* Batched observation of the last reset/step (DroneEnv.py:365-415,468-492):
+ *   tasks   f32 [N, max_tasks, 21]: id, x, y, status(-1 pad), current_reqs[6], alloc_reqs[6], init_time,
+ *                                   end_time, type_idx/6, unmet, age
+ *   legal   u8  [N, A, max_tasks]   legal_mask        pad u8 [N, max_tasks]  mask
+ *   agents  f32 [N, A, 9]           agent_position(2), agent_caps(6), alloc_task
+ *   flags   f32 [N, 5]              event_flags
+ * Any pointer may be NULL. */
+int muavta_observe(MuavtaEnv* env, float* tasks, uint8_t* legal, uint8_t* pad, float* agents, float* flags);
+
+/* rewards / terminations / truncations of the last step: reward f64 [N] (shared by all agents of an
+ * env, DroneEnv.py:1162-1178,1202), done u8 [N] (terminated | truncated << 1). */
+int muavta_step_result(MuavtaEnv* env, double* reward, uint8_t* done);
+
+/* calculate_metrics() for every env, f64 [N, 30] in the key order of DroneEnv.py:1286-1319. */
+int muavta_metrics(MuavtaEnv* env, double* out);
+
+/* Copy one state field of all envs to host / overwrite it from host (tests, object proxies). */
+int muavta_get(MuavtaEnv* env, MuavtaField field, void* dst, size_t bytes);
+int muavta_set(MuavtaEnv* env, MuavtaField field, const void* src, size_t bytes);
+
+/* Whole-state snapshot (checkpoint/resume): bytes = n_envs * dims.state_bytes. */
+int muavta_get_state(MuavtaEnv* env, void* dst, size_t bytes);
+int muavta_set_state(MuavtaEnv* env, const void* src, size_t bytes);
+
+/* Stand-alone batched solver with scipy.optimize.linear_sum_assignment's exact tie rules
+ * (call site HungarianAllocator.py:181): `n` problems, each cost f64 [nr, nc] row-major (nr, nc <= 64
+ * x 128); row/col i64 [n, min(nr, nc)].  Runs on HIP device `device`. */
+int muavta_lsap(int32_t device, const double* cost, int32_t n, int32_t nr, int32_t nc, int64_t* row, int64_t* col);
+
+/* core_sim.SimCore.avoid_obstacles (core_sim/src/sim_core.rs:25-59) for n (position, movement)
+ * pairs against one obstacle list, evaluated on the device. */
+int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double* movement, int32_t n,
+                           const double* obstacles, int32_t n_obstacles, double* out);
+
+/* Device pointers for zero-copy consumers in the same process (torch.from_blob etc.). */
+int muavta_device_ptrs(MuavtaEnv* env, void** state, void** obs_tasks, void** obs_legal, void** obs_agents,
+                       void** metrics, void** stream);
+
+/* Wall-clock of the last muavta_rollout kernel, measured with HIP events on the handle's stream (ms). */
+int muavta_last_kernel_ms(MuavtaEnv* env, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUAVTA_H */

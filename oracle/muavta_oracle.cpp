@@ -1,0 +1,1630 @@
+/*
+ * muavta_oracle.cpp — CPU restatement of the reference's hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle: a serial, object-for-object restatement (one env per handle, no
+ * GPU, no threads) of
+ *     mUAV_TA/DroneEnv.py            MultiUAVEnv.reset / step / metrics
+ *     mUAV_TA/DroneEnvComponents.py  UAV / Task / Threat methods (incl. their list-mutation quirks)
+ *     core_sim/src/sim_core.rs       SimCore::avoid_obstacles
+ *     TaskAllocation/OptimizationBased/HungarianAllocator.py   allocate_tasks
+ *     scipy.optimize.linear_sum_assignment (scipy 1.15.3, rectangular_lsap: Crouse's shortest
+ *         augmenting path — third-party, restated from its published algorithm)
+ *     CPython 3.10 random.Random (MT19937 + seed/getrandbits/_randbelow/shuffle/choice/uniform)
+ * each function citing the reference file:line it follows.  It is pinned against golden vectors
+ * captured by RUNNING the reference in the build container (tools/gen_golden.py ->
+ * tests/golden/*.npz; checked by tests/test_oracle_golden.py): bit-exact per-step state for 17 traced
+ * episodes and final metrics for 240 more.  Exception: avoid_obstacles with K>0 obstacles is pinned by
+ * no reference test or live configuration ("parity unpinned" for K>0; K=0 is the identity).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The
+ * product (multi-uav-ta-gym-env_amd/csrc) never includes, links or calls it.
+ *
+ * Build: g++ -O2 -ffp-contract=off -shared -fPIC (see oracle/Makefile).  -ffp-contract=off matters:
+ * every FMA below is explicit because numpy's 1-D norm is sqrt(fma(y,y,x*x)) in the reference's run.
+ */
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../include/muavta.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// CPython random.Random  (Modules/_randommodule.c + Lib/random.py, Python 3.10)
+// ------------------------------------------------------------------------------------------------
+struct PyRandom {
+  uint32_t mt[624];
+  int idx;
+  uint64_t words_drawn = 0;
+
+  void init_genrand(uint32_t s) {
+    mt[0] = s;
+    for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    idx = 624;
+  }
+  void init_by_array(const uint32_t* key, int len) {
+    init_genrand(19650218u);
+    int i = 1, j = 0;
+    int k = 624 > len ? 624 : len;
+    for (; k; k--) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+      i++; j++;
+      if (i >= 624) { mt[0] = mt[623]; i = 1; }
+      if (j >= len) j = 0;
+    }
+    for (k = 623; k; k--) {
+      mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+      i++;
+      if (i >= 624) { mt[0] = mt[623]; i = 1; }
+    }
+    mt[0] = 0x80000000u;
+  }
+  // random.Random(int): key = 32-bit little-endian chunks of abs(seed) (random_seed()).
+  void seed(uint64_t s) {
+    uint32_t key[2] = {(uint32_t)(s & 0xffffffffu), (uint32_t)(s >> 32)};
+    init_by_array(key, key[1] ? 2 : 1);
+    words_drawn = 0;
+  }
+  uint32_t next32() {
+    if (idx >= 624) {
+      int kk;
+      uint32_t y;
+      for (kk = 0; kk < 624 - 397; kk++) {
+        y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+        mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      for (; kk < 623; kk++) {
+        y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+        mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      }
+      y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+      mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+      idx = 0;
+    }
+    uint32_t y = mt[idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    words_drawn++;
+    return y;
+  }
+  double random() {
+    uint32_t a = next32() >> 5, b = next32() >> 6;
+    return (a * 67108864.0 + b) * (1.0 / 9007199254740992.0);
+  }
+  uint64_t getrandbits(int k) {  // k in 1..64
+    if (k <= 32) return next32() >> (32 - k);
+    uint64_t lo = next32();
+    uint64_t hi = next32();
+    int rem = k - 32;
+    if (rem < 32) hi >>= (32 - rem);
+    return lo | (hi << 32);
+  }
+  static int bit_length(uint64_t n) { int b = 0; while (n) { b++; n >>= 1; } return b; }
+  uint64_t randbelow(uint64_t n) {  // Random._randbelow_with_getrandbits
+    int k = bit_length(n);
+    uint64_t r = getrandbits(k);
+    while (r >= n) r = getrandbits(k);
+    return r;
+  }
+  int64_t randint(int64_t a, int64_t b) { return a + (int64_t)randbelow((uint64_t)(b - a) + 1u); }
+  double uniform(double a, double b) { return a + (b - a) * random(); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// scipy.optimize.linear_sum_assignment (rectangular_lsap.cpp, scipy 1.15.3)
+// ------------------------------------------------------------------------------------------------
+int lsap_solve(const double* cost_in, int nr_in, int nc_in, int64_t* a, int64_t* b) {
+  int nr = nr_in, nc = nc_in;
+  if (nr == 0 || nc == 0) return 0;
+  bool transpose = nc < nr;
+  std::vector<double> temp;
+  const double* cost = cost_in;
+  if (transpose) {
+    temp.resize((size_t)nr * nc);
+    for (int i = 0; i < nr; i++)
+      for (int j = 0; j < nc; j++) temp[(size_t)j * nr + i] = cost_in[(size_t)i * nc + j];
+    std::swap(nr, nc);
+    cost = temp.data();
+  }
+  const double INF = std::numeric_limits<double>::infinity();
+  std::vector<double> u(nr, 0.0), v(nc, 0.0), spc(nc);
+  std::vector<int> path(nc, -1), col4row(nr, -1), row4col(nc, -1), remaining(nc);
+  std::vector<char> SR(nr), SC(nc);
+  for (int cur = 0; cur < nr; cur++) {
+    double minVal = 0;
+    int i = cur;
+    int num_remaining = nc;
+    for (int it = 0; it < nc; it++) remaining[it] = nc - it - 1;
+    std::fill(SR.begin(), SR.end(), 0);
+    std::fill(SC.begin(), SC.end(), 0);
+    std::fill(spc.begin(), spc.end(), INF);
+    int sink = -1;
+    while (sink == -1) {
+      int index = -1;
+      double lowest = INF;
+      SR[i] = 1;
+      for (int it = 0; it < num_remaining; it++) {
+        int j = remaining[it];
+        double r = minVal + cost[(size_t)i * nc + j] - u[i] - v[j];
+        if (r < spc[j]) { path[j] = i; spc[j] = r; }
+        if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+      }
+      minVal = lowest;
+      if (minVal == INF) return -1;
+      int j = remaining[index];
+      if (row4col[j] == -1) sink = j; else i = row4col[j];
+      SC[j] = 1;
+      remaining[index] = remaining[--num_remaining];
+    }
+    u[cur] += minVal;
+    for (int r = 0; r < nr; r++)
+      if (SR[r] && r != cur) u[r] += minVal - spc[col4row[r]];
+    for (int j = 0; j < nc; j++)
+      if (SC[j]) v[j] -= minVal - spc[j];
+    int j = sink;
+    while (true) {
+      int r = path[j];
+      row4col[j] = r;
+      std::swap(col4row[r], j);
+      if (r == cur) break;
+    }
+  }
+  if (transpose) {
+    std::vector<int> order(nr);
+    for (int i = 0; i < nr; i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return col4row[x] < col4row[y]; });
+    for (int i = 0; i < nr; i++) { a[i] = col4row[order[i]]; b[i] = order[i]; }
+  } else {
+    for (int i = 0; i < nr; i++) { a[i] = i; b[i] = col4row[i]; }
+  }
+  return nr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scene constants (mUAV_TA/MultiDroneEnvData.py:8-85)
+// ------------------------------------------------------------------------------------------------
+const double AREA_W = 1200.0, AREA_H = 700.0, CONTACT_LINE = 550.0, BASE_X = 400.0, BASE_Y = 680.0;
+const double CAP_TABLE[7][6] = {
+    {0.1, 1.0, 0.0, 0.2, 0.0, 0.0},  // R1
+    {0.1, 0.6, 0.0, 0.1, 0.0, 0.0},  // R2
+    {0.1, 0.8, 0.0, 0.2, 0.0, 1.0},  // E1
+    {0.1, 0.0, 0.7, 1.0, 1.0, 1.0},  // F1
+    {0.1, 0.0, 1.0, 0.6, 0.8, 1.0},  // F2
+    {0.0, 0.0, 0.2, 0.5, 1.0, 1.0},  // T1
+    {0.0, 0.0, 0.2, 0.4, 0.8, 0.8},  // T2
+};
+const double MAX_SPEED[7] = {5.0, 8.0, 5.0, 20.0, 15.0, 14.0, 12.0};
+const double ENGAGE_RANGE[7] = {0.0, 0.0, 0.0, 40.0, 30.0, 35.0, 25.0};
+const double FAIL_MULT[7] = {1.2, 0.8, 1.5, 1.5, 0.8, 1.8, 1.0};
+const int TASK_DURATION[6] = {1, 10, 5, 5, 0, 1};  // Hold, Rec, Att, Def, Int, Det
+const double EPS = 1e-12;
+
+inline double norm2(double x, double y) { return std::sqrt(std::fma(y, y, x * x)); }  // np.linalg.norm (1-D)
+
+struct Vec { double x, y; };
+
+struct Task {  // DroneEnvComponents.py:223-263
+  int id = 0;
+  Vec pos{0, 0};
+  int type = 0;
+  double orgReqs[6] = {0}, allocatedReqs[6] = {0}, doneReqs[6] = {0}, currentReqs[6] = {0};
+  std::vector<std::pair<int, double>> allocationDetails;  // agent id -> time_at_task (insertion order)
+  int status = 0;
+  int task_duration = 0;
+  double initTime = -1, doneTime = -1;
+  int created_at = 0;
+  double final_quality = -1;
+  int relative_threat = -1;
+  bool escort = false;   // kind == "Escort"
+  int protected_agent = -1, protected_task = -1;
+  bool has_eligible = false;
+  uint32_t eligible_mask = 0;
+  int required_agents = 0;
+  bool has_deadline = false;
+  int hard_deadline = 0;
+  bool outcome_counted = false;
+  std::vector<char> bucket;  // allocation_table[id] as a set of agent ids
+  bool reached = false;
+
+  int details_find(int agent) const {
+    for (size_t i = 0; i < allocationDetails.size(); i++) if (allocationDetails[i].first == agent) return (int)i;
+    return -1;
+  }
+};
+
+struct UAV {  // DroneEnvComponents.py:7-52
+  int id, name_idx, type;
+  Vec pos;
+  int state = 0, task_start = -1, fail_event = -1;
+  double caps[6];
+  int attackCap = 0;
+  double max_speed, engage_range, fail_multiplier;
+  std::vector<int> tasks;  // task ids (0 == idle task)
+  bool re_eval = false;
+  int last_task = -1;  // -1 == None
+  int commit_until = 0;
+  double next_free_time = 0;
+  Vec next_free_position;
+};
+
+struct Threat {  // DroneEnvComponents.py:331-350
+  int id, type, group;
+  Vec pos;
+  double max_speed, engage_range, attack, defence;
+  int target_agent = -1, mission_target_agent = -1, intercepting_agent = -1;
+  int relative_task = -1, relative_detect_task = -1;
+  int attackCap = 4;
+  int status = 1;
+};
+
+struct Area { double tlx, tly, w, h; };
+
+struct Event { int tag, arg; };
+
+struct Env {
+  MuavtaParams P;
+  int n_agents = 0, n_tasks = 0, max_tasks = 0;
+  double max_coord = 1200.0, threat_generation_probability, threat_wide;
+  PyRandom rndAgent, rndObs, rndTgt, rndMission;
+  std::vector<UAV> agents;
+  std::vector<Task> tasks;          // tasks[0] is the idle task; tasks[id] for id >= 1 == self.tasks[id-1]
+  std::vector<Threat> threats_all;  // by threat id
+  std::vector<int> threats;         // active list (ids), append order
+  std::vector<std::vector<int>> threats_groups;
+  std::vector<Area> mission_areas;
+  std::vector<std::array<double, 3>> obstacles;
+  bool failed = false;
+  std::vector<Event> event_list, done_events;
+  std::vector<std::pair<int, int>> pending_reveals;
+  std::vector<std::vector<char>> known;  // [agent][task id]
+  std::vector<std::pair<int, int>> escort_by_recon;  // insertion-ordered dict recon agent id -> escort task id
+  std::vector<int> last_tasks_info;
+  std::vector<double> agent_distances;
+  int time_steps = 0, conclusion_time = 0;
+  double F_Reward = 0, step_reward = 0, total_distance = 0, reward_norm_factor = 1, last_reward = 0;
+  int n_reallocations = 0, n_task_switches = 0, n_arrivals = 0, n_missed_windows = 0, n_on_time = 0,
+      n_windowed_tasks = 0, idle_reserve_steps = 0, burst_region_toggle = 0, next_task_id = 1, next_threat_id = 0,
+      escort_requests = 0, escort_completed = 0, escort_failed = 0, escort_required_steps = 0,
+      escort_covered_steps = 0, protection_breaches = 0, threats_intercepted = 0, recon_losses = 0,
+      escort_losses = 0, mutual_support_engagements = 0, protected_rec_completed = 0, n_reached = 0;
+  bool pending_reset = false, terminated = false, truncated = false, did_reset = false;
+  // HungarianAllocator state (HungarianAllocator.py:20-25)
+  long long last_plan_step = -1000000000LL;
+  int n_replans = 0, n_calls = 0;
+  std::vector<std::pair<int, int>> last_actions;  // (agent id, task id) chosen by the last allocate
+  // capture of every LSAP call of the last allocate (tests)
+  std::vector<double> lsap_costs;
+  std::vector<int> lsap_shapes;
+  std::vector<int64_t> lsap_rows, lsap_cols;
+
+  explicit Env(const MuavtaParams& p) : P(p) {
+    for (int g = 0; g < P.n_agent_groups; g++) n_agents += P.agent_count[g];        // DroneEnv.py:119
+    int s = 0;
+    for (int g = 0; g < P.n_task_groups; g++) s += P.task_count[g];
+    n_tasks = s + 1;                                                               // :145
+    max_tasks = n_tasks + 28;                                                      // :147
+    threat_generation_probability = 0.7 / P.simulation_frame_rate * 0.02;          // :162
+    threat_wide = AREA_W / 10;                                                     // :164
+  }
+
+  // ---- Task / UAV methods -------------------------------------------------------------------
+  Task make_task(int id, Vec pos, int type) {  // Task.__init__ (DroneEnvComponents.py:224-263)
+    Task t;
+    t.id = id; t.pos = pos; t.type = type;
+    t.task_duration = TASK_DURATION[type];
+    t.bucket.assign(n_agents, 0);
+    return t;
+  }
+  void set_req(Task& t, int type, double v) { t.orgReqs[type] = v; t.currentReqs[type] = v; }
+
+  void removeAgentCap(Task& t, UAV& a) {  // DroneEnvComponents.py:280-301
+    if (t.status != 2) {
+      int k = t.details_find(a.id);
+      if (k >= 0) {
+        for (int c = 0; c < 6; c++) t.allocatedReqs[c] -= a.caps[c];
+        double det = t.allocationDetails[k].second;
+        t.allocationDetails.erase(t.allocationDetails.begin() + k);
+        if (!t.allocationDetails.empty()) {
+          if (det == t.initTime) {
+            double m = t.allocationDetails[0].second;
+            for (auto& d : t.allocationDetails) m = d.second < m ? d.second : m;
+            t.initTime = m;
+          }
+          if (det + t.task_duration == t.doneTime) {
+            double m = t.allocationDetails[0].second;
+            for (auto& d : t.allocationDetails) m = d.second > m ? d.second : m;
+            t.doneTime = m + t.task_duration;
+          }
+        } else {
+          t.initTime = -1;
+          t.doneTime = -1;
+        }
+      }
+    }
+  }
+  void addAgentCap(Task& t, UAV& a, double time_at_task) {  // DroneEnvComponents.py:306-326
+    if (t.status != 2) {
+      double time_end_task = time_at_task + t.task_duration;
+      int k = t.details_find(a.id);
+      if (k >= 0) t.allocationDetails[k].second = time_at_task;
+      else t.allocationDetails.push_back({a.id, time_at_task});
+      for (int c = 0; c < 6; c++) t.allocatedReqs[c] += a.caps[c];
+      if (time_at_task < t.initTime || t.initTime == -1) {
+        t.initTime = time_at_task;
+        if (t.doneTime == -1) t.doneTime = time_end_task;
+      }
+      if (time_end_task > t.doneTime) t.doneTime = time_end_task;
+      t.status = 1;
+    }
+  }
+  static bool in_queue(const UAV& a, int tid) { return std::find(a.tasks.begin(), a.tasks.end(), tid) != a.tasks.end(); }
+
+  bool uav_allocate(UAV& a, int tid, int time_step) {  // DroneEnvComponents.py:55-95
+    Task& t = tasks[tid];
+    if (!in_queue(a, tid) && t.status != 2) {
+      a.re_eval = false;
+      a.last_task = -1;
+      if (t.id != 0) {
+        double time_to_task = norm2(a.next_free_position.x - t.pos.x, a.next_free_position.y - t.pos.y) / a.max_speed;
+        double start_time = (a.next_free_time - time_step) > 0 ? a.next_free_time : (double)time_step;
+        double end_time = start_time + time_to_task + t.task_duration;
+        if (a.tasks[0] == 0) {
+          a.tasks[0] = tid;
+          a.task_start = -1;
+          a.state = 1;
+        } else {
+          a.tasks.push_back(tid);
+        }
+        a.next_free_time = end_time;
+        a.next_free_position = t.pos;
+        addAgentCap(t, a, time_to_task);
+        return true;
+      } else {
+        a.tasks.assign(1, 0);
+        a.next_free_time = 0;
+        a.next_free_position = a.pos;
+        return false;
+      }
+    }
+    return false;
+  }
+  // UAV.desAllocate (DroneEnvComponents.py:97-113).  Returns {removed, list_replaced}.
+  bool uav_desAllocate(UAV& a, int tid, bool* replaced = nullptr) {
+    if (replaced) *replaced = false;
+    auto it = std::find(a.tasks.begin(), a.tasks.end(), tid);
+    if (it != a.tasks.end() && tid != 0) {
+      a.tasks.erase(it);
+      a.next_free_time = time_steps;
+      a.next_free_position = a.pos;
+      a.commit_until = 0;
+      removeAgentCap(tasks[tid], a);
+      if (a.tasks.empty()) {
+        a.tasks.assign(1, 0);
+        if (replaced) *replaced = true;  // python rebinds self.tasks to a NEW list; an active `for` keeps the old (empty) one
+      }
+      return true;
+    }
+    return false;
+  }
+  // `for task in self.tasks: self.desAllocate(task)` — iterating the list being mutated
+  // (DroneEnvComponents.py:115-119,122-127): the iterator index advances past the element that
+  // slid into the freed position, so every other queued task survives.
+  void iterate_desallocate(UAV& a) {
+    size_t i = 0;
+    while (i < a.tasks.size()) {
+      bool replaced = false;
+      uav_desAllocate(a, a.tasks[i], &replaced);
+      if (replaced) break;
+      i++;
+    }
+  }
+  void uav_desallocateAll(UAV& a) { iterate_desallocate(a); a.commit_until = 0; }
+  void uav_outOfService(UAV& a) { a.state = -1; a.commit_until = 0; iterate_desallocate(a); }
+
+  bool uav_taskDone(UAV& a, int tid) {  // DroneEnvComponents.py:143-179
+    if (tid != a.tasks[0]) return false;
+    a.tasks.erase(a.tasks.begin());
+    a.task_start = -1;
+    Task& t = tasks[tid];
+    if (t.type == MUAVTA_ATT) {
+      a.attackCap -= 1;
+      if (a.attackCap <= 0) a.caps[t.type] = 0;
+    }
+    while (!a.tasks.empty()) {
+      if (tasks[a.tasks[0]].status == 2 || a.tasks[0] == 0) a.tasks.erase(a.tasks.begin());
+      else break;
+    }
+    if (a.tasks.empty() || a.tasks[0] == 0) {
+      if (a.re_eval) { a.last_task = -1; a.re_eval = false; }
+      a.tasks.assign(1, 0);
+      a.next_free_time = 0;
+      a.next_free_position = a.pos;
+      a.state = 0;
+    } else {
+      a.state = 1;
+    }
+    return true;
+  }
+
+  // ---- env helpers ---------------------------------------------------------------------------
+  int alloc_task_id() { return next_task_id++; }
+  static bool is_recon(int type) { return type == MUAVTA_R1 || type == MUAVTA_R2; }
+  bool is_escort_type(int type) const { return (P.escort_agent_type_mask >> type) & 1u; }
+
+  void push_task(Task&& t) {
+    tasks.push_back(std::move(t));
+    for (auto& k : known) k.push_back(0);
+  }
+
+  bool is_task_action_valid(const UAV& a, const Task& t) const {  // DroneEnv.py:341-363
+    if (t.status == 2) return false;
+    if (!a.tasks.empty() && a.tasks[0] == t.id) return true;
+    if (t.has_eligible && !((t.eligible_mask >> a.type) & 1u)) return false;
+    if (P.capability_mask && a.caps[t.type] <= 0) return false;
+    if (P.saturate_mask && t.allocatedReqs[t.type] >= t.orgReqs[t.type]) return false;
+    return true;
+  }
+
+  Vec random_position(PyRandom& rng, double min_distance, double own_range, bool contact_line, const Area* area, bool check_obs) {
+    // DroneEnv.py:1371-1410
+    double limit_line = contact_line ? CONTACT_LINE : 0;
+    int tries = 0;
+    while (tries < 100) {
+      double x, y;
+      if (area) {
+        x = rng.uniform(area->tlx, area->tlx + area->w);
+        y = rng.uniform(area->tly, area->tly + area->h);
+      } else {
+        x = rng.uniform(own_range + min_distance, AREA_W - own_range - min_distance);
+        y = rng.uniform(own_range + min_distance,
+                        AREA_H - own_range - min_distance - ((limit_line != 0) ? (AREA_H - limit_line) : 0));
+      }
+      bool valid = true;
+      if (check_obs) {
+        for (auto& ob : obstacles) {
+          double d = norm2(x - ob[0], y - ob[1]) - own_range;
+          if (d < ob[2] + min_distance) { valid = false; break; }
+        }
+      }
+      if (valid) return Vec{x, y};
+      tries++;
+    }
+    failed = true;  // the reference raises ValueError here (:1410)
+    return Vec{std::nan(""), std::nan("")};
+  }
+
+  // core_sim/src/sim_core.rs:25-59
+  Vec avoid_obstacles(Vec pos, Vec mov) const {
+    Vec av{0.0, 0.0};
+    const double PI = 3.14159265358979323846;
+    for (auto& ob : obstacles) {
+      double dx = ob[0] - pos.x, dy = ob[1] - pos.y;
+      double d_obs = std::sqrt(dx * dx + dy * dy);
+      double d_zone = d_obs - ob[2];
+      if (d_zone < 40.0) {
+        double nx = dx / d_zone, ny = dy / d_zone;
+        double force = std::log(std::fmax(1.05, d_zone));
+        force = 0.5 / (1.0 - force);
+        double ang = std::atan2(mov.y, mov.x) - std::atan2(dy, dx);
+        ang = std::fmod(ang + PI, 2.0 * PI) - PI;
+        double rx, ry;
+        if (ang > 0.0) { rx = ny; ry = -nx; } else { rx = -ny; ry = nx; }
+        av.x += rx * force;
+        av.y += ry * force;
+      }
+    }
+    return av;
+  }
+
+  static Vec norm_vector(Vec v) {  // MultiDroneEnvUtils.py:168-177
+    double m = norm2(v.x, v.y);
+    if (m == 0) return Vec{0, 0};
+    return Vec{v.x / m, v.y / m};
+  }
+
+  // ---- reset (DroneEnv.py:522-762) -----------------------------------------------------------
+  void reset(uint64_t seed) {
+    rndAgent.seed(seed);
+    rndObs.seed((uint64_t)rndAgent.randint(0, INT64_MAX));
+    rndTgt.seed((uint64_t)rndAgent.randint(0, INT64_MAX));
+    rndMission.seed((uint64_t)rndAgent.randint(0, INT64_MAX));
+
+    agents.clear(); tasks.clear(); threats.clear(); threats_all.clear(); threats_groups.clear();
+    mission_areas.clear(); event_list.clear(); done_events.clear(); pending_reveals.clear(); known.clear();
+    escort_by_recon.clear(); last_tasks_info.clear();
+    conclusion_time = P.max_time_steps + 1;
+    F_Reward = 0; n_reallocations = n_task_switches = n_arrivals = 0; pending_reset = false;
+    n_missed_windows = n_on_time = n_windowed_tasks = idle_reserve_steps = burst_region_toggle = 0;
+    next_task_id = 1; next_threat_id = 0;
+    escort_requests = escort_completed = escort_failed = escort_required_steps = escort_covered_steps = 0;
+    protection_breaches = threats_intercepted = recon_losses = escort_losses = mutual_support_engagements = 0;
+    protected_rec_completed = 0; n_reached = 0;
+    last_plan_step = -1000000000LL; n_replans = 0; n_calls = 0; last_actions.clear();
+    terminated = truncated = false; last_reward = 0;
+
+    // obstacles (:579-583)
+    obstacles.clear();
+    failed = false;
+    for (int o = 0; o < P.num_obstacles; o++) {
+      double size = (double)rndObs.randint(30, 100);
+      Vec p = random_position(rndObs, 20, size, true, nullptr, true);
+      obstacles.push_back({p.x, p.y, size});
+    }
+
+    // idle task (:589)
+    tasks.push_back(make_task(0, Vec{0, 0}, MUAVTA_HOLD));
+    set_req(tasks[0], MUAVTA_HOLD, 0.0);
+
+    // agents (:591-612)
+    std::vector<int> agents_list(n_agents);
+    for (int i = 0; i < n_agents; i++) agents_list[i] = i;
+    for (int i = n_agents - 1; i >= 1; i--) {  // Random.shuffle
+      int j = (int)rndAgent.randbelow((uint64_t)i + 1);
+      std::swap(agents_list[i], agents_list[j]);
+    }
+    agents.resize(n_agents);
+    int pop = 0, name_idx = 0;
+    for (int g = 0; g < P.n_agent_groups; g++) {
+      for (int i = 0; i < P.agent_count[g]; i++) {
+        int agent_id = agents_list[pop++];
+        UAV a;
+        a.id = agent_id; a.name_idx = name_idx++; a.type = P.agent_type[g];
+        a.pos = P.random_init_pos ? random_position(rndAgent, 20, 3, false, nullptr, true) : Vec{BASE_X, BASE_Y};
+        for (int c = 0; c < 6; c++) a.caps[c] = CAP_TABLE[a.type][c];
+        a.attackCap = (a.type == MUAVTA_F1 || a.type == MUAVTA_F2) ? 10 : 0;
+        a.max_speed = MAX_SPEED[a.type] / P.simulation_frame_rate * 0.02;  // :611
+        a.engage_range = ENGAGE_RANGE[a.type];
+        a.fail_multiplier = FAIL_MULT[a.type];
+        a.tasks.assign(1, 0);
+        a.next_free_position = a.pos;
+        agents[agent_id] = a;
+      }
+    }
+    // fail events (:616-618)
+    for (auto& a : agents)
+      if (rndAgent.random() < P.fail_rate * a.fail_multiplier)
+        a.fail_event = (int)rndAgent.randint(1, P.max_time_steps == -1 ? 1000 : P.max_time_steps);
+    // mission areas (:621-634): SquareArea(center, area_width, area_width)
+    for (int i = 0; i < 3; i++) {
+      double area_width = (double)(1200 * rndMission.randint(10, 20)) / 100;
+      double area_height = (double)(700 * rndMission.randint(10, 20)) / 100;
+      Vec c = random_position(rndMission, std::fmax(area_width, area_height), 3, false, nullptr, false);
+      mission_areas.push_back(Area{c.x - area_width / 2, c.y - area_width / 2, area_width, area_width});
+    }
+    // static tasks (:641-667)
+    int hold_tasks_num = 0;
+    for (int g = 0; g < P.n_task_groups; g++) {
+      for (int i = 0; i < P.task_count[g]; i++) {
+        const Area* sel = &mission_areas[rndMission.randbelow(mission_areas.size())];
+        int tid = alloc_task_id();
+        Vec p;
+        int type = P.task_type[g];
+        if (type != MUAVTA_HOLD) {
+          p = random_position(rndTgt, 20, 3, true, sel, true);
+        } else {
+          p = Vec{(double)(int)((hold_tasks_num + 1) * AREA_W / 5), (double)(int)(AREA_H / 4)};
+          hold_tasks_num++;
+        }
+        Task t = make_task(tid, p, type);
+        set_req(t, type, 1.0);
+        tasks.push_back(std::move(t));
+      }
+    }
+    double possible = 0;
+    for (size_t k = 1; k < tasks.size(); k++) possible += tasks[k].orgReqs[tasks[k].type];
+    reward_norm_factor = (possible * 1 + possible) / 1000;  // :675 (final_rew_factor=1, reward_multiplifier=1000)
+    // threats (:685-729)
+    threats_groups.resize(P.n_threat_groups);
+    for (int ng = 0; ng < P.n_threat_groups; ng++) {
+      double gx = (double)rndAgent.randint((int)(0 + threat_wide), (int)(AREA_W - threat_wide));
+      int gtype = P.threat_type[ng];
+      int tid = alloc_task_id();
+      Task det = make_task(tid, Vec{gx, AREA_H / 5}, MUAVTA_DET);
+      set_req(det, MUAVTA_DET, (double)P.threat_count[ng]);
+      tasks.push_back(std::move(det));
+      for (int k = 0; k < P.threat_count[ng]; k++) {
+        Threat th;
+        th.pos = Vec{(double)rndAgent.randint((int)(gx - threat_wide), (int)(gx + threat_wide)), 0.0};
+        th.id = next_threat_id++;
+        th.type = gtype; th.group = ng;
+        th.max_speed = MAX_SPEED[gtype] / P.simulation_frame_rate * 0.02;  // :725
+        th.engage_range = ENGAGE_RANGE[gtype];
+        th.attack = CAP_TABLE[gtype][2];
+        th.defence = CAP_TABLE[gtype][3];
+        th.relative_detect_task = tid;
+        threats_all.push_back(th);
+        threats_groups[ng].push_back(th.id);
+      }
+    }
+    time_steps = 0;
+    agent_distances.assign(n_agents, 0.0);
+    total_distance = 0;
+    // static tasks known to everyone (:757-758)
+    known.assign(n_agents, std::vector<char>(tasks.size(), 1));
+    for (auto& k : known) k[0] = 0;
+    generate_observations();
+    did_reset = true;
+  }
+
+  void generate_observations() {  // only the part with side effects: last_tasks_info (:492)
+    last_tasks_info.clear();
+    for (size_t k = 1; k < tasks.size(); k++)
+      if (tasks[k].status != 2) last_tasks_info.push_back((int)k);
+  }
+
+  // ---- step (DroneEnv.py:774-1206) -----------------------------------------------------------
+  void releaseAllTasks(int for_task_type) {  // :1442-1480
+    int ft = for_task_type < 0 ? for_task_type + 6 : for_task_type;  // python negative index
+    bool available[7] = {false};
+    for (auto& a : agents) {
+      if (a.caps[ft] > 0) {
+        if (a.state != -1) {
+          if (!a.tasks.empty()) { a.re_eval = true; a.last_task = a.tasks[0]; }
+          uav_desallocateAll(a);
+          available[a.type] = true;
+        }
+      }
+    }
+    for (size_t k = 1; k < tasks.size(); k++) {
+      Task& t = tasks[k];
+      if (t.status != 2 && t.type == for_task_type) {
+        double cum_cap = 0;
+        for (int ty = 0; ty < 7; ty++) if (available[ty]) cum_cap += CAP_TABLE[ty][t.type];
+        if (cum_cap == 0) {
+          t.status = 2;
+          if (!t.reached) {
+            t.reached = true; n_reached++;
+            t.status = 2;
+            if (n_reached == n_tasks) conclusion_time = time_steps;
+          }
+        } else {
+          t.status = 0;
+          std::fill(t.bucket.begin(), t.bucket.end(), 0);
+        }
+      }
+    }
+  }
+
+  int count_unallocated() const {  // :1434-1440 (bucket 0 == idle is never filled)
+    int n = 1;
+    for (size_t k = 1; k < tasks.size(); k++) {
+      bool any = false;
+      for (char c : tasks[k].bucket) any |= (c != 0);
+      if (!any) n++;
+    }
+    return n;
+  }
+
+  double calculate_agent_expected_reward(const UAV& a) const {  // :1216-1229
+    double total;
+    if (a.tasks.size() >= 2) {
+      const Task& t = tasks[a.tasks[a.tasks.size() - 2]];
+      total = norm2(a.next_free_position.x - t.pos.x, a.next_free_position.y - t.pos.y);
+    } else {
+      total = norm2(a.next_free_position.x - a.pos.x, a.next_free_position.y - a.pos.y);
+    }
+    return -1.0 * total / max_coord;
+  }
+
+  void register_dynamic_task(Task& t) {  // :1491-1504
+    if (P.hard_windows && !t.has_deadline) {
+      t.has_deadline = true;
+      t.hard_deadline = time_steps + P.window_length;
+      n_windowed_tasks++;
+    }
+    if (P.threat_delay > 0 || P.sense_radius > 0) {
+      pending_reveals.push_back({time_steps + std::max(P.threat_delay, 0), t.id});
+    } else {
+      for (auto& k : known) k[t.id] = 1;
+    }
+  }
+
+  void wps_mark_window_outcome(Task& t, bool success) {  // :1543-1555
+    if (!t.has_deadline) return;
+    if (t.outcome_counted) return;
+    t.outcome_counted = true;
+    if (success && time_steps <= t.hard_deadline) { n_on_time++; F_Reward += P.on_time_bonus; }
+    else { n_missed_windows++; F_Reward -= P.miss_penalty; }
+  }
+
+  bool counts_for_mission_done(const Task& t) const {  // :1878-1886
+    if (t.id == 0) return true;
+    if (t.escort) return true;
+    if (t.type == MUAVTA_DET || t.type == MUAVTA_HOLD) return true;
+    return t.status == 2;
+  }
+  bool all_mission_done() const {
+    for (size_t k = 1; k < tasks.size(); k++) if (!counts_for_mission_done(tasks[k])) return false;
+    return true;
+  }
+
+  int escort_lookup(int recon_id) const {
+    for (auto& e : escort_by_recon) if (e.first == recon_id) return e.second;
+    return -1;
+  }
+  void escort_pop(int recon_id) {
+    for (size_t i = 0; i < escort_by_recon.size(); i++)
+      if (escort_by_recon[i].first == recon_id) { escort_by_recon.erase(escort_by_recon.begin() + i); return; }
+  }
+
+  int create_escort_for(int recon_id, int rec_task) {  // :1888-1917
+    if (!P.escort_enabled) return -1;
+    int ex = escort_lookup(recon_id);
+    if (ex >= 0) return ex;
+    UAV& r = agents[recon_id];
+    int tid = alloc_task_id();
+    Task e = make_task(tid, r.pos, MUAVTA_DEF);
+    set_req(e, MUAVTA_DEF, P.escort_requirement);
+    e.escort = true;
+    e.protected_agent = recon_id;
+    e.protected_task = rec_task;
+    e.has_eligible = true;
+    e.eligible_mask = P.escort_agent_type_mask;
+    e.required_agents = std::max(2, (int)std::ceil(P.escort_requirement));
+    e.created_at = time_steps;
+    push_task(std::move(e));
+    register_dynamic_task(tasks[tid]);
+    escort_by_recon.push_back({recon_id, tid});
+    escort_requests++;
+    event_list.push_back({MUAVTA_EV_ESCORT_CREATED, tid});
+    event_list.push_back({MUAVTA_EV_RESET_ALLOCATION, MUAVTA_DEF});
+    pending_reset = true;
+    return tid;
+  }
+  void release_escort_agents(int escort_id) {  // :1919-1936
+    for (auto& a : agents) {
+      if (a.state == -1) continue;
+      bool held = in_queue(a, escort_id);
+      if (held) uav_desAllocate(a, escort_id);
+      if (held) {
+        if (a.tasks.empty() || a.tasks[0] == 0) {
+          a.tasks.assign(1, 0);
+          a.state = 0;
+          a.commit_until = 0;
+          a.next_free_time = time_steps;
+          a.next_free_position = a.pos;
+        }
+      }
+    }
+  }
+  void retire_escort(int escort_id, bool failed) {  // :1938-1950
+    if (escort_id < 0 || tasks[escort_id].status == 2) return;
+    release_escort_agents(escort_id);
+    tasks[escort_id].status = 2;
+    int recon = tasks[escort_id].protected_agent;
+    if (recon >= 0) escort_pop(recon);
+    if (failed) escort_failed++; else escort_completed++;
+    event_list.push_back({MUAVTA_EV_ESCORT_RETIRED, escort_id});
+  }
+  void retire_escort_for(int recon_id, bool failed) {  // :1952-1957
+    int e = escort_lookup(recon_id);
+    if (e >= 0) retire_escort(e, failed);
+  }
+  void on_protected_rec_done(int recon_id, bool success) {  // :1959-1962
+    if (success) protected_rec_completed++;
+    retire_escort_for(recon_id, !success);
+  }
+  // :1746-1764 — fighters on the protected agent's escort task within radius, nearest first
+  std::vector<int> escort_fighters_near(int protected_id, double radius) const {
+    std::vector<int> out;
+    if (protected_id < 0) return out;
+    int e = escort_lookup(protected_id);
+    if (e < 0 || tasks[e].status == 2) return out;
+    std::vector<std::pair<double, int>> nearby;
+    const UAV& p = agents[protected_id];
+    for (auto& a : agents) {
+      if (a.state == -1 || !is_escort_type(a.type)) continue;
+      if (a.tasks.empty() || a.tasks[0] != e) continue;
+      double d = norm2(a.pos.x - p.pos.x, a.pos.y - p.pos.y);
+      if (d <= radius) nearby.push_back({d, a.id});
+    }
+    std::stable_sort(nearby.begin(), nearby.end(), [](const std::pair<double, int>& x, const std::pair<double, int>& y) { return x.first < y.first; });
+    for (auto& n : nearby) out.push_back(n.second);
+    return out;
+  }
+
+  int get_closest_agent(Vec pos) const {  // :1691-1723
+    double minF = std::numeric_limits<double>::infinity(), minW = minF;
+    int cF = -1, cW = -1;
+    for (auto& a : agents) {
+      if (a.state != -1 && a.state != 4) {
+        double d = norm2(a.pos.x - pos.x, a.pos.y - pos.y);
+        if (a.type == MUAVTA_F1 || a.type == MUAVTA_F2) { if (d < minF) { minF = d; cF = a.id; } }
+        else { if (d < minW) { minW = d; cW = a.id; } }
+      }
+    }
+    return cW >= 0 ? cW : cF;
+  }
+
+  void generate_threat() {  // :1601-1643
+    for (auto& group : threats_groups) {
+      if (!group.empty() && time_steps > 40 && time_steps % 10 == 0) {
+        if (rndAgent.random() < threat_generation_probability) {
+          int n_spawn = 1;
+          if (P.burst_mode) n_spawn = std::min(P.burst_size, (int)group.size());
+          for (int bi = 0; bi < n_spawn; bi++) {
+            if (group.empty()) break;
+            int hid = group.front();
+            group.erase(group.begin());
+            Threat& th = threats_all[hid];
+            if (P.dual_region_bursts) {
+              double mid = AREA_W * 0.5;
+              double wide = std::fmax(threat_wide, 40.0);
+              double x;
+              if ((burst_region_toggle + bi) % 2 == 0) x = rndAgent.uniform(wide, mid - wide);
+              else x = rndAgent.uniform(mid + wide, AREA_W - wide);
+              th.pos = Vec{x, th.pos.y};
+            }
+            th.target_agent = get_closest_agent(th.pos);
+            th.mission_target_agent = th.target_agent;
+            int tid = alloc_task_id();
+            // TaskFromThreat (:1861-1876)
+            Task t = make_task(tid, th.pos, MUAVTA_INT);
+            set_req(t, MUAVTA_INT, 2.0);
+            set_req(t, MUAVTA_ATT, th.defence * 2);
+            set_req(t, MUAVTA_DEF, th.attack * 2);
+            t.relative_threat = hid;
+            t.created_at = time_steps;
+            if (th.type == MUAVTA_T1) { t.required_agents = 2; t.has_eligible = true; t.eligible_mask = P.escort_agent_type_mask; }
+            push_task(std::move(t));
+            th.relative_task = tid;
+            threats.push_back(hid);
+            tasks[th.relative_detect_task].currentReqs[5] -= 1.0;
+            register_dynamic_task(tasks[tid]);
+            event_list.push_back({MUAVTA_EV_NEW_THREAT, tid});
+            event_list.push_back({MUAVTA_EV_RESET_ALLOCATION, MUAVTA_INT});
+            pending_reset = true;
+          }
+          if (P.dual_region_bursts && n_spawn > 0) burst_region_toggle = (burst_region_toggle + 1) % 2;
+        }
+      }
+    }
+  }
+
+  void retarget_threat_via_escort(Threat& th) {  // :1766-1779
+    int mission = th.mission_target_agent >= 0 ? th.mission_target_agent : th.target_agent;
+    if (mission < 0 || agents[mission].state == -1) return;
+    if (!is_recon(agents[mission].type)) return;
+    std::vector<int> escorts = escort_fighters_near(mission, P.escort_intercept_radius);
+    if (escorts.empty()) { th.target_agent = mission; th.intercepting_agent = -1; return; }
+    th.target_agent = escorts[0];
+    th.intercepting_agent = escorts[0];
+  }
+
+  void handle_threat_engagement(Threat& th) {  // :1781-1858
+    std::vector<int> defenders;
+    int primary = th.target_agent;
+    int mission = th.mission_target_agent >= 0 ? th.mission_target_agent : primary;
+    if (P.escort_enabled && mission >= 0 && is_recon(agents[mission].type)) {
+      defenders = escort_fighters_near(mission, P.mutual_support_radius);
+      if (!defenders.empty()) {
+        primary = defenders[0];
+        th.target_agent = primary;
+        th.intercepting_agent = primary;
+      }
+    }
+    if (primary < 0) return;
+    UAV& pa = agents[primary];
+    double attDiff, defDiff, engageDiff;
+    if (defenders.size() >= 2) {
+      mutual_support_engagements++;
+      double att_sum = 0, def_sum = 0, eng_sum = 0;
+      for (int d : defenders) att_sum += agents[d].caps[2];
+      for (int d : defenders) def_sum += agents[d].caps[3];
+      for (int d : defenders) eng_sum += agents[d].engage_range;
+      eng_sum = eng_sum / (double)defenders.size();
+      attDiff = att_sum / std::fmax(th.attack, 1e-6);
+      defDiff = def_sum / std::fmax(th.defence, 1e-6);
+      engageDiff = eng_sum / std::fmax(th.engage_range, 1e-6);
+    } else {
+      attDiff = pa.caps[2] / std::fmax(th.attack, 1e-6);
+      defDiff = pa.caps[3] / std::fmax(th.defence, 1e-6);
+      engageDiff = pa.engage_range / std::fmax(th.engage_range, 1e-6);
+    }
+    double avg_diff = (attDiff + defDiff + engageDiff) / 3;
+    double neutralize_prob = avg_diff / (avg_diff + 1);
+    double rnd = rndAgent.random();
+    Task& rt = tasks[th.relative_task];
+    if (rnd < neutralize_prob) {
+      th.status = 2;
+      rt.status = 2;
+      wps_mark_window_outcome(rt, true);
+      threats_intercepted++;
+      pa.attackCap -= 1;
+      if (pa.attackCap <= 0) pa.caps[3] = 0;
+      if (!pa.tasks.empty() && pa.tasks[0] == th.relative_task) uav_taskDone(pa, th.relative_task);
+      step_reward += 1.0;
+    } else {
+      th.attackCap -= 1;
+      pa.attackCap -= 1;
+      if (pa.attackCap <= 0) {
+        pa.caps[3] = 0;
+        bool was_recon = is_recon(pa.type);
+        bool was_escort = is_escort_type(pa.type);
+        uav_outOfService(pa);
+        if (was_recon) { recon_losses++; protection_breaches++; retire_escort_for(primary, true); }
+        else if (was_escort) escort_losses++;
+        step_reward -= 1.0;
+      }
+      if (th.attackCap <= 0) {
+        th.status = 0;
+        rt.status = 2;
+        wps_mark_window_outcome(rt, false);
+      } else {
+        th.target_agent = get_closest_agent(th.pos);
+        th.mission_target_agent = th.target_agent;
+      }
+    }
+  }
+
+  void update_threats() {  // :1725-1744
+    std::vector<int> live;
+    for (int hid : threats) if (threats_all[hid].status != 2) live.push_back(hid);
+    for (int hid : live) {
+      Threat& th = threats_all[hid];
+      if (th.status == 0 || th.target_agent < 0) {
+        th.pos = Vec{th.pos.x + th.max_speed * 0.0, th.pos.y + th.max_speed * -1.0};
+      } else {
+        if (P.escort_enabled) retarget_threat_via_escort(th);
+        const UAV& tg = agents[th.target_agent];
+        Vec d = norm_vector(Vec{tg.pos.x - th.pos.x, tg.pos.y - th.pos.y});
+        th.pos = Vec{th.pos.x + th.max_speed * d.x, th.pos.y + th.max_speed * d.y};
+        const UAV& tg2 = agents[th.target_agent];
+        if (norm2(tg2.pos.x - th.pos.x, tg2.pos.y - th.pos.y) < th.engage_range) handle_threat_engagement(th);
+      }
+      Task& rt = tasks[th.relative_task];
+      rt.pos = th.pos;
+      if (th.pos.y <= 0) {
+        rt.status = 2;
+        wps_mark_window_outcome(rt, false);
+      }
+    }
+  }
+
+  void inject_dynamic_arrivals() {  // :1646-1689
+    if (P.arrival_rate <= 0 || time_steps < 5) return;
+    if (rndTgt.random() >= P.arrival_rate) return;
+    if ((int)tasks.size() - 1 >= max_tasks - 1) return;
+    int type = rndTgt.randbelow(2) == 0 ? MUAVTA_ATT : MUAVTA_REC;
+    int tid = alloc_task_id();
+    const Area* sel = mission_areas.empty() ? nullptr : &mission_areas[rndMission.randbelow(mission_areas.size())];
+    Vec p;
+    if (P.dual_region_bursts) {
+      double mid = AREA_W * 0.5, wide = 40.0, x;
+      if (rndTgt.random() < 0.5) x = rndTgt.uniform(wide, mid - wide);
+      else x = rndTgt.uniform(mid + wide, AREA_W - wide);
+      double y = rndTgt.uniform(AREA_H * 0.2, AREA_H * 0.8);
+      p = Vec{x, y};
+    } else {
+      p = random_position(rndTgt, 20, 3, true, sel, true);
+    }
+    Task t = make_task(tid, p, type);
+    set_req(t, type, 1.0);
+    t.created_at = time_steps;
+    push_task(std::move(t));
+    n_arrivals++;
+    register_dynamic_task(tasks[tid]);
+    event_list.push_back({MUAVTA_EV_NEW_THREAT, tid});
+    event_list.push_back({MUAVTA_EV_RESET_ALLOCATION, type});
+    pending_reset = true;
+  }
+
+  void sync_escorts() {  // :1964-2000
+    for (auto& a : agents) {
+      if (a.state == -1 || !is_recon(a.type)) continue;
+      if (a.tasks.empty() || a.tasks[0] == 0) continue;
+      Task& cur = tasks[a.tasks[0]];
+      if (cur.type == MUAVTA_REC && cur.status != 2 && escort_lookup(a.id) < 0) create_escort_for(a.id, cur.id);
+    }
+    std::vector<std::pair<int, int>> items = escort_by_recon;
+    for (auto& it : items) {
+      int eid = it.second;
+      Task& e = tasks[eid];
+      int recon = e.protected_agent;
+      int rec_task = e.protected_task;
+      bool dead = recon < 0 || agents[recon].state == -1;
+      bool idle = recon >= 0 && (agents[recon].tasks.empty() || agents[recon].tasks[0] == 0 ||
+                                 agents[recon].state == 0 || agents[recon].state == 3);
+      bool rec_done = rec_task >= 0 && tasks[rec_task].status == 2;
+      bool wrong_task = recon >= 0 && !agents[recon].tasks.empty() && agents[recon].tasks[0] != 0 &&
+                        (rec_task < 0 || agents[recon].tasks[0] != rec_task);
+      if (dead || idle || rec_done || wrong_task) { retire_escort(eid, dead); continue; }
+      tasks[eid].pos = agents[recon].pos;
+      escort_required_steps++;
+      if (!escort_fighters_near(recon, P.escort_radius).empty()) escort_covered_steps++;
+    }
+  }
+
+  void wps_update_sensing() {  // :1506-1523
+    if (P.sense_radius <= 0) return;
+    for (auto& a : agents) {
+      if (a.state == -1) continue;
+      for (size_t k = 1; k < tasks.size(); k++) {
+        Task& t = tasks[k];
+        if (t.status == 2) continue;
+        if (known[a.id][k]) continue;
+        if (t.created_at <= 0 && !t.has_deadline) continue;
+        double d = norm2(a.pos.x - t.pos.x, a.pos.y - t.pos.y);
+        if (d <= P.sense_radius) known[a.id][k] = 1;
+      }
+    }
+  }
+  void wps_process_reveals() {  // :1525-1541
+    if (pending_reveals.empty()) return;
+    std::vector<std::pair<int, int>> remaining;
+    for (auto& pr : pending_reveals) {
+      if (time_steps >= pr.first) {
+        if (P.share_knowledge) for (auto& k : known) k[pr.second] = 1;
+      } else {
+        remaining.push_back(pr);
+      }
+    }
+    pending_reveals.swap(remaining);
+  }
+  void wps_expire_windows() {  // :1557-1573
+    if (!P.hard_windows) return;
+    for (size_t k = 1; k < tasks.size(); k++) {
+      Task& t = tasks[k];
+      if (!t.has_deadline || t.status == 2) continue;
+      if (time_steps > t.hard_deadline) {
+        t.status = 2;
+        t.final_quality = 0.0;
+        wps_mark_window_outcome(t, false);
+        if (!t.reached) { t.reached = true; n_reached++; }
+        for (auto& a : agents)
+          if (!a.tasks.empty() && a.tasks[0] == t.id) uav_desallocateAll(a);
+      }
+    }
+  }
+  void wps_track_reserve() {  // :1575-1580
+    int live = 0, idle = 0;
+    for (auto& a : agents) if (a.state != -1) { live++; if (a.tasks.empty() || a.tasks[0] == 0) idle++; }
+    if (!live) return;
+    idle_reserve_steps += idle;
+  }
+
+  static double np_sum(const std::vector<double>& d) {  // numpy pairwise_sum for n <= 128
+    size_t n = d.size();
+    if (n < 8) { double r = 0.; for (size_t i = 0; i < n; i++) r += d[i]; return r; }
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = d[k];
+    size_t i;
+    for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; k++) r[k] += d[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; i++) res += d[i];
+    return res;
+  }
+
+  int step(int n_act, const int32_t* act_agent, const int32_t* act_index) {
+    double action_reward = 0, distance_reward = 0, quality_reward = 0, S_quality_reward = 0, time_reward = 0;
+    step_reward = 0;
+    time_steps += 1;                                                                    // :796
+    std::vector<Vec> prev(n_agents);
+    for (int i = 0; i < n_agents; i++) prev[i] = agents[i].pos;
+    done_events.clear();                                                                // :800-805
+    while (!event_list.empty()) {
+      Event ev = event_list.front();
+      event_list.erase(event_list.begin());
+      done_events.push_back(ev);
+      if (ev.tag == MUAVTA_EV_RESET_ALLOCATION) releaseAllTasks(ev.arg);
+    }
+    // ---- task allocation (:813-933) ----
+    for (int k = 0; k < n_act; k++) {
+      if (act_agent[k] < 0) break;
+      UAV& agent = agents[act_agent[k]];
+      if (agent.state == -1) continue;
+      int idx = act_index[k];
+      if (idx < 0) idx += (int)last_tasks_info.size();  // python negative indexing
+      if (idx < 0 || idx >= (int)last_tasks_info.size()) { action_reward += -1; continue; }
+      Task& task = tasks[last_tasks_info[idx]];
+      if (!agent.tasks.empty()) {
+        Task& head = tasks[agent.tasks[0]];
+        if (head.id != task.id) {
+          if (head.id != 0) {
+            S_quality_reward -= 0.1;
+            S_quality_reward -= agent.caps[head.type];
+            n_reallocations += 1;
+            if (task.id != 0) { n_task_switches += 1; agent.commit_until = 0; }
+            double dist_old = norm2(agent.pos.x - head.pos.x, agent.pos.y - head.pos.y);
+            double dist_new = norm2(agent.pos.x - task.pos.x, agent.pos.y - task.pos.y);
+            distance_reward += (dist_old - dist_new) / max_coord;
+          } else {
+            S_quality_reward += 0.05;
+            if (pending_reset && P.dynamic_idle_penalty != 0) S_quality_reward -= P.dynamic_idle_penalty;
+          }
+        } else {
+          if (head.id != 0) S_quality_reward += 0.05; else S_quality_reward -= 0.50;
+          continue;
+        }
+      }
+      if (!P.multiple_tasks_per_agent) {  // EnvUtils.desallocateAll([agent], env) (MultiDroneEnvUtils.py:183-205)
+        std::vector<int> snapshot = agent.tasks;
+        for (int tid : snapshot)
+          if (uav_desAllocate(agent, tid)) tasks[tid].bucket[agent.id] = 0;
+        agent.tasks.assign(1, 0);
+        agent.next_free_time = time_steps;
+        agent.next_free_position = agent.pos;
+      }
+      if (!is_task_action_valid(agent, task)) { action_reward += -1; continue; }
+      if (uav_allocate(agent, task.id, time_steps)) {
+        task.bucket[agent.id] = 1;
+        double agentCap = agent.caps[task.type];
+        double missingCapBefore = task.currentReqs[task.type] - (task.allocatedReqs[task.type] - agentCap);
+        missingCapBefore = missingCapBefore > 0 ? missingCapBefore : 0;
+        double addedCap = missingCapBefore - std::fmax(missingCapBefore - agentCap, 0.0);
+        if (addedCap <= 0) S_quality_reward -= 1.5;
+        S_quality_reward += addedCap;
+        task.status = 1;
+        distance_reward += calculate_agent_expected_reward(agent);
+        if (agent.state != 1 && agent.state != -1) agent.state = 1;
+        if (P.escort_enabled && task.type == MUAVTA_REC && is_recon(agent.type) && escort_lookup(agent.id) < 0)
+          create_escort_for(agent.id, task.id);
+      }
+    }
+    // ---- movement state machine (:965-1129) ----
+    const Vec base{BASE_X, BASE_Y};
+    for (int i = 0; i < n_agents; i++) {
+      UAV& agent = agents[i];
+      if (agent.state == -1) continue;
+      if (agent.fail_event == time_steps) {
+        agent.state = -1;
+        uav_desallocateAll(agent);
+        event_list.push_back({MUAVTA_EV_RESET_ALLOCATION, -1});
+        event_list.push_back({MUAVTA_EV_AGENT_FAIL, agent.id});
+        pending_reset = true;
+        continue;
+      }
+      Vec movement{0, 0}, avoid{0, 0};
+      if (agent.state == 0 && !agent.re_eval) {
+        bool idle_task = agent.tasks.empty() || agent.tasks[0] == 0;
+        if (idle_task && norm2(agent.pos.x - base.x, agent.pos.y - base.y) > agent.max_speed + 5) agent.state = 3;
+      }
+      if (!agent.tasks.empty() || agent.re_eval) {
+        int cur_id = agent.re_eval ? agent.last_task : agent.tasks[0];
+        Task& cur = tasks[cur_id];
+        if (cur.status == 2) {
+          uav_desAllocate(agent, cur_id);
+          agent.re_eval = false;
+          agent.last_task = -1;
+        } else if (cur.id != 0) {
+          if (agent.state == 1) {
+            double dx = cur.pos.x - agent.pos.x, dy = cur.pos.y - agent.pos.y;
+            double distance_task = norm2(dx, dy);
+            Vec dir_norm{0, 0};
+            if (!(std::fabs(distance_task) < EPS)) dir_norm = Vec{dx / distance_task, dy / distance_task};
+            if (cur.type == MUAVTA_INT) {
+              if (distance_task < agent.engage_range) {
+                agent.state = 2;
+                threats_all[cur.relative_threat].target_agent = agent.id;
+                agent.task_start = time_steps;
+              } else {
+                movement = dir_norm;
+                avoid = avoid_obstacles(agent.pos, movement);
+              }
+            } else if (distance_task < agent.max_speed) {
+              agent.state = 2;
+              agent.task_start = time_steps;
+              agent.pos = cur.pos;
+            } else {
+              movement = dir_norm;
+              avoid = avoid_obstacles(agent.pos, movement);
+            }
+          } else if (agent.state == 2) {
+            if (cur.type == MUAVTA_INT) {
+              double d = norm2(cur.pos.x - agent.pos.x, cur.pos.y - agent.pos.y);
+              if (d >= agent.engage_range) agent.state = 1;
+            }
+            if (agent.task_start == -1) {
+              agent.task_start = time_steps;
+              agent.pos = cur.pos;
+            } else {
+              if ((time_steps - agent.task_start) >= cur.task_duration && cur.id != 0 && cur.type != MUAVTA_HOLD &&
+                  cur.type != MUAVTA_DEF && cur.type != MUAVTA_INT && cur.type != MUAVTA_DET && cur.status != 2) {
+                Task& task = cur;
+                uav_taskDone(agent, task.id);
+                for (int c = 0; c < 6; c++) task.doneReqs[c] += agent.caps[c];
+                for (int c = 0; c < 6; c++) task.currentReqs[c] -= agent.caps[c];
+                removeAgentCap(task, agent);
+                if (task.doneReqs[task.type] >= task.orgReqs[task.type]) {
+                  if (!task.escort && !task.reached) { task.reached = true; n_reached++; }
+                  if (task.status != 2) {
+                    quality_reward += task.orgReqs[task.type] * 2;
+                    F_Reward += task.orgReqs[task.type] * 1 / reward_norm_factor;
+                    if (!task.escort) wps_mark_window_outcome(task, true);
+                    task.status = 2;
+                    if (task.type == MUAVTA_REC && is_recon(agent.type)) on_protected_rec_done(agent.id, true);
+                    if (all_mission_done()) conclusion_time = time_steps;
+                  }
+                } else {
+                  quality_reward += agent.caps[task.type];
+                }
+              } else {
+                movement = Vec{0, 0};  // UAV.doTask
+              }
+            }
+          }
+        }
+      }
+      if (agent.state == 3) {
+        if (norm2(agent.pos.x - base.x, agent.pos.y - base.y) < agent.max_speed + 5) {
+          agent.state = 0;
+        } else {
+          movement = norm_vector(Vec{base.x - agent.pos.x, base.y - agent.pos.y});
+          avoid = avoid_obstacles(agent.pos, movement);
+        }
+      }
+      Vec mv = norm_vector(Vec{movement.x + avoid.x, movement.y + avoid.y});
+      mv = Vec{mv.x * agent.max_speed, mv.y * agent.max_speed};
+      agent.pos = Vec{agent.pos.x + mv.x, agent.pos.y + mv.y};
+      agent.pos.x = std::fmin(std::fmax(agent.pos.x, 0.0), AREA_W);
+      agent.pos.y = std::fmin(std::fmax(agent.pos.y, 0.0), AREA_H);
+    }
+    // ---- distances (:1131-1138): norm(axis=1) is plain sqrt(x*x+y*y) ----
+    std::vector<double> dists(n_agents);
+    for (int i = 0; i < n_agents; i++) {
+      double dx = agents[i].pos.x - prev[i].x, dy = agents[i].pos.y - prev[i].y;
+      dists[i] = std::sqrt(dx * dx + dy * dy);
+      agent_distances[i] += dists[i];
+    }
+    total_distance += np_sum(dists);
+    double time_penaulty = -(double)(n_tasks - n_reached) / n_tasks * ((double)time_steps / P.max_time_steps);
+    double alloc_reward = 0;
+    if (time_steps > n_tasks + 1) alloc_reward = -(double)count_unallocated();
+    generate_threat();
+    update_threats();
+    inject_dynamic_arrivals();
+    if (P.escort_enabled) sync_escorts();
+    wps_update_sensing();
+    wps_process_reveals();
+    wps_expire_windows();
+    wps_track_reserve();
+    if (pending_reset) {
+      for (auto& a : agents)
+        if (a.state != -1 && !a.tasks.empty() && a.tasks[0] != 0) { pending_reset = false; break; }
+    }
+    const double* rw = P.reward_weights;
+    double total = rw[0] * action_reward + rw[1] * distance_reward + rw[2] * quality_reward + rw[3] * S_quality_reward +
+                   rw[4] * n_tasks * time_reward + rw[5] * alloc_reward + rw[6] * time_penaulty + rw[7] * step_reward;
+    last_reward = total / reward_norm_factor / P.max_time_steps;
+    bool all_done = tasks.size() > 1 && all_mission_done();
+    bool timed_out = (time_steps >= P.max_time_steps) && (P.max_time_steps > 0);
+    bool done = timed_out || (P.early_terminate && all_done);
+    if (all_done && conclusion_time > P.max_time_steps) conclusion_time = time_steps;
+    terminated = P.early_terminate && all_done && !timed_out;
+    truncated = timed_out;
+    generate_observations();
+    if (done) last_reward = F_Reward;
+    return done ? 1 : 0;
+  }
+
+  void metrics(double* m) const {  // calculate_metrics (:1231-1319)
+    double F_quality = tasks.size() > 1 ? 0.0 : std::nan("");
+    double F_Time = 1.0 / conclusion_time * P.max_time_steps;
+    double F_distance = total_distance > 0 ? 1 / total_distance * max_coord : 0;
+    int Losses = 0, Kills = 0;
+    for (auto& a : agents) Losses += (a.state == -1);
+    for (int hid : threats) Kills += (threats_all[hid].status == 2);
+    double dist_term = 0.01 * total_distance / std::fmax(max_coord, 1.0);
+    double rematch = P.reassign_penalty * (double)n_task_switches;
+    double s_wps = 12.0 * (double)n_on_time - 30.0 * (double)n_missed_windows - dist_term - rematch;
+    double escort_cov = (double)escort_covered_steps / std::max(escort_required_steps, 1);
+    double s_esc = s_wps + 20.0 * (double)protected_rec_completed - 30.0 * (double)recon_losses + 20.0 * escort_cov;
+    int k = 0;
+    m[k++] = F_Time; m[k++] = F_distance; m[k++] = F_quality; m[k++] = F_Reward; m[k++] = s_wps; m[k++] = s_esc;
+    m[k++] = Losses; m[k++] = Kills; m[k++] = conclusion_time; m[k++] = total_distance; m[k++] = n_reallocations;
+    m[k++] = n_task_switches; m[k++] = n_arrivals; m[k++] = (double)tasks.size() - 1; m[k++] = n_reached;
+    m[k++] = n_missed_windows; m[k++] = n_on_time; m[k++] = n_windowed_tasks;
+    m[k++] = (double)n_on_time / std::max(n_on_time + n_missed_windows, 1);
+    m[k++] = (double)idle_reserve_steps / std::max(time_steps * std::max(n_agents, 1), 1);
+    m[k++] = escort_cov; m[k++] = protected_rec_completed; m[k++] = recon_losses; m[k++] = escort_losses;
+    m[k++] = threats_intercepted; m[k++] = mutual_support_engagements; m[k++] = protection_breaches;
+    m[k++] = escort_requests; m[k++] = escort_completed; m[k++] = escort_failed;
+  }
+
+  // ---- HungarianAllocator.allocate_tasks (HungarianAllocator.py:72-208) + harness glue -------
+  static bool is_escort_task(const Task& t) { return t.escort || (double)t.required_agents > 0; }
+  static double residual_demand(const Task& t) {
+    if (is_escort_task(t)) {
+      double required = t.required_agents ? (double)t.required_agents : 1.0;
+      double allocated = (double)t.allocationDetails.size();
+      return std::fmax(required - allocated, 0.0);
+    }
+    return std::fmax(t.currentReqs[t.type] - t.allocatedReqs[t.type], 0.0);
+  }
+  bool should_replan(const std::vector<Event>& events, int interval) const {  // :27-41
+    if ((long long)time_steps - last_plan_step >= interval) return true;
+    return !events.empty();  // every tag the env emits is in the allocator's trigger set
+  }
+  // returns number of (agent, task) actions; also fills act_agent/act_index as _apply_assign would
+  int allocate(int interval, int use_visibility, int32_t* act_agent, int32_t* act_index, int cap) {
+    n_calls++;
+    last_actions.clear();
+    lsap_costs.clear(); lsap_shapes.clear(); lsap_rows.clear(); lsap_cols.clear();
+    interval = std::max(1, interval);
+    int n_out = 0;
+    auto finish = [&]() { if (n_out < cap && act_agent) act_agent[n_out] = -1; return n_out; };
+    if (!should_replan(done_events, interval)) return finish();
+    std::vector<int> live;  // env.get_live_agents()
+    for (auto& a : agents) if (a.state != -1) live.push_back(a.id);
+    std::vector<int> open_tasks;  // _open_tasks(env) filtered again by allocate_tasks (same predicate)
+    for (size_t k = 1; k < tasks.size(); k++)
+      if (tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_tasks.push_back((int)k);
+    if (live.empty() || open_tasks.empty()) return finish();
+    bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
+    std::vector<double> residuals(tasks.size(), 0.0);
+    for (int t : open_tasks) residuals[t] = residual_demand(tasks[t]);
+    std::vector<int> free_agents = live;
+    std::vector<std::pair<int, int>> actions;
+    while (!free_agents.empty()) {
+      std::vector<int> round_tasks;
+      for (int t : open_tasks) if (residuals[t] > 1e-9) round_tasks.push_back(t);
+      if (round_tasks.empty()) break;
+      int nr = (int)free_agents.size(), nc = (int)round_tasks.size();
+      std::vector<double> cost((size_t)nr * nc, 1e6);
+      for (int i = 0; i < nr; i++) {
+        const UAV& a = agents[free_agents[i]];
+        for (int j = 0; j < nc; j++) {
+          const Task& t = tasks[round_tasks[j]];
+          if (vis && !known[a.id][t.id]) continue;
+          if (t.has_eligible && !((t.eligible_mask >> a.type) & 1u)) continue;
+          double urgency = 0.0;
+          if (t.has_deadline) {
+            int remaining = std::max(t.hard_deadline - time_steps, 0);
+            urgency = 1.0 - std::fmin(remaining / 40.0, 1.0);
+          }
+          double delivered = is_escort_task(t) ? 1.0 : a.caps[t.type];
+          double base_cost;
+          if (delivered <= 0) {
+            base_cost = 1e6;
+          } else {
+            double dist = norm2(a.pos.x - t.pos.x, a.pos.y - t.pos.y);
+            double missing = std::fmax(residuals[t.id], 1e-6);
+            base_cost = dist / std::fmax(max_coord, 1.0) - 0.5 * std::fmin(delivered, missing) - 0.4 * 0.0 - 0.6 * urgency;
+          }
+          if (base_cost < 1e5 / 2) cost[(size_t)i * nc + j] = base_cost - 0.0;
+        }
+      }
+      int m = std::min(nr, nc);
+      std::vector<int64_t> row(m), col(m);
+      lsap_solve(cost.data(), nr, nc, row.data(), col.data());
+      lsap_shapes.push_back(nr); lsap_shapes.push_back(nc);
+      lsap_costs.insert(lsap_costs.end(), cost.begin(), cost.end());
+      lsap_rows.insert(lsap_rows.end(), row.begin(), row.end());
+      lsap_cols.insert(lsap_cols.end(), col.begin(), col.end());
+      std::vector<int> accepted;
+      for (int k = 0; k < m; k++) {
+        if (cost[(size_t)row[k] * nc + col[k]] >= 1e5 / 2) continue;
+        int aid = free_agents[row[k]], tid = round_tasks[col[k]];
+        const Task& t = tasks[tid];
+        double delivered = is_escort_task(t) ? 1.0 : agents[aid].caps[t.type];
+        actions.push_back({aid, tid});
+        residuals[tid] = std::fmax(residuals[tid] - delivered, 0.0);
+        accepted.push_back(aid);
+      }
+      if (accepted.empty()) break;
+      std::vector<int> nf;
+      for (int a : free_agents) if (std::find(accepted.begin(), accepted.end(), a) == accepted.end()) nf.push_back(a);
+      free_agents.swap(nf);
+    }
+    last_plan_step = time_steps;
+    n_replans++;
+    // _apply_assign (experiments/wps_eval.py:55-61): first assignment per agent wins
+    std::vector<char> seen(n_agents, 0);
+    for (auto& pr : actions) {
+      auto it = std::find(last_tasks_info.begin(), last_tasks_info.end(), pr.second);
+      if (it == last_tasks_info.end()) continue;
+      if (seen[pr.first]) continue;
+      seen[pr.first] = 1;
+      last_actions.push_back(pr);
+      if (n_out < cap && act_agent) { act_agent[n_out] = pr.first; act_index[n_out] = (int)(it - last_tasks_info.begin()); }
+      n_out++;
+    }
+    return finish();
+  }
+};
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C surface (ctypes) — test infrastructure
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+void* orc_create(const MuavtaParams* p) { return new Env(*p); }
+void orc_destroy(void* h) { delete (Env*)h; }
+void orc_reset(void* h, uint64_t seed) { ((Env*)h)->reset(seed); }
+int orc_step(void* h, int n_act, const int32_t* act_agent, const int32_t* act_index) {
+  return ((Env*)h)->step(n_act, act_agent, act_index);
+}
+int orc_allocate(void* h, int interval, int use_vis, int32_t* act_agent, int32_t* act_index, int cap) {
+  return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap);
+}
+// reset(seed) + n_steps x (allocate -> step); returns steps executed
+int orc_rollout(void* h, uint64_t seed, int do_reset, int n_steps, int interval, int use_vis) {
+  Env* e = (Env*)h;
+  if (do_reset) e->reset(seed);
+  std::vector<int32_t> aa(e->n_agents + 1), ai(e->n_agents + 1);
+  int s = 0;
+  for (; s < n_steps; s++) {
+    int n = e->allocate(interval, use_vis, aa.data(), ai.data(), e->n_agents);
+    if (e->step(n, aa.data(), ai.data())) { s++; break; }
+  }
+  return s;
+}
+void orc_metrics(void* h, double* out) { ((Env*)h)->metrics(out); }
+int orc_lsap(const double* cost, int nr, int nc, int64_t* row, int64_t* col) { return lsap_solve(cost, nr, nc, row, col); }
+
+void orc_dims(void* h, int32_t* out) {
+  Env* e = (Env*)h;
+  out[0] = e->n_agents; out[1] = (int)e->tasks.size(); out[2] = (int)e->threats_all.size(); out[3] = e->max_tasks;
+  out[4] = (int)e->last_tasks_info.size(); out[5] = (int)e->done_events.size(); out[6] = (int)e->last_actions.size();
+  out[7] = (int)e->lsap_shapes.size() / 2; out[8] = e->n_replans; out[9] = e->time_steps;
+  out[10] = (int)e->pending_reveals.size(); out[11] = e->n_reached; out[12] = e->pending_reset;
+  out[13] = e->terminated; out[14] = e->truncated;
+  size_t q = 0;
+  for (auto& a : e->agents) q = std::max(q, a.tasks.size());
+  out[15] = (int)q;
+}
+// agents: f64 [A, 16]: x, y, state, head, qlen, nft, nfpx, nfpy, attackCap, task_start, re_eval, last_task, type, name_idx, fail_event, dist ; caps [A,6]; queue [A,Q]
+void orc_get_agents(void* h, double* rows, double* caps, int32_t* queue, int qcap) {
+  Env* e = (Env*)h;
+  for (auto& a : e->agents) {
+    double* r = rows + (size_t)a.id * 16;
+    r[0] = a.pos.x; r[1] = a.pos.y; r[2] = a.state; r[3] = a.tasks.empty() ? -1 : a.tasks[0]; r[4] = (double)a.tasks.size();
+    r[5] = a.next_free_time; r[6] = a.next_free_position.x; r[7] = a.next_free_position.y; r[8] = a.attackCap;
+    r[9] = a.task_start; r[10] = a.re_eval; r[11] = a.last_task; r[12] = a.type; r[13] = a.name_idx; r[14] = a.fail_event;
+    r[15] = e->agent_distances[a.id];
+    for (int c = 0; c < 6; c++) caps[(size_t)a.id * 6 + c] = a.caps[c];
+    for (int k = 0; k < qcap; k++) queue[(size_t)a.id * qcap + k] = k < (int)a.tasks.size() ? a.tasks[k] : -1;
+  }
+}
+// tasks by id (row 0 = idle): f64 [NT, 14]: status, x, y, initTime, doneTime, n_details, type, deadline(-1), created_at, required, escort, protected_agent, eligible_mask(-1 none), reached ; reqs [NT, 3, 6] cur/alloc/done
+void orc_get_tasks(void* h, double* rows, double* reqs) {
+  Env* e = (Env*)h;
+  for (size_t k = 0; k < e->tasks.size(); k++) {
+    const Task& t = e->tasks[k];
+    double* r = rows + k * 14;
+    r[0] = t.status; r[1] = t.pos.x; r[2] = t.pos.y; r[3] = t.initTime; r[4] = t.doneTime; r[5] = (double)t.allocationDetails.size();
+    r[6] = t.type; r[7] = t.has_deadline ? t.hard_deadline : -1; r[8] = t.created_at; r[9] = t.required_agents; r[10] = t.escort;
+    r[11] = t.protected_agent; r[12] = t.has_eligible ? (double)t.eligible_mask : -1; r[13] = t.reached;
+    for (int c = 0; c < 6; c++) { reqs[k * 18 + c] = t.currentReqs[c]; reqs[k * 18 + 6 + c] = t.allocatedReqs[c]; reqs[k * 18 + 12 + c] = t.doneReqs[c]; }
+  }
+}
+void orc_get_known(void* h, uint8_t* out) {  // [A, NT]
+  Env* e = (Env*)h;
+  size_t nt = e->tasks.size();
+  for (int a = 0; a < e->n_agents; a++) for (size_t k = 0; k < nt; k++) out[a * nt + k] = e->known[a][k];
+}
+// threats by id: f64 [H, 8]: status(-9 not spawned), x, y, target, mission target, attackCap, task id, type
+void orc_get_threats(void* h, double* rows) {
+  Env* e = (Env*)h;
+  for (auto& th : e->threats_all) {
+    double* r = rows + (size_t)th.id * 8;
+    bool active = std::find(e->threats.begin(), e->threats.end(), th.id) != e->threats.end();
+    r[0] = active ? th.status : -9; r[1] = th.pos.x; r[2] = th.pos.y; r[3] = th.target_agent; r[4] = th.mission_target_agent;
+    r[5] = th.attackCap; r[6] = th.relative_task; r[7] = th.type;
+  }
+}
+void orc_get_scalars(void* h, double* s) {  // MUAVTA_S_* order
+  Env* e = (Env*)h;
+  s[0] = e->time_steps; s[1] = e->last_reward; s[2] = e->F_Reward; s[3] = e->total_distance; s[4] = e->n_on_time;
+  s[5] = e->n_missed_windows; s[6] = e->n_windowed_tasks; s[7] = e->n_task_switches; s[8] = e->n_reallocations;
+  s[9] = e->n_arrivals; s[10] = e->idle_reserve_steps; s[11] = e->conclusion_time; s[12] = e->escort_requests;
+  s[13] = e->escort_completed; s[14] = e->escort_failed; s[15] = e->escort_required_steps; s[16] = e->escort_covered_steps;
+  s[17] = e->protection_breaches; s[18] = e->threats_intercepted; s[19] = e->recon_losses; s[20] = e->escort_losses;
+  s[21] = e->mutual_support_engagements; s[22] = e->protected_rec_completed; s[23] = e->n_replans;
+}
+void orc_get_open(void* h, int32_t* ids) { Env* e = (Env*)h; for (size_t i = 0; i < e->last_tasks_info.size(); i++) ids[i] = e->last_tasks_info[i]; }
+void orc_get_events(void* h, int32_t* ev) { Env* e = (Env*)h; for (size_t i = 0; i < e->done_events.size(); i++) { ev[2 * i] = e->done_events[i].tag; ev[2 * i + 1] = e->done_events[i].arg; } }
+void orc_get_actions(void* h, int32_t* out) { Env* e = (Env*)h; for (size_t i = 0; i < e->last_actions.size(); i++) { out[2 * i] = e->last_actions[i].first; out[2 * i + 1] = e->last_actions[i].second; } }
+int64_t orc_get_lsap(void* h, int32_t* shapes, double* costs, int64_t* rows, int64_t* cols) {
+  Env* e = (Env*)h;
+  if (shapes) std::copy(e->lsap_shapes.begin(), e->lsap_shapes.end(), shapes);
+  if (costs) std::copy(e->lsap_costs.begin(), e->lsap_costs.end(), costs);
+  if (rows) std::copy(e->lsap_rows.begin(), e->lsap_rows.end(), rows);
+  if (cols) std::copy(e->lsap_cols.begin(), e->lsap_cols.end(), cols);
+  return (int64_t)e->lsap_costs.size();
+}
+// Observation tensors in muavta_observe's layout (DroneEnv.py:365-415,468-492)
+void orc_observe(void* h, float* tinfo, uint8_t* legal, uint8_t* pad, float* ag, float* flags) {
+  Env* e = (Env*)h;
+  int T = e->max_tasks, A = e->n_agents;
+  std::vector<int> open;
+  for (size_t k = 1; k < e->tasks.size(); k++) if (e->tasks[k].status != 2) open.push_back((int)k);
+  int n = (int)open.size();
+  double mts = (double)std::max(e->P.max_time_steps, 1);
+  auto write_row = [&](int j, const Task& t, bool extras) {
+    float* r = tinfo + (size_t)j * 21;
+    r[0] = (float)t.id; r[1] = (float)(t.pos.x / e->max_coord); r[2] = (float)(t.pos.y / e->max_coord); r[3] = (float)t.status;
+    for (int c = 0; c < 6; c++) { r[4 + c] = (float)t.currentReqs[c]; r[10 + c] = (float)t.allocatedReqs[c]; }
+    for (int c = 16; c < 21; c++) r[c] = 0.f;
+    if (!extras) return;
+    if (e->P.include_time_windows) {
+      r[16] = (float)((t.initTime - e->time_steps) / mts);
+      r[17] = (float)((t.doneTime - e->time_steps) / mts);
+      r[18] = (float)((double)t.type / 6.0);
+    }
+    double unmet = std::fmax(t.currentReqs[t.type] - t.allocatedReqs[t.type], 0.0);
+    r[19] = (float)(unmet / std::fmax(t.orgReqs[t.type], 1e-6));
+    r[20] = (float)std::fmin((e->time_steps - (double)t.created_at) / mts, 1.0);
+  };
+  if (tinfo) {
+    std::fill(tinfo, tinfo + (size_t)T * 21, 0.f);
+    for (int j = 0; j < T; j++) tinfo[(size_t)j * 21 + 3] = -1.f;
+    if (n == 0) write_row(0, e->tasks[0], false);
+    for (int j = 0; j < n && j < T; j++) write_row(j, e->tasks[open[j]], true);
+  }
+  int nrows = n == 0 ? 1 : n;
+  if (pad) for (int j = 0; j < T; j++) pad[j] = j < nrows;
+  for (int i = 0; i < A; i++) {
+    const UAV& a = e->agents[i];
+    if (legal) {
+      uint8_t* L = legal + (size_t)i * T;
+      std::fill(L, L + T, 0);
+      if (a.state == 2) {
+        // :475-479 — only the row whose id equals the agent's head task
+        if (n == 0) { if (a.tasks[0] == 0) L[0] = 1; }
+        else for (int j = 0; j < n && j < T; j++) L[j] = e->tasks[open[j]].id == a.tasks[0];
+      } else if (n == 0) {
+        L[0] = 1;
+      } else {
+        bool any = false;
+        for (int j = 0; j < n && j < T; j++) { L[j] = e->is_task_action_valid(a, e->tasks[open[j]]); any |= L[j]; }
+        if (!any) {
+          int cur = a.tasks.empty() ? -1 : a.tasks[0];
+          bool found = false;
+          for (int j = 0; j < n && j < T; j++) if (e->tasks[open[j]].id == cur) { L[j] = 1; found = true; break; }
+          if (!found) L[0] = 1;
+        }
+      }
+    }
+    if (ag) {
+      float* r = ag + (size_t)i * 9;
+      r[0] = (float)(a.pos.x / e->max_coord); r[1] = (float)(a.pos.y / e->max_coord);
+      for (int c = 0; c < 6; c++) r[2 + c] = (float)a.caps[c];
+      r[8] = (float)a.tasks[0];
+    }
+  }
+  if (flags) {
+    float fail = 0, threat = 0, reset = 0;
+    for (auto& ev : e->event_list) {
+      if (ev.tag == MUAVTA_EV_AGENT_FAIL) fail = 1; else if (ev.tag == MUAVTA_EV_NEW_THREAT) threat = 1;
+      else if (ev.tag == MUAVTA_EV_RESET_ALLOCATION) reset = 1;
+    }
+    flags[0] = fail; flags[1] = threat; flags[2] = reset;
+    flags[3] = (float)((double)e->time_steps / mts);
+    flags[4] = (float)((double)n / std::max(e->max_tasks, 1));
+  }
+}
+
+// ---- CPython random known-answer hooks ----
+void* orc_rng_new(uint64_t seed) { PyRandom* r = new PyRandom(); r->seed(seed); return r; }
+void orc_rng_free(void* r) { delete (PyRandom*)r; }
+double orc_rng_random(void* r) { return ((PyRandom*)r)->random(); }
+int64_t orc_rng_randint(void* r, int64_t a, int64_t b) { return ((PyRandom*)r)->randint(a, b); }
+double orc_rng_uniform(void* r, double a, double b) { return ((PyRandom*)r)->uniform(a, b); }
+uint64_t orc_rng_randbelow(void* r, uint64_t n) { return ((PyRandom*)r)->randbelow(n); }
+void orc_rng_shuffle(void* r, int64_t* x, int n) {
+  for (int i = n - 1; i >= 1; i--) { int j = (int)((PyRandom*)r)->randbelow((uint64_t)i + 1); std::swap(x[i], x[j]); }
+}
+double orc_norm2(double x, double y) { return norm2(x, y); }
+double orc_np_sum(const double* d, int n) { return Env::np_sum(std::vector<double>(d, d + n)); }
+void orc_avoid_obstacles(const double* obstacles, int n_obs, const double* pos, const double* mov, double* out) {
+  MuavtaParams p{};
+  p.simulation_frame_rate = 0.01;
+  Env e(p);
+  for (int o = 0; o < n_obs; o++) e.obstacles.push_back({obstacles[3 * o], obstacles[3 * o + 1], obstacles[3 * o + 2]});
+  Vec v = e.avoid_obstacles(Vec{pos[0], pos[1]}, Vec{mov[0], mov[1]});
+  out[0] = v.x; out[1] = v.y;
+}
+
+}  // extern "C"

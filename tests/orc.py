@@ -1,0 +1,149 @@
+"""ctypes wrapper around oracle/liboracle.so — test infrastructure (the checker, never the product)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        src = os.path.join(ORACLE_DIR, "muavta_oracle.cpp")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
+        L = C.CDLL(so)
+        L.orc_create.restype = C.c_void_p
+        L.orc_rng_new.restype = C.c_void_p
+        L.orc_rng_random.restype = C.c_double
+        L.orc_rng_uniform.restype = C.c_double
+        L.orc_rng_randint.restype = C.c_int64
+        L.orc_rng_randbelow.restype = C.c_uint64
+        L.orc_norm2.restype = C.c_double
+        L.orc_np_sum.restype = C.c_double
+        L.orc_get_lsap.restype = C.c_int64
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t=C.c_void_p):
+    return a.ctypes.data_as(t)
+
+
+class OracleEnv:
+    QCAP = 16
+
+    def __init__(self, params):
+        self.L = lib()
+        self.params = params
+        self.h = C.c_void_p(self.L.orc_create(C.byref(params)))
+        self.A = params.n_agents
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def reset(self, seed):
+        self.L.orc_reset(self.h, C.c_uint64(seed))
+
+    def dims(self):
+        d = np.zeros(16, dtype=np.int32)
+        self.L.orc_dims(self.h, _p(d))
+        keys = ["n_agents", "n_task_ids", "n_threats", "max_tasks", "n_open", "n_events", "n_actions", "n_lsap",
+                "n_replans", "time_steps", "n_pending", "n_reached", "pending_reset", "terminated", "truncated", "max_queue"]
+        return dict(zip(keys, d.tolist()))
+
+    def allocate(self, interval, use_vis=1):
+        aa = np.full(self.A + 1, -1, dtype=np.int32)
+        ai = np.zeros(self.A + 1, dtype=np.int32)
+        n = self.L.orc_allocate(self.h, int(interval), int(use_vis), _p(aa), _p(ai), self.A)
+        return aa[:n].copy(), ai[:n].copy()
+
+    def step(self, act_agent, act_index):
+        aa = np.ascontiguousarray(act_agent, dtype=np.int32)
+        ai = np.ascontiguousarray(act_index, dtype=np.int32)
+        return self.L.orc_step(self.h, len(aa), _p(aa), _p(ai))
+
+    def rollout(self, seed, n_steps, interval, use_vis=1, do_reset=1):
+        return self.L.orc_rollout(self.h, C.c_uint64(seed), int(do_reset), int(n_steps), int(interval), int(use_vis))
+
+    def metrics(self):
+        m = np.zeros(30)
+        self.L.orc_metrics(self.h, _p(m))
+        return m
+
+    def agents(self):
+        rows = np.zeros((self.A, 16)); caps = np.zeros((self.A, 6)); q = np.zeros((self.A, self.QCAP), dtype=np.int32)
+        self.L.orc_get_agents(self.h, _p(rows), _p(caps), _p(q), self.QCAP)
+        return rows, caps, q
+
+    def tasks(self):
+        nt = self.dims()["n_task_ids"]
+        rows = np.zeros((nt, 14)); reqs = np.zeros((nt, 3, 6))
+        self.L.orc_get_tasks(self.h, _p(rows), _p(reqs))
+        return rows, reqs
+
+    def known(self):
+        nt = self.dims()["n_task_ids"]
+        k = np.zeros((self.A, nt), dtype=np.uint8)
+        self.L.orc_get_known(self.h, _p(k))
+        return k.astype(bool)
+
+    def threats(self):
+        rows = np.zeros((self.dims()["n_threats"], 8))
+        self.L.orc_get_threats(self.h, _p(rows))
+        return rows
+
+    def scalars(self):
+        s = np.zeros(24)
+        self.L.orc_get_scalars(self.h, _p(s))
+        return s
+
+    def open_ids(self):
+        ids = np.zeros(self.dims()["n_open"], dtype=np.int32)
+        self.L.orc_get_open(self.h, _p(ids))
+        return ids
+
+    def events(self):
+        ev = np.zeros((self.dims()["n_events"], 2), dtype=np.int32)
+        self.L.orc_get_events(self.h, _p(ev))
+        return ev
+
+    def last_actions(self):
+        a = np.zeros((self.dims()["n_actions"], 2), dtype=np.int32)
+        self.L.orc_get_actions(self.h, _p(a))
+        return a
+
+    def lsap_calls(self):
+        n = self.dims()["n_lsap"]
+        shapes = np.zeros((n, 2), dtype=np.int32)
+        total = self.L.orc_get_lsap(self.h, _p(shapes), None, None, None)
+        costs = np.zeros(total); nrc = int(np.minimum(shapes[:, 0], shapes[:, 1]).sum()) if n else 0
+        rows = np.zeros(nrc, dtype=np.int64); cols = np.zeros(nrc, dtype=np.int64)
+        self.L.orc_get_lsap(self.h, _p(shapes), _p(costs), _p(rows), _p(cols))
+        return shapes, costs, rows, cols
+
+    def observe(self):
+        T = self.dims()["max_tasks"]
+        ti = np.zeros((T, 21), dtype=np.float32); legal = np.zeros((self.A, T), dtype=np.uint8)
+        pad = np.zeros(T, dtype=np.uint8); ag = np.zeros((self.A, 9), dtype=np.float32); fl = np.zeros(5, dtype=np.float32)
+        self.L.orc_observe(self.h, _p(ti), _p(legal), _p(pad), _p(ag), _p(fl))
+        return ti, legal.astype(bool), pad.astype(bool), ag, fl
+
+
+def lsap(cost):
+    cost = np.ascontiguousarray(cost, dtype=np.float64)
+    nr, nc = cost.shape
+    m = min(nr, nc)
+    row = np.zeros(m, dtype=np.int64); col = np.zeros(m, dtype=np.int64)
+    n = lib().orc_lsap(_p(cost), nr, nc, _p(row), _p(col))
+    assert n == m
+    return row, col

@@ -1,0 +1,193 @@
+"""Pins the CPU oracle (oracle/muavta_oracle.cpp) against vectors captured from the reference itself
+(tools/gen_golden.py -> tests/golden/*.npz).  Integer/index/mask data must be identical; every f64
+must be bit-identical too (the oracle reproduces the reference's operation order), which is stricter
+than the 1e-5 the north-star asks for."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import orc
+from muavta_amd.params import METRIC_KEYS, params_for_case
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+TRACES = sorted(glob.glob(os.path.join(GOLDEN, "trace_*.npz")))
+METRICS = sorted(glob.glob(os.path.join(GOLDEN, "metrics_*.npz")))
+
+
+def _case_of(path, prefix):
+    name = os.path.basename(path)[len(prefix):-4]
+    return name
+
+
+def check_state(e, g, s, tag):
+    """Compare oracle state after step s with the golden snapshot row s."""
+    rows, caps, q = e.agents()
+    A = rows.shape[0]
+    assert np.array_equal(rows[:, 0:2], g["pos"][s]), f"{tag} step {s}: agent positions"
+    assert np.array_equal(rows[:, 2].astype(int), g["state"][s].astype(int)), f"{tag} step {s}: agent state"
+    assert np.array_equal(rows[:, 3].astype(int), g["head"][s]), f"{tag} step {s}: head task"
+    gq = g["queue"][s]
+    assert np.array_equal(q[:, : gq.shape[1]], gq), f"{tag} step {s}: queues"
+    assert np.array_equal(rows[:, 5], g["nft"][s]), f"{tag} step {s}: next_free_time"
+    assert np.array_equal(rows[:, 6:8], g["nfp"][s]), f"{tag} step {s}: next_free_position"
+    assert np.array_equal(caps, g["caps"][s]), f"{tag} step {s}: caps"
+    assert np.array_equal(rows[:, 8].astype(int), g["attack_cap"][s]), f"{tag} step {s}: attackCap"
+    assert np.array_equal(rows[:, 9].astype(int), g["task_start"][s]), f"{tag} step {s}: task_start"
+    assert np.array_equal(rows[:, 10].astype(int), g["re_eval"][s].astype(int)), f"{tag} step {s}: re_eval"
+    assert np.array_equal(rows[:, 11].astype(int), g["last_task"][s]), f"{tag} step {s}: last_task"
+    assert np.array_equal(rows[:, 15], g["agent_dist"][s]), f"{tag} step {s}: agent_distances"
+    trow, reqs = e.tasks()
+    nt = trow.shape[0]
+    gs = g["t_status"][s]
+    assert np.all(gs[nt:] == -9), f"{tag} step {s}: oracle has fewer tasks than the reference"
+    assert np.all(gs[1:nt] != -9), f"{tag} step {s}: oracle has more tasks than the reference"
+    assert np.array_equal(trow[1:, 0].astype(int), gs[1:nt].astype(int)), f"{tag} step {s}: task status"
+    assert np.array_equal(trow[1:, 1:3], g["t_pos"][s][1:nt]), f"{tag} step {s}: task positions"
+    assert np.array_equal(reqs[1:, 0], g["t_cur"][s][1:nt]), f"{tag} step {s}: currentReqs"
+    assert np.array_equal(reqs[1:, 1], g["t_alloc"][s][1:nt]), f"{tag} step {s}: allocatedReqs"
+    assert np.array_equal(reqs[1:, 2], g["t_done"][s][1:nt]), f"{tag} step {s}: doneReqs"
+    assert np.array_equal(trow[1:, 3], g["t_init"][s][1:nt]), f"{tag} step {s}: initTime"
+    assert np.array_equal(trow[1:, 4], g["t_donetime"][s][1:nt]), f"{tag} step {s}: doneTime"
+    assert np.array_equal(trow[1:, 5].astype(int), g["t_ndet"][s][1:nt].astype(int)), f"{tag} step {s}: allocationDetails"
+    st = g["t_static"][1:nt]
+    assert np.array_equal(trow[1:, 6:11].astype(int), st), f"{tag} step {s}: task type/deadline/created/required/escort"
+    NT = int(g["n_task_ids"])
+    known = np.unpackbits(g["known"][s], axis=-1)[:, :NT].astype(bool)
+    assert np.array_equal(e.known()[:, 1:], known[:, 1:nt]), f"{tag} step {s}: known-task masks"
+    th = e.threats()
+    assert np.array_equal(th[:, 0].astype(int), g["h_status"][s].astype(int)), f"{tag} step {s}: threat status"
+    act = th[:, 0] != -9
+    assert np.array_equal(th[act, 1:3], g["h_pos"][s][act]), f"{tag} step {s}: threat positions"
+    assert np.array_equal(th[act, 3].astype(int), g["h_target"][s][act]), f"{tag} step {s}: threat targets"
+    assert np.array_equal(th[act, 5].astype(int), g["h_acap"][s][act]), f"{tag} step {s}: threat attackCap"
+    sc = e.scalars()
+    gsc = g["scalars"][s]
+    # golden scalar order: SCALARS list of tools/gen_golden.py + pending_reset, n_reached, n_pending
+    ours = [sc[2], sc[3], sc[4], sc[5], sc[6], sc[7], sc[8], sc[9], sc[10], sc[11], sc[12], sc[13], sc[14], sc[15],
+            sc[16], sc[17], sc[18], sc[19], sc[20], sc[21], sc[22]]
+    d = e.dims()
+    ours += [d["pending_reset"], d["n_reached"], d["n_pending"]]
+    assert np.array_equal(np.array(ours, dtype=np.float64), gsc), f"{tag} step {s}: scalar counters {ours} vs {gsc}"
+    assert sc[1] == g["reward"][s], f"{tag} step {s}: reward"
+    lo, hi = g["open_ptr"][s], g["open_ptr"][s + 1]
+    assert np.array_equal(e.open_ids(), g["open_ids"][lo:hi]), f"{tag} step {s}: last_tasks_info order"
+    ti, legal, pad, ag, fl = e.observe()
+    T = int(g["max_tasks"])
+    assert np.array_equal(ti, g["obs_tasks"][s]), f"{tag} step {s}: obs tasks_info"
+    glegal = np.unpackbits(g["obs_legal"][s], axis=-1)[:, :T].astype(bool)
+    assert np.array_equal(legal, glegal), f"{tag} step {s}: legal_mask"
+    assert np.array_equal(ag, g["obs_agent"][s]), f"{tag} step {s}: obs agent rows"
+    assert np.array_equal(fl, g["obs_flags"][s]), f"{tag} step {s}: event_flags"
+
+
+@pytest.mark.parametrize("path", TRACES, ids=[os.path.basename(p)[6:-4] for p in TRACES])
+def test_trace_bit_exact(path):
+    g = np.load(path)
+    name = os.path.basename(path)[6:-4]
+    case, seed = name.rsplit("_s", 1)
+    seed = int(seed)
+    interval = int(g["interval"])
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(seed)
+    rows, _, _ = e.agents()
+    assert np.array_equal(rows[:, 12].astype(int), g["agent_type"])
+    assert np.array_equal(rows[:, 13].astype(int), g["agent_name_idx"])
+    assert np.array_equal(rows[:, 14].astype(int), g["fail_event"])
+    check_state(e, g, 0, name)
+    S = g["pos"].shape[0] - 1
+    acts, evs = g["actions"], g["events"]
+    lsap_i = 0
+    lsap_off = 0
+    rc_off = 0
+    for s in range(S):
+        aa, ai = e.allocate(interval, 1)
+        ga = acts[acts[:, 0] == s]
+        assert np.array_equal(aa, ga[:, 1]), f"{name} t={s}: assigned agents {aa} vs {ga[:, 1]}"
+        assert np.array_equal(ai, ga[:, 3]), f"{name} t={s}: assigned open-list indices"
+        assert np.array_equal(e.last_actions()[:, 1], ga[:, 2]), f"{name} t={s}: assigned task ids"
+        shapes, costs, rws, cls = e.lsap_calls()
+        off = ro = 0
+        for k in range(len(shapes)):
+            assert int(g["lsap_step"][lsap_i]) == s
+            nr, nc = shapes[k]
+            assert (nr, nc) == tuple(g["lsap_shape"][lsap_i]), f"{name} t={s}: LSAP shape"
+            m = min(nr, nc)
+            assert np.array_equal(costs[off:off + nr * nc], g["lsap_cost"][lsap_off:lsap_off + nr * nc]), f"{name} t={s}: LSAP cost matrix"
+            assert np.array_equal(rws[ro:ro + m], g["lsap_row"][rc_off:rc_off + m])
+            assert np.array_equal(cls[ro:ro + m], g["lsap_col"][rc_off:rc_off + m])
+            off += nr * nc; ro += m; lsap_off += nr * nc; rc_off += m; lsap_i += 1
+        e.step(aa, ai)
+        ge = evs[evs[:, 0] == s + 1][:, 1:]
+        assert np.array_equal(e.events(), ge), f"{name} t={s + 1}: drained events"
+        check_state(e, g, s + 1, name)
+    assert lsap_i == len(g["lsap_step"])
+    assert np.array_equal(e.metrics(), g["metrics"]), f"{name}: final metrics"
+    assert e.dims()["n_replans"] == int(g["n_replans"])
+
+
+@pytest.mark.parametrize("path", METRICS, ids=[os.path.basename(p)[8:-4] for p in METRICS])
+def test_metrics_many_seeds(path):
+    g = np.load(path)
+    case = os.path.basename(path)[8:-4]
+    assert list(g["keys"]) == METRIC_KEYS
+    interval = int(g["interval"])
+    e = orc.OracleEnv(params_for_case(case))
+    for seed, want in enumerate(g["metrics"]):
+        n = e.rollout(seed, 150, interval, 1)
+        assert n == 150
+        got = e.metrics()
+        assert np.array_equal(got, want), f"{case} seed {seed}: {dict(zip(METRIC_KEYS, got - want))}"
+        assert e.dims()["n_replans"] == int(g["n_replans"][seed])
+
+
+def test_lsap_known_answers():
+    g = np.load(os.path.join(GOLDEN, "lsap_cases.npz"))
+    off = ro = 0
+    for nr, nc in g["shape"]:
+        c = g["cost"][off:off + nr * nc].reshape(nr, nc)
+        m = min(nr, nc)
+        r, cc = orc.lsap(c)
+        assert np.array_equal(r, g["row"][ro:ro + m]) and np.array_equal(cc, g["col"][ro:ro + m]), (nr, nc)
+        off += nr * nc; ro += m
+
+
+def test_cpython_random_known_answers():
+    import ctypes as C
+    g = np.load(os.path.join(GOLDEN, "mt_kat.npz"))
+    L = orc.lib()
+    for i, seed in enumerate(g["seeds"]):
+        r = C.c_void_p(L.orc_rng_new(C.c_uint64(int(seed))))
+        got = [L.orc_rng_random(r) for _ in range(8)]
+        assert got == list(g["random"][i][:8])
+        got = [L.orc_rng_randint(r, C.c_int64(0), C.c_int64(2**63 - 1)) for _ in range(4)]
+        assert got == [int(x) for x in g["randint63"][i]]
+        got = [L.orc_rng_randint(r, C.c_int64(1), C.c_int64(150)) for _ in range(8)] + \
+              [L.orc_rng_randint(r, C.c_int64(120), C.c_int64(1080)) for _ in range(4)]
+        assert got == list(g["randint"][i])
+        got = [L.orc_rng_uniform(r, C.c_double(3.5), C.c_double(1196.25)) for _ in range(4)]
+        assert got == list(g["uniform"][i])
+        got = [L.orc_rng_randbelow(r, C.c_uint64(2)) for _ in range(8)] + [L.orc_rng_randbelow(r, C.c_uint64(3)) for _ in range(8)]
+        assert got == list(g["choice"][i])
+        x = np.arange(16, dtype=np.int64)
+        L.orc_rng_shuffle(r, x.ctypes.data_as(C.c_void_p), 16)
+        assert list(x) == list(g["shuffle16"][i])
+        for _ in range(700):
+            L.orc_rng_random(r)
+        assert L.orc_rng_random(r) == g["random"][i][8]
+        L.orc_rng_free(r)
+
+
+def test_numpy_bit_patterns():
+    import ctypes as C
+    g = np.load(os.path.join(GOLDEN, "numpy_kat.npz"))
+    L = orc.lib()
+    v = g["vec"]
+    got = np.array([L.orc_norm2(C.c_double(x), C.c_double(y)) for x, y in v])
+    assert np.array_equal(got, g["norm_1d"])          # np.linalg.norm(1-D) == sqrt(fma(y, y, x*x))
+    assert np.array_equal(np.sqrt(v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]), g["norm_axis1"])
+    for n in (4, 8, 14, 16, 24, 40, 64):
+        d = g[f"sum{n}_in"]
+        got = np.array([L.orc_np_sum(np.ascontiguousarray(r).ctypes.data_as(C.c_void_p), n) for r in d])
+        assert np.array_equal(got, g[f"sum{n}_out"]), n
