@@ -107,36 +107,46 @@ typedef struct MuavtaDims {
   int32_t obs_agent_width;/* 9 floats per agent row */
   int32_t queue_cap, event_cap, action_cap;
   int64_t state_bytes;    /* bytes of one env's device state blob */
+  int32_t n_threats;      /* sum(threat_count): leading dim of the THREAT_* fields */
+  int32_t known_words;    /* ceil(tile_tasks / 32) */
+  int32_t lds_bytes;      /* LDS one workgroup (= one env) occupies */
+  int32_t reserved;
 } MuavtaDims;
 
-/* State fields readable with muavta_get (row-major, leading dim n_envs). */
+/* State fields readable with muavta_get (row-major, leading dim n_envs; A = n_agents, T = tile_tasks,
+ * H = n_threats, Q = queue_cap, E = event_cap).  Task fields are indexed by SLOT: the device keeps
+ * only live tasks (open, or retired but still queued by a live agent) in T recycled slots; TASK_ID
+ * maps slot -> Task.id (-1 = free) and ids stay monotone as in the reference (DroneEnv.py:325-328). */
 typedef enum MuavtaField {
-  MUAVTA_F_AGENT_POS = 0,      /* f64 [N, A, 2]      UAV.position                         */
-  MUAVTA_F_AGENT_STATE,        /* i32 [N, A]         UAV.state                            */
-  MUAVTA_F_AGENT_HEAD,         /* i32 [N, A]         UAV.tasks[0].id                      */
-  MUAVTA_F_AGENT_QUEUE,        /* i32 [N, A, Q]      UAV.tasks ids, -1 padded             */
-  MUAVTA_F_AGENT_NFT,          /* f64 [N, A]         UAV.next_free_time                   */
-  MUAVTA_F_AGENT_NFP,          /* f64 [N, A, 2]      UAV.next_free_position               */
-  MUAVTA_F_AGENT_CAPS,         /* f64 [N, A, 6]      UAV.currentCap2Task                  */
-  MUAVTA_F_AGENT_ATTACK_CAP,   /* i32 [N, A]         UAV.attackCap                        */
-  MUAVTA_F_AGENT_TYPE,         /* i32 [N, A]         UAV.typeIdx                          */
-  MUAVTA_F_AGENT_NAME_IDX,     /* i32 [N, A]         index of UAV.name in possible_agents */
-  MUAVTA_F_AGENT_DIST,         /* f64 [N, A]         env.agent_distances                  */
-  MUAVTA_F_TASK_ID,            /* i32 [N, T]         Task.id of slot (-1 = free slot)     */
-  MUAVTA_F_TASK_STATUS,        /* i32 [N, T]                                              */
-  MUAVTA_F_TASK_POS,           /* f64 [N, T, 2]                                           */
-  MUAVTA_F_TASK_CUR,           /* f64 [N, T, 6]      Task.currentReqs                     */
-  MUAVTA_F_TASK_ALLOC,         /* f64 [N, T, 6]      Task.allocatedReqs                   */
-  MUAVTA_F_TASK_DONE,          /* f64 [N, T, 6]      Task.doneReqs                        */
-  MUAVTA_F_TASK_META,          /* i32 [N, T, 8]      type, deadline(-1 none), created_at, required_agents, escort, n_alloc, protected_agent(-1), eligible_mask */
-  MUAVTA_F_TASK_TIMES,         /* f64 [N, T, 2]      initTime, doneTime                   */
-  MUAVTA_F_KNOWN,              /* u32 [N, A, ceil(T/32)]  bit s of row a: agent a knows the task in slot s */
-  MUAVTA_F_THREAT_POS,         /* f64 [N, H, 2]                                           */
+  MUAVTA_F_AGENT_POS = 0,      /* f64 [N, A, 2]      UAV.position                            (rw) */
+  MUAVTA_F_AGENT_STATE,        /* i32 [N, A]         UAV.state                               (rw) */
+  MUAVTA_F_AGENT_HEAD,         /* i32 [N, A]         UAV.tasks[0].id                              */
+  MUAVTA_F_AGENT_QUEUE,        /* i32 [N, A, Q]      UAV.tasks ids ([0] == [task_idle]), -1 padded */
+  MUAVTA_F_AGENT_NFT,          /* f64 [N, A]         UAV.next_free_time                      (rw) */
+  MUAVTA_F_AGENT_NFP,          /* f64 [N, A, 2]      UAV.next_free_position                  (rw) */
+  MUAVTA_F_AGENT_CAPS,         /* f64 [N, A, 6]      UAV.currentCap2Task                     (rw) */
+  MUAVTA_F_AGENT_ATTACK_CAP,   /* i32 [N, A]         UAV.attackCap                           (rw) */
+  MUAVTA_F_AGENT_TYPE,         /* i32 [N, A]         UAV.typeIdx                                  */
+  MUAVTA_F_AGENT_NAME_IDX,     /* i32 [N, A]         index of UAV.name in possible_agents         */
+  MUAVTA_F_AGENT_DIST,         /* f64 [N, A]         env.agent_distances                          */
+  MUAVTA_F_AGENT_MISC,         /* i32 [N, A, 6]      task_start, fail_event, re_eval, last_task id (-1 None), commit_until, len(tasks) (rw except last) */
+  MUAVTA_F_TASK_ID,            /* i32 [N, T]         Task.id of the slot (-1 = free)              */
+  MUAVTA_F_TASK_STATUS,        /* i32 [N, T]                                                 (rw) */
+  MUAVTA_F_TASK_POS,           /* f64 [N, T, 2]                                              (rw) */
+  MUAVTA_F_TASK_CUR,           /* f64 [N, T, 6]      Task.currentReqs                        (rw) */
+  MUAVTA_F_TASK_ALLOC,         /* f64 [N, T, 6]      Task.allocatedReqs                      (rw) */
+  MUAVTA_F_TASK_ORG_DONE,      /* f64 [N, T, 2]      orgReqs[typeIdx], doneReqs[typeIdx]     (rw) */
+  MUAVTA_F_TASK_META,          /* i32 [N, T, 8]      type, hard_deadline(-1 none), created_at, required_agents (w), escort, len(allocationDetails), protected_agent(-1), eligible type mask(-1 none) */
+  MUAVTA_F_TASK_TIMES,         /* f64 [N, T, 2]      initTime, doneTime                      (rw) */
+  MUAVTA_F_KNOWN,              /* u32 [N, A, ceil(T/32)]  bit s of row a: agent a knows the task in slot s (rw) */
+  MUAVTA_F_THREAT_POS,         /* f64 [N, H, 2]                                              (rw) */
   MUAVTA_F_THREAT_META,        /* i32 [N, H, 6]      status(-9 not spawned), target agent, mission target, attackCap, task id, type */
-  MUAVTA_F_SCALARS,            /* f64 [N, 24]        see MUAVTA_S_* below                 */
-  MUAVTA_F_OPEN_IDS,           /* i32 [N, T]         env.last_tasks_info ids in order, -1 padded */
+  MUAVTA_F_SCALARS,            /* f64 [N, 28]        see MUAVTA_S_* below                         */
+  MUAVTA_F_OPEN_IDS,           /* i32 [N, T]         env.last_tasks_info ids in order, -1 padded  */
   MUAVTA_F_EVENTS,             /* i32 [N, E, 2]      events drained by the last step (infos['events']), tag -1 padded */
-  MUAVTA_F_ERROR,              /* i32 [N]            0 or a MUAVTA_E_CAPACITY detail code */
+  MUAVTA_F_EVENT_LIST,         /* i32 [N, E, 2]      env.event_list (generated by the last step, not yet drained)     */
+  MUAVTA_F_STAGED_ACTIONS,     /* i32 [N, tile_agents, 3]  (agent, task id, open-list index) left by muavta_allocate, -1 padded */
+  MUAVTA_F_ERROR,              /* i32 [N]            0 or the tile that overflowed                */
   MUAVTA_F_COUNT_
 } MuavtaField;
 
@@ -147,7 +157,8 @@ enum {
   MUAVTA_S_IDLE_RESERVE, MUAVTA_S_CONCLUSION_TIME, MUAVTA_S_ESCORT_REQUESTS, MUAVTA_S_ESCORT_COMPLETED,
   MUAVTA_S_ESCORT_FAILED, MUAVTA_S_ESCORT_REQUIRED_STEPS, MUAVTA_S_ESCORT_COVERED_STEPS,
   MUAVTA_S_PROTECTION_BREACHES, MUAVTA_S_THREATS_INTERCEPTED, MUAVTA_S_RECON_LOSSES, MUAVTA_S_ESCORT_LOSSES,
-  MUAVTA_S_MUTUAL_SUPPORT, MUAVTA_S_PROTECTED_REC, MUAVTA_S_N_REPLANS, MUAVTA_N_SCALARS
+  MUAVTA_S_MUTUAL_SUPPORT, MUAVTA_S_PROTECTED_REC, MUAVTA_S_N_REPLANS, MUAVTA_S_PENDING_RESET, MUAVTA_S_N_REACHED,
+  MUAVTA_S_N_PENDING_REVEALS, MUAVTA_S_N_TASKS_CREATED, MUAVTA_N_SCALARS
 };
 
 typedef struct MuavtaEnv MuavtaEnv; /* opaque */
@@ -224,8 +235,19 @@ int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double
 int muavta_device_ptrs(MuavtaEnv* env, void** state, void** obs_tasks, void** obs_legal, void** obs_agents,
                        void** metrics, void** stream);
 
-/* Wall-clock of the last muavta_rollout kernel, measured with HIP events on the handle's stream (ms). */
+/* Duration of the last muavta_rollout launch, measured with HIP events recorded on the handle's own
+ * stream around the kernel (ms).  Blocks until that launch has finished. */
 int muavta_last_kernel_ms(MuavtaEnv* env, float* ms);
+/* Block until everything queued on the handle's stream has finished. */
+int muavta_sync(MuavtaEnv* env);
+/* Metrics written by the last muavta_rollout itself (f64 [N, 30]); no extra launch. */
+int muavta_rollout_metrics(MuavtaEnv* env, double* out);
+/* Rebuild the observation tensors from the current state (after muavta_set / muavta_set_state). */
+int muavta_refresh_observation(MuavtaEnv* env);
+/* Raw MT19937 tapes of the env's random.Random streams (checkpoint/resume next to get/set_state):
+ * u32 [N, 4 streams (agent, obs, tgt, mission), 2 blocks, 624]. */
+int muavta_get_rng(MuavtaEnv* env, void* dst, size_t bytes);
+int muavta_set_rng(MuavtaEnv* env, const void* src, size_t bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,232 @@
+"""``BatchedMultiUAVEnv`` — N independent mUAV_TA environments on one MI355X.
+
+Thin numpy view over the C ABI (include/muavta.h): every method maps to one entry point, which maps
+to the reference surface cited there (MultiUAVEnv.reset / step / observe / calculate_metrics and
+HungarianAllocator.allocate_tasks).  No simulation logic lives in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import native
+from .native import MuavtaError
+from .params import METRIC_KEYS, N_METRICS, N_SCALARS, MuavtaDims, MuavtaParams, params_from_config
+
+# MuavtaField enum (include/muavta.h)
+F = {name: i for i, name in enumerate([
+    "AGENT_POS", "AGENT_STATE", "AGENT_HEAD", "AGENT_QUEUE", "AGENT_NFT", "AGENT_NFP", "AGENT_CAPS", "AGENT_ATTACK_CAP",
+    "AGENT_TYPE", "AGENT_NAME_IDX", "AGENT_DIST", "AGENT_MISC", "TASK_ID", "TASK_STATUS", "TASK_POS", "TASK_CUR",
+    "TASK_ALLOC", "TASK_ORG_DONE", "TASK_META", "TASK_TIMES", "KNOWN", "THREAT_POS", "THREAT_META", "SCALARS",
+    "OPEN_IDS", "EVENTS", "EVENT_LIST", "STAGED_ACTIONS", "ERROR"])}
+
+
+def _vp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchedMultiUAVEnv:
+    def __init__(self, config, n_envs: int, device: int = 0, flags=None, **tiles):
+        self.params = config if isinstance(config, MuavtaParams) else params_from_config(config, flags, **tiles)
+        self.L = native.lib()
+        self.h = C.c_void_p()
+        rc = self.L.muavta_create(C.byref(self.params), int(n_envs), int(device), C.byref(self.h))
+        if rc != 0:
+            msg = self.L.muavta_last_error(None).decode()
+            self.h = C.c_void_p()
+            raise MuavtaError(f"muavta_create failed ({rc}): {msg}")
+        d = MuavtaDims()
+        self._ck(self.L.muavta_dims(self.h, C.byref(d)))
+        self.dims = d
+        self.n_envs, self.n_agents = d.n_envs, d.n_agents
+        self.T, self.H, self.Q, self.E, self.A_tile = d.tile_tasks, d.n_threats, d.queue_cap, d.event_cap, d.tile_agents
+        self.max_tasks = d.max_tasks
+        self.possible_agents = self.params.possible_agents
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc: int):
+        if rc != 0:
+            raise MuavtaError(f"muavta error {rc}: {self.L.muavta_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.muavta_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ env surface
+    def reset(self, seeds: Sequence[int]):
+        s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+        if s.shape != (self.n_envs,):
+            raise ValueError(f"seeds must have shape ({self.n_envs},)")
+        self._ck(self.L.muavta_reset(self.h, _vp(s)))
+
+    def step(self, act_agent: np.ndarray, act_index: np.ndarray):
+        """act_* : int32 [n_envs, action_cap]; act_agent -1 terminates an env's list."""
+        aa = np.ascontiguousarray(act_agent, dtype=np.int32)
+        ai = np.ascontiguousarray(act_index, dtype=np.int32)
+        want = (self.n_envs, self.A_tile)
+        if aa.shape != want or ai.shape != want:
+            raise ValueError(f"actions must have shape {want}")
+        self._ck(self.L.muavta_step(self.h, _vp(aa), _vp(ai)))
+
+    def pack_actions(self, per_env):
+        """[(agent_id, open_index), ...] per env -> the two padded arrays `step` takes."""
+        aa = np.full((self.n_envs, self.A_tile), -1, dtype=np.int32)
+        ai = np.zeros((self.n_envs, self.A_tile), dtype=np.int32)
+        for n, acts in enumerate(per_env):
+            for k, (a, i) in enumerate(acts):
+                aa[n, k], ai[n, k] = a, i
+        return aa, ai
+
+    def allocate(self, replan_interval: int = 20, use_visibility: bool = True, fetch: bool = True):
+        if not fetch:
+            self._ck(self.L.muavta_allocate(self.h, int(replan_interval), int(use_visibility), None, None))
+            return None
+        aa = np.empty((self.n_envs, self.A_tile), dtype=np.int32)
+        ai = np.empty((self.n_envs, self.A_tile), dtype=np.int32)
+        self._ck(self.L.muavta_allocate(self.h, int(replan_interval), int(use_visibility), _vp(aa), _vp(ai)))
+        return aa, ai
+
+    def step_staged(self):
+        self._ck(self.L.muavta_step_staged(self.h))
+
+    def rollout(self, seeds: Optional[Sequence[int]], n_steps: int = 150, replan_interval: int = 20,
+                use_visibility: bool = True, write_obs: bool = True):
+        s = None
+        if seeds is not None:
+            s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+            if s.shape != (self.n_envs,):
+                raise ValueError(f"seeds must have shape ({self.n_envs},)")
+        self._ck(self.L.muavta_rollout(self.h, _vp(s), int(n_steps), int(replan_interval), int(use_visibility), int(write_obs)))
+
+    def sync(self):
+        self._ck(self.L.muavta_sync(self.h))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        self._ck(self.L.muavta_last_kernel_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
+    def observe(self):
+        N, A, MT = self.n_envs, self.n_agents, self.max_tasks
+        tasks = np.empty((N, MT, 21), dtype=np.float32)
+        legal = np.empty((N, A, MT), dtype=np.uint8)
+        pad = np.empty((N, MT), dtype=np.uint8)
+        agents = np.empty((N, A, 9), dtype=np.float32)
+        flags = np.empty((N, 5), dtype=np.float32)
+        self._ck(self.L.muavta_observe(self.h, _vp(tasks), _vp(legal), _vp(pad), _vp(agents), _vp(flags)))
+        return {"tasks": tasks, "legal_mask": legal.astype(bool), "mask": pad.astype(bool), "agents": agents, "event_flags": flags}
+
+    def step_result(self):
+        r = np.empty(self.n_envs, dtype=np.float64)
+        d = np.empty(self.n_envs, dtype=np.uint8)
+        self._ck(self.L.muavta_step_result(self.h, _vp(r), _vp(d)))
+        return r, (d & 1).astype(bool), (d & 2).astype(bool)
+
+    def metrics(self) -> np.ndarray:
+        m = np.empty((self.n_envs, N_METRICS), dtype=np.float64)
+        self._ck(self.L.muavta_metrics(self.h, _vp(m)))
+        return m
+
+    def rollout_metrics(self) -> np.ndarray:
+        m = np.empty((self.n_envs, N_METRICS), dtype=np.float64)
+        self._ck(self.L.muavta_rollout_metrics(self.h, _vp(m)))
+        return m
+
+    def metrics_dicts(self):
+        return [dict(zip(METRIC_KEYS, row)) for row in self.metrics()]
+
+    def refresh_observation(self):
+        self._ck(self.L.muavta_refresh_observation(self.h))
+
+    # ------------------------------------------------------------------ state access
+    def _shape(self, name):
+        N, A, T, H, Q, E = self.n_envs, self.n_agents, self.T, self.H, self.Q, self.E
+        f64, i32, u32 = np.float64, np.int32, np.uint32
+        return {
+            "AGENT_POS": ((N, A, 2), f64), "AGENT_STATE": ((N, A), i32), "AGENT_HEAD": ((N, A), i32),
+            "AGENT_QUEUE": ((N, A, Q), i32), "AGENT_NFT": ((N, A), f64), "AGENT_NFP": ((N, A, 2), f64),
+            "AGENT_CAPS": ((N, A, 6), f64), "AGENT_ATTACK_CAP": ((N, A), i32), "AGENT_TYPE": ((N, A), i32),
+            "AGENT_NAME_IDX": ((N, A), i32), "AGENT_DIST": ((N, A), f64), "AGENT_MISC": ((N, A, 6), i32),
+            "TASK_ID": ((N, T), i32), "TASK_STATUS": ((N, T), i32), "TASK_POS": ((N, T, 2), f64),
+            "TASK_CUR": ((N, T, 6), f64), "TASK_ALLOC": ((N, T, 6), f64), "TASK_ORG_DONE": ((N, T, 2), f64),
+            "TASK_META": ((N, T, 8), i32), "TASK_TIMES": ((N, T, 2), f64), "KNOWN": ((N, A, self.dims.known_words), u32),
+            "THREAT_POS": ((N, H, 2), f64), "THREAT_META": ((N, H, 6), i32), "SCALARS": ((N, N_SCALARS), f64),
+            "OPEN_IDS": ((N, T), i32), "EVENTS": ((N, E, 2), i32), "EVENT_LIST": ((N, E, 2), i32),
+            "STAGED_ACTIONS": ((N, self.A_tile, 3), i32), "ERROR": ((N,), i32),
+        }[name]
+
+    def get(self, name: str) -> np.ndarray:
+        shape, dt = self._shape(name)
+        out = np.empty(shape, dtype=dt)
+        self._ck(self.L.muavta_get(self.h, F[name], _vp(out), out.nbytes))
+        return out
+
+    def set(self, name: str, value: np.ndarray):
+        shape, dt = self._shape(name)
+        v = np.ascontiguousarray(value, dtype=dt)
+        if v.shape != shape:
+            raise ValueError(f"{name} must have shape {shape}")
+        self._ck(self.L.muavta_set(self.h, F[name], _vp(v), v.nbytes))
+
+    def get_state(self) -> np.ndarray:
+        buf = np.empty(self.n_envs * self.dims.state_bytes, dtype=np.uint8)
+        self._ck(self.L.muavta_get_state(self.h, _vp(buf), buf.nbytes))
+        return buf
+
+    def set_state(self, buf: np.ndarray):
+        b = np.ascontiguousarray(buf, dtype=np.uint8)
+        self._ck(self.L.muavta_set_state(self.h, _vp(b), b.nbytes))
+
+    def get_rng(self) -> np.ndarray:
+        buf = np.empty((self.n_envs, 4, 2, 624), dtype=np.uint32)
+        self._ck(self.L.muavta_get_rng(self.h, _vp(buf), buf.nbytes))
+        return buf
+
+    def set_rng(self, buf: np.ndarray):
+        b = np.ascontiguousarray(buf, dtype=np.uint32)
+        self._ck(self.L.muavta_set_rng(self.h, _vp(b), b.nbytes))
+
+    def device_ptrs(self):
+        ptrs = [C.c_void_p() for _ in range(6)]
+        self._ck(self.L.muavta_device_ptrs(self.h, *[C.byref(p) for p in ptrs]))
+        keys = ["state", "obs_tasks", "obs_legal", "obs_agents", "metrics", "stream"]
+        return {k: p.value for k, p in zip(keys, ptrs)}
+
+
+def lsap(cost: np.ndarray, device: int = 0):
+    """Batched scipy-compatible linear_sum_assignment on the GPU: cost [n, nr, nc] (or [nr, nc])."""
+    c = np.ascontiguousarray(cost, dtype=np.float64)
+    single = c.ndim == 2
+    if single:
+        c = c[None]
+    n, nr, nc = c.shape
+    m = min(nr, nc)
+    row = np.empty((n, m), dtype=np.int64)
+    col = np.empty((n, m), dtype=np.int64)
+    L = native.lib()
+    rc = L.muavta_lsap(int(device), _vp(c), n, nr, nc, _vp(row), _vp(col))
+    if rc != 0:
+        raise MuavtaError(f"muavta_lsap failed ({rc}): {L.muavta_last_error(None).decode()}")
+    return (row[0], col[0]) if single else (row, col)
+
+
+def avoid_obstacles(agent_pos, obstacles, movement, device: int = 0):
+    """core_sim.SimCore.avoid_obstacles for n (position, movement) pairs (core_sim/src/sim_core.rs:25-59)."""
+    p = np.ascontiguousarray(np.atleast_2d(agent_pos), dtype=np.float64)
+    m = np.ascontiguousarray(np.atleast_2d(movement), dtype=np.float64)
+    o = np.ascontiguousarray(np.asarray(obstacles, dtype=np.float64).reshape(-1, 3))
+    out = np.empty_like(p)
+    L = native.lib()
+    rc = L.muavta_avoid_obstacles(int(device), _vp(p), _vp(m), p.shape[0], _vp(o) if len(o) else None, len(o), _vp(out))
+    if rc != 0:
+        raise MuavtaError(f"muavta_avoid_obstacles failed ({rc}): {L.muavta_last_error(None).decode()}")
+    return out

@@ -1,0 +1,1538 @@
+// muavta_device.h — device-side simulation of ONE env instance by ONE workgroup (gfx950, wave64).
+//
+// Execution model: the env's state blob sits in LDS (EnvState).  A step is a sequence of phases;
+// phases whose iterations are independent (pairwise sensing, the agent x task cost tile, distance
+// bookkeeping, slot GC, observation rows, MT19937 regeneration) are spread over the 64 lanes, and
+// the order-dependent bookkeeping of the reference (action application in dict order, the per-agent
+// state machine in agents_obj order, threat engagements that consume the shared RNG stream, the
+// shortest-augmenting-path LSAP) runs on lane 0 against LDS.  Phases are separated by workgroup
+// barriers.  Everything is f64 with -ffp-contract=off; FMAs are explicit where numpy emits them.
+//
+// Every routine cites the reference lines it restates (mUAV_TA/DroneEnv.py unless another file is
+// named).  This file is the product path; it shares no code with oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "muavta_state.h"
+
+#define DEV __device__ __forceinline__
+#define DEVN __device__ __noinline__
+
+namespace muavta {
+
+constexpr int WG = 64;  // one wave64 per env
+
+// ---- scene constants (mUAV_TA/MultiDroneEnvData.py:8-85) ------------------------------------------
+constexpr double AREA_W = 1200.0, AREA_H = 700.0, CONTACT_LINE = 550.0, BASE_X = 400.0, BASE_Y = 680.0;
+constexpr double MAX_COORD = 1200.0;
+__constant__ double CAP_TABLE[7][6] = {
+    {0.1, 1.0, 0.0, 0.2, 0.0, 0.0}, {0.1, 0.6, 0.0, 0.1, 0.0, 0.0}, {0.1, 0.8, 0.0, 0.2, 0.0, 1.0},
+    {0.1, 0.0, 0.7, 1.0, 1.0, 1.0}, {0.1, 0.0, 1.0, 0.6, 0.8, 1.0}, {0.0, 0.0, 0.2, 0.5, 1.0, 1.0},
+    {0.0, 0.0, 0.2, 0.4, 0.8, 0.8}};
+__constant__ double ENGAGE_RANGE[7] = {0.0, 0.0, 0.0, 40.0, 30.0, 35.0, 25.0};
+__constant__ double FAIL_MULT[7] = {1.2, 0.8, 1.5, 1.5, 0.8, 1.8, 1.0};
+__constant__ int TASK_DURATION[6] = {1, 10, 5, 5, 0, 1};
+
+DEV double norm2(double x, double y) { return sqrt(fma(y, y, x * x)); }  // np.linalg.norm of a 2-vector
+DEV bool is_recon(int t) { return t == MUAVTA_R1 || t == MUAVTA_R2; }
+DEV bool is_fighter(int t) { return t == MUAVTA_F1 || t == MUAVTA_F2; }
+
+template <class TL>
+struct alignas(16) Scratch {
+  enum { A = TL::A, T = TL::T };
+  double cost[A * T];  // LSAP cost tile, R x C row-major with R = min(nr, nc)
+  double u[A], v[T], spc[T], resid[T];
+  int32_t path[T], col4row[A], row4col[T], remaining[T], freeA[A], roundT[T];
+  uint8_t SR[A], SC[T];
+};
+
+// ====================================================================================================
+// CPython random.Random on a per-env tape in HBM: each stream keeps two consecutive raw MT19937
+// blocks (2 x 624 words); lane 0 tempers words at the cursor, and the whole wave regenerates a
+// consumed block at a step boundary (Modules/_randommodule.c genrand_uint32 / init_by_array).
+// ====================================================================================================
+enum { ST_AGENT = 0, ST_OBS = 1, ST_TGT = 2, ST_MISSION = 3 };
+
+DEV uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t m) {
+  uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return m ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+// dst = next MT block after src (src/dst: LDS or global, distinct buffers).  All lanes.
+DEV void mt_twist(const uint32_t* src, uint32_t* dst) {
+  const int lane = threadIdx.x;
+  for (int k = lane; k < 227; k += WG) dst[k] = mt_mix(src[k], src[k + 1], src[k + 397]);
+  __syncthreads();
+  for (int k = 227 + lane; k < 454; k += WG) dst[k] = mt_mix(src[k], src[k + 1], dst[k - 227]);
+  __syncthreads();
+  for (int k = 454 + lane; k < 623; k += WG) dst[k] = mt_mix(src[k], src[k + 1], dst[k - 227]);
+  __syncthreads();
+  if (lane == 0) dst[623] = mt_mix(src[623], dst[0], dst[396]);
+  __syncthreads();
+}
+// init_by_array(key[0..len)) into mt[624] (LDS).  One lane.
+DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
+  uint32_t g = 19650218u;  // init_genrand(19650218) generated on the fly
+  uint32_t prev = g;
+  mt[0] = g;
+  int j = 0;
+  for (int i = 1; i < 624; i++) {
+    g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
+    uint32_t key = j ? k1 : k0;
+    prev = (g ^ ((prev ^ (prev >> 30)) * 1664525u)) + key + (uint32_t)j;
+    mt[i] = prev;
+    j++;
+    if (j >= len) j = 0;
+  }
+  // 624th iteration of the first loop: i wrapped to 1 with mt[0] = mt[623]
+  mt[0] = prev;
+  {
+    uint32_t key = j ? k1 : k0;
+    prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key + (uint32_t)j;
+    mt[1] = prev;
+  }
+  for (int i = 2; i < 624; i++) {
+    prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+    mt[i] = prev;
+  }
+  mt[0] = prev;
+  prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+  mt[1] = prev;
+  mt[0] = 0x80000000u;
+}
+
+template <class TL>
+struct Sim {
+  typedef EnvState<TL> State;
+  enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
+  State& S;
+  Scratch<TL>& X;
+  const DevParams& P;
+  uint32_t* tape;  // [4][1248] in HBM
+  int lane;
+
+  __device__ Sim(State& s, Scratch<TL>& x, const DevParams& p, uint32_t* t) : S(s), X(x), P(p), tape(t), lane(threadIdx.x) {}
+
+  DEV void fail(int code) { if (S.error == 0) S.error = code; }
+
+  // ---------------------------------------------------------------- RNG (lane 0 unless noted)
+  DEV uint32_t next32(int st) {
+    uint32_t p = S.rng_idx[st];
+    uint32_t blk = (p >> 16) & 1u, off = p & 0xffffu;  // high half: which block is "current"
+    if (off >= 1248u) { fail(MUAVTA_ERR_POSITION); off = 1247u; }
+    uint32_t b = off >= 624u ? (blk ^ 1u) : blk;
+    uint32_t o = off >= 624u ? off - 624u : off;
+    uint32_t y = tape[st * MUAVTA_RNG_WORDS + b * 624u + o];
+    S.rng_idx[st] = (blk << 16) | (off + 1u);
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
+  DEV double rnd(int st) {  // random.random()
+    uint32_t a = next32(st) >> 5, b = next32(st) >> 6;
+    return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+  }
+  DEV uint64_t getrandbits(int st, int k) {
+    if (k <= 32) return (uint64_t)(next32(st) >> (32 - k));
+    uint64_t lo = next32(st), hi = next32(st);
+    int rem = k - 32;
+    if (rem < 32) hi >>= (32 - rem);
+    return lo | (hi << 32);
+  }
+  DEV uint64_t randbelow(int st, uint64_t n) {  // Random._randbelow_with_getrandbits
+    int k = 64 - __clzll((long long)n);
+    uint64_t r = getrandbits(st, k);
+    while (r >= n) r = getrandbits(st, k);
+    return r;
+  }
+  DEV int64_t randint(int st, int64_t a, int64_t b) { return a + (int64_t)randbelow(st, (uint64_t)(b - a) + 1u); }
+  DEV double uniform(int st, double a, double b) { return a + (b - a) * rnd(st); }
+
+  // All lanes: regenerate consumed blocks (called at step boundaries, uniform control flow).
+  DEV void rng_refill() {
+    for (int st = 0; st < 4; st++) {
+      uint32_t p = S.rng_idx[st];
+      uint32_t blk = (p >> 16) & 1u, off = p & 0xffffu;
+      if (off >= 624u) {  // block `blk` fully consumed: it becomes twist(other)
+        uint32_t* base = tape + st * MUAVTA_RNG_WORDS;
+        mt_twist(base + (blk ^ 1u) * 624u, base + blk * 624u);
+        if (lane == 0) S.rng_idx[st] = ((blk ^ 1u) << 16) | (off - 624u);
+        __syncthreads();
+      }
+    }
+  }
+  // All lanes: seed stream(s).  `scr` = LDS scratch of >= 2*624 words.
+  DEV void rng_seed_pair(uint32_t* scr, int stA, uint64_t seedA, int stB, uint64_t seedB) {
+    if (lane == 0) mt_seed(scr, (uint32_t)seedA, (uint32_t)(seedA >> 32), (seedA >> 32) ? 2 : 1);
+    if (lane == 1 && stB >= 0) mt_seed(scr + 624, (uint32_t)seedB, (uint32_t)(seedB >> 32), (seedB >> 32) ? 2 : 1);
+    __syncthreads();
+    uint32_t* bA = tape + stA * MUAVTA_RNG_WORDS;
+    mt_twist(scr, bA);
+    mt_twist(bA, bA + 624);
+    if (stB >= 0) {
+      uint32_t* bB = tape + stB * MUAVTA_RNG_WORDS;
+      mt_twist(scr + 624, bB);
+      mt_twist(bB, bB + 624);
+    }
+    if (lane == 0) { S.rng_idx[stA] = 0; if (stB >= 0) S.rng_idx[stB] = 0; }
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- references & queues (lane 0)
+  DEV bool ref_valid(int id, int slot) const { return slot >= 0 && S.t_id[slot] == id; }
+  DEV bool ref_retired(int id, int slot) const { return !ref_valid(id, slot) || S.t_status[slot] == 2; }
+  DEV int head_id(int a) const { return S.a_qlen[a] > 0 ? S.a_qid[a][0] : 0; }
+  DEV int queue_find(int a, int id) const {
+    for (int k = 0; k < S.a_qlen[a]; k++) if (S.a_qid[a][k] == id) return k;
+    return -1;
+  }
+  DEV void queue_erase(int a, int k) {
+    int n = S.a_qlen[a];
+    for (int i = k; i + 1 < n; i++) {
+      S.a_qid[a][i] = S.a_qid[a][i + 1];
+      S.a_qslot[a][i] = S.a_qslot[a][i + 1];
+      S.a_qtime[a][i] = S.a_qtime[a][i + 1];
+    }
+    S.a_qlen[a] = n - 1;
+  }
+  DEV bool escort_type(int t) const { return (P.escort_mask >> t) & 1u; }
+
+  // Task.removeAgentCap (DroneEnvComponents.py:280-301); `det` = allocationDetails[agent][1].
+  // The agent's own queue entry must already be gone.
+  DEV void remove_agent_cap(int s, int a, double det) {
+    if (S.t_status[s] == 2) return;
+    for (int c = 0; c < 6; c++) S.t_alloc[c][s] -= S.a_caps[c][a];
+    S.t_ndet[s] -= 1;
+    if (S.t_ndet[s] > 0) {
+      const int id = S.t_id[s];
+      const double dur = (double)TASK_DURATION[S.t_type[s]];
+      bool first = true;
+      double mn = 0, mx = 0;
+      for (int b = 0; b < P.n_agents; b++)
+        for (int k = 0; k < S.a_qlen[b]; k++)
+          if (S.a_qid[b][k] == id) {
+            double t = S.a_qtime[b][k];
+            if (first) { mn = mx = t; first = false; }
+            else { mn = t < mn ? t : mn; mx = t > mx ? t : mx; }
+          }
+      if (det == S.t_init[s]) S.t_init[s] = mn;
+      if (det + dur == S.t_dtime[s]) S.t_dtime[s] = mx + dur;
+    } else {
+      S.t_init[s] = -1;
+      S.t_dtime[s] = -1;
+    }
+  }
+  // UAV.desAllocate (DroneEnvComponents.py:97-113) for a task id that IS in the queue at position k.
+  DEV void des_allocate_at(int a, int k) {
+    int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
+    double det = S.a_qtime[a][k];
+    queue_erase(a, k);
+    S.a_nft[a] = (double)S.time_steps;
+    S.a_nfx[a] = S.a_px[a];
+    S.a_nfy[a] = S.a_py[a];
+    S.a_commit[a] = 0;
+    if (ref_valid(id, slot)) remove_agent_cap(slot, a, det);
+  }
+  DEV bool des_allocate(int a, int id) {
+    int k = queue_find(a, id);
+    if (k < 0 || id == 0) return false;
+    des_allocate_at(a, k);
+    return true;
+  }
+  // `for task in self.tasks: self.desAllocate(task)` over the list being mutated
+  // (DroneEnvComponents.py:115-119,122-127): every other queued task survives.
+  DEV void iterate_desallocate(int a) {
+    int i = 0;
+    while (i < S.a_qlen[a]) {
+      des_allocate_at(a, i);
+      if (S.a_qlen[a] == 0) break;  // python rebinds tasks=[idle]; the running iterator sees an empty list
+      i++;
+    }
+  }
+  DEV void desallocate_all(int a) { iterate_desallocate(a); S.a_commit[a] = 0; }
+  DEV void out_of_service(int a) { S.a_state[a] = -1; S.a_commit[a] = 0; iterate_desallocate(a); }
+
+  // UAV.taskDone (DroneEnvComponents.py:143-179)
+  DEV bool task_done(int a, int id, int type) {
+    if (S.a_qlen[a] == 0 || S.a_qid[a][0] != id) return false;
+    queue_erase(a, 0);
+    S.a_task_start[a] = -1;
+    if (type == MUAVTA_ATT) {
+      S.a_acap[a] -= 1;
+      if (S.a_acap[a] <= 0) S.a_caps[MUAVTA_ATT][a] = 0;
+    }
+    while (S.a_qlen[a] > 0 && ref_retired(S.a_qid[a][0], S.a_qslot[a][0])) queue_erase(a, 0);
+    if (S.a_qlen[a] == 0) {
+      if (S.a_reeval[a]) { S.a_last_id[a] = -1; S.a_last_slot[a] = -1; S.a_reeval[a] = 0; }
+      S.a_nft[a] = 0;
+      S.a_nfx[a] = S.a_px[a];
+      S.a_nfy[a] = S.a_py[a];
+      S.a_state[a] = 0;
+    } else {
+      S.a_state[a] = 1;
+    }
+    return true;
+  }
+  // UAV.allocate (DroneEnvComponents.py:55-95) for a real task (id != 0) in slot s
+  DEV bool uav_allocate(int a, int s) {
+    int id = S.t_id[s];
+    if (queue_find(a, id) >= 0 || S.t_status[s] == 2) return false;
+    S.a_reeval[a] = 0;
+    S.a_last_id[a] = -1;
+    S.a_last_slot[a] = -1;
+    double time_to_task = norm2(S.a_nfx[a] - S.t_px[s], S.a_nfy[a] - S.t_py[s]) / P.speed[S.a_type[a]];
+    double start_time = (S.a_nft[a] - (double)S.time_steps) > 0 ? S.a_nft[a] : (double)S.time_steps;
+    double dur = (double)TASK_DURATION[S.t_type[s]];
+    double end_time = start_time + time_to_task + dur;
+    int n = S.a_qlen[a];
+    if (n == 0) {
+      S.a_task_start[a] = -1;
+      S.a_state[a] = 1;
+    }
+    if (n >= Q) { fail(MUAVTA_ERR_QUEUE); return false; }
+    S.a_qid[a][n] = id;
+    S.a_qslot[a][n] = s;
+    S.a_qtime[a][n] = time_to_task;
+    S.a_qlen[a] = n + 1;
+    S.a_nft[a] = end_time;
+    S.a_nfx[a] = S.t_px[s];
+    S.a_nfy[a] = S.t_py[s];
+    // Task.addAgentCap (DroneEnvComponents.py:306-326); status != 2 checked above
+    double time_end = time_to_task + dur;
+    S.t_ndet[s] += 1;
+    for (int c = 0; c < 6; c++) S.t_alloc[c][s] += S.a_caps[c][a];
+    if (time_to_task < S.t_init[s] || S.t_init[s] == -1) {
+      S.t_init[s] = time_to_task;
+      if (S.t_dtime[s] == -1) S.t_dtime[s] = time_end;
+    }
+    if (time_end > S.t_dtime[s]) S.t_dtime[s] = time_end;
+    S.t_status[s] = 1;
+    return true;
+  }
+
+  // ---------------------------------------------------------------- tasks / events (lane 0)
+  DEV void push_event(int tag, int arg) {
+    int n = S.n_events;
+    if (n >= E) { fail(MUAVTA_ERR_EVENTS); return; }
+    S.ev_tag[n] = tag;
+    S.ev_arg[n] = arg;
+    S.n_events = n + 1;
+  }
+  // Task.__init__ (DroneEnvComponents.py:224-263) into a free slot; returns the slot or -1
+  DEV int new_task(double x, double y, int type, double req) {
+    int id = S.next_task_id++;  // _alloc_task_id (:325-328)
+    int s = -1;
+    for (int k = 0; k < T; k++) if (S.t_id[k] < 0) { s = k; break; }
+    if (s < 0) { fail(MUAVTA_ERR_TASK_SLOTS); return -1; }
+    S.t_id[s] = id;
+    S.t_px[s] = x; S.t_py[s] = y;
+    for (int c = 0; c < 6; c++) { S.t_cur[c][s] = 0; S.t_alloc[c][s] = 0; }
+    S.t_cur[type][s] = req;
+    S.t_org[s] = req; S.t_done[s] = 0;
+    S.t_init[s] = -1; S.t_dtime[s] = -1;
+    S.t_status[s] = 0; S.t_type[s] = type; S.t_created[s] = 0; S.t_deadline[s] = -1; S.t_required[s] = 0;
+    S.t_flags[s] = 0; S.t_elig[s] = 0; S.t_threat[s] = -1;
+    S.t_prot_agent[s] = -1; S.t_prot_id[s] = -1; S.t_prot_slot[s] = -1;
+    S.t_ndet[s] = 0; S.t_bucket[s] = 0;
+    for (int a = 0; a < A; a++) S.known[a][s >> 5] &= ~(1u << (s & 31));
+    S.t_order[S.n_order++] = s;
+    return s;
+  }
+  DEV void know_all(int s) { for (int a = 0; a < P.n_agents; a++) S.known[a][s >> 5] |= 1u << (s & 31); }
+
+  // _register_dynamic_task (:1491-1504)
+  DEV void register_dynamic(int s) {
+    if (P.hard_windows && !(S.t_flags[s] & TF_DEADLINE)) {
+      S.t_flags[s] |= TF_DEADLINE;
+      S.t_deadline[s] = S.time_steps + P.window_length;
+      S.n_windowed_tasks++;
+    }
+    if (P.threat_delay > 0 || P.sense_radius > 0) {
+      int n = S.n_pending;
+      if (n >= R) { fail(MUAVTA_ERR_PENDING); return; }
+      S.pend_time[n] = S.time_steps + (P.threat_delay > 0 ? P.threat_delay : 0);
+      S.pend_id[n] = S.t_id[s];
+      S.pend_slot[n] = s;
+      S.n_pending = n + 1;
+    } else {
+      know_all(s);
+    }
+  }
+  // _wps_mark_window_outcome (:1543-1555) on explicit (flags, deadline) storage
+  DEV void mark_outcome(int32_t& flags, int deadline, bool success) {
+    if (!(flags & TF_DEADLINE)) return;
+    if (flags & TF_COUNTED) return;
+    flags |= TF_COUNTED;
+    if (success && S.time_steps <= deadline) { S.n_on_time++; S.F_Reward += P.on_time_bonus; }
+    else { S.n_missed_windows++; S.F_Reward -= P.miss_penalty; }
+  }
+  DEV void mark_outcome_slot(int s, bool success) { mark_outcome(S.t_flags[s], S.t_deadline[s], success); }
+
+  DEV bool counts_for_mission_done(int s) const {  // :1878-1886
+    if (S.t_flags[s] & TF_ESCORT) return true;
+    int ty = S.t_type[s];
+    if (ty == MUAVTA_DET || ty == MUAVTA_HOLD) return true;
+    return S.t_status[s] == 2;
+  }
+  DEV bool all_mission_done() const {  // freed slots are retired tasks, which always count as done
+    for (int k = 0; k < S.n_order; k++) if (!counts_for_mission_done(S.t_order[k])) return false;
+    return true;
+  }
+  DEV bool action_valid(int a, int s) const {  // _is_task_action_valid (:341-363)
+    if (S.t_status[s] == 2) return false;
+    if (S.a_qlen[a] > 0 && S.a_qid[a][0] == S.t_id[s]) return true;
+    if ((S.t_flags[s] & TF_ELIGIBLE) && !((S.t_elig[s] >> S.a_type[a]) & 1u)) return false;
+    int ty = S.t_type[s];
+    if (P.capability_mask && S.a_caps[ty][a] <= 0) return false;
+    if (P.saturate_mask && S.t_alloc[ty][s] >= S.t_org[s]) return false;
+    return true;
+  }
+
+  // ---------------------------------------------------------------- escorts (lane 0)
+  DEV int escort_lookup(int recon) const {
+    for (int k = 0; k < S.n_escorts; k++) if (S.esc_agent[k] == recon) return k;
+    return -1;
+  }
+  DEV void create_escort_for(int recon, int rec_slot) {  // _create_escort_for (:1888-1917)
+    if (!P.escort_enabled) return;
+    if (escort_lookup(recon) >= 0) return;
+    int s = new_task(S.a_px[recon], S.a_py[recon], MUAVTA_DEF, P.escort_requirement);
+    if (s < 0) return;
+    S.t_flags[s] |= TF_ESCORT | TF_ELIGIBLE;
+    S.t_elig[s] = P.escort_mask;
+    S.t_prot_agent[s] = recon;
+    S.t_prot_id[s] = S.t_id[rec_slot];
+    S.t_prot_slot[s] = rec_slot;
+    S.t_required[s] = P.escort_required_agents;
+    S.t_created[s] = S.time_steps;
+    register_dynamic(s);
+    int n = S.n_escorts;
+    if (n >= A) { fail(MUAVTA_ERR_ESCORTS); return; }
+    S.esc_agent[n] = recon; S.esc_id[n] = S.t_id[s]; S.esc_slot[n] = s;
+    S.n_escorts = n + 1;
+    S.escort_requests++;
+    push_event(MUAVTA_EV_ESCORT_CREATED, S.t_id[s]);
+    push_event(MUAVTA_EV_RESET_ALLOCATION, MUAVTA_DEF);
+    S.pending_reset = 1;
+  }
+  DEV void retire_escort_entry(int k, bool failed) {  // _retire_escort (:1938-1950) for map entry k
+    int s = S.esc_slot[k], id = S.esc_id[k];
+    if (S.t_status[s] == 2) return;
+    // _release_escort_agents (:1919-1936)
+    for (int a = 0; a < P.n_agents; a++) {
+      if (S.a_state[a] == -1) continue;
+      if (des_allocate(a, id)) {
+        if (S.a_qlen[a] == 0) {
+          S.a_state[a] = 0;
+          S.a_commit[a] = 0;
+          S.a_nft[a] = (double)S.time_steps;
+          S.a_nfx[a] = S.a_px[a];
+          S.a_nfy[a] = S.a_py[a];
+        }
+      }
+    }
+    S.t_status[s] = 2;
+    int recon = S.t_prot_agent[s];
+    int kk = escort_lookup(recon);
+    if (kk >= 0) {
+      for (int i = kk; i + 1 < S.n_escorts; i++) {
+        S.esc_agent[i] = S.esc_agent[i + 1]; S.esc_id[i] = S.esc_id[i + 1]; S.esc_slot[i] = S.esc_slot[i + 1];
+      }
+      S.n_escorts--;
+    }
+    if (failed) S.escort_failed++; else S.escort_completed++;
+    push_event(MUAVTA_EV_ESCORT_RETIRED, id);
+  }
+  DEV void retire_escort_for(int recon, bool failed) {  // :1952-1957
+    int k = escort_lookup(recon);
+    if (k >= 0) retire_escort_entry(k, failed);
+  }
+  // _escort_fighters_near (:1746-1764): nearest-first list into out[], returns count.
+  // Stable insertion sort == python's sort(key=dist) on (dist, agent) pairs built in id order.
+  DEV int escort_fighters_near(int prot, double radius, int* out, double* outd) {
+    int k = escort_lookup(prot);
+    if (k < 0 || S.t_status[S.esc_slot[k]] == 2) return 0;
+    int eid = S.esc_id[k];
+    int n = 0;
+    for (int a = 0; a < P.n_agents; a++) {
+      if (S.a_state[a] == -1 || !escort_type(S.a_type[a])) continue;
+      if (S.a_qlen[a] == 0 || S.a_qid[a][0] != eid) continue;
+      double d = norm2(S.a_px[a] - S.a_px[prot], S.a_py[a] - S.a_py[prot]);
+      if (d <= radius) {
+        int i = n;
+        while (i > 0 && outd[i - 1] > d) { outd[i] = outd[i - 1]; out[i] = out[i - 1]; i--; }
+        outd[i] = d; out[i] = a;
+        n++;
+      }
+    }
+    return n;
+  }
+  DEV int closest_escort(int prot, double radius, int* count) {  // first element + count of the list above
+    int k = escort_lookup(prot);
+    *count = 0;
+    if (k < 0 || S.t_status[S.esc_slot[k]] == 2) return -1;
+    int eid = S.esc_id[k];
+    int best = -1, n = 0;
+    double bd = 0;
+    for (int a = 0; a < P.n_agents; a++) {
+      if (S.a_state[a] == -1 || !escort_type(S.a_type[a])) continue;
+      if (S.a_qlen[a] == 0 || S.a_qid[a][0] != eid) continue;
+      double d = norm2(S.a_px[a] - S.a_px[prot], S.a_py[a] - S.a_py[prot]);
+      if (d <= radius) { if (n == 0 || d < bd) { bd = d; best = a; } n++; }
+    }
+    *count = n;
+    return best;
+  }
+
+  // ---------------------------------------------------------------- releaseAllTasks (:1442-1480)
+  DEV void release_all_tasks(int for_type) {
+    int ft = for_type < 0 ? for_type + 6 : for_type;  // python negative index -> caps[-1] == Det
+    uint32_t avail = 0;
+    for (int a = 0; a < P.n_agents; a++) {
+      if (S.a_caps[ft][a] > 0 && S.a_state[a] != -1) {
+        S.a_reeval[a] = 1;  // len(agent.tasks) > 0 always holds in python ([task_idle] counts)
+        if (S.a_qlen[a] > 0) { S.a_last_id[a] = S.a_qid[a][0]; S.a_last_slot[a] = S.a_qslot[a][0]; }
+        else { S.a_last_id[a] = 0; S.a_last_slot[a] = -1; }
+        desallocate_all(a);
+        avail |= 1u << S.a_type[a];
+      }
+    }
+    for (int k = 0; k < S.n_order; k++) {
+      int s = S.t_order[k];
+      if (S.t_status[s] != 2 && S.t_type[s] == for_type) {
+        double cum = 0;
+        for (int ty = 0; ty < 7; ty++) if ((avail >> ty) & 1u) cum += CAP_TABLE[ty][for_type];
+        if (cum == 0) {
+          S.t_status[s] = 2;
+          if (!(S.t_flags[s] & TF_REACHED)) {
+            S.t_flags[s] |= TF_REACHED;
+            S.n_reached++;
+            if (S.n_reached == P.n_tasks) S.conclusion_time = S.time_steps;
+          }
+        } else {
+          S.t_status[s] = 0;
+          S.t_bucket[s] = 0;
+        }
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- geometry helpers
+  DEV void norm_vector(double& x, double& y) {  // EnvUtils.norm_vector (MultiDroneEnvUtils.py:168-177)
+    double m = norm2(x, y);
+    if (m == 0) { x = 0; y = 0; return; }
+    x = x / m; y = y / m;
+  }
+  // core_sim SimCore::avoid_obstacles (core_sim/src/sim_core.rs:25-59); Rust `%` == fmod
+  DEV void avoid_obstacles(double px, double py, double mx, double my, double& ax, double& ay) {
+    ax = 0.0; ay = 0.0;
+    const double PI = 3.14159265358979323846;
+    for (int o = 0; o < P.num_obstacles; o++) {
+      double dx = S.obst[o][0] - px, dy = S.obst[o][1] - py;
+      double d_zone = sqrt(dx * dx + dy * dy) - S.obst[o][2];
+      if (d_zone < 40.0) {
+        double nx = dx / d_zone, ny = dy / d_zone;
+        double force = log(fmax(1.05, d_zone));
+        force = 0.5 / (1.0 - force);
+        double ang = atan2(my, mx) - atan2(dy, dx);
+        ang = fmod(ang + PI, 2.0 * PI) - PI;
+        double rx, ry;
+        if (ang > 0.0) { rx = ny; ry = -nx; } else { rx = -ny; ry = nx; }
+        ax += rx * force;
+        ay += ry * force;
+      }
+    }
+  }
+  // random_position (:1371-1410)
+  DEV void random_position(int st, double min_distance, double own_range, bool contact_line, int area, bool check_obs,
+                           double& ox, double& oy) {
+    double limit_line = contact_line ? CONTACT_LINE : 0;
+    for (int tries = 0; tries < 100; tries++) {
+      double x, y;
+      if (area >= 0) {
+        double tlx = S.area[area][0], tly = S.area[area][1], w = S.area[area][2];
+        x = uniform(st, tlx, tlx + w);
+        y = uniform(st, tly, tly + w);
+      } else {
+        x = uniform(st, own_range + min_distance, AREA_W - own_range - min_distance);
+        y = uniform(st, own_range + min_distance,
+                    AREA_H - own_range - min_distance - ((limit_line != 0) ? (AREA_H - limit_line) : 0));
+      }
+      bool valid = true;
+      if (check_obs) {
+        for (int o = 0; o < P.num_obstacles && o < 8; o++) {
+          if (S.obst[o][2] < 0) break;  // not created yet
+          double d = norm2(x - S.obst[o][0], y - S.obst[o][1]) - own_range;
+          if (d < S.obst[o][2] + min_distance) { valid = false; break; }
+        }
+      }
+      if (valid) { ox = x; oy = y; return; }
+    }
+    fail(MUAVTA_ERR_POSITION);
+    ox = 0; oy = 0;
+  }
+  DEV int closest_agent(double x, double y) const {  // get_closest_agent (:1691-1723)
+    double minF = __builtin_huge_val(), minW = __builtin_huge_val();
+    int cF = -1, cW = -1;
+    for (int a = 0; a < P.n_agents; a++) {
+      int st = S.a_state[a];
+      if (st != -1 && st != 4) {
+        double d = norm2(S.a_px[a] - x, S.a_py[a] - y);
+        if (is_fighter(S.a_type[a])) { if (d < minF) { minF = d; cF = a; } }
+        else { if (d < minW) { minW = d; cW = a; } }
+      }
+    }
+    return cW >= 0 ? cW : cF;
+  }
+
+  // ====================================================================================================
+  // reset (:522-762).  All lanes enter; RNG seeding is cooperative, the rest runs on lane 0.
+  // ====================================================================================================
+  DEV void reset(uint64_t seed) {
+    // zero the whole blob (all lanes)
+    {
+      uint32_t* w = reinterpret_cast<uint32_t*>(&S);
+      for (int i = lane; i < (int)(sizeof(State) / 4); i += WG) w[i] = 0;
+    }
+    __syncthreads();
+    uint32_t* scr = reinterpret_cast<uint32_t*>(&X);
+    rng_seed_pair(scr, ST_AGENT, seed, -1, 0);
+    if (lane == 0) {  // :535-538
+      uint64_t s_obs = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);
+      uint64_t s_tgt = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);
+      uint64_t s_mis = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);
+      uint64_t* sd = reinterpret_cast<uint64_t*>(&S.area[0][0]);  // parked until the areas are built
+      sd[0] = s_obs; sd[1] = s_tgt; sd[2] = s_mis;
+    }
+    __syncthreads();
+    uint64_t s_obs, s_tgt, s_mis;
+    {
+      const uint64_t* sd = reinterpret_cast<const uint64_t*>(&S.area[0][0]);
+      s_obs = sd[0]; s_tgt = sd[1]; s_mis = sd[2];
+    }
+    __syncthreads();
+    rng_seed_pair(scr, ST_TGT, s_tgt, ST_MISSION, s_mis);
+    if (P.num_obstacles > 0) rng_seed_pair(scr, ST_OBS, s_obs, -1, 0);
+    if (lane == 0) reset_serial();
+    __syncthreads();
+    finish_step_parallel(false);
+  }
+
+  DEV void reset_serial() {
+    const int nA = P.n_agents;
+    S.conclusion_time = P.max_time_steps + 1;
+    S.next_task_id = 1;
+    S.last_plan_step = -1000000000;
+    for (int k = 0; k < T; k++) S.t_id[k] = -1;
+    for (int h = 0; h < H; h++) { S.h_status[h] = -9; S.h_target[h] = -1; S.h_mission[h] = -1; S.h_intercept[h] = -1; S.h_task_id[h] = -1; S.h_task_slot[h] = -1; }
+    for (int a = 0; a < A; a++) { S.a_state[a] = -1; S.a_last_id[a] = -1; S.a_last_slot[a] = -1; S.a_fail[a] = -1; S.a_task_start[a] = -1; S.a_name[a] = -1; S.a_type[a] = 0; }
+    // obstacles (:579-583)
+    for (int o = 0; o < 8; o++) S.obst[o][2] = -1.0;
+    for (int o = 0; o < P.num_obstacles && o < 8; o++) {
+      double size = (double)randint(ST_OBS, 30, 100);
+      double x, y;
+      random_position(ST_OBS, 20, size, true, -1, true, x, y);
+      S.obst[o][0] = x; S.obst[o][1] = y; S.obst[o][2] = size;
+    }
+    // agents (:591-612): shuffle ids, create in config order
+    int32_t* ids = X.path;  // scratch (T >= A)
+    for (int i = 0; i < nA; i++) ids[i] = i;
+    for (int i = nA - 1; i >= 1; i--) {
+      int j = (int)randbelow(ST_AGENT, (uint64_t)i + 1);
+      int t = ids[i]; ids[i] = ids[j]; ids[j] = t;
+    }
+    int pop = 0;
+    for (int g = 0; g < P.n_agent_groups; g++)
+      for (int i = 0; i < P.agent_count[g]; i++) {
+        int a = ids[pop];
+        int ty = P.agent_type[g];
+        S.a_name[a] = pop;
+        pop++;
+        S.a_type[a] = ty;
+        if (P.random_init_pos) random_position(ST_AGENT, 20, 3, false, -1, true, S.a_px[a], S.a_py[a]);
+        else { S.a_px[a] = BASE_X; S.a_py[a] = BASE_Y; }
+        for (int c = 0; c < 6; c++) S.a_caps[c][a] = CAP_TABLE[ty][c];
+        S.a_acap[a] = is_fighter(ty) ? 10 : 0;
+        S.a_state[a] = 0;
+        S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
+      }
+    // fail events (:616-618)
+    for (int a = 0; a < nA; a++)
+      if (rnd(ST_AGENT) < P.fail_rate * FAIL_MULT[S.a_type[a]])
+        S.a_fail[a] = (int)randint(ST_AGENT, 1, P.max_time_steps == -1 ? 1000 : P.max_time_steps);
+    // mission areas (:621-634): SquareArea(center, area_width, area_width)
+    for (int i = 0; i < 3; i++) {
+      double aw = (double)(1200 * randint(ST_MISSION, 10, 20)) / 100;
+      double ah = (double)(700 * randint(ST_MISSION, 10, 20)) / 100;
+      double cx, cy;
+      random_position(ST_MISSION, fmax(aw, ah), 3, false, -1, false, cx, cy);
+      S.area[i][0] = cx - aw / 2; S.area[i][1] = cy - aw / 2; S.area[i][2] = aw;
+    }
+    // static tasks (:641-667)
+    int hold_num = 0;
+    for (int g = 0; g < P.n_task_groups; g++)
+      for (int i = 0; i < P.task_count[g]; i++) {
+        int sel = (int)randbelow(ST_MISSION, 3);
+        int ty = P.task_type[g];
+        double x, y;
+        if (ty != MUAVTA_HOLD) random_position(ST_TGT, 20, 3, true, sel, true, x, y);
+        else { x = (double)(int)((hold_num + 1) * AREA_W / 5); y = (double)(int)(AREA_H / 4); hold_num++; }
+        new_task(x, y, ty, 1.0);
+      }
+    // threat groups (:685-729)
+    int hid = 0;
+    const double wide = AREA_W / 10;
+    for (int g = 0; g < P.n_threat_groups; g++) {
+      double gx = (double)randint(ST_AGENT, (int)(0 + wide), (int)(AREA_W - wide));
+      int det = new_task(gx, AREA_H / 5, MUAVTA_DET, (double)P.threat_count[g]);
+      S.g_next[g] = hid;
+      for (int k = 0; k < P.threat_count[g]; k++) {
+        double sx = (double)randint(ST_AGENT, (int)(gx - wide), (int)(gx + wide));
+        if (hid < H) {
+          S.h_px[hid] = sx; S.h_py[hid] = 0.0;
+          S.h_type[hid] = P.threat_type[g]; S.h_group[hid] = g;
+          S.h_det_slot[hid] = det; S.h_acap[hid] = 4; S.h_status[hid] = -9;
+        }
+        hid++;
+      }
+      S.g_end[g] = hid;
+    }
+    // static / initial tasks are known to everyone (:757-758)
+    for (int k = 0; k < S.n_order; k++) know_all(S.t_order[k]);
+    S.did_reset = 1;
+  }
+
+  // ====================================================================================================
+  // step (:774-1206).  n_act staged actions in S.act_agent / S.act_slot (slot < 0: invalid index).
+  // ====================================================================================================
+  DEV void step(bool write_obs_flag) {
+    rng_refill();
+    // previous positions stay in registers of the lane that owns the agent
+    double prev_x = 0, prev_y = 0;
+    if (lane < P.n_agents) { prev_x = S.a_px[lane]; prev_y = S.a_py[lane]; }
+    __syncthreads();
+    double r_action = 0, r_distance = 0, r_quality = 0, r_squality = 0;
+    if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
+    __syncthreads();
+    // distances (:1131-1138): np.linalg.norm(axis=1) == sqrt(x*x + y*y), no fma
+    if (lane < P.n_agents) {
+      double dx = S.a_px[lane] - prev_x, dy = S.a_py[lane] - prev_y;
+      double d = sqrt(dx * dx + dy * dy);
+      S.a_dist[lane] += d;
+      X.u[lane < A ? lane : 0] = d;
+    }
+    __syncthreads();
+    if (lane == 0) step_serial_b();
+    __syncthreads();
+    sense_parallel();  // _wps_update_sensing (:1506-1523)
+    __syncthreads();
+    if (lane == 0) step_serial_c(r_action, r_distance, r_quality, r_squality);
+    __syncthreads();
+    finish_step_parallel(true);
+  }
+
+  // events drain, action application, movement state machine
+  DEV void step_serial_a(double& action_reward, double& distance_reward, double& quality_reward, double& S_quality_reward) {
+    S.step_reward = 0;
+    S.time_steps += 1;  // :796
+    // drain the event queue (:800-805)
+    int nev = S.n_events;
+    S.n_dev = nev;
+    for (int k = 0; k < nev; k++) { S.dev_tag[k] = S.ev_tag[k]; S.dev_arg[k] = S.ev_arg[k]; }
+    S.n_events = 0;
+    for (int k = 0; k < nev; k++)
+      if (S.dev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) release_all_tasks(S.dev_arg[k]);
+    // ---- task allocation (:813-933) ----
+    for (int k = 0; k < S.n_act; k++) {
+      int a = S.act_agent[k];
+      if (a < 0) break;
+      if (S.a_state[a] == -1) continue;
+      int s = S.act_slot[k];
+      if (s < 0) { action_reward += -1; continue; }  // index beyond last_tasks_info (:835-838)
+      int tid = S.t_id[s];
+      {
+        int hid_ = head_id(a);
+        if (hid_ != tid) {
+          if (hid_ != 0) {
+            int hs = S.a_qslot[a][0];  // kept alive by the GC while it heads a live agent's queue
+            S_quality_reward -= 0.1;
+            S_quality_reward -= S.a_caps[S.t_type[hs]][a];
+            S.n_reallocations += 1;
+            S.n_task_switches += 1;
+            S.a_commit[a] = 0;
+            double dist_old = norm2(S.a_px[a] - S.t_px[hs], S.a_py[a] - S.t_py[hs]);
+            double dist_new = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
+            distance_reward += (dist_old - dist_new) / MAX_COORD;
+          } else {
+            S_quality_reward += 0.05;
+            if (S.pending_reset && P.dynamic_idle_penalty != 0) S_quality_reward -= P.dynamic_idle_penalty;
+          }
+        } else {
+          S_quality_reward += 0.05;  // head is a real task (idle can never be indexed)
+          continue;
+        }
+      }
+      if (!P.multiple_tasks_per_agent) {  // EnvUtils.desallocateAll([agent], env) (MultiDroneEnvUtils.py:183-205)
+        while (S.a_qlen[a] > 0) {
+          int qs = S.a_qslot[a][0], qi = S.a_qid[a][0];
+          des_allocate_at(a, 0);
+          if (ref_valid(qi, qs)) S.t_bucket[qs] &= ~(1ull << a);
+        }
+        S.a_nft[a] = (double)S.time_steps;
+        S.a_nfx[a] = S.a_px[a];
+        S.a_nfy[a] = S.a_py[a];
+      }
+      if (!action_valid(a, s)) { action_reward += -1; continue; }
+      if (uav_allocate(a, s)) {
+        S.t_bucket[s] |= 1ull << a;
+        int ty = S.t_type[s];
+        double agentCap = S.a_caps[ty][a];
+        double missing = S.t_cur[ty][s] - (S.t_alloc[ty][s] - agentCap);
+        missing = missing > 0 ? missing : 0;
+        double addedCap = missing - fmax(missing - agentCap, 0.0);
+        if (addedCap <= 0) S_quality_reward -= 1.5;
+        S_quality_reward += addedCap;
+        S.t_status[s] = 1;
+        {  // calculate_agent_expected_reward (:1216-1229)
+          int n = S.a_qlen[a];
+          double total;
+          if (n >= 2) {
+            int ps = S.a_qslot[a][n - 2];  // live agents' queue entries are never freed by the GC
+            total = norm2(S.a_nfx[a] - S.t_px[ps], S.a_nfy[a] - S.t_py[ps]);
+          } else {
+            total = norm2(S.a_nfx[a] - S.a_px[a], S.a_nfy[a] - S.a_py[a]);
+          }
+          distance_reward += -1.0 * total / MAX_COORD;
+        }
+        if (S.a_state[a] != 1 && S.a_state[a] != -1) S.a_state[a] = 1;
+        if (P.escort_enabled && ty == MUAVTA_REC && is_recon(S.a_type[a]) && escort_lookup(a) < 0) create_escort_for(a, s);
+      }
+    }
+    // ---- movement state machine (:965-1129) ----
+    for (int a = 0; a < P.n_agents; a++) {
+      if (S.a_state[a] == -1) continue;
+      if (S.a_fail[a] == S.time_steps) {  // :972-981
+        S.a_state[a] = -1;
+        desallocate_all(a);
+        push_event(MUAVTA_EV_RESET_ALLOCATION, -1);
+        push_event(MUAVTA_EV_AGENT_FAIL, a);
+        S.pending_reset = 1;
+        continue;
+      }
+      const double speed = P.speed[S.a_type[a]];
+      double mvx = 0, mvy = 0, avx = 0, avy = 0;
+      double px = S.a_px[a], py = S.a_py[a];
+      if (S.a_state[a] == 0 && !S.a_reeval[a]) {  // :987-993
+        if (S.a_qlen[a] == 0 && norm2(px - BASE_X, py - BASE_Y) > speed + 5) S.a_state[a] = 3;
+      }
+      {
+        // current task: last_task while re_eval, else the head (:996-1002); id 0 == task_idle
+        int cid, cs;
+        if (S.a_reeval[a]) { cid = S.a_last_id[a]; cs = S.a_last_slot[a]; }
+        else if (S.a_qlen[a] > 0) { cid = S.a_qid[a][0]; cs = S.a_qslot[a][0]; }
+        else { cid = 0; cs = -1; }
+        if (cid != 0 && ref_retired(cid, cs)) {  // :1004-1007 (task_idle.status is never 2)
+          des_allocate(a, cid);
+          S.a_reeval[a] = 0;
+          S.a_last_id[a] = -1; S.a_last_slot[a] = -1;
+        } else if (cid != 0) {
+          const int ty = S.t_type[cs];
+          const double engage = ENGAGE_RANGE[S.a_type[a]];
+          if (S.a_state[a] == 1) {  // navigating (:1012-1048)
+            double dx = S.t_px[cs] - px, dy = S.t_py[cs] - py;
+            double dist = norm2(dx, dy);
+            double ux = 0, uy = 0;
+            if (!(fabs(dist) < 1e-12)) { ux = dx / dist; uy = dy / dist; }
+            if (ty == MUAVTA_INT) {
+              if (dist < engage) {
+                S.a_state[a] = 2;
+                S.h_target[S.t_threat[cs]] = a;
+                S.a_task_start[a] = S.time_steps;
+              } else {
+                mvx = ux; mvy = uy;
+                avoid_obstacles(px, py, mvx, mvy, avx, avy);
+              }
+            } else if (dist < speed) {
+              S.a_state[a] = 2;
+              S.a_task_start[a] = S.time_steps;
+              px = S.t_px[cs]; py = S.t_py[cs];
+            } else {
+              mvx = ux; mvy = uy;
+              avoid_obstacles(px, py, mvx, mvy, avx, avy);
+            }
+          } else if (S.a_state[a] == 2) {  // in task (:1051-1110)
+            if (ty == MUAVTA_INT) {
+              double d = norm2(S.t_px[cs] - px, S.t_py[cs] - py);
+              if (d >= engage) S.a_state[a] = 1;
+            }
+            if (S.a_task_start[a] == -1) {
+              S.a_task_start[a] = S.time_steps;
+              px = S.t_px[cs]; py = S.t_py[cs];
+            } else if ((S.time_steps - S.a_task_start[a]) >= TASK_DURATION[ty] && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
+                       ty != MUAVTA_INT && ty != MUAVTA_DET) {
+              // task concluded by this agent (:1079-1107)
+              S.a_px[a] = px; S.a_py[a] = py;  // taskDone reads agent.position
+              double det = S.a_qlen[a] > 0 ? S.a_qtime[a][0] : 0.0;
+              bool was_head = task_done(a, cid, ty);
+              S.t_done[cs] += S.a_caps[ty][a];
+              for (int c = 0; c < 6; c++) S.t_cur[c][cs] -= S.a_caps[c][a];
+              if (was_head) remove_agent_cap(cs, a, det);
+              if (S.t_done[cs] >= S.t_org[cs]) {
+                const bool esc = S.t_flags[cs] & TF_ESCORT;
+                if (!esc && !(S.t_flags[cs] & TF_REACHED)) { S.t_flags[cs] |= TF_REACHED; S.n_reached++; }
+                quality_reward += S.t_org[cs] * 2;
+                S.F_Reward += S.t_org[cs] * 1 / P.reward_norm_factor;
+                if (!esc) mark_outcome_slot(cs, true);
+                S.t_status[cs] = 2;
+                if (ty == MUAVTA_REC && is_recon(S.a_type[a])) {  // _on_protected_rec_done (:1959-1962)
+                  S.protected_rec_completed++;
+                  retire_escort_for(a, false);
+                }
+                if (all_mission_done()) S.conclusion_time = S.time_steps;
+              } else {
+                quality_reward += S.a_caps[ty][a];
+              }
+            }
+          }
+        }
+      }
+      if (S.a_state[a] == 3) {  // returning to base (:1114-1121)
+        if (norm2(px - BASE_X, py - BASE_Y) < speed + 5) {
+          S.a_state[a] = 0;
+        } else {
+          mvx = BASE_X - px; mvy = BASE_Y - py;
+          norm_vector(mvx, mvy);
+          avoid_obstacles(px, py, mvx, mvy, avx, avy);
+        }
+      }
+      double mx = mvx + avx, my = mvy + avy;  // :1123-1127
+      norm_vector(mx, my);
+      mx = mx * speed; my = my * speed;
+      px = px + mx; py = py + my;
+      S.a_px[a] = fmin(fmax(px, 0.0), AREA_W);
+      S.a_py[a] = fmin(fmax(py, 0.0), AREA_H);
+    }
+  }
+
+  // total distance, threats, arrivals, escorts
+  DEV void step_serial_b() {
+    {  // np.sum(dists) (:1138): numpy pairwise summation (8 accumulators for n >= 8)
+      const int n = P.n_agents;
+      const double* d = X.u;
+      double res;
+      if (n < 8) { res = 0.; for (int i = 0; i < n; i++) res += d[i]; }
+      else {
+        double r[8];
+        for (int k = 0; k < 8; k++) r[k] = d[k];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; k++) r[k] += d[i + k];
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += d[i];
+      }
+      S.total_distance += res;
+    }
+    generate_threat();
+    update_threats();
+    inject_dynamic_arrivals();
+    if (P.escort_enabled) sync_escorts();
+  }
+
+  DEV void generate_threat() {  // :1601-1643
+    for (int g = 0; g < P.n_threat_groups; g++) {
+      int left = S.g_end[g] - S.g_next[g];
+      if (left > 0 && S.time_steps > 40 && S.time_steps % 10 == 0) {
+        if (rnd(ST_AGENT) < P.threat_prob) {
+          int n_spawn = 1;
+          if (P.burst_mode) n_spawn = P.burst_size < left ? P.burst_size : left;
+          for (int bi = 0; bi < n_spawn; bi++) {
+            if (S.g_next[g] >= S.g_end[g]) break;
+            int h = S.g_next[g]++;
+            if (h >= H) { fail(MUAVTA_ERR_TASK_SLOTS); break; }
+            if (P.dual_region_bursts) {
+              double mid = AREA_W * 0.5;
+              double wide = fmax(AREA_W / 10, 40.0);
+              double x;
+              if ((S.burst_region_toggle + bi) % 2 == 0) x = uniform(ST_AGENT, wide, mid - wide);
+              else x = uniform(ST_AGENT, mid + wide, AREA_W - wide);
+              S.h_px[h] = x;
+            }
+            int tgt = closest_agent(S.h_px[h], S.h_py[h]);
+            S.h_target[h] = tgt;
+            S.h_mission[h] = tgt;
+            // TaskFromThreat (:1861-1876)
+            int ty = S.h_type[h];
+            double attack = CAP_TABLE[ty][2], defence = CAP_TABLE[ty][3];
+            int s = new_task(S.h_px[h], S.h_py[h], MUAVTA_INT, 2.0);
+            if (s >= 0) {
+              S.t_cur[MUAVTA_ATT][s] = defence * 2;
+              S.t_cur[MUAVTA_DEF][s] = attack * 2;
+              S.t_threat[s] = h;
+              S.t_created[s] = S.time_steps;
+              if (ty == MUAVTA_T1) { S.t_required[s] = 2; S.t_flags[s] |= TF_ELIGIBLE; S.t_elig[s] = P.escort_mask; }
+              S.h_task_id[h] = S.t_id[s];
+              S.h_task_slot[h] = s;
+            }
+            S.h_status[h] = 1;
+            S.h_order[S.n_active_threats++] = h;
+            S.t_cur[5][S.h_det_slot[h]] -= 1.0;
+            if (s >= 0) {
+              register_dynamic(s);
+              push_event(MUAVTA_EV_NEW_THREAT, S.t_id[s]);
+            }
+            push_event(MUAVTA_EV_RESET_ALLOCATION, MUAVTA_INT);
+            S.pending_reset = 1;
+          }
+          if (P.dual_region_bursts && n_spawn > 0) S.burst_region_toggle = (S.burst_region_toggle + 1) % 2;
+        }
+      }
+    }
+  }
+
+  // the threat's Int task: live slot, or the (flags, deadline) copy kept on the threat once freed
+  DEV void threat_task_retire(int h, bool success) {
+    int s = S.h_task_slot[h];
+    if (ref_valid(S.h_task_id[h], s)) { S.t_status[s] = 2; mark_outcome_slot(s, success); }
+    else mark_outcome(S.h_tflags[h], S.h_tdeadline[h], success);
+  }
+
+  DEV void handle_threat_engagement(int h) {  // :1781-1858
+    int primary = S.h_target[h];
+    int mission = S.h_mission[h] >= 0 ? S.h_mission[h] : primary;
+    int n_def = 0;
+    int* defs = X.remaining;       // scratch lists (T >= A)
+    double* defd = X.v;
+    if (P.escort_enabled && mission >= 0 && is_recon(S.a_type[mission])) {
+      n_def = escort_fighters_near(mission, P.mutual_support_radius, defs, defd);
+      if (n_def > 0) {
+        primary = defs[0];
+        S.h_target[h] = primary;
+        S.h_intercept[h] = primary;
+      }
+    }
+    if (primary < 0) return;
+    const int hty = S.h_type[h];
+    const double t_att = CAP_TABLE[hty][2], t_def = CAP_TABLE[hty][3], t_rng = ENGAGE_RANGE[hty];
+    double attDiff, defDiff, engageDiff;
+    if (n_def >= 2) {
+      S.mutual_support_engagements++;
+      double att_sum = 0, def_sum = 0, eng_sum = 0;
+      for (int k = 0; k < n_def; k++) att_sum += S.a_caps[2][defs[k]];
+      for (int k = 0; k < n_def; k++) def_sum += S.a_caps[3][defs[k]];
+      for (int k = 0; k < n_def; k++) eng_sum += ENGAGE_RANGE[S.a_type[defs[k]]];
+      eng_sum = eng_sum / (double)n_def;
+      attDiff = att_sum / fmax(t_att, 1e-6);
+      defDiff = def_sum / fmax(t_def, 1e-6);
+      engageDiff = eng_sum / fmax(t_rng, 1e-6);
+    } else {
+      attDiff = S.a_caps[2][primary] / fmax(t_att, 1e-6);
+      defDiff = S.a_caps[3][primary] / fmax(t_def, 1e-6);
+      engageDiff = ENGAGE_RANGE[S.a_type[primary]] / fmax(t_rng, 1e-6);
+    }
+    double avg_diff = (attDiff + defDiff + engageDiff) / 3;
+    double prob = avg_diff / (avg_diff + 1);
+    double r = rnd(ST_AGENT);
+    if (r < prob) {
+      S.h_status[h] = 2;
+      threat_task_retire(h, true);
+      S.threats_intercepted++;
+      S.a_acap[primary] -= 1;
+      if (S.a_acap[primary] <= 0) S.a_caps[3][primary] = 0;
+      if (S.a_qlen[primary] > 0 && S.a_qid[primary][0] == S.h_task_id[h]) task_done(primary, S.h_task_id[h], MUAVTA_INT);
+      S.step_reward += 1.0;
+    } else {
+      S.h_acap[h] -= 1;
+      S.a_acap[primary] -= 1;
+      if (S.a_acap[primary] <= 0) {
+        S.a_caps[3][primary] = 0;
+        bool was_recon = is_recon(S.a_type[primary]);
+        bool was_escort = escort_type(S.a_type[primary]);
+        out_of_service(primary);
+        if (was_recon) { S.recon_losses++; S.protection_breaches++; retire_escort_for(primary, true); }
+        else if (was_escort) S.escort_losses++;
+        S.step_reward -= 1.0;
+      }
+      if (S.h_acap[h] <= 0) {
+        S.h_status[h] = 0;
+        threat_task_retire(h, false);
+      } else {
+        int tgt = closest_agent(S.h_px[h], S.h_py[h]);
+        S.h_target[h] = tgt;
+        S.h_mission[h] = tgt;
+      }
+    }
+  }
+
+  DEV void update_threats() {  // :1725-1744
+    const int n = S.n_active_threats;
+    // python snapshots [t for t in self.threats if t.status != 2] before the loop
+    uint64_t livemask[(H + 63) / 64] = {0};
+    for (int k = 0; k < n; k++) if (S.h_status[S.h_order[k]] != 2) livemask[k >> 6] |= 1ull << (k & 63);
+    for (int k = 0; k < n; k++) {
+      if (!((livemask[k >> 6] >> (k & 63)) & 1ull)) continue;
+      int h = S.h_order[k];
+      const double speed = P.speed[S.h_type[h]];
+      if (S.h_status[h] == 0 || S.h_target[h] < 0) {
+        S.h_px[h] = S.h_px[h] + speed * 0.0;
+        S.h_py[h] = S.h_py[h] + speed * -1.0;
+      } else {
+        if (P.escort_enabled) {  // _retarget_threat_via_escort (:1766-1779)
+          int mission = S.h_mission[h] >= 0 ? S.h_mission[h] : S.h_target[h];
+          if (mission >= 0 && S.a_state[mission] != -1 && is_recon(S.a_type[mission])) {
+            int cnt;
+            int e0 = closest_escort(mission, P.escort_intercept_radius, &cnt);
+            if (cnt == 0) { S.h_target[h] = mission; S.h_intercept[h] = -1; }
+            else { S.h_target[h] = e0; S.h_intercept[h] = e0; }
+          }
+        }
+        int tg = S.h_target[h];
+        double dx = S.a_px[tg] - S.h_px[h], dy = S.a_py[tg] - S.h_py[h];
+        norm_vector(dx, dy);
+        S.h_px[h] = S.h_px[h] + speed * dx;
+        S.h_py[h] = S.h_py[h] + speed * dy;
+        if (norm2(S.a_px[tg] - S.h_px[h], S.a_py[tg] - S.h_py[h]) < ENGAGE_RANGE[S.h_type[h]]) handle_threat_engagement(h);
+      }
+      int s = S.h_task_slot[h];
+      bool live = ref_valid(S.h_task_id[h], s);
+      if (live) { S.t_px[s] = S.h_px[h]; S.t_py[s] = S.h_py[h]; }
+      if (S.h_py[h] <= 0) threat_task_retire(h, false);
+    }
+  }
+
+  DEV void inject_dynamic_arrivals() {  // :1646-1689
+    if (P.arrival_rate <= 0 || S.time_steps < 5) return;
+    if (rnd(ST_TGT) >= P.arrival_rate) return;
+    if (S.next_task_id - 1 >= P.max_tasks - 1) return;  // len(self.tasks) >= max_tasks - 1
+    int ty = randbelow(ST_TGT, 2) == 0 ? MUAVTA_ATT : MUAVTA_REC;
+    // the reference allocates the id before drawing the mission area; ids are only consumed here
+    int sel = (int)randbelow(ST_MISSION, 3);
+    double x, y;
+    if (P.dual_region_bursts) {
+      double mid = AREA_W * 0.5, wide = 40.0;
+      if (rnd(ST_TGT) < 0.5) x = uniform(ST_TGT, wide, mid - wide);
+      else x = uniform(ST_TGT, mid + wide, AREA_W - wide);
+      y = uniform(ST_TGT, AREA_H * 0.2, AREA_H * 0.8);
+    } else {
+      random_position(ST_TGT, 20, 3, true, sel, true, x, y);
+    }
+    int s = new_task(x, y, ty, 1.0);
+    S.n_arrivals++;
+    if (s >= 0) {
+      S.t_created[s] = S.time_steps;
+      register_dynamic(s);
+      push_event(MUAVTA_EV_NEW_THREAT, S.t_id[s]);
+    }
+    push_event(MUAVTA_EV_RESET_ALLOCATION, ty);
+    S.pending_reset = 1;
+  }
+
+  DEV void sync_escorts() {  // :1964-2000
+    for (int a = 0; a < P.n_agents; a++) {
+      if (S.a_state[a] == -1 || !is_recon(S.a_type[a])) continue;
+      if (S.a_qlen[a] == 0) continue;
+      int cid = S.a_qid[a][0], cs = S.a_qslot[a][0];
+      if (ref_retired(cid, cs)) continue;
+      if (S.t_type[cs] == MUAVTA_REC && escort_lookup(a) < 0) create_escort_for(a, cs);
+    }
+    // iterate a snapshot of the map (retiring pops entries)
+    int n = S.n_escorts;
+    int32_t* snap = X.row4col;  // T >= A
+    for (int k = 0; k < n; k++) snap[k] = S.esc_agent[k];
+    for (int k = 0; k < n; k++) {
+      int recon = snap[k];
+      int kk = escort_lookup(recon);
+      if (kk < 0) continue;
+      int es = S.esc_slot[kk];
+      int rid = S.t_prot_id[es], rs = S.t_prot_slot[es];
+      bool dead = S.a_state[recon] == -1;
+      bool idle = S.a_qlen[recon] == 0 || S.a_state[recon] == 0 || S.a_state[recon] == 3;
+      bool rec_done = ref_retired(rid, rs);
+      bool wrong_task = S.a_qlen[recon] > 0 && S.a_qid[recon][0] != rid;
+      if (dead || idle || rec_done || wrong_task) { retire_escort_entry(kk, dead); continue; }
+      S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon];
+      S.escort_required_steps++;
+      int cnt;
+      closest_escort(recon, P.escort_radius, &cnt);
+      if (cnt > 0) S.escort_covered_steps++;
+    }
+  }
+
+  // _wps_update_sensing (:1506-1523): agent x live-slot pairs over the wave, distance tile in registers
+  DEV void sense_parallel() {
+    if (P.sense_radius <= 0) return;
+    const int nA = P.n_agents, nO = S.n_order;
+    for (int p = lane; p < nA * nO; p += WG) {
+      int a = p / nO, s = S.t_order[p - a * nO];
+      if (S.a_state[a] == -1) continue;
+      if (S.t_status[s] == 2) continue;
+      if ((S.known[a][s >> 5] >> (s & 31)) & 1u) continue;
+      if (S.t_created[s] <= 0 && !(S.t_flags[s] & TF_DEADLINE)) continue;
+      double d = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
+      if (d <= P.sense_radius) atomicOr(&S.known[a][s >> 5], 1u << (s & 31));
+    }
+  }
+
+  // reveals, window expiry, reserve tracking, reward, done flags
+  DEV void step_serial_c(double action_reward, double distance_reward, double quality_reward, double S_quality_reward) {
+    // _wps_process_reveals (:1525-1541)
+    if (S.n_pending > 0) {
+      int w = 0;
+      for (int k = 0; k < S.n_pending; k++) {
+        if (S.time_steps >= S.pend_time[k]) {
+          if (P.share_knowledge && ref_valid(S.pend_id[k], S.pend_slot[k])) know_all(S.pend_slot[k]);
+        } else {
+          S.pend_time[w] = S.pend_time[k]; S.pend_id[w] = S.pend_id[k]; S.pend_slot[w] = S.pend_slot[k];
+          w++;
+        }
+      }
+      S.n_pending = w;
+    }
+    // _wps_expire_windows (:1557-1573)
+    if (P.hard_windows) {
+      for (int k = 0; k < S.n_order; k++) {
+        int s = S.t_order[k];
+        if (!(S.t_flags[s] & TF_DEADLINE) || S.t_status[s] == 2) continue;
+        if (S.time_steps > S.t_deadline[s]) {
+          S.t_status[s] = 2;
+          mark_outcome_slot(s, false);
+          if (!(S.t_flags[s] & TF_REACHED)) { S.t_flags[s] |= TF_REACHED; S.n_reached++; }
+          int id = S.t_id[s];
+          for (int a = 0; a < P.n_agents; a++)
+            if (S.a_qlen[a] > 0 && S.a_qid[a][0] == id) desallocate_all(a);
+        }
+      }
+    }
+    // _wps_track_reserve (:1575-1580) and the pending-reset latch (:1156-1160)
+    int idle = 0;
+    bool responding = false;
+    for (int a = 0; a < P.n_agents; a++)
+      if (S.a_state[a] != -1) { if (S.a_qlen[a] == 0) idle++; else responding = true; }
+    S.idle_reserve_steps += idle;
+    if (S.pending_reset && responding) S.pending_reset = 0;
+    // shared reward (:1140-1145,1162-1178)
+    double time_penaulty = -(double)(P.n_tasks - S.n_reached) / (double)P.n_tasks * ((double)S.time_steps / (double)P.max_time_steps);
+    double alloc_reward = 0;
+    if (S.time_steps > P.n_tasks + 1) {  // -len(unallocated_tasks()) (:1434-1440); bucket 0 (idle) is always empty
+      int n = 1 + S.n_retired_empty_buckets;
+      for (int k = 0; k < S.n_order; k++) if (S.t_bucket[S.t_order[k]] == 0) n++;
+      alloc_reward = -(double)n;
+    }
+    double total = P.rw[0] * action_reward + P.rw[1] * distance_reward + P.rw[2] * quality_reward + P.rw[3] * S_quality_reward +
+                   P.rw[4] * (double)P.n_tasks * 0.0 + P.rw[5] * alloc_reward + P.rw[6] * time_penaulty + P.rw[7] * S.step_reward;
+    S.last_reward = total / P.reward_norm_factor / (double)P.max_time_steps;
+    bool all_done = (S.next_task_id > 1) && all_mission_done();
+    bool timed_out = (S.time_steps >= P.max_time_steps) && (P.max_time_steps > 0);
+    bool done = timed_out || (P.early_terminate && all_done);
+    if (all_done && S.conclusion_time > P.max_time_steps) S.conclusion_time = S.time_steps;
+    S.terminated = P.early_terminate && all_done && !timed_out;
+    S.truncated = timed_out;
+    if (done) S.last_reward = S.F_Reward;  // :1202
+  }
+
+  // ---------------------------------------------------------------- end of step: slot GC + open list
+  // Retired slots are recycled unless a LIVE agent still queues them (their type/position is read by
+  // the switch penalty and expected-distance terms, :852-861,:1219-1220).  Parallel over slots.
+  DEV void finish_step_parallel(bool gc) {
+    if (gc) {
+      for (int s = lane; s < T; s += WG) {
+        if (S.t_id[s] >= 0 && S.t_status[s] == 2) {
+          const int id = S.t_id[s];
+          bool ref = false;
+          for (int a = 0; a < P.n_agents && !ref; a++) {
+            if (S.a_state[a] == -1) continue;
+            for (int k = 0; k < S.a_qlen[a]; k++) if (S.a_qid[a][k] == id) { ref = true; break; }
+          }
+          if (!ref) {
+            int h = S.t_threat[s];
+            if (h >= 0) { S.h_tflags[h] = S.t_flags[s] & (TF_DEADLINE | TF_COUNTED); S.h_tdeadline[h] = S.t_deadline[s]; }
+            if (S.t_bucket[s] == 0) atomicAdd(&S.n_retired_empty_buckets, 1);
+            S.t_id[s] = -1;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (lane == 0) {
+      int w = 0, no = 0;
+      for (int k = 0; k < S.n_order; k++) {
+        int s = S.t_order[k];
+        if (S.t_id[s] < 0) continue;
+        S.t_order[w++] = s;
+        if (S.t_status[s] != 2) S.open_slot[no++] = s;  // last_tasks_info (:492)
+      }
+      S.n_order = w;
+      S.n_open = no;
+      S.n_act = 0;
+    }
+    __syncthreads();
+  }
+
+  // ====================================================================================================
+  // Observation tensors (:365-415,:468-492), written straight to HBM by all lanes.
+  // ====================================================================================================
+  DEV void write_obs(float* o_tasks, uint8_t* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags) {
+    const int MT = P.max_tasks, nA = P.n_agents;
+    const int n = S.n_open;
+    const double mts = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1);
+    if (o_tasks) {
+      for (int p = lane; p < MT * 21; p += WG) {
+        int j = p / 21, c = p - j * 21;
+        float v = 0.f;
+        if (j < n) {
+          int s = S.open_slot[j];
+          int ty = S.t_type[s];
+          if (c == 0) v = (float)S.t_id[s];
+          else if (c == 1) v = (float)(S.t_px[s] / MAX_COORD);
+          else if (c == 2) v = (float)(S.t_py[s] / MAX_COORD);
+          else if (c == 3) v = (float)S.t_status[s];
+          else if (c < 10) v = (float)S.t_cur[c - 4][s];
+          else if (c < 16) v = (float)S.t_alloc[c - 10][s];
+          else if (c == 16) v = P.include_time_windows ? (float)((S.t_init[s] - (double)S.time_steps) / mts) : 0.f;
+          else if (c == 17) v = P.include_time_windows ? (float)((S.t_dtime[s] - (double)S.time_steps) / mts) : 0.f;
+          else if (c == 18) v = P.include_time_windows ? (float)((double)ty / 6.0) : 0.f;
+          else if (c == 19) { double unmet = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0); v = (float)(unmet / fmax(S.t_org[s], 1e-6)); }
+          else v = (float)fmin(((double)S.time_steps - (double)S.t_created[s]) / mts, 1.0);
+        } else if (j == 0 && n == 0) {
+          v = 0.f;  // the idle task row: id 0, position (0,0), status 0, all reqs 0
+        } else if (c == 3) {
+          v = -1.f;
+        }
+        o_tasks[p] = v;
+      }
+    }
+    const int nrows = n == 0 ? 1 : n;
+    if (o_pad) for (int j = lane; j < MT; j += WG) o_pad[j] = j < nrows;
+    if (o_legal) {
+      for (int p = lane; p < nA * MT; p += WG) {
+        int a = p / MT, j = p - a * MT;
+        uint8_t v = 0;
+        if (n == 0) {
+          v = (j == 0) && (S.a_state[a] != 2 || S.a_qlen[a] == 0);
+        } else if (j < n) {
+          int s = S.open_slot[j];
+          int hid_ = head_id(a);
+          if (S.a_state[a] == 2) v = S.t_id[s] == hid_;
+          else v = action_valid(a, s);
+        }
+        o_legal[p] = v;
+      }
+      __syncthreads();
+      // rows with no legal action fall back to the current task, else column 0 (:401-408)
+      if (n > 0 && lane < nA && S.a_state[lane] != 2) {
+        const int a = lane;
+        bool any = false;
+        for (int j = 0; j < n; j++) any |= action_valid(a, S.open_slot[j]);
+        if (!any) {
+          int cur = S.a_qlen[a] > 0 ? S.a_qid[a][0] : 0, at = 0;
+          for (int j = 0; j < n; j++) if (S.t_id[S.open_slot[j]] == cur) { at = j; break; }
+          o_legal[a * MT + at] = 1;
+        }
+      }
+    }
+    if (o_agents) {
+      for (int p = lane; p < nA * 9; p += WG) {
+        int a = p / 9, c = p - a * 9;
+        float v;
+        if (c == 0) v = (float)(S.a_px[a] / MAX_COORD);
+        else if (c == 1) v = (float)(S.a_py[a] / MAX_COORD);
+        else if (c < 8) v = (float)S.a_caps[c - 2][a];
+        else v = (float)head_id(a);
+        o_agents[p] = v;
+      }
+    }
+    if (o_flags && lane == 0) {  // _event_flag_vector (:417-438)
+      float f = 0, t = 0, r = 0;
+      for (int k = 0; k < S.n_events; k++) {
+        if (S.ev_tag[k] == MUAVTA_EV_AGENT_FAIL) f = 1; else if (S.ev_tag[k] == MUAVTA_EV_NEW_THREAT) t = 1;
+        else if (S.ev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) r = 1;
+      }
+      o_flags[0] = f; o_flags[1] = t; o_flags[2] = r;
+      o_flags[3] = (float)((double)S.time_steps / mts);
+      o_flags[4] = (float)((double)n / (double)(P.max_tasks > 1 ? P.max_tasks : 1));
+    }
+  }
+
+  // ====================================================================================================
+  // HungarianAllocator.allocate_tasks (TaskAllocation/OptimizationBased/HungarianAllocator.py:72-208)
+  // + _open_tasks / _apply_assign glue (experiments/paper_eval.py:85-101, wps_eval.py:55-61).
+  // Result: S.act_agent / S.act_slot / S.act_index, S.n_act.
+  // ====================================================================================================
+  DEV bool is_escort_task(int s) const { return (S.t_flags[s] & TF_ESCORT) || S.t_required[s] > 0; }
+  DEV double residual_demand(int s) const {
+    if (is_escort_task(s)) {
+      double required = S.t_required[s] ? (double)S.t_required[s] : 1.0;
+      return fmax(required - (double)S.t_ndet[s], 0.0);
+    }
+    int ty = S.t_type[s];
+    return fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+  }
+
+  DEV void allocate(int interval, int use_visibility) {
+    __shared__ int sh_go, sh_nr, sh_nc, sh_nopen;
+    interval = interval < 1 ? 1 : interval;
+    if (lane == 0) {
+      S.n_calls++;
+      S.n_act = 0;
+      // should_replan (:27-41): every tag the env emits is in the trigger set
+      bool go = (S.time_steps - S.last_plan_step >= interval) || (S.n_dev > 0);
+      int nfree = 0, nopen = 0;
+      if (go) {
+        for (int a = 0; a < P.n_agents; a++) if (S.a_state[a] != -1) X.freeA[nfree++] = a;
+        for (int k = 0; k < S.n_open; k++) {
+          int s = S.open_slot[k];
+          double r = residual_demand(s);
+          X.resid[s] = r;
+          if (r > 0) nopen++;
+        }
+        if (nfree == 0 || nopen == 0) go = false;
+      }
+      sh_go = go; sh_nr = nfree; sh_nopen = nopen;
+    }
+    __syncthreads();
+    if (!sh_go) return;
+    const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
+    while (true) {
+      if (lane == 0) {  // round_tasks: open tasks (that had residual > 0 initially) with residual > 1e-9
+        int nc = 0;
+        for (int k = 0; k < S.n_open; k++) { int s = S.open_slot[k]; if (X.resid[s] > 1e-9) X.roundT[nc++] = k; }
+        sh_nc = nc;
+      }
+      __syncthreads();
+      const int nr = sh_nr, nc = sh_nc;
+      if (nr == 0 || nc == 0) break;
+      const bool tr = nc < nr;              // scipy transposes so that rows <= cols
+      const int Rr = tr ? nc : nr, Cc = tr ? nr : nc;
+      // ---- cost tile (:137-179), one (agent, task) pair per lane ----
+      for (int p = lane; p < nr * nc; p += WG) {
+        int i = p / nc, j = p - i * nc;
+        int a = X.freeA[i], s = S.open_slot[X.roundT[j]];
+        double c = 1e6;
+        bool ok = !(vis && !((S.known[a][s >> 5] >> (s & 31)) & 1u));
+        if (ok && (S.t_flags[s] & TF_ELIGIBLE) && !((S.t_elig[s] >> S.a_type[a]) & 1u)) ok = false;
+        if (ok) {
+          double urgency = 0.0;
+          if (S.t_flags[s] & TF_DEADLINE) {
+            int remaining = S.t_deadline[s] - S.time_steps;
+            remaining = remaining > 0 ? remaining : 0;
+            urgency = 1.0 - fmin((double)remaining / 40.0, 1.0);
+          }
+          double delivered = is_escort_task(s) ? 1.0 : S.a_caps[S.t_type[s]][a];
+          if (delivered > 0) {  // _cost (:43-70), left-to-right, priority = 0
+            double dist = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
+            double missing = fmax(X.resid[s], 1e-6);
+            double base = dist / fmax(MAX_COORD, 1.0) - 0.5 * fmin(delivered, missing) - 0.4 * 0.0 - 0.6 * urgency;
+            if (base < 1e5 / 2) c = base - 0.0;
+          }
+        }
+        X.cost[tr ? (j * Cc + i) : (i * Cc + j)] = c;
+      }
+      __syncthreads();
+      if (lane == 0) {
+        lsap(Rr, Cc);
+        // accept (:182-204) in ascending agent order (scipy returns rows sorted)
+        int n_acc = 0;
+        for (int i = 0; i < nr; i++) {
+          int j = tr ? X.row4col[i] : X.col4row[i];
+          if (j < 0) continue;
+          double c = X.cost[tr ? (j * Cc + i) : (i * Cc + j)];
+          if (c >= 1e5 / 2) continue;
+          int a = X.freeA[i], oi = X.roundT[j], s = S.open_slot[oi];
+          double delivered = is_escort_task(s) ? 1.0 : S.a_caps[S.t_type[s]][a];
+          int n = S.n_act;
+          S.act_agent[n] = a; S.act_slot[n] = s; S.act_index[n] = oi;
+          S.n_act = n + 1;
+          X.resid[s] = fmax(X.resid[s] - delivered, 0.0);
+          X.freeA[i] = -1;
+          n_acc++;
+        }
+        int w = 0;
+        for (int i = 0; i < nr; i++) if (X.freeA[i] >= 0) X.freeA[w++] = X.freeA[i];
+        sh_nr = n_acc ? w : 0;  // no accept -> stop
+      }
+      __syncthreads();
+    }
+    if (lane == 0) {
+      S.last_plan_step = S.time_steps;
+      S.n_replans++;
+    }
+    __syncthreads();
+  }
+
+  // scipy.optimize.linear_sum_assignment (rectangular_lsap, scipy 1.15.3) on X.cost[nr x nc], nr <= nc.
+  // Lane 0.  Tie rule kept literally: a column replaces the running minimum when strictly lower, or
+  // equal and still unassigned; the scan runs over `remaining` (filled in reverse, swap-removed).
+  DEV void lsap(int nr, int nc) {
+    const double INF = __builtin_huge_val();
+    for (int i = 0; i < nr; i++) { X.u[i] = 0; X.col4row[i] = -1; }
+    for (int j = 0; j < nc; j++) { X.v[j] = 0; X.row4col[j] = -1; X.path[j] = -1; }
+    for (int cur = 0; cur < nr; cur++) {
+      double minVal = 0;
+      int i = cur;
+      int num_remaining = nc;
+      for (int it = 0; it < nc; it++) { X.remaining[it] = nc - it - 1; X.SC[it] = 0; X.spc[it] = INF; }
+      for (int r = 0; r < nr; r++) X.SR[r] = 0;
+      int sink = -1;
+      while (sink == -1) {
+        int index = -1;
+        double lowest = INF;
+        X.SR[i] = 1;
+        const double ui = X.u[i];
+        const double* crow = X.cost + i * nc;
+        for (int it = 0; it < num_remaining; it++) {
+          int j = X.remaining[it];
+          double r = minVal + crow[j] - ui - X.v[j];
+          double sp = X.spc[j];
+          if (r < sp) { X.path[j] = i; X.spc[j] = r; sp = r; }
+          if (sp < lowest || (sp == lowest && X.row4col[j] == -1)) { lowest = sp; index = it; }
+        }
+        minVal = lowest;
+        if (minVal == INF) { fail(MUAVTA_ERR_LSAP); return; }
+        int j = X.remaining[index];
+        if (X.row4col[j] == -1) sink = j; else i = X.row4col[j];
+        X.SC[j] = 1;
+        X.remaining[index] = X.remaining[--num_remaining];
+      }
+      X.u[cur] += minVal;
+      for (int r = 0; r < nr; r++) if (X.SR[r] && r != cur) X.u[r] += minVal - X.spc[X.col4row[r]];
+      for (int j = 0; j < nc; j++) if (X.SC[j]) X.v[j] -= minVal - X.spc[j];
+      int j = sink;
+      while (true) {
+        int r = X.path[j];
+        X.row4col[j] = r;
+        int t = X.col4row[r]; X.col4row[r] = j; j = t;
+        if (r == cur) break;
+      }
+    }
+  }
+
+  // calculate_metrics (:1231-1319) -> out[30]
+  DEV void metrics(double* m) {
+    if (lane != 0) return;
+    double F_quality = S.next_task_id > 1 ? 0.0 : __builtin_nan("");
+    double F_Time = 1.0 / (double)S.conclusion_time * (double)P.max_time_steps;
+    double F_distance = S.total_distance > 0 ? 1 / S.total_distance * MAX_COORD : 0;
+    int Losses = 0, Kills = 0;
+    for (int a = 0; a < P.n_agents; a++) Losses += (S.a_state[a] == -1);
+    for (int k = 0; k < S.n_active_threats; k++) Kills += (S.h_status[S.h_order[k]] == 2);
+    double dist_term = 0.01 * S.total_distance / fmax(MAX_COORD, 1.0);
+    double rematch = P.reassign_penalty * (double)S.n_task_switches;
+    double s_wps = 12.0 * (double)S.n_on_time - 30.0 * (double)S.n_missed_windows - dist_term - rematch;
+    int req = S.escort_required_steps > 1 ? S.escort_required_steps : 1;
+    double escort_cov = (double)S.escort_covered_steps / (double)req;
+    double s_esc = s_wps + 20.0 * (double)S.protected_rec_completed - 30.0 * (double)S.recon_losses + 20.0 * escort_cov;
+    int k = 0;
+    m[k++] = F_Time; m[k++] = F_distance; m[k++] = F_quality; m[k++] = S.F_Reward; m[k++] = s_wps; m[k++] = s_esc;
+    m[k++] = Losses; m[k++] = Kills; m[k++] = S.conclusion_time; m[k++] = S.total_distance; m[k++] = S.n_reallocations;
+    m[k++] = S.n_task_switches; m[k++] = S.n_arrivals; m[k++] = S.next_task_id - 1; m[k++] = S.n_reached;
+    m[k++] = S.n_missed_windows; m[k++] = S.n_on_time; m[k++] = S.n_windowed_tasks;
+    int den = S.n_on_time + S.n_missed_windows; den = den > 1 ? den : 1;
+    m[k++] = (double)S.n_on_time / (double)den;
+    int den2 = S.time_steps * (P.n_agents > 1 ? P.n_agents : 1); den2 = den2 > 1 ? den2 : 1;
+    m[k++] = (double)S.idle_reserve_steps / (double)den2;
+    m[k++] = escort_cov; m[k++] = S.protected_rec_completed; m[k++] = S.recon_losses; m[k++] = S.escort_losses;
+    m[k++] = S.threats_intercepted; m[k++] = S.mutual_support_engagements; m[k++] = S.protection_breaches;
+    m[k++] = S.escort_requests; m[k++] = S.escort_completed; m[k++] = S.escort_failed;
+  }
+};
+
+}  // namespace muavta

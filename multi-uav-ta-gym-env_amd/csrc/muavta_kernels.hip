@@ -1,0 +1,888 @@
+// muavta_kernels.hip — gfx950 kernels + the C ABI of include/muavta.h.
+//
+// One workgroup (one wave64) simulates one env instance with its state blob resident in LDS
+// (see muavta_device.h).  Kernels:
+//   k_reset     seeds -> initial state                              (MultiUAVEnv.reset)
+//   k_step      load blob -> apply actions + step -> store blob     (MultiUAVEnv.step)
+//   k_allocate  load blob -> Local-Hungarian -> staged actions      (HungarianAllocator.allocate_tasks)
+//   k_rollout   [reset] + n x (allocate -> step) in ONE launch, blob never leaves LDS in between
+//   k_metrics   calculate_metrics for every env
+//   k_lsap / k_avoid   stand-alone solver / obstacle-avoidance entry points
+// There is no CPU fallback: without a HIP device every entry point fails with MUAVTA_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "muavta_device.h"
+
+using namespace muavta;
+
+namespace {
+
+struct ObsPtrs {
+  float* tasks;    // [N, max_tasks, 21]
+  uint8_t* legal;  // [N, A, max_tasks]
+  uint8_t* pad;    // [N, max_tasks]
+  float* agents;   // [N, A, 9]
+  float* flags;    // [N, 5]
+  double* reward;  // [N]
+  uint8_t* done;   // [N]
+};
+
+template <class TL>
+__device__ __forceinline__ void obs_for_env(Sim<TL>& sim, const DevParams& P, const ObsPtrs& O, int env) {
+  const size_t mt = (size_t)P.max_tasks, nA = (size_t)P.n_agents;
+  sim.write_obs(O.tasks + (size_t)env * mt * 21, O.legal + (size_t)env * nA * mt, O.pad + (size_t)env * mt,
+                O.agents + (size_t)env * nA * 9, O.flags + (size_t)env * 5);
+  if (threadIdx.x == 0) {
+    O.reward[env] = sim.S.last_reward;
+    O.done[env] = (uint8_t)((sim.S.terminated ? 1 : 0) | (sim.S.truncated ? 2 : 0));
+  }
+}
+
+// 16-byte-per-lane coalesced copy between the HBM blob and LDS.
+__device__ __forceinline__ void copy16(void* dst, const void* src, int bytes) {
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+  for (int i = threadIdx.x; i < bytes / 16; i += WG) d[i] = s[i];
+}
+
+template <class TL>
+struct Lds {
+  EnvState<TL>* S;
+  Scratch<TL>* X;
+  __device__ Lds(unsigned char* smem) {
+    S = reinterpret_cast<EnvState<TL>*>(smem);
+    X = reinterpret_cast<Scratch<TL>*>(smem + ((sizeof(EnvState<TL>) + 15) & ~size_t(15)));
+  }
+  static size_t bytes() { return ((sizeof(EnvState<TL>) + 15) & ~size_t(15)) + sizeof(Scratch<TL>); }
+};
+
+extern __shared__ __align__(16) unsigned char smem[];
+
+template <class TL>
+__global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, ObsPtrs O) {
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  sim.reset(seeds[env]);
+  obs_for_env(sim, P, O, env);
+  __syncthreads();
+  copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
+}
+
+// act_agent == nullptr: use the actions staged in the blob by k_allocate
+template <class TL>
+__global__ __launch_bounds__(WG) void k_step(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, const int32_t* act_agent,
+                                             const int32_t* act_index, int act_cap, ObsPtrs O) {
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  __syncthreads();
+  Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  if (act_agent && threadIdx.x == 0) {
+    EnvState<TL>& S = *L.S;
+    int n = 0;
+    for (int k = 0; k < act_cap && n < TL::A; k++) {
+      int a = act_agent[(size_t)env * act_cap + k];
+      if (a < 0) break;
+      int idx = act_index[(size_t)env * act_cap + k];
+      if (idx < 0) idx += S.n_open;  // python negative indexing into last_tasks_info
+      S.act_agent[n] = a;
+      S.act_slot[n] = (idx >= 0 && idx < S.n_open) ? S.open_slot[idx] : -1;
+      S.act_index[n] = idx;
+      n++;
+    }
+    S.n_act = n;
+  }
+  __syncthreads();
+  sim.step(true);
+  obs_for_env(sim, P, O, env);
+  __syncthreads();
+  copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
+}
+
+template <class TL>
+__global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, int interval, int use_vis,
+                                                 int32_t* out_agent, int32_t* out_index, int act_cap) {
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  __syncthreads();
+  Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  sim.allocate(interval, use_vis);
+  __syncthreads();
+  if (out_agent) {
+    const EnvState<TL>& S = *L.S;
+    for (int k = threadIdx.x; k < act_cap; k += WG) {
+      out_agent[(size_t)env * act_cap + k] = k < S.n_act ? S.act_agent[k] : -1;
+      out_index[(size_t)env * act_cap + k] = k < S.n_act ? S.act_index[k] : 0;
+    }
+  }
+  copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
+}
+
+template <class TL>
+__global__ __launch_bounds__(WG) void k_rollout(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, int n_steps,
+                                                int interval, int use_vis, int write_obs, ObsPtrs O, double* metrics) {
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  if (seeds) {
+    sim.reset(seeds[env]);
+  } else {
+    copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+    __syncthreads();
+  }
+  for (int t = 0; t < n_steps; t++) {
+    if (L.S->terminated || L.S->truncated) break;  // uniform: read from LDS after a barrier
+    sim.allocate(interval, use_vis);
+    sim.step(true);
+    if (write_obs) obs_for_env(sim, P, O, env);
+    __syncthreads();
+  }
+  if (!write_obs) obs_for_env(sim, P, O, env);
+  sim.metrics(metrics + (size_t)env * MUAVTA_N_METRICS);
+  __syncthreads();
+  copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
+}
+
+template <class TL>
+__global__ __launch_bounds__(WG) void k_metrics(DevParams P, EnvState<TL>* blobs, double* metrics) {
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  __syncthreads();
+  Sim<TL> sim(*L.S, *L.X, P, nullptr);
+  sim.metrics(metrics + (size_t)env * MUAVTA_N_METRICS);
+}
+
+template <class TL>
+__global__ __launch_bounds__(WG) void k_observe(DevParams P, EnvState<TL>* blobs, ObsPtrs O) {
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  __syncthreads();
+  Sim<TL> sim(*L.S, *L.X, P, nullptr);
+  obs_for_env(sim, P, O, env);
+}
+
+// Stand-alone LSAP: one problem per workgroup, cost tile staged in LDS (transposed when nc < nr).
+__global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc, int64_t* row, int64_t* col) {
+  typedef Tile64 TL;
+  Lds<TL> L(smem);
+  DevParams dummy;
+  Sim<TL> sim(*L.S, *L.X, dummy, nullptr);
+  const int prob = blockIdx.x;
+  const double* c = cost + (size_t)prob * nr * nc;
+  const bool tr = nc < nr;
+  const int Rr = tr ? nc : nr, Cc = tr ? nr : nc;
+  for (int p = threadIdx.x; p < nr * nc; p += WG) {
+    int i = p / nc, j = p - i * nc;
+    L.X->cost[tr ? (j * Cc + i) : (i * Cc + j)] = c[p];
+  }
+  if (threadIdx.x == 0) L.S->error = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    sim.lsap(Rr, Cc);
+    int64_t* r = row + (size_t)prob * Rr;
+    int64_t* cc = col + (size_t)prob * Rr;
+    int n = 0;
+    if (!tr) { for (int i = 0; i < nr; i++) { r[n] = i; cc[n] = L.X->col4row[i]; n++; } }
+    else { for (int i = 0; i < nr; i++) if (L.X->row4col[i] >= 0) { r[n] = i; cc[n] = L.X->row4col[i]; n++; } }
+  }
+}
+
+__global__ void k_avoid(const double* pos, const double* mov, int n, const double* obst, int n_obs, double* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // same arithmetic as Sim::avoid_obstacles (core_sim/src/sim_core.rs:25-59)
+  double px = pos[2 * i], py = pos[2 * i + 1], mx = mov[2 * i], my = mov[2 * i + 1];
+  double ax = 0.0, ay = 0.0;
+  const double PI = 3.14159265358979323846;
+  for (int o = 0; o < n_obs; o++) {
+    double dx = obst[3 * o] - px, dy = obst[3 * o + 1] - py;
+    double d_zone = sqrt(dx * dx + dy * dy) - obst[3 * o + 2];
+    if (d_zone < 40.0) {
+      double nx = dx / d_zone, ny = dy / d_zone;
+      double force = log(fmax(1.05, d_zone));
+      force = 0.5 / (1.0 - force);
+      double ang = atan2(my, mx) - atan2(dy, dx);
+      ang = fmod(ang + PI, 2.0 * PI) - PI;
+      double rx, ry;
+      if (ang > 0.0) { rx = ny; ry = -nx; } else { rx = -ny; ry = nx; }
+      ax += rx * force;
+      ay += ry * force;
+    }
+  }
+  out[2 * i] = ax;
+  out[2 * i + 1] = ay;
+}
+
+// ====================================================================================================
+// Host side
+// ====================================================================================================
+thread_local std::string g_create_error;
+
+#define HIPCHK(env, expr)                                                                         \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) {                                                                       \
+      (env)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                             \
+      return MUAVTA_E_HIP;                                                                        \
+    }                                                                                             \
+  } while (0)
+
+enum TileKind { TK16 = 0, TK24 = 1, TK64 = 2 };
+
+}  // namespace
+
+struct MuavtaEnv {
+  DevParams P;
+  MuavtaParams params;
+  int tile = TK16;
+  int n_envs = 0, device = 0;
+  int A = 0, T = 0, H = 0, E = 0, R = 0;
+  size_t state_bytes = 0, lds_bytes = 0;
+  void* blobs = nullptr;
+  uint32_t* tapes = nullptr;
+  uint64_t* d_seeds = nullptr;
+  int32_t *d_act_agent = nullptr, *d_act_index = nullptr;
+  double* d_metrics = nullptr;
+  ObsPtrs O{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float last_ms = 0.f;
+  bool did_reset = false;
+  std::vector<unsigned char> host_blobs;  // cache for muavta_get
+  bool host_valid = false;
+  std::string err;
+};
+
+namespace {
+
+template <class TL>
+int launch_attr(MuavtaEnv* e) {
+  size_t lds = Lds<TL>::bytes();
+  e->lds_bytes = lds;
+  if (lds > 48 * 1024) {
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reset<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_allocate<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_metrics<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_observe<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  return MUAVTA_OK;
+}
+
+#define DISPATCH(e, CALL)                    \
+  switch ((e)->tile) {                       \
+    case TK16: { typedef Tile16 TL; CALL; } break; \
+    case TK24: { typedef Tile24 TL; CALL; } break; \
+    default:   { typedef Tile64 TL; CALL; } break; \
+  }
+
+int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
+  memset(d, 0, sizeof(*d));
+  if (p->abi_version != MUAVTA_ABI_VERSION) { *err = "abi_version mismatch"; return MUAVTA_E_ARG; }
+  if (p->n_agent_groups < 1 || p->n_agent_groups > MUAVTA_MAX_GROUPS || p->n_task_groups < 0 || p->n_task_groups > MUAVTA_MAX_GROUPS ||
+      p->n_threat_groups < 0 || p->n_threat_groups > MUAVTA_MAX_GROUPS) { *err = "group counts out of range"; return MUAVTA_E_ARG; }
+  d->n_agent_groups = p->n_agent_groups; d->n_task_groups = p->n_task_groups; d->n_threat_groups = p->n_threat_groups;
+  int nA = 0, nT = 0, nH = 0;
+  double possible = 0;  // DroneEnv.py:670-675, summed in task creation order
+  for (int g = 0; g < p->n_agent_groups; g++) {
+    if (p->agent_type[g] < 0 || p->agent_type[g] > MUAVTA_F2 || p->agent_count[g] < 0) { *err = "bad agent group"; return MUAVTA_E_ARG; }
+    d->agent_type[g] = p->agent_type[g]; d->agent_count[g] = p->agent_count[g]; nA += p->agent_count[g];
+  }
+  for (int g = 0; g < p->n_task_groups; g++) {
+    int ty = p->task_type[g];
+    if (ty != MUAVTA_HOLD && ty != MUAVTA_REC && ty != MUAVTA_ATT) { *err = "static task types are Hold/Rec/Att"; return MUAVTA_E_ARG; }
+    d->task_type[g] = ty; d->task_count[g] = p->task_count[g]; nT += p->task_count[g];
+    for (int i = 0; i < p->task_count[g]; i++) possible += 1.0;
+  }
+  for (int g = 0; g < p->n_threat_groups; g++) {
+    int ty = p->threat_type[g];
+    if (ty != MUAVTA_T1 && ty != MUAVTA_T2) { *err = "threat types are T1/T2"; return MUAVTA_E_ARG; }
+    d->threat_type[g] = ty; d->threat_count[g] = p->threat_count[g]; nH += p->threat_count[g];
+    possible += (double)p->threat_count[g];
+  }
+  if (nA < 1) { *err = "no agents"; return MUAVTA_E_ARG; }
+  if (p->num_obstacles < 0 || p->num_obstacles > 8) { *err = "num_obstacles must be in 0..8"; return MUAVTA_E_ARG; }
+  if (p->max_time_steps < 1) { *err = "max_time_steps must be >= 1"; return MUAVTA_E_ARG; }
+  d->n_agents = nA; d->n_tasks = nT + 1; d->max_tasks = d->n_tasks + 28; d->n_threats = nH;
+  d->max_time_steps = p->max_time_steps; d->multiple_tasks_per_agent = p->multiple_tasks_per_agent;
+  d->early_terminate = p->early_terminate; d->capability_mask = p->capability_mask; d->saturate_mask = p->saturate_mask;
+  d->include_time_windows = p->include_time_windows; d->threat_delay = p->threat_delay; d->hard_windows = p->hard_windows;
+  d->window_length = p->window_length; d->burst_mode = p->burst_mode; d->burst_size = p->burst_size;
+  d->dual_region_bursts = p->dual_region_bursts; d->share_knowledge = p->share_knowledge; d->escort_enabled = p->escort_enabled;
+  d->num_obstacles = p->num_obstacles; d->random_init_pos = p->random_init_pos;
+  int need = (int)std::ceil(p->escort_requirement);
+  d->escort_required_agents = need > 2 ? need : 2;
+  d->escort_mask = p->escort_agent_type_mask;
+  static const double MAX_SPEED[7] = {5.0, 8.0, 5.0, 20.0, 15.0, 14.0, 12.0};  // MultiDroneEnvData.py:32-38
+  for (int t = 0; t < 7; t++) d->speed[t] = MAX_SPEED[t] / p->simulation_frame_rate * 0.02;
+  d->threat_prob = 0.7 / p->simulation_frame_rate * 0.02;
+  d->reward_norm_factor = (possible * 1 + possible) / 1000;
+  d->fail_rate = p->fail_rate; d->arrival_rate = p->arrival_rate; d->dynamic_idle_penalty = p->dynamic_idle_penalty;
+  d->sense_radius = p->sense_radius; d->miss_penalty = p->miss_penalty; d->on_time_bonus = p->on_time_bonus;
+  d->reassign_penalty = p->reassign_penalty; d->escort_radius = p->escort_radius; d->escort_requirement = p->escort_requirement;
+  d->escort_intercept_radius = p->escort_intercept_radius; d->mutual_support_radius = p->mutual_support_radius;
+  for (int i = 0; i < 8; i++) d->rw[i] = p->reward_weights[i];
+  return MUAVTA_OK;
+}
+
+template <class TL>
+size_t blob_bytes() { return sizeof(EnvState<TL>); }
+
+int sync_host(MuavtaEnv* e) {
+  if (e->host_valid) return MUAVTA_OK;
+  e->host_blobs.resize((size_t)e->n_envs * e->state_bytes);
+  HIPCHK(e, hipMemcpyAsync(e->host_blobs.data(), e->blobs, e->host_blobs.size(), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->host_valid = true;
+  return MUAVTA_OK;
+}
+
+// Gather one field out of the host copy of the blobs.
+template <class TL>
+int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
+  typedef EnvState<TL> St;
+  const int N = e->n_envs, A = e->P.n_agents, T = TL::T, H = e->P.n_threats, Q = TL::Q, E = TL::E, KW = TL::KW;
+  St* blobs = reinterpret_cast<St*>(e->host_blobs.data());
+  size_t need = 0;
+  auto chk = [&](size_t n) { need = n; return bytes == n; };
+  double* D = (double*)dst;
+  int32_t* I = (int32_t*)dst;
+  uint32_t* U = (uint32_t*)dst;
+#define BAD() do { e->err = "muavta_get/set: buffer size mismatch, need " + std::to_string(need) + " bytes"; return MUAVTA_E_ARG; } while (0)
+#define RW(dstv, srcv) do { if (scatter) (srcv) = (dstv); else (dstv) = (srcv); } while (0)
+  switch (f) {
+    case MUAVTA_F_AGENT_POS:
+      if (!chk((size_t)N * A * 2 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) { RW(D[((size_t)n * A + a) * 2], blobs[n].a_px[a]); RW(D[((size_t)n * A + a) * 2 + 1], blobs[n].a_py[a]); }
+      break;
+    case MUAVTA_F_AGENT_NFP:
+      if (!chk((size_t)N * A * 2 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) { RW(D[((size_t)n * A + a) * 2], blobs[n].a_nfx[a]); RW(D[((size_t)n * A + a) * 2 + 1], blobs[n].a_nfy[a]); }
+      break;
+    case MUAVTA_F_AGENT_NFT:
+      if (!chk((size_t)N * A * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) RW(D[(size_t)n * A + a], blobs[n].a_nft[a]);
+      break;
+    case MUAVTA_F_AGENT_DIST:
+      if (!chk((size_t)N * A * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) RW(D[(size_t)n * A + a], blobs[n].a_dist[a]);
+      break;
+    case MUAVTA_F_AGENT_CAPS:
+      if (!chk((size_t)N * A * 6 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) for (int c = 0; c < 6; c++) RW(D[((size_t)n * A + a) * 6 + c], blobs[n].a_caps[c][a]);
+      break;
+    case MUAVTA_F_AGENT_STATE:
+      if (!chk((size_t)N * A * 4)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) RW(I[(size_t)n * A + a], blobs[n].a_state[a]);
+      break;
+    case MUAVTA_F_AGENT_HEAD:
+      if (!chk((size_t)N * A * 4)) BAD();
+      if (scatter) { e->err = "AGENT_HEAD is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) I[(size_t)n * A + a] = blobs[n].a_qlen[a] > 0 ? blobs[n].a_qid[a][0] : 0;
+      break;
+    case MUAVTA_F_AGENT_QUEUE:
+      if (!chk((size_t)N * A * Q * 4)) BAD();
+      if (scatter) { e->err = "AGENT_QUEUE is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) for (int k = 0; k < Q; k++)
+        I[((size_t)n * A + a) * Q + k] = k < blobs[n].a_qlen[a] ? blobs[n].a_qid[a][k] : (k == 0 ? 0 : -1);
+      break;
+    case MUAVTA_F_AGENT_ATTACK_CAP:
+      if (!chk((size_t)N * A * 4)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) RW(I[(size_t)n * A + a], blobs[n].a_acap[a]);
+      break;
+    case MUAVTA_F_AGENT_TYPE:
+      if (!chk((size_t)N * A * 4)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) RW(I[(size_t)n * A + a], blobs[n].a_type[a]);
+      break;
+    case MUAVTA_F_AGENT_NAME_IDX:
+      if (!chk((size_t)N * A * 4)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) RW(I[(size_t)n * A + a], blobs[n].a_name[a]);
+      break;
+    case MUAVTA_F_AGENT_MISC:
+      if (!chk((size_t)N * A * 6 * 4)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) {
+        int32_t* r = I + ((size_t)n * A + a) * 6;
+        RW(r[0], blobs[n].a_task_start[a]); RW(r[1], blobs[n].a_fail[a]); RW(r[2], blobs[n].a_reeval[a]);
+        RW(r[3], blobs[n].a_last_id[a]); RW(r[4], blobs[n].a_commit[a]);
+        if (!scatter) r[5] = blobs[n].a_qlen[a];
+      }
+      break;
+    case MUAVTA_F_TASK_ID:
+      if (!chk((size_t)N * T * 4)) BAD();
+      if (scatter) { e->err = "TASK_ID is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) I[(size_t)n * T + s] = blobs[n].t_id[s];
+      break;
+    case MUAVTA_F_TASK_STATUS:
+      if (!chk((size_t)N * T * 4)) BAD();
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) RW(I[(size_t)n * T + s], blobs[n].t_status[s]);
+      break;
+    case MUAVTA_F_TASK_POS:
+      if (!chk((size_t)N * T * 2 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) { RW(D[((size_t)n * T + s) * 2], blobs[n].t_px[s]); RW(D[((size_t)n * T + s) * 2 + 1], blobs[n].t_py[s]); }
+      break;
+    case MUAVTA_F_TASK_CUR:
+      if (!chk((size_t)N * T * 6 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) for (int c = 0; c < 6; c++) RW(D[((size_t)n * T + s) * 6 + c], blobs[n].t_cur[c][s]);
+      break;
+    case MUAVTA_F_TASK_ALLOC:
+      if (!chk((size_t)N * T * 6 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) for (int c = 0; c < 6; c++) RW(D[((size_t)n * T + s) * 6 + c], blobs[n].t_alloc[c][s]);
+      break;
+    case MUAVTA_F_TASK_ORG_DONE:
+      if (!chk((size_t)N * T * 2 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) { RW(D[((size_t)n * T + s) * 2], blobs[n].t_org[s]); RW(D[((size_t)n * T + s) * 2 + 1], blobs[n].t_done[s]); }
+      break;
+    case MUAVTA_F_TASK_TIMES:
+      if (!chk((size_t)N * T * 2 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) { RW(D[((size_t)n * T + s) * 2], blobs[n].t_init[s]); RW(D[((size_t)n * T + s) * 2 + 1], blobs[n].t_dtime[s]); }
+      break;
+    case MUAVTA_F_TASK_META:
+      if (!chk((size_t)N * T * 8 * 4)) BAD();
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) {
+        int32_t* r = I + ((size_t)n * T + s) * 8;
+        St& b = blobs[n];
+        if (scatter) { b.t_required[s] = r[3]; continue; }  // required_agents is the only field callers write (test_escort.py:107)
+        r[0] = b.t_type[s]; r[1] = (b.t_flags[s] & TF_DEADLINE) ? b.t_deadline[s] : -1; r[2] = b.t_created[s]; r[3] = b.t_required[s];
+        r[4] = (b.t_flags[s] & TF_ESCORT) ? 1 : 0; r[5] = b.t_ndet[s]; r[6] = b.t_prot_agent[s];
+        r[7] = (b.t_flags[s] & TF_ELIGIBLE) ? (int32_t)b.t_elig[s] : -1;
+      }
+      break;
+    case MUAVTA_F_KNOWN:
+      if (!chk((size_t)N * A * KW * 4)) BAD();
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) for (int w = 0; w < KW; w++) RW(U[((size_t)n * A + a) * KW + w], blobs[n].known[a][w]);
+      break;
+    case MUAVTA_F_THREAT_POS:
+      if (!chk((size_t)N * H * 2 * 8)) BAD();
+      for (int n = 0; n < N; n++) for (int h = 0; h < H; h++) { RW(D[((size_t)n * H + h) * 2], blobs[n].h_px[h]); RW(D[((size_t)n * H + h) * 2 + 1], blobs[n].h_py[h]); }
+      break;
+    case MUAVTA_F_THREAT_META:
+      if (!chk((size_t)N * H * 6 * 4)) BAD();
+      if (scatter) { e->err = "THREAT_META is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int h = 0; h < H; h++) {
+        int32_t* r = I + ((size_t)n * H + h) * 6;
+        St& b = blobs[n];
+        r[0] = b.h_status[h]; r[1] = b.h_target[h]; r[2] = b.h_mission[h]; r[3] = b.h_acap[h]; r[4] = b.h_task_id[h]; r[5] = b.h_type[h];
+      }
+      break;
+    case MUAVTA_F_SCALARS:
+      if (!chk((size_t)N * MUAVTA_N_SCALARS * 8)) BAD();
+      if (scatter) { e->err = "SCALARS is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) {
+        St& b = blobs[n];
+        double* s = D + (size_t)n * MUAVTA_N_SCALARS;
+        s[0] = b.time_steps; s[1] = b.last_reward; s[2] = b.F_Reward; s[3] = b.total_distance; s[4] = b.n_on_time;
+        s[5] = b.n_missed_windows; s[6] = b.n_windowed_tasks; s[7] = b.n_task_switches; s[8] = b.n_reallocations;
+        s[9] = b.n_arrivals; s[10] = b.idle_reserve_steps; s[11] = b.conclusion_time; s[12] = b.escort_requests;
+        s[13] = b.escort_completed; s[14] = b.escort_failed; s[15] = b.escort_required_steps; s[16] = b.escort_covered_steps;
+        s[17] = b.protection_breaches; s[18] = b.threats_intercepted; s[19] = b.recon_losses; s[20] = b.escort_losses;
+        s[21] = b.mutual_support_engagements; s[22] = b.protected_rec_completed; s[23] = b.n_replans;
+        s[24] = b.pending_reset; s[25] = b.n_reached; s[26] = b.n_pending; s[27] = b.next_task_id - 1;
+      }
+      break;
+    case MUAVTA_F_OPEN_IDS:
+      if (!chk((size_t)N * T * 4)) BAD();
+      if (scatter) { e->err = "OPEN_IDS is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int k = 0; k < T; k++) I[(size_t)n * T + k] = k < blobs[n].n_open ? blobs[n].t_id[blobs[n].open_slot[k]] : -1;
+      break;
+    case MUAVTA_F_EVENTS:
+      if (!chk((size_t)N * E * 2 * 4)) BAD();
+      if (scatter) { e->err = "EVENTS is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int k = 0; k < E; k++) {
+        I[((size_t)n * E + k) * 2] = k < blobs[n].n_dev ? blobs[n].dev_tag[k] : -1;
+        I[((size_t)n * E + k) * 2 + 1] = k < blobs[n].n_dev ? blobs[n].dev_arg[k] : 0;
+      }
+      break;
+    case MUAVTA_F_EVENT_LIST:
+      if (!chk((size_t)N * E * 2 * 4)) BAD();
+      if (scatter) { e->err = "EVENT_LIST is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int k = 0; k < E; k++) {
+        I[((size_t)n * E + k) * 2] = k < blobs[n].n_events ? blobs[n].ev_tag[k] : -1;
+        I[((size_t)n * E + k) * 2 + 1] = k < blobs[n].n_events ? blobs[n].ev_arg[k] : 0;
+      }
+      break;
+    case MUAVTA_F_STAGED_ACTIONS:
+      if (!chk((size_t)N * TL::A * 3 * 4)) BAD();
+      if (scatter) { e->err = "STAGED_ACTIONS is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int k = 0; k < TL::A; k++) {
+        St& b = blobs[n];
+        int32_t* r = I + ((size_t)n * TL::A + k) * 3;
+        bool v = k < b.n_act;
+        r[0] = v ? b.act_agent[k] : -1; r[1] = v && b.act_slot[k] >= 0 ? b.t_id[b.act_slot[k]] : -1; r[2] = v ? b.act_index[k] : -1;
+      }
+      break;
+    case MUAVTA_F_ERROR:
+      if (!chk((size_t)N * 4)) BAD();
+      if (scatter) { e->err = "ERROR is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) I[n] = blobs[n].error;
+      break;
+    default:
+      e->err = "unknown field";
+      return MUAVTA_E_ARG;
+  }
+#undef BAD
+#undef RW
+  return MUAVTA_OK;
+}
+
+template <class TL>
+int check_errors(MuavtaEnv* e) {  // scan the per-env error words after a synchronising call
+  typedef EnvState<TL> St;
+  St* blobs = reinterpret_cast<St*>(e->host_blobs.data());
+  for (int n = 0; n < e->n_envs; n++)
+    if (blobs[n].error) {
+      e->err = "env " + std::to_string(n) + " overflowed a tile (code " + std::to_string(blobs[n].error) +
+               ": 1=task slots 2=agent queue 3=events 4=pending reveals 5=random_position 6=escorts 7=lsap)";
+      return MUAVTA_E_CAPACITY;
+    }
+  return MUAVTA_OK;
+}
+
+}  // namespace
+
+// ====================================================================================================
+// C ABI
+// ====================================================================================================
+extern "C" {
+
+const char* muavta_last_error(const MuavtaEnv* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
+
+int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, MuavtaEnv** out) {
+  if (!params || !out || n_envs < 1) { g_create_error = "muavta_create: bad arguments"; return MUAVTA_E_ARG; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) {
+    g_create_error = "muavta_create: no HIP device visible; this library is the MI355X path and has no CPU fallback";
+    return MUAVTA_E_NO_DEVICE;
+  }
+  if (device < 0 || device >= ndev) { g_create_error = "muavta_create: device index out of range"; return MUAVTA_E_ARG; }
+  MuavtaEnv* e = new (std::nothrow) MuavtaEnv();
+  if (!e) { g_create_error = "out of memory"; return MUAVTA_E_ARG; }
+  int rc = fill_dev_params(params, &e->P, &g_create_error);
+  if (rc) { delete e; return rc; }
+  e->params = *params;
+  e->n_envs = n_envs;
+  e->device = device;
+  int ta = params->tile_agents > e->P.n_agents ? params->tile_agents : e->P.n_agents;
+  int tt = params->tile_tasks > 0 ? params->tile_tasks : 32;
+  int th = params->tile_threats > e->P.n_threats ? params->tile_threats : e->P.n_threats;
+  if (ta <= Tile16::A && tt <= Tile16::T && th <= Tile16::H) e->tile = TK16;
+  else if (ta <= Tile24::A && tt <= Tile24::T && th <= Tile24::H) e->tile = TK24;
+  else if (ta <= Tile64::A && tt <= Tile64::T && th <= Tile64::H) e->tile = TK64;
+  else { g_create_error = "muavta_create: requested tile exceeds 64 agents x 128 task slots x 48 threats"; delete e; return MUAVTA_E_ARG; }
+  DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->state_bytes = sizeof(EnvState<TL>); });
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); muavta_destroy(e); return MUAVTA_E_HIP; } } while (0)
+  CK(hipSetDevice(device));
+  CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+  CK(hipEventCreate(&e->ev0));
+  CK(hipEventCreate(&e->ev1));
+  const size_t N = (size_t)n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
+  CK(hipMalloc(&e->blobs, N * e->state_bytes));
+  CK(hipMemsetAsync(e->blobs, 0, N * e->state_bytes, e->stream));
+  CK(hipMalloc(&e->tapes, N * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * sizeof(uint32_t)));
+  CK(hipMalloc(&e->d_seeds, N * sizeof(uint64_t)));
+  CK(hipMalloc(&e->d_act_agent, N * e->A * sizeof(int32_t)));
+  CK(hipMalloc(&e->d_act_index, N * e->A * sizeof(int32_t)));
+  CK(hipMalloc(&e->d_metrics, N * MUAVTA_N_METRICS * sizeof(double)));
+  CK(hipMalloc(&e->O.tasks, N * mt * 21 * sizeof(float)));
+  CK(hipMalloc(&e->O.legal, N * nA * mt));
+  CK(hipMalloc(&e->O.pad, N * mt));
+  CK(hipMalloc(&e->O.agents, N * nA * 9 * sizeof(float)));
+  CK(hipMalloc(&e->O.flags, N * 5 * sizeof(float)));
+  CK(hipMalloc(&e->O.reward, N * sizeof(double)));
+  CK(hipMalloc(&e->O.done, N));
+#undef CK
+  int arc = MUAVTA_OK;
+  DISPATCH(e, arc = launch_attr<TL>(e));
+  if (arc) { g_create_error = e->err; muavta_destroy(e); return arc; }
+  *out = e;
+  return MUAVTA_OK;
+}
+
+int muavta_destroy(MuavtaEnv* e) {
+  if (!e) return MUAVTA_OK;
+  hipSetDevice(e->device);
+  if (e->stream) hipStreamSynchronize(e->stream);
+  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics);
+  hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
+  if (e->ev0) hipEventDestroy(e->ev0);
+  if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->stream) hipStreamDestroy(e->stream);
+  delete e;
+  return MUAVTA_OK;
+}
+
+int muavta_dims(const MuavtaEnv* e, MuavtaDims* d) {
+  if (!e || !d) return MUAVTA_E_ARG;
+  d->n_envs = e->n_envs; d->n_agents = e->P.n_agents; d->tile_agents = e->A; d->tile_tasks = e->T; d->tile_threats = e->H;
+  d->max_tasks = e->P.max_tasks; d->obs_task_width = 21; d->obs_agent_width = 9; d->queue_cap = MUAVTA_QCAP; d->event_cap = e->E;
+  d->action_cap = e->A; d->state_bytes = (int64_t)e->state_bytes;
+  d->n_threats = e->P.n_threats; d->known_words = (e->T + 31) / 32; d->lds_bytes = (int32_t)e->lds_bytes; d->reserved = 0;
+  return MUAVTA_OK;
+}
+
+int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
+  if (!e || !seeds) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, e->d_seeds,
+                                 (EnvState<TL>*)e->blobs, e->tapes, e->O));
+  HIPCHK(e, hipGetLastError());
+  e->did_reset = true;
+  e->host_valid = false;
+  return MUAVTA_OK;
+}
+
+static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
+  if (!e->did_reset) { e->err = "step before reset"; return MUAVTA_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  const int32_t *da = nullptr, *di = nullptr;
+  if (aa) {
+    size_t bytes = (size_t)e->n_envs * e->A * sizeof(int32_t);
+    HIPCHK(e, hipMemcpyAsync(e->d_act_agent, aa, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_act_index, ai, bytes, hipMemcpyHostToDevice, e->stream));
+    da = e->d_act_agent; di = e->d_act_index;
+  }
+  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs,
+                                 e->tapes, da, di, e->A, e->O));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
+  return MUAVTA_OK;
+}
+
+int muavta_step(MuavtaEnv* e, const int32_t* act_agent, const int32_t* act_index) {
+  if (!e || !act_agent || !act_index) return MUAVTA_E_ARG;
+  return step_impl(e, act_agent, act_index);
+}
+int muavta_step_staged(MuavtaEnv* e) {
+  if (!e) return MUAVTA_E_ARG;
+  return step_impl(e, nullptr, nullptr);
+}
+
+int muavta_allocate(MuavtaEnv* e, int32_t interval, int32_t use_vis, int32_t* act_agent, int32_t* act_index) {
+  if (!e) return MUAVTA_E_ARG;
+  if (!e->did_reset) { e->err = "allocate before reset"; return MUAVTA_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs,
+                                 e->tapes, interval, use_vis, e->d_act_agent, e->d_act_index, e->A));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
+  if (act_agent && act_index) {
+    size_t bytes = (size_t)e->n_envs * e->A * sizeof(int32_t);
+    HIPCHK(e, hipMemcpyAsync(act_agent, e->d_act_agent, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(act_index, e->d_act_index, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+  }
+  return MUAVTA_OK;
+}
+
+int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t interval, int32_t use_vis, int32_t write_obs) {
+  if (!e || n_steps < 0) return MUAVTA_E_ARG;
+  if (!seeds && !e->did_reset) { e->err = "rollout without seeds before reset"; return MUAVTA_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  const uint64_t* ds = nullptr;
+  if (seeds) {
+    HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+    ds = e->d_seeds;
+  }
+  HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, ds, (EnvState<TL>*)e->blobs,
+                                 e->tapes, n_steps, interval, use_vis, write_obs, e->O, e->d_metrics));
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+  e->did_reset = true;
+  e->host_valid = false;
+  return MUAVTA_OK;
+}
+
+int muavta_sync(MuavtaEnv* e) {
+  if (!e) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
+  if (!e || !ms) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipEventSynchronize(e->ev1));
+  HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+  e->last_ms = *ms;
+  return MUAVTA_OK;
+}
+
+int muavta_observe(MuavtaEnv* e, float* tasks, uint8_t* legal, uint8_t* pad, float* agents, float* flags) {
+  if (!e) return MUAVTA_E_ARG;
+  if (!e->did_reset) { e->err = "observe before reset"; return MUAVTA_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
+  if (tasks) HIPCHK(e, hipMemcpyAsync(tasks, e->O.tasks, N * mt * 21 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  if (legal) HIPCHK(e, hipMemcpyAsync(legal, e->O.legal, N * nA * mt, hipMemcpyDeviceToHost, e->stream));
+  if (pad) HIPCHK(e, hipMemcpyAsync(pad, e->O.pad, N * mt, hipMemcpyDeviceToHost, e->stream));
+  if (agents) HIPCHK(e, hipMemcpyAsync(agents, e->O.agents, N * nA * 9 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  if (flags) HIPCHK(e, hipMemcpyAsync(flags, e->O.flags, N * 5 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from the current state (after muavta_set)
+  if (!e) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  DISPATCH(e, hipLaunchKernelGGL(k_observe<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs, e->O));
+  HIPCHK(e, hipGetLastError());
+  return MUAVTA_OK;
+}
+
+int muavta_step_result(MuavtaEnv* e, double* reward, uint8_t* done) {
+  if (!e) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  if (reward) HIPCHK(e, hipMemcpyAsync(reward, e->O.reward, (size_t)e->n_envs * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  if (done) HIPCHK(e, hipMemcpyAsync(done, e->O.done, (size_t)e->n_envs, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_metrics(MuavtaEnv* e, double* out) {
+  if (!e || !out) return MUAVTA_E_ARG;
+  if (!e->did_reset) { e->err = "metrics before reset"; return MUAVTA_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  DISPATCH(e, hipLaunchKernelGGL(k_metrics<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs, e->d_metrics));
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  int rc = sync_host(e);
+  if (rc) return rc;
+  DISPATCH(e, rc = check_errors<TL>(e));
+  return rc;
+}
+
+int muavta_get(MuavtaEnv* e, MuavtaField field, void* dst, size_t bytes) {
+  if (!e || !dst) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc = sync_host(e);
+  if (rc) return rc;
+  DISPATCH(e, rc = gather<TL>(e, field, dst, bytes, false));
+  return rc;
+}
+
+int muavta_set(MuavtaEnv* e, MuavtaField field, const void* src, size_t bytes) {
+  if (!e || !src) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  int rc = sync_host(e);
+  if (rc) return rc;
+  DISPATCH(e, rc = gather<TL>(e, field, const_cast<void*>(src), bytes, true));
+  if (rc) return rc;
+  HIPCHK(e, hipMemcpyAsync(e->blobs, e->host_blobs.data(), e->host_blobs.size(), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_get_state(MuavtaEnv* e, void* dst, size_t bytes) {
+  if (!e || !dst || bytes != (size_t)e->n_envs * e->state_bytes) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(dst, e->blobs, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+int muavta_set_state(MuavtaEnv* e, const void* src, size_t bytes) {
+  if (!e || !src || bytes != (size_t)e->n_envs * e->state_bytes) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(e->blobs, src, bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->host_valid = false;
+  e->did_reset = true;
+  return MUAVTA_OK;
+}
+int muavta_get_rng(MuavtaEnv* e, void* dst, size_t bytes) {  // raw MT tapes, for checkpoint/resume next to get_state
+  size_t need = e ? (size_t)e->n_envs * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * 4 : 0;
+  if (!e || !dst || bytes != need) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(dst, e->tapes, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+int muavta_set_rng(MuavtaEnv* e, const void* src, size_t bytes) {
+  size_t need = e ? (size_t)e->n_envs * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * 4 : 0;
+  if (!e || !src || bytes != need) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(e->tapes, src, bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_device_ptrs(MuavtaEnv* e, void** state, void** obs_tasks, void** obs_legal, void** obs_agents, void** metrics, void** stream) {
+  if (!e) return MUAVTA_E_ARG;
+  if (state) *state = e->blobs;
+  if (obs_tasks) *obs_tasks = e->O.tasks;
+  if (obs_legal) *obs_legal = e->O.legal;
+  if (obs_agents) *obs_agents = e->O.agents;
+  if (metrics) *metrics = e->d_metrics;
+  if (stream) *stream = (void*)e->stream;
+  return MUAVTA_OK;
+}
+
+int muavta_rollout_metrics(MuavtaEnv* e, double* out) {  // metrics written by the last muavta_rollout (no extra kernel)
+  if (!e || !out) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_lsap(int32_t device, const double* cost, int32_t n, int32_t nr, int32_t nc, int64_t* row, int64_t* col) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "muavta_lsap: no HIP device"; return MUAVTA_E_NO_DEVICE; }
+  if (!cost || !row || !col || n < 1 || nr < 1 || nc < 1) { g_create_error = "muavta_lsap: bad arguments"; return MUAVTA_E_ARG; }
+  int mn = nr < nc ? nr : nc, mx = nr < nc ? nc : nr;
+  if (mn > Tile64::A || mx > Tile64::T) { g_create_error = "muavta_lsap: at most 64 x 128"; return MUAVTA_E_ARG; }
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); hipFree(dc); hipFree(dr); hipFree(dcl); return MUAVTA_E_HIP; } } while (0)
+  double* dc = nullptr; int64_t *dr = nullptr, *dcl = nullptr;
+  CK(hipSetDevice(device));
+  size_t cb = (size_t)n * nr * nc * sizeof(double), rb = (size_t)n * mn * sizeof(int64_t);
+  CK(hipMalloc(&dc, cb)); CK(hipMalloc(&dr, rb)); CK(hipMalloc(&dcl, rb));
+  CK(hipMemcpy(dc, cost, cb, hipMemcpyHostToDevice));
+  size_t lds = Lds<Tile64>::bytes();
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_lsap, dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
+  CK(hipGetLastError());
+  CK(hipMemcpy(row, dr, rb, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(col, dcl, rb, hipMemcpyDeviceToHost));
+#undef CK
+  hipFree(dc); hipFree(dr); hipFree(dcl);
+  return MUAVTA_OK;
+}
+
+int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double* movement, int32_t n, const double* obstacles,
+                           int32_t n_obstacles, double* out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "muavta_avoid_obstacles: no HIP device"; return MUAVTA_E_NO_DEVICE; }
+  if (!agent_pos || !movement || !out || n < 1 || n_obstacles < 0 || (n_obstacles > 0 && !obstacles)) return MUAVTA_E_ARG;
+  double *dp = nullptr, *dm = nullptr, *dob = nullptr, *dout = nullptr;
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); hipFree(dp); hipFree(dm); hipFree(dob); hipFree(dout); return MUAVTA_E_HIP; } } while (0)
+  CK(hipSetDevice(device));
+  CK(hipMalloc(&dp, (size_t)n * 16)); CK(hipMalloc(&dm, (size_t)n * 16)); CK(hipMalloc(&dout, (size_t)n * 16));
+  CK(hipMalloc(&dob, (size_t)(n_obstacles > 0 ? n_obstacles : 1) * 24));
+  CK(hipMemcpy(dp, agent_pos, (size_t)n * 16, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dm, movement, (size_t)n * 16, hipMemcpyHostToDevice));
+  if (n_obstacles > 0) CK(hipMemcpy(dob, obstacles, (size_t)n_obstacles * 24, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_avoid, dim3((n + 255) / 256), dim3(256), 0, 0, dp, dm, n, dob, n_obstacles, dout);
+  CK(hipGetLastError());
+  CK(hipMemcpy(out, dout, (size_t)n * 16, hipMemcpyDeviceToHost));
+#undef CK
+  hipFree(dp); hipFree(dm); hipFree(dob); hipFree(dout);
+  return MUAVTA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,132 @@
+// muavta_state.h — per-environment state blob, shared by host and device code.
+//
+// One env instance == one contiguous, 16-byte aligned blob.  The SAME bytes live (a) in HBM as
+// `blob[n_envs]` and (b) in the LDS of the workgroup that simulates the env: kernels move it with
+// coalesced 16-B/lane copies and run every step against the LDS copy.  Inside the blob every agent /
+// task / threat field is its own array (SoA), so a wave reading "all positions" or "all statuses"
+// touches consecutive LDS banks.  All geometry is f64 (1e-5 absolute on coordinates up to 1200 rules
+// out f32), ids/states are i32, masks are bits.
+//
+// Reference objects restated here: UAV / Task / Threat (mUAV_TA/DroneEnvComponents.py:7-52,223-263,
+// 331-350) and the MultiUAVEnv counters (mUAV_TA/DroneEnv.py:218-243,550-576).
+#pragma once
+#include <stdint.h>
+
+#include "../../include/muavta.h"
+
+#define MUAVTA_QCAP 8  // agent queue depth (reference max measured: 6)
+
+// Per-env error codes stored in EnvState::error (first error wins).
+enum {
+  MUAVTA_ERR_NONE = 0,
+  MUAVTA_ERR_TASK_SLOTS = 1,   // no free task slot (raise tile_tasks)
+  MUAVTA_ERR_QUEUE = 2,        // agent queue deeper than MUAVTA_QCAP
+  MUAVTA_ERR_EVENTS = 3,       // event list overflow
+  MUAVTA_ERR_PENDING = 4,      // pending-reveal list overflow
+  MUAVTA_ERR_POSITION = 5,     // random_position failed 100 times (reference raises ValueError)
+  MUAVTA_ERR_ESCORTS = 6,
+  MUAVTA_ERR_LSAP = 7,
+};
+
+// Task flag bits.
+enum { TF_ESCORT = 1, TF_COUNTED = 2, TF_REACHED = 4, TF_ELIGIBLE = 8, TF_DEADLINE = 16 };
+
+// Kernel-argument block: config + host-derived constants (all computed with the reference's
+// operation order on the host so device and oracle agree bit for bit).
+struct DevParams {
+  int32_t n_agents, n_tasks /* DroneEnv.py:145 */, max_tasks /* :147 */, n_threats;
+  int32_t n_agent_groups, agent_type[MUAVTA_MAX_GROUPS], agent_count[MUAVTA_MAX_GROUPS];
+  int32_t n_task_groups, task_type[MUAVTA_MAX_GROUPS], task_count[MUAVTA_MAX_GROUPS];
+  int32_t n_threat_groups, threat_type[MUAVTA_MAX_GROUPS], threat_count[MUAVTA_MAX_GROUPS];
+  int32_t max_time_steps, multiple_tasks_per_agent, early_terminate, capability_mask, saturate_mask,
+      include_time_windows, threat_delay, hard_windows, window_length, burst_mode, burst_size,
+      dual_region_bursts, share_knowledge, escort_enabled, num_obstacles, random_init_pos,
+      escort_required_agents /* max(2, ceil(escort_requirement)), DroneEnv.py:1907 */;
+  uint32_t escort_mask;
+  double speed[7];          // maxSpeeds[type] / frame_rate * 0.02            (DroneEnv.py:611,725)
+  double threat_prob;       // 0.7 / frame_rate * 0.02                         (:162)
+  double reward_norm_factor;// (possible + possible) / 1000                    (:670-675)
+  double fail_rate, arrival_rate, dynamic_idle_penalty, sense_radius, miss_penalty, on_time_bonus,
+      reassign_penalty, escort_radius, escort_requirement, escort_intercept_radius, mutual_support_radius;
+  double rw[8];
+};
+
+template <int A_, int T_, int H_, int R_, int E_>
+struct Tile {
+  static constexpr int A = A_;  // agents
+  static constexpr int T = T_;  // live task slots
+  static constexpr int H = H_;  // threats
+  static constexpr int R = R_;  // pending reveals
+  static constexpr int E = E_;  // events per list
+  static constexpr int Q = MUAVTA_QCAP;
+  static constexpr int KW = (T_ + 31) / 32;  // known-mask words per agent
+};
+
+template <class TL>
+struct alignas(16) EnvState {
+  enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
+  // ---- agents (index = UAV.id = position in agents_obj) ------------------------------------
+  double a_px[A], a_py[A];          // position
+  double a_nfx[A], a_nfy[A];        // next_free_position
+  double a_nft[A];                  // next_free_time
+  double a_dist[A];                 // env.agent_distances
+  double a_caps[6][A];              // currentCap2Task
+  double a_qtime[A][Q];             // allocationDetails[agent][1] (time_to_task) of each queued task
+  int32_t a_qid[A][Q];              // queued task ids (head first); qlen == 0 <=> [task_idle]
+  int32_t a_qslot[A][Q];            // slot hint for a_qid (valid iff t_id[slot] == id)
+  int32_t a_qlen[A];
+  int32_t a_state[A], a_task_start[A], a_fail[A], a_acap[A], a_type[A], a_name[A];
+  int32_t a_reeval[A], a_last_id[A], a_last_slot[A], a_commit[A];
+  // ---- task slots -----------------------------------------------------------------------------
+  double t_px[T], t_py[T];
+  double t_cur[6][T], t_alloc[6][T];  // currentReqs, allocatedReqs
+  double t_org[T], t_done[T];         // orgReqs[typeIdx], doneReqs[typeIdx]
+  double t_init[T], t_dtime[T];       // initTime, doneTime
+  int32_t t_id[T];                    // -1 = free slot
+  int32_t t_status[T], t_type[T], t_created[T], t_deadline[T], t_required[T], t_flags[T];
+  uint32_t t_elig[T];
+  int32_t t_threat[T];                // relative_threat (threat id) or -1
+  int32_t t_prot_agent[T], t_prot_id[T], t_prot_slot[T];  // escort: protected agent / Rec task
+  int32_t t_ndet[T];                  // len(allocationDetails)
+  uint64_t t_bucket[T];               // allocation_table[id] as agent bitmask
+  int32_t t_order[T];                 // live slots in ascending id (== creation) order
+  int32_t open_slot[T];               // env.last_tasks_info (slots), status != 2 at last observation
+  uint32_t known[A][KW];              // agent_known_tasks as slot bitmask
+  // ---- threats (index = Threat.id) ------------------------------------------------------------
+  double h_px[H], h_py[H];
+  int32_t h_status[H];                // -9 = still waiting in its group
+  int32_t h_target[H], h_mission[H], h_intercept[H];
+  int32_t h_task_id[H], h_task_slot[H], h_det_slot[H], h_acap[H], h_type[H], h_group[H];
+  int32_t h_tflags[H];                // copy of the Int task's TF_DEADLINE|TF_COUNTED once its slot is freed
+  int32_t h_tdeadline[H];
+  int32_t h_order[H];                 // env.threats (spawn order)
+  int32_t g_next[MUAVTA_MAX_GROUPS], g_end[MUAVTA_MAX_GROUPS];  // threats_groups as [next, end) id ranges
+  // ---- lists ------------------------------------------------------------------------------------
+  int32_t ev_tag[E], ev_arg[E];       // env.event_list (generated this step)
+  int32_t dev_tag[E], dev_arg[E];     // infos['events'] (drained at the start of the last step)
+  int32_t pend_time[R], pend_id[R], pend_slot[R];
+  int32_t esc_agent[A], esc_id[A], esc_slot[A];  // _escort_by_recon in insertion order
+  int32_t act_agent[A], act_slot[A], act_index[A];  // actions staged by the allocator
+  double area[3][3];                  // mission areas: top-left x, y, width (height == width)
+  double obst[8][3];
+  // ---- scalars --------------------------------------------------------------------------------
+  double F_Reward, total_distance, last_reward, step_reward;
+  int32_t time_steps, conclusion_time, n_order, n_open, n_active_threats, n_events, n_dev, n_pending, n_escorts, n_act;
+  int32_t next_task_id, n_reached, n_retired_empty_buckets;
+  int32_t n_reallocations, n_task_switches, n_arrivals, n_missed_windows, n_on_time, n_windowed_tasks,
+      idle_reserve_steps, burst_region_toggle, escort_requests, escort_completed, escort_failed,
+      escort_required_steps, escort_covered_steps, protection_breaches, threats_intercepted, recon_losses,
+      escort_losses, mutual_support_engagements, protected_rec_completed;
+  int32_t pending_reset, terminated, truncated, error, did_reset;
+  int32_t last_plan_step, n_replans, n_calls;  // HungarianAllocator state
+  uint32_t rng_idx[4];                // cursor into each stream's 2x624-word tape (agent, obs, tgt, mission)
+  int32_t pad_[3];
+};
+
+// Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
+typedef Tile<16, 32, 16, 64, 48> Tile16;
+typedef Tile<24, 48, 24, 128, 64> Tile24;
+typedef Tile<64, 128, 48, 128, 96> Tile64;
+
+#define MUAVTA_RNG_STREAMS 4
+#define MUAVTA_RNG_WORDS 1248  // two consecutive MT19937 blocks per stream

@@ -1,0 +1,100 @@
+"""Loader for the HIP shared library (csrc/ -> libmuavta.so) behind the C ABI of include/muavta.h.
+
+The library is the product: there is no Python or CPU fallback.  If it is missing, or no MI355X is
+visible, the calls fail loudly (``MuavtaError``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+from .params import MuavtaDims, MuavtaParams
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+SO_PATH = os.path.join(PKG_DIR, "libmuavta.so")
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+
+EXPORTS = [
+    "muavta_create", "muavta_destroy", "muavta_last_error", "muavta_dims", "muavta_reset", "muavta_step",
+    "muavta_allocate", "muavta_step_staged", "muavta_rollout", "muavta_observe", "muavta_step_result",
+    "muavta_metrics", "muavta_get", "muavta_set", "muavta_get_state", "muavta_set_state", "muavta_lsap",
+    "muavta_avoid_obstacles", "muavta_device_ptrs", "muavta_last_kernel_ms", "muavta_sync",
+    "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng",
+]
+
+
+class MuavtaError(RuntimeError):
+    pass
+
+
+def sources():
+    return [os.path.join(CSRC, f) for f in ("muavta_kernels.hip", "muavta_device.h", "muavta_state.h")] + [
+        os.path.join(os.path.dirname(PKG_DIR), "include", "muavta.h")]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    return any(os.path.getmtime(s) > t for s in sources())
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compile the kernels for gfx950 with hipcc (works without a GPU)."""
+    if not force and not needs_build():
+        return SO_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", SO_PATH, os.path.join(CSRC, "muavta_kernels.hip")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise MuavtaError(
+            f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+    L = C.CDLL(SO_PATH)
+    vp, i32, u64p = C.c_void_p, C.c_int32, C.c_void_p
+    L.muavta_create.argtypes = [C.POINTER(MuavtaParams), i32, i32, C.POINTER(vp)]
+    L.muavta_destroy.argtypes = [vp]
+    L.muavta_last_error.argtypes = [vp]
+    L.muavta_last_error.restype = C.c_char_p
+    L.muavta_dims.argtypes = [vp, C.POINTER(MuavtaDims)]
+    L.muavta_reset.argtypes = [vp, u64p]
+    L.muavta_step.argtypes = [vp, vp, vp]
+    L.muavta_allocate.argtypes = [vp, i32, i32, vp, vp]
+    L.muavta_step_staged.argtypes = [vp]
+    L.muavta_rollout.argtypes = [vp, u64p, i32, i32, i32, i32]
+    L.muavta_observe.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.muavta_step_result.argtypes = [vp, vp, vp]
+    L.muavta_metrics.argtypes = [vp, vp]
+    L.muavta_rollout_metrics.argtypes = [vp, vp]
+    L.muavta_get.argtypes = [vp, i32, vp, C.c_size_t]
+    L.muavta_set.argtypes = [vp, i32, vp, C.c_size_t]
+    L.muavta_get_state.argtypes = [vp, vp, C.c_size_t]
+    L.muavta_set_state.argtypes = [vp, vp, C.c_size_t]
+    L.muavta_get_rng.argtypes = [vp, vp, C.c_size_t]
+    L.muavta_set_rng.argtypes = [vp, vp, C.c_size_t]
+    L.muavta_lsap.argtypes = [i32, vp, i32, i32, i32, vp, vp]
+    L.muavta_avoid_obstacles.argtypes = [i32, vp, vp, i32, vp, i32, vp]
+    L.muavta_device_ptrs.argtypes = [vp] + [C.POINTER(vp)] * 6
+    L.muavta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.muavta_sync.argtypes = [vp]
+    L.muavta_refresh_observation.argtypes = [vp]
+    for name in EXPORTS:
+        if name != "muavta_last_error":
+            getattr(L, name).restype = C.c_int
+    _LIB = L
+    return L

@@ -14,7 +14,7 @@ from typing import Any, Dict, Optional
 ABI_VERSION = 1
 MAX_GROUPS = 8
 N_METRICS = 30
-N_SCALARS = 24
+N_SCALARS = 28
 
 UAV_TYPES = ["R1", "R2", "E1", "F1", "F2", "T1", "T2"]           # MultiDroneEnvData.py:15
 TASK_TYPES = ["Hold", "Rec", "Att", "Def", "Int", "Det"]          # MultiDroneEnvData.py:18
