@@ -163,6 +163,10 @@ enum {
 
 typedef struct MuavtaEnv MuavtaEnv; /* opaque */
 
+/* out[0] = sizeof(MuavtaParams), out[1] = sizeof(MuavtaDims), out[2] = MUAVTA_ABI_VERSION: lets a
+ * foreign-language binding verify its struct layout before the first call.  Needs no GPU. */
+int muavta_abi_sizes(int32_t* out);
+
 /* MultiUAVEnv(config) for n_envs independent instances on HIP device `device` (DroneEnv.py:73-323).
  * Fails with MUAVTA_E_NO_DEVICE when no GPU is present. */
 int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, MuavtaEnv** out);

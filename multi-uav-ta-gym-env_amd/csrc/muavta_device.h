@@ -319,11 +319,41 @@ struct Sim {
     S.ev_arg[n] = arg;
     S.n_events = n + 1;
   }
+  // A retired slot may be recycled once no LIVE agent queues it (its type/position are still read by
+  // the switch penalty and the expected-distance term, :852-861,:1219-1220).
+  DEV bool slot_unreferenced(int id) const {
+    for (int a = 0; a < P.n_agents; a++) {
+      if (S.a_state[a] == -1) continue;
+      for (int k = 0; k < S.a_qlen[a]; k++) if (S.a_qid[a][k] == id) return false;
+    }
+    return true;
+  }
+  DEV void release_slot(int s) {
+    int h = S.t_threat[s];
+    if (h >= 0) { S.h_tflags[h] = S.t_flags[s] & (TF_DEADLINE | TF_COUNTED); S.h_tdeadline[h] = S.t_deadline[s]; }
+    if (S.t_bucket[s] == 0) atomicAdd(&S.n_retired_empty_buckets, 1);
+    S.t_id[s] = -1;
+  }
+  DEV int reclaim_slot_serial() {
+    for (int k = 0; k < S.n_order; k++) {
+      int s = S.t_order[k];
+      if (S.t_status[s] != 2 || !slot_unreferenced(S.t_id[s])) continue;
+      bool staged = false;  // actions still to be applied this step may name it (-> invalid-action penalty)
+      for (int j = 0; j < S.n_act; j++) staged |= (S.act_slot[j] == s);
+      if (staged) continue;
+      release_slot(s);
+      for (int i = k; i + 1 < S.n_order; i++) S.t_order[i] = S.t_order[i + 1];
+      S.n_order--;
+      return s;
+    }
+    return -1;
+  }
   // Task.__init__ (DroneEnvComponents.py:224-263) into a free slot; returns the slot or -1
   DEV int new_task(double x, double y, int type, double req) {
     int id = S.next_task_id++;  // _alloc_task_id (:325-328)
     int s = -1;
     for (int k = 0; k < T; k++) if (S.t_id[k] < 0) { s = k; break; }
+    if (s < 0) s = reclaim_slot_serial();  // tile full mid-step: recycle a retired slot before the end-of-step GC
     if (s < 0) { fail(MUAVTA_ERR_TASK_SLOTS); return -1; }
     S.t_id[s] = id;
     S.t_px[s] = x; S.t_py[s] = y;
@@ -410,6 +440,7 @@ struct Sim {
     int n = S.n_escorts;
     if (n >= A) { fail(MUAVTA_ERR_ESCORTS); return; }
     S.esc_agent[n] = recon; S.esc_id[n] = S.t_id[s]; S.esc_slot[n] = s;
+    S.esc_pid[n] = S.t_prot_id[s]; S.esc_pslot[n] = rec_slot;
     S.n_escorts = n + 1;
     S.escort_requests++;
     push_event(MUAVTA_EV_ESCORT_CREATED, S.t_id[s]);
@@ -418,7 +449,8 @@ struct Sim {
   }
   DEV void retire_escort_entry(int k, bool failed) {  // _retire_escort (:1938-1950) for map entry k
     int s = S.esc_slot[k], id = S.esc_id[k];
-    if (S.t_status[s] == 2) return;
+    // an escort that expired by its hard window keeps its map entry forever (status == 2 -> early return)
+    if (ref_retired(id, s)) return;
     // _release_escort_agents (:1919-1936)
     for (int a = 0; a < P.n_agents; a++) {
       if (S.a_state[a] == -1) continue;
@@ -438,6 +470,7 @@ struct Sim {
     if (kk >= 0) {
       for (int i = kk; i + 1 < S.n_escorts; i++) {
         S.esc_agent[i] = S.esc_agent[i + 1]; S.esc_id[i] = S.esc_id[i + 1]; S.esc_slot[i] = S.esc_slot[i + 1];
+        S.esc_pid[i] = S.esc_pid[i + 1]; S.esc_pslot[i] = S.esc_pslot[i + 1];
       }
       S.n_escorts--;
     }
@@ -452,7 +485,7 @@ struct Sim {
   // Stable insertion sort == python's sort(key=dist) on (dist, agent) pairs built in id order.
   DEV int escort_fighters_near(int prot, double radius, int* out, double* outd) {
     int k = escort_lookup(prot);
-    if (k < 0 || S.t_status[S.esc_slot[k]] == 2) return 0;
+    if (k < 0 || ref_retired(S.esc_id[k], S.esc_slot[k])) return 0;
     int eid = S.esc_id[k];
     int n = 0;
     for (int a = 0; a < P.n_agents; a++) {
@@ -471,7 +504,7 @@ struct Sim {
   DEV int closest_escort(int prot, double radius, int* count) {  // first element + count of the list above
     int k = escort_lookup(prot);
     *count = 0;
-    if (k < 0 || S.t_status[S.esc_slot[k]] == 2) return -1;
+    if (k < 0 || ref_retired(S.esc_id[k], S.esc_slot[k])) return -1;
     int eid = S.esc_id[k];
     int best = -1, n = 0;
     double bd = 0;
@@ -932,6 +965,14 @@ struct Sim {
       }
       S.total_distance += res;
     }
+    // :1140-1145 — evaluated here, before this step's spawns / expiries change the counts
+    S.r_time_penalty = -(double)(P.n_tasks - S.n_reached) / (double)P.n_tasks * ((double)S.time_steps / (double)P.max_time_steps);
+    S.r_alloc = 0;
+    if (S.time_steps > P.n_tasks + 1) {  // -len(unallocated_tasks()) (:1434-1440); bucket 0 (idle) is always empty
+      int n = 1 + S.n_retired_empty_buckets;
+      for (int k = 0; k < S.n_order; k++) if (S.t_bucket[S.t_order[k]] == 0) n++;
+      S.r_alloc = -(double)n;
+    }
     generate_threat();
     update_threats();
     inject_dynamic_arrivals();
@@ -1143,13 +1184,13 @@ struct Sim {
       int kk = escort_lookup(recon);
       if (kk < 0) continue;
       int es = S.esc_slot[kk];
-      int rid = S.t_prot_id[es], rs = S.t_prot_slot[es];
+      int rid = S.esc_pid[kk], rs = S.esc_pslot[kk];
       bool dead = S.a_state[recon] == -1;
       bool idle = S.a_qlen[recon] == 0 || S.a_state[recon] == 0 || S.a_state[recon] == 3;
       bool rec_done = ref_retired(rid, rs);
       bool wrong_task = S.a_qlen[recon] > 0 && S.a_qid[recon][0] != rid;
       if (dead || idle || rec_done || wrong_task) { retire_escort_entry(kk, dead); continue; }
-      S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon];
+      if (ref_valid(S.esc_id[kk], es)) { S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon]; }
       S.escort_required_steps++;
       int cnt;
       closest_escort(recon, P.escort_radius, &cnt);
@@ -1210,16 +1251,13 @@ struct Sim {
     S.idle_reserve_steps += idle;
     if (S.pending_reset && responding) S.pending_reset = 0;
     // shared reward (:1140-1145,1162-1178)
-    double time_penaulty = -(double)(P.n_tasks - S.n_reached) / (double)P.n_tasks * ((double)S.time_steps / (double)P.max_time_steps);
-    double alloc_reward = 0;
-    if (S.time_steps > P.n_tasks + 1) {  // -len(unallocated_tasks()) (:1434-1440); bucket 0 (idle) is always empty
-      int n = 1 + S.n_retired_empty_buckets;
-      for (int k = 0; k < S.n_order; k++) if (S.t_bucket[S.t_order[k]] == 0) n++;
-      alloc_reward = -(double)n;
-    }
+    const double time_penaulty = S.r_time_penalty, alloc_reward = S.r_alloc;
     double total = P.rw[0] * action_reward + P.rw[1] * distance_reward + P.rw[2] * quality_reward + P.rw[3] * S_quality_reward +
                    P.rw[4] * (double)P.n_tasks * 0.0 + P.rw[5] * alloc_reward + P.rw[6] * time_penaulty + P.rw[7] * S.step_reward;
     S.last_reward = total / P.reward_norm_factor / (double)P.max_time_steps;
+#ifdef MUAVTA_DEBUG
+    if (blockIdx.x == 0 && S.time_steps <= 2) printf("DEV t=%d a=%.17g d=%.17g q=%.17g s=%.17g tp=%.17g al=%.17g sr=%.17g\n", S.time_steps, action_reward, distance_reward, quality_reward, S_quality_reward, time_penaulty, alloc_reward, S.step_reward);
+#endif
     bool all_done = (S.next_task_id > 1) && all_mission_done();
     bool timed_out = (S.time_steps >= P.max_time_steps) && (P.max_time_steps > 0);
     bool done = timed_out || (P.early_terminate && all_done);
@@ -1235,20 +1273,7 @@ struct Sim {
   DEV void finish_step_parallel(bool gc) {
     if (gc) {
       for (int s = lane; s < T; s += WG) {
-        if (S.t_id[s] >= 0 && S.t_status[s] == 2) {
-          const int id = S.t_id[s];
-          bool ref = false;
-          for (int a = 0; a < P.n_agents && !ref; a++) {
-            if (S.a_state[a] == -1) continue;
-            for (int k = 0; k < S.a_qlen[a]; k++) if (S.a_qid[a][k] == id) { ref = true; break; }
-          }
-          if (!ref) {
-            int h = S.t_threat[s];
-            if (h >= 0) { S.h_tflags[h] = S.t_flags[s] & (TF_DEADLINE | TF_COUNTED); S.h_tdeadline[h] = S.t_deadline[s]; }
-            if (S.t_bucket[s] == 0) atomicAdd(&S.n_retired_empty_buckets, 1);
-            S.t_id[s] = -1;
-          }
-        }
+        if (S.t_id[s] >= 0 && S.t_status[s] == 2 && slot_unreferenced(S.t_id[s])) release_slot(s);
       }
       __syncthreads();
     }

@@ -248,7 +248,7 @@ struct MuavtaEnv {
   MuavtaParams params;
   int tile = TK16;
   int n_envs = 0, device = 0;
-  int A = 0, T = 0, H = 0, E = 0, R = 0;
+  int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
   size_t state_bytes = 0, lds_bytes = 0;
   void* blobs = nullptr;
   uint32_t* tapes = nullptr;
@@ -296,7 +296,7 @@ int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
       p->n_threat_groups < 0 || p->n_threat_groups > MUAVTA_MAX_GROUPS) { *err = "group counts out of range"; return MUAVTA_E_ARG; }
   d->n_agent_groups = p->n_agent_groups; d->n_task_groups = p->n_task_groups; d->n_threat_groups = p->n_threat_groups;
   int nA = 0, nT = 0, nH = 0;
-  double possible = 0;  // DroneEnv.py:670-675, summed in task creation order
+  double possible = 0;  // DroneEnv.py:670-675: summed over the static tasks only (Det tasks are created later, :685)
   for (int g = 0; g < p->n_agent_groups; g++) {
     if (p->agent_type[g] < 0 || p->agent_type[g] > MUAVTA_F2 || p->agent_count[g] < 0) { *err = "bad agent group"; return MUAVTA_E_ARG; }
     d->agent_type[g] = p->agent_type[g]; d->agent_count[g] = p->agent_count[g]; nA += p->agent_count[g];
@@ -311,7 +311,6 @@ int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
     int ty = p->threat_type[g];
     if (ty != MUAVTA_T1 && ty != MUAVTA_T2) { *err = "threat types are T1/T2"; return MUAVTA_E_ARG; }
     d->threat_type[g] = ty; d->threat_count[g] = p->threat_count[g]; nH += p->threat_count[g];
-    possible += (double)p->threat_count[g];
   }
   if (nA < 1) { *err = "no agents"; return MUAVTA_E_ARG; }
   if (p->num_obstacles < 0 || p->num_obstacles > 8) { *err = "num_obstacles must be in 0..8"; return MUAVTA_E_ARG; }
@@ -557,6 +556,15 @@ int check_errors(MuavtaEnv* e) {  // scan the per-env error words after a synchr
 // ====================================================================================================
 extern "C" {
 
+// sizeof() of the ABI structs, so a binding can verify its own layout: out[0] = MuavtaParams, out[1] = MuavtaDims
+int muavta_abi_sizes(int32_t* out) {
+  if (!out) return MUAVTA_E_ARG;
+  out[0] = (int32_t)sizeof(MuavtaParams);
+  out[1] = (int32_t)sizeof(MuavtaDims);
+  out[2] = MUAVTA_ABI_VERSION;
+  return MUAVTA_OK;
+}
+
 const char* muavta_last_error(const MuavtaEnv* env) { return env ? env->err.c_str() : g_create_error.c_str(); }
 
 int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, MuavtaEnv** out) {
@@ -582,7 +590,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   else if (ta <= Tile24::A && tt <= Tile24::T && th <= Tile24::H) e->tile = TK24;
   else if (ta <= Tile64::A && tt <= Tile64::T && th <= Tile64::H) e->tile = TK64;
   else { g_create_error = "muavta_create: requested tile exceeds 64 agents x 128 task slots x 48 threats"; delete e; return MUAVTA_E_ARG; }
-  DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->state_bytes = sizeof(EnvState<TL>); });
+  DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->Q = TL::Q; e->state_bytes = sizeof(EnvState<TL>); });
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); muavta_destroy(e); return MUAVTA_E_HIP; } } while (0)
   CK(hipSetDevice(device));
   CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -627,7 +635,7 @@ int muavta_destroy(MuavtaEnv* e) {
 int muavta_dims(const MuavtaEnv* e, MuavtaDims* d) {
   if (!e || !d) return MUAVTA_E_ARG;
   d->n_envs = e->n_envs; d->n_agents = e->P.n_agents; d->tile_agents = e->A; d->tile_tasks = e->T; d->tile_threats = e->H;
-  d->max_tasks = e->P.max_tasks; d->obs_task_width = 21; d->obs_agent_width = 9; d->queue_cap = MUAVTA_QCAP; d->event_cap = e->E;
+  d->max_tasks = e->P.max_tasks; d->obs_task_width = 21; d->obs_agent_width = 9; d->queue_cap = e->Q; d->event_cap = e->E;
   d->action_cap = e->A; d->state_bytes = (int64_t)e->state_bytes;
   d->n_threats = e->P.n_threats; d->known_words = (e->T + 31) / 32; d->lds_bytes = (int32_t)e->lds_bytes; d->reserved = 0;
   return MUAVTA_OK;

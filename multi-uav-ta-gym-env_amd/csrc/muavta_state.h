@@ -14,13 +14,12 @@
 
 #include "../../include/muavta.h"
 
-#define MUAVTA_QCAP 8  // agent queue depth (reference max measured: 6)
 
 // Per-env error codes stored in EnvState::error (first error wins).
 enum {
   MUAVTA_ERR_NONE = 0,
   MUAVTA_ERR_TASK_SLOTS = 1,   // no free task slot (raise tile_tasks)
-  MUAVTA_ERR_QUEUE = 2,        // agent queue deeper than MUAVTA_QCAP
+  MUAVTA_ERR_QUEUE = 2,        // agent queue deeper than Tile::Q
   MUAVTA_ERR_EVENTS = 3,       // event list overflow
   MUAVTA_ERR_PENDING = 4,      // pending-reveal list overflow
   MUAVTA_ERR_POSITION = 5,     // random_position failed 100 times (reference raises ValueError)
@@ -51,14 +50,14 @@ struct DevParams {
   double rw[8];
 };
 
-template <int A_, int T_, int H_, int R_, int E_>
+template <int A_, int T_, int H_, int R_, int E_, int Q_>
 struct Tile {
   static constexpr int A = A_;  // agents
   static constexpr int T = T_;  // live task slots
   static constexpr int H = H_;  // threats
   static constexpr int R = R_;  // pending reveals
   static constexpr int E = E_;  // events per list
-  static constexpr int Q = MUAVTA_QCAP;
+  static constexpr int Q = Q_;  // agent queue depth (reference max measured: 6 / 10 / 5 on the three tiles)
   static constexpr int KW = (T_ + 31) / 32;  // known-mask words per agent
 };
 
@@ -105,12 +104,14 @@ struct alignas(16) EnvState {
   int32_t ev_tag[E], ev_arg[E];       // env.event_list (generated this step)
   int32_t dev_tag[E], dev_arg[E];     // infos['events'] (drained at the start of the last step)
   int32_t pend_time[R], pend_id[R], pend_slot[R];
-  int32_t esc_agent[A], esc_id[A], esc_slot[A];  // _escort_by_recon in insertion order
+  int32_t esc_agent[A], esc_id[A], esc_slot[A];  // _escort_by_recon in insertion order (entries of escorts that
+  int32_t esc_pid[A], esc_pslot[A];              // expired by window are never popped, as in the reference); protected Rec task
   int32_t act_agent[A], act_slot[A], act_index[A];  // actions staged by the allocator
   double area[3][3];                  // mission areas: top-left x, y, width (height == width)
   double obst[8][3];
   // ---- scalars --------------------------------------------------------------------------------
   double F_Reward, total_distance, last_reward, step_reward;
+  double r_time_penalty, r_alloc;     // reward terms evaluated mid-step (DroneEnv.py:1140-1145), before the world dynamics
   int32_t time_steps, conclusion_time, n_order, n_open, n_active_threats, n_events, n_dev, n_pending, n_escorts, n_act;
   int32_t next_task_id, n_reached, n_retired_empty_buckets;
   int32_t n_reallocations, n_task_switches, n_arrivals, n_missed_windows, n_on_time, n_windowed_tasks,
@@ -124,9 +125,9 @@ struct alignas(16) EnvState {
 };
 
 // Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
-typedef Tile<16, 32, 16, 64, 48> Tile16;
-typedef Tile<24, 48, 24, 128, 64> Tile24;
-typedef Tile<64, 128, 48, 128, 96> Tile64;
+typedef Tile<16, 32, 16, 64, 48, 8> Tile16;
+typedef Tile<24, 48, 24, 128, 64, 16> Tile24;
+typedef Tile<64, 128, 48, 128, 96, 8> Tile64;
 
 #define MUAVTA_RNG_STREAMS 4
 #define MUAVTA_RNG_WORDS 1248  // two consecutive MT19937 blocks per stream

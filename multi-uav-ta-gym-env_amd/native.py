@@ -22,7 +22,7 @@ EXPORTS = [
     "muavta_allocate", "muavta_step_staged", "muavta_rollout", "muavta_observe", "muavta_step_result",
     "muavta_metrics", "muavta_get", "muavta_set", "muavta_get_state", "muavta_set_state", "muavta_lsap",
     "muavta_avoid_obstacles", "muavta_device_ptrs", "muavta_last_kernel_ms", "muavta_sync",
-    "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng",
+    "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
 ]
 
 
@@ -93,8 +93,14 @@ def lib() -> C.CDLL:
     L.muavta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.muavta_sync.argtypes = [vp]
     L.muavta_refresh_observation.argtypes = [vp]
+    L.muavta_abi_sizes.argtypes = [C.POINTER(i32 * 3)]
     for name in EXPORTS:
         if name != "muavta_last_error":
             getattr(L, name).restype = C.c_int
+    sizes = (i32 * 3)()
+    L.muavta_abi_sizes(C.byref(sizes))
+    if (sizes[0], sizes[1]) != (C.sizeof(MuavtaParams), C.sizeof(MuavtaDims)):
+        raise MuavtaError(f"ABI layout mismatch: library {sizes[0]}/{sizes[1]} bytes vs binding "
+                          f"{C.sizeof(MuavtaParams)}/{C.sizeof(MuavtaDims)} (MuavtaParams/MuavtaDims)")
     _LIB = L
     return L

@@ -27,6 +27,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 #include <string>
 #include <utility>
@@ -1295,6 +1297,7 @@ struct Env {
     double total = rw[0] * action_reward + rw[1] * distance_reward + rw[2] * quality_reward + rw[3] * S_quality_reward +
                    rw[4] * n_tasks * time_reward + rw[5] * alloc_reward + rw[6] * time_penaulty + rw[7] * step_reward;
     last_reward = total / reward_norm_factor / P.max_time_steps;
+    if (getenv("ORC_DEBUG") && time_steps <= 2) printf("ORC t=%d a=%.17g d=%.17g q=%.17g s=%.17g tp=%.17g al=%.17g sr=%.17g\n", time_steps, action_reward, distance_reward, quality_reward, S_quality_reward, time_penaulty, alloc_reward, step_reward);
     bool all_done = tasks.size() > 1 && all_mission_done();
     bool timed_out = (time_steps >= P.max_time_steps) && (P.max_time_steps > 0);
     bool done = timed_out || (P.early_terminate && all_done);
