@@ -22,6 +22,16 @@ namespace muavta {
 
 constexpr int WG = 64;  // one wave64 per env
 
+// Phase separator for a ONE-wave workgroup: LDS instructions of a wave are executed in issue order, so
+// a later ds_read of another lane's ds_write needs no s_barrier and, unlike __syncthreads(), no
+// vmcnt(0) drain of the observation / tape stores still in flight.  Global-memory hand-offs between
+// lanes (MT19937 regeneration) keep the full __syncthreads().
+__device__ __forceinline__ void lds_sync() {
+  static_assert(WG == 64, "lds_sync() assumes the workgroup is a single wave64");
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- scene constants (mUAV_TA/MultiDroneEnvData.py:8-85) ------------------------------------------
 constexpr double AREA_W = 1200.0, AREA_H = 700.0, CONTACT_LINE = 550.0, BASE_X = 400.0, BASE_Y = 680.0;
 constexpr double MAX_COORD = 1200.0;
@@ -100,9 +110,20 @@ DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
   mt[0] = 0x80000000u;
 }
 
+#ifdef MUAVTA_PROF
+__device__ unsigned long long g_prof[32];
+#define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; } } while (0)
+#else
+#define PROF(i) do { } while (0)
+#endif
+
 template <class TL>
 struct Sim {
   typedef EnvState<TL> State;
+#ifdef MUAVTA_PROF
+  unsigned long long prof_acc[24] = {0}, prof_last = 0;
+  __device__ void prof_flush() { if (threadIdx.x == 0) for (int i = 0; i < 24; i++) atomicAdd(&g_prof[i], prof_acc[i]); }
+#endif
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   State& S;
   Scratch<TL>& X;
@@ -628,7 +649,7 @@ struct Sim {
       uint32_t* w = reinterpret_cast<uint32_t*>(&S);
       for (int i = lane; i < (int)(sizeof(State) / 4); i += WG) w[i] = 0;
     }
-    __syncthreads();
+    lds_sync();
     uint32_t* scr = reinterpret_cast<uint32_t*>(&X);
     rng_seed_pair(scr, ST_AGENT, seed, -1, 0);
     if (lane == 0) {  // :535-538
@@ -638,17 +659,17 @@ struct Sim {
       uint64_t* sd = reinterpret_cast<uint64_t*>(&S.area[0][0]);  // parked until the areas are built
       sd[0] = s_obs; sd[1] = s_tgt; sd[2] = s_mis;
     }
-    __syncthreads();
+    lds_sync();
     uint64_t s_obs, s_tgt, s_mis;
     {
       const uint64_t* sd = reinterpret_cast<const uint64_t*>(&S.area[0][0]);
       s_obs = sd[0]; s_tgt = sd[1]; s_mis = sd[2];
     }
-    __syncthreads();
+    lds_sync();
     rng_seed_pair(scr, ST_TGT, s_tgt, ST_MISSION, s_mis);
     if (P.num_obstacles > 0) rng_seed_pair(scr, ST_OBS, s_obs, -1, 0);
     if (lane == 0) reset_serial();
-    __syncthreads();
+    lds_sync();
     finish_step_parallel(false);
   }
 
@@ -740,14 +761,22 @@ struct Sim {
   // step (:774-1206).  n_act staged actions in S.act_agent / S.act_slot (slot < 0: invalid index).
   // ====================================================================================================
   DEV void step(bool write_obs_flag) {
+    PROF(0);
     rng_refill();
+    PROF(1);
     // previous positions stay in registers of the lane that owns the agent
     double prev_x = 0, prev_y = 0;
     if (lane < P.n_agents) { prev_x = S.a_px[lane]; prev_y = S.a_py[lane]; }
-    __syncthreads();
+    lds_sync();
     double r_action = 0, r_distance = 0, r_quality = 0, r_squality = 0;
     if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
-    __syncthreads();
+    lds_sync();
+    PROF(3);
+    const int first_serial = move_parallel();
+    lds_sync();
+    if (lane == 0 && first_serial < P.n_agents) step_serial_move(first_serial, r_quality);
+    lds_sync();
+    PROF(4);
     // distances (:1131-1138): np.linalg.norm(axis=1) == sqrt(x*x + y*y), no fma
     if (lane < P.n_agents) {
       double dx = S.a_px[lane] - prev_x, dy = S.a_py[lane] - prev_y;
@@ -755,14 +784,139 @@ struct Sim {
       S.a_dist[lane] += d;
       X.u[lane < A ? lane : 0] = d;
     }
-    __syncthreads();
+    lds_sync();
+    PROF(5);
     if (lane == 0) step_serial_b();
-    __syncthreads();
+    lds_sync();
+    PROF(6);
     sense_parallel();  // _wps_update_sensing (:1506-1523)
-    __syncthreads();
-    if (lane == 0) step_serial_c(r_action, r_distance, r_quality, r_squality);
-    __syncthreads();
+    lds_sync();
+    PROF(7);
+    {
+      // wave-wide pre-checks so that lane 0 only walks the lists when something is due this step
+      bool due = false, expiring = false, idle = false, resp = false, blocking = false;
+      for (int k = lane; k < S.n_pending; k += WG) due |= S.time_steps >= S.pend_time[k];
+      for (int k = lane; k < S.n_order; k += WG) {
+        const int s = S.t_order[k];
+        expiring |= (S.t_flags[s] & TF_DEADLINE) && S.t_status[s] != 2 && S.time_steps > S.t_deadline[s];
+      }
+      const bool any_due = __ballot(due) != 0ull;
+      const bool any_exp = P.hard_windows && __ballot(expiring) != 0ull;
+      if (lane == 0 && (any_due || any_exp)) step_serial_c_lists(any_due, any_exp);
+      lds_sync();
+      if (lane < P.n_agents && S.a_state[lane] != -1) { idle = S.a_qlen[lane] == 0; resp = !idle; }
+      for (int k = lane; k < S.n_order; k += WG) blocking |= !counts_for_mission_done(S.t_order[k]);
+      const int n_idle = __popcll(__ballot(idle));
+      const bool responding = __ballot(resp) != 0ull;
+      const bool all_done_tasks = __ballot(blocking) == 0ull;
+      if (lane == 0) step_serial_c(r_action, r_distance, r_quality, r_squality, n_idle, responding, all_done_tasks);
+    }
+    lds_sync();
+    PROF(8);
     finish_step_parallel(true);
+    PROF(9);
+  }
+
+  // Per-agent geometry of the movement state machine, one agent per lane: distance / unit direction to
+  // the current task and the resulting displacement, and the same towards the base.  Positions of an
+  // agent change only at its own turn and task positions do not change inside the loop, so the serial
+  // pass can consume these as long as the agent's current task is still the one seen here.
+  struct MovePre { double dist, nav_dx, nav_dy, base_d, rtb_dx, rtb_dy; };
+  DEV double* pre_f(int k) { return X.cost + k * A; }          // 6 arrays of A doubles in the (idle) cost tile
+  DEV int32_t* pre_id() { return X.remaining; }                // T >= A
+  DEV void displacement(double px, double py, double ux, double uy, double speed, double& ddx, double& ddy) {
+    double avx, avy;
+    avoid_obstacles(px, py, ux, uy, avx, avy);
+    double mx = ux + avx, my = uy + avy;  // :1123
+    norm_vector(mx, my);
+    ddx = mx * speed; ddy = my * speed;
+  }
+  // The movement state machine (:965-1129) with one agent per lane.  An agent's turn only touches its
+  // own fields unless it (a) fails, (b) engages an Int task (rewrites the threat's target) or
+  // (c) concludes a task; those are "events".  Agents BEFORE the first event agent (agents_obj order)
+  // are therefore independent of everything later in the loop and commit their lane's result; from
+  // the first event agent on, lane 0 replays the reference's serial loop (step_serial_move), reusing the
+  // geometry the lanes left in the cost tile.  Returns the index the serial replay starts at.
+  DEV int move_parallel() {
+    const int a = lane;
+    const bool live = a < P.n_agents && S.a_state[a] != -1;
+    bool evt = false, pop_head = false;
+    int new_st = 0, new_ts = 0, cid = 0, cs = -1;
+    double px = 0, py = 0, ddx = 0.0, ddy = 0.0;
+    if (a < P.n_agents) pre_id()[a] = -2;
+    if (live) {
+      if (S.a_fail[a] == S.time_steps) {
+        evt = true;
+      } else {
+        px = S.a_px[a]; py = S.a_py[a];
+        const double speed = P.speed[S.a_type[a]];
+        new_st = S.a_state[a]; new_ts = S.a_task_start[a];
+        const double base_d = norm2(px - BASE_X, py - BASE_Y);
+        pre_f(3)[a] = base_d;
+        double rdx, rdy;
+        {
+          double bx = BASE_X - px, by = BASE_Y - py;
+          norm_vector(bx, by);  // :1119
+          displacement(px, py, bx, by, speed, rdx, rdy);
+          pre_f(4)[a] = rdx; pre_f(5)[a] = rdy;
+        }
+        const int qlen = S.a_qlen[a], reeval = S.a_reeval[a];
+        if (new_st == 0 && !reeval && qlen == 0 && base_d > speed + 5) new_st = 3;  // :987-993
+        if (reeval) { cid = S.a_last_id[a]; cs = S.a_last_slot[a]; }
+        else if (qlen > 0) { cid = S.a_qid[a][0]; cs = S.a_qslot[a][0]; }
+        if (cid != 0 && ref_retired(cid, cs)) {
+          pop_head = true;  // :1004-1007, own queue only (the task is retired: removeAgentCap is a no-op)
+        } else if (cid != 0) {
+          const int ty = S.t_type[cs];
+          const double engage = ENGAGE_RANGE[S.a_type[a]];
+          double dx = S.t_px[cs] - px, dy = S.t_py[cs] - py;
+          const double dist = norm2(dx, dy);
+          double ux = 0, uy = 0;
+          if (!(fabs(dist) < 1e-12)) { ux = dx / dist; uy = dy / dist; }
+          double ndx, ndy;
+          displacement(px, py, ux, uy, speed, ndx, ndy);
+          pre_f(0)[a] = dist; pre_f(1)[a] = ndx; pre_f(2)[a] = ndy;
+          pre_id()[a] = cid;
+          if (new_st == 1) {
+            if (ty == MUAVTA_INT) {
+              if (dist < engage) evt = true;
+              else { ddx = ndx; ddy = ndy; }
+            } else if (dist < speed) {
+              new_st = 2; new_ts = S.time_steps;
+              px = S.t_px[cs]; py = S.t_py[cs];
+            } else { ddx = ndx; ddy = ndy; }
+          } else if (new_st == 2) {
+            if (ty == MUAVTA_INT && dist >= engage) new_st = 1;
+            if (new_ts == -1) {
+              new_ts = S.time_steps;
+              px = S.t_px[cs]; py = S.t_py[cs];
+            } else if ((S.time_steps - new_ts) >= TASK_DURATION[ty] && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
+                       ty != MUAVTA_INT && ty != MUAVTA_DET) {
+              evt = true;
+            }
+          }
+        }
+        if (new_st == 3) {  // :1114-1121
+          if (base_d < speed + 5) new_st = 0;
+          else { ddx = rdx; ddy = rdy; }
+        }
+      }
+    }
+    const unsigned long long em = __ballot(evt);
+    const int first = em ? __ffsll((long long)em) - 1 : P.n_agents;
+    if (live && a < first) {  // commit: own fields only
+      if (pop_head) {
+        des_allocate(a, cid);
+        S.a_reeval[a] = 0;
+        S.a_last_id[a] = -1; S.a_last_slot[a] = -1;
+      }
+      S.a_state[a] = new_st;
+      S.a_task_start[a] = new_ts;
+      px = px + ddx; py = py + ddy;  // :1125-1127
+      S.a_px[a] = fmin(fmax(px, 0.0), AREA_W);
+      S.a_py[a] = fmin(fmax(py, 0.0), AREA_H);
+    }
+    return first;
   }
 
   // events drain, action application, movement state machine
@@ -776,6 +930,7 @@ struct Sim {
     S.n_events = 0;
     for (int k = 0; k < nev; k++)
       if (S.dev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) release_all_tasks(S.dev_arg[k]);
+    PROF(2);
     // ---- task allocation (:813-933) ----
     for (int k = 0; k < S.n_act; k++) {
       int a = S.act_agent[k];
@@ -842,8 +997,11 @@ struct Sim {
         if (P.escort_enabled && ty == MUAVTA_REC && is_recon(S.a_type[a]) && escort_lookup(a) < 0) create_escort_for(a, s);
       }
     }
-    // ---- movement state machine (:965-1129) ----
-    for (int a = 0; a < P.n_agents; a++) {
+  }
+
+  // ---- movement state machine (:965-1129), agents_obj order, lane 0 ----
+  DEV void step_serial_move(int first, double& quality_reward) {
+    for (int a = first; a < P.n_agents; a++) {
       if (S.a_state[a] == -1) continue;
       if (S.a_fail[a] == S.time_steps) {  // :972-981
         S.a_state[a] = -1;
@@ -854,10 +1012,11 @@ struct Sim {
         continue;
       }
       const double speed = P.speed[S.a_type[a]];
-      double mvx = 0, mvy = 0, avx = 0, avy = 0;
       double px = S.a_px[a], py = S.a_py[a];
+      const double base_d = pre_f(3)[a];
+      double ddx = 0.0, ddy = 0.0;  // displacement of this step (movement normalised twice, times max_speed)
       if (S.a_state[a] == 0 && !S.a_reeval[a]) {  // :987-993
-        if (S.a_qlen[a] == 0 && norm2(px - BASE_X, py - BASE_Y) > speed + 5) S.a_state[a] = 3;
+        if (S.a_qlen[a] == 0 && base_d > speed + 5) S.a_state[a] = 3;
       }
       {
         // current task: last_task while re_eval, else the head (:996-1002); id 0 == task_idle
@@ -872,32 +1031,35 @@ struct Sim {
         } else if (cid != 0) {
           const int ty = S.t_type[cs];
           const double engage = ENGAGE_RANGE[S.a_type[a]];
-          if (S.a_state[a] == 1) {  // navigating (:1012-1048)
+          double dist, ndx, ndy;
+          if (pre_id()[a] == cid) {  // geometry computed by the agent's lane is still current
+            dist = pre_f(0)[a]; ndx = pre_f(1)[a]; ndy = pre_f(2)[a];
+          } else {                   // current task changed under an earlier agent's completion / escort retirement
             double dx = S.t_px[cs] - px, dy = S.t_py[cs] - py;
-            double dist = norm2(dx, dy);
+            dist = norm2(dx, dy);
             double ux = 0, uy = 0;
             if (!(fabs(dist) < 1e-12)) { ux = dx / dist; uy = dy / dist; }
+            displacement(px, py, ux, uy, speed, ndx, ndy);
+          }
+          if (S.a_state[a] == 1) {  // navigating (:1012-1048)
             if (ty == MUAVTA_INT) {
               if (dist < engage) {
                 S.a_state[a] = 2;
                 S.h_target[S.t_threat[cs]] = a;
                 S.a_task_start[a] = S.time_steps;
               } else {
-                mvx = ux; mvy = uy;
-                avoid_obstacles(px, py, mvx, mvy, avx, avy);
+                ddx = ndx; ddy = ndy;
               }
             } else if (dist < speed) {
               S.a_state[a] = 2;
               S.a_task_start[a] = S.time_steps;
               px = S.t_px[cs]; py = S.t_py[cs];
             } else {
-              mvx = ux; mvy = uy;
-              avoid_obstacles(px, py, mvx, mvy, avx, avy);
+              ddx = ndx; ddy = ndy;
             }
           } else if (S.a_state[a] == 2) {  // in task (:1051-1110)
             if (ty == MUAVTA_INT) {
-              double d = norm2(S.t_px[cs] - px, S.t_py[cs] - py);
-              if (d >= engage) S.a_state[a] = 1;
+              if (dist >= engage) S.a_state[a] = 1;
             }
             if (S.a_task_start[a] == -1) {
               S.a_task_start[a] = S.time_steps;
@@ -930,19 +1092,11 @@ struct Sim {
           }
         }
       }
-      if (S.a_state[a] == 3) {  // returning to base (:1114-1121)
-        if (norm2(px - BASE_X, py - BASE_Y) < speed + 5) {
-          S.a_state[a] = 0;
-        } else {
-          mvx = BASE_X - px; mvy = BASE_Y - py;
-          norm_vector(mvx, mvy);
-          avoid_obstacles(px, py, mvx, mvy, avx, avy);
-        }
+      if (S.a_state[a] == 3) {  // returning to base (:1114-1121); the position is still the one the lane saw
+        if (base_d < speed + 5) S.a_state[a] = 0;
+        else { ddx = pre_f(4)[a]; ddy = pre_f(5)[a]; }
       }
-      double mx = mvx + avx, my = mvy + avy;  // :1123-1127
-      norm_vector(mx, my);
-      mx = mx * speed; my = my * speed;
-      px = px + mx; py = py + my;
+      px = px + ddx; py = py + ddy;  // :1125-1127
       S.a_px[a] = fmin(fmax(px, 0.0), AREA_W);
       S.a_py[a] = fmin(fmax(py, 0.0), AREA_H);
     }
@@ -1213,10 +1367,9 @@ struct Sim {
     }
   }
 
-  // reveals, window expiry, reserve tracking, reward, done flags
-  DEV void step_serial_c(double action_reward, double distance_reward, double quality_reward, double S_quality_reward) {
-    // _wps_process_reveals (:1525-1541)
-    if (S.n_pending > 0) {
+  // _wps_process_reveals (:1525-1541) and _wps_expire_windows (:1557-1573); lane 0, only when due
+  DEV void step_serial_c_lists(bool any_due, bool any_exp) {
+    if (any_due) {
       int w = 0;
       for (int k = 0; k < S.n_pending; k++) {
         if (S.time_steps >= S.pend_time[k]) {
@@ -1228,8 +1381,7 @@ struct Sim {
       }
       S.n_pending = w;
     }
-    // _wps_expire_windows (:1557-1573)
-    if (P.hard_windows) {
+    if (any_exp) {
       for (int k = 0; k < S.n_order; k++) {
         int s = S.t_order[k];
         if (!(S.t_flags[s] & TF_DEADLINE) || S.t_status[s] == 2) continue;
@@ -1243,22 +1395,17 @@ struct Sim {
         }
       }
     }
-    // _wps_track_reserve (:1575-1580) and the pending-reset latch (:1156-1160)
-    int idle = 0;
-    bool responding = false;
-    for (int a = 0; a < P.n_agents; a++)
-      if (S.a_state[a] != -1) { if (S.a_qlen[a] == 0) idle++; else responding = true; }
+  }
+  // reserve tracking (:1575-1580), pending-reset latch (:1156-1160), shared reward (:1162-1178), done flags
+  DEV void step_serial_c(double action_reward, double distance_reward, double quality_reward, double S_quality_reward,
+                         int idle, bool responding, bool all_done_tasks) {
     S.idle_reserve_steps += idle;
     if (S.pending_reset && responding) S.pending_reset = 0;
-    // shared reward (:1140-1145,1162-1178)
     const double time_penaulty = S.r_time_penalty, alloc_reward = S.r_alloc;
     double total = P.rw[0] * action_reward + P.rw[1] * distance_reward + P.rw[2] * quality_reward + P.rw[3] * S_quality_reward +
                    P.rw[4] * (double)P.n_tasks * 0.0 + P.rw[5] * alloc_reward + P.rw[6] * time_penaulty + P.rw[7] * S.step_reward;
     S.last_reward = total / P.reward_norm_factor / (double)P.max_time_steps;
-#ifdef MUAVTA_DEBUG
-    if (blockIdx.x == 0 && S.time_steps <= 2) printf("DEV t=%d a=%.17g d=%.17g q=%.17g s=%.17g tp=%.17g al=%.17g sr=%.17g\n", S.time_steps, action_reward, distance_reward, quality_reward, S_quality_reward, time_penaulty, alloc_reward, S.step_reward);
-#endif
-    bool all_done = (S.next_task_id > 1) && all_mission_done();
+    bool all_done = (S.next_task_id > 1) && all_done_tasks;
     bool timed_out = (S.time_steps >= P.max_time_steps) && (P.max_time_steps > 0);
     bool done = timed_out || (P.early_terminate && all_done);
     if (all_done && S.conclusion_time > P.max_time_steps) S.conclusion_time = S.time_steps;
@@ -1275,95 +1422,163 @@ struct Sim {
       for (int s = lane; s < T; s += WG) {
         if (S.t_id[s] >= 0 && S.t_status[s] == 2 && slot_unreferenced(S.t_id[s])) release_slot(s);
       }
-      __syncthreads();
+      lds_sync();
     }
-    if (lane == 0) {
+    {  // compact t_order (drop freed slots) and rebuild last_tasks_info (:492) with ballot + popcount
+      const int n = S.n_order;
       int w = 0, no = 0;
-      for (int k = 0; k < S.n_order; k++) {
-        int s = S.t_order[k];
-        if (S.t_id[s] < 0) continue;
-        S.t_order[w++] = s;
-        if (S.t_status[s] != 2) S.open_slot[no++] = s;  // last_tasks_info (:492)
+      for (int base = 0; base < n; base += WG) {
+        const int k = base + lane;
+        int s = -1;
+        bool alive = false, open = false;
+        if (k < n) {
+          s = S.t_order[k];
+          alive = S.t_id[s] >= 0;
+          open = alive && S.t_status[s] != 2;
+        }
+        const unsigned long long am = __ballot(alive), om = __ballot(open);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        lds_sync();  // every lane has read its t_order entry before any is overwritten
+        if (alive) S.t_order[w + __popcll(am & below)] = s;
+        if (open) S.open_slot[no + __popcll(om & below)] = s;
+        w += __popcll(am);
+        no += __popcll(om);
       }
-      S.n_order = w;
-      S.n_open = no;
-      S.n_act = 0;
+      if (lane == 0) { S.n_order = w; S.n_open = no; S.n_act = 0; }
     }
-    __syncthreads();
+    lds_sync();
   }
 
   // ====================================================================================================
   // Observation tensors (:365-415,:468-492), written straight to HBM by all lanes.
   // ====================================================================================================
+  // One task ROW per lane (21 floats built in registers, staged in LDS, streamed out 16 B per lane);
+  // legal_mask: one row per lane x a loop over agents, the "no legal action" fallback (:401-408) by ballot.
+  DEV void stream_out(void* dst, const void* lds_src, int bytes) {  // dst 4-byte aligned at least
+    const int lane_ = lane;
+    if ((((uintptr_t)dst) & 15) == 0) {
+      uint4* d = reinterpret_cast<uint4*>(dst);
+      const uint4* q = reinterpret_cast<const uint4*>(lds_src);
+      const int n16 = bytes >> 4;
+      for (int i = lane_; i < n16; i += WG) d[i] = q[i];
+      uint8_t* db = reinterpret_cast<uint8_t*>(dst);
+      const uint8_t* sb = reinterpret_cast<const uint8_t*>(lds_src);
+      for (int i = (n16 << 4) + lane_; i < bytes; i += WG) db[i] = sb[i];
+    } else if ((bytes & 3) == 0 && (((uintptr_t)dst) & 3) == 0) {
+      uint32_t* d = reinterpret_cast<uint32_t*>(dst);
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(lds_src);
+      for (int i = lane_; i < (bytes >> 2); i += WG) d[i] = q[i];
+    } else {
+      uint8_t* db = reinterpret_cast<uint8_t*>(dst);
+      const uint8_t* sb = reinterpret_cast<const uint8_t*>(lds_src);
+      for (int i = lane_; i < bytes; i += WG) db[i] = sb[i];
+    }
+  }
   DEV void write_obs(float* o_tasks, uint8_t* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags) {
     const int MT = P.max_tasks, nA = P.n_agents;
     const int n = S.n_open;
     const double mts = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1);
+    float* stage = reinterpret_cast<float*>(&X);  // >= max_tasks * 84 bytes (checked at create)
+    PROF(15);
     if (o_tasks) {
-      for (int p = lane; p < MT * 21; p += WG) {
-        int j = p / 21, c = p - j * 21;
-        float v = 0.f;
+      for (int j = lane; j < MT; j += WG) {
+        float* r = stage + j * 21;
         if (j < n) {
-          int s = S.open_slot[j];
-          int ty = S.t_type[s];
-          if (c == 0) v = (float)S.t_id[s];
-          else if (c == 1) v = (float)(S.t_px[s] / MAX_COORD);
-          else if (c == 2) v = (float)(S.t_py[s] / MAX_COORD);
-          else if (c == 3) v = (float)S.t_status[s];
-          else if (c < 10) v = (float)S.t_cur[c - 4][s];
-          else if (c < 16) v = (float)S.t_alloc[c - 10][s];
-          else if (c == 16) v = P.include_time_windows ? (float)((S.t_init[s] - (double)S.time_steps) / mts) : 0.f;
-          else if (c == 17) v = P.include_time_windows ? (float)((S.t_dtime[s] - (double)S.time_steps) / mts) : 0.f;
-          else if (c == 18) v = P.include_time_windows ? (float)((double)ty / 6.0) : 0.f;
-          else if (c == 19) { double unmet = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0); v = (float)(unmet / fmax(S.t_org[s], 1e-6)); }
-          else v = (float)fmin(((double)S.time_steps - (double)S.t_created[s]) / mts, 1.0);
-        } else if (j == 0 && n == 0) {
-          v = 0.f;  // the idle task row: id 0, position (0,0), status 0, all reqs 0
-        } else if (c == 3) {
-          v = -1.f;
+          const int s = S.open_slot[j];
+          const int ty = S.t_type[s];
+          r[0] = (float)S.t_id[s];
+          r[1] = (float)(S.t_px[s] / MAX_COORD);
+          r[2] = (float)(S.t_py[s] / MAX_COORD);
+          r[3] = (float)S.t_status[s];
+#pragma unroll
+          for (int c = 0; c < 6; c++) { r[4 + c] = (float)S.t_cur[c][s]; r[10 + c] = (float)S.t_alloc[c][s]; }
+          if (P.include_time_windows) {
+            r[16] = (float)((S.t_init[s] - (double)S.time_steps) / mts);
+            r[17] = (float)((S.t_dtime[s] - (double)S.time_steps) / mts);
+            r[18] = (float)((double)ty / 6.0);
+          } else { r[16] = 0.f; r[17] = 0.f; r[18] = 0.f; }
+          const double unmet = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+          r[19] = (float)(unmet / fmax(S.t_org[s], 1e-6));
+          r[20] = (float)fmin(((double)S.time_steps - (double)S.t_created[s]) / mts, 1.0);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 21; c++) r[c] = 0.f;
+          if (!(j == 0 && n == 0)) r[3] = -1.f;  // pad rows are {"status": -1}; with no open task row 0 is task_idle
         }
-        o_tasks[p] = v;
       }
+      lds_sync();
+      PROF(16);
+      stream_out(o_tasks, stage, MT * 21 * 4);
+      lds_sync();
+      PROF(17);
     }
     const int nrows = n == 0 ? 1 : n;
     if (o_pad) for (int j = lane; j < MT; j += WG) o_pad[j] = j < nrows;
     if (o_legal) {
-      for (int p = lane; p < nA * MT; p += WG) {
-        int a = p / MT, j = p - a * MT;
-        uint8_t v = 0;
-        if (n == 0) {
-          v = (j == 0) && (S.a_state[a] != 2 || S.a_qlen[a] == 0);
-        } else if (j < n) {
-          int s = S.open_slot[j];
-          int hid_ = head_id(a);
-          if (S.a_state[a] == 2) v = S.t_id[s] == hid_;
-          else v = action_valid(a, s);
+      uint8_t* lg = reinterpret_cast<uint8_t*>(&X);  // [nA][MT] bytes
+      // lane a keeps agent a's (state, head id, type); the agent loop broadcasts them with v_readlane
+      int my_st = 0, my_hid = 0, my_ty = 0;
+      if (lane < nA) { my_st = S.a_state[lane]; my_hid = head_id(lane); my_ty = S.a_type[lane]; }
+      for (int base = 0; base < MT; base += WG) {
+        const int j = base + lane;
+        const bool in_n = j < n;
+        int tid = -1, ty = 0;
+        uint32_t elig = 0xffffffffu;
+        bool saturated = false;
+        if (in_n) {
+          const int s = S.open_slot[j];
+          tid = S.t_id[s];
+          ty = S.t_type[s];
+          if (S.t_flags[s] & TF_ELIGIBLE) elig = S.t_elig[s];
+          saturated = P.saturate_mask && S.t_alloc[ty][s] >= S.t_org[s];
         }
-        o_legal[p] = v;
-      }
-      __syncthreads();
-      // rows with no legal action fall back to the current task, else column 0 (:401-408)
-      if (n > 0 && lane < nA && S.a_state[lane] != 2) {
-        const int a = lane;
-        bool any = false;
-        for (int j = 0; j < n; j++) any |= action_valid(a, S.open_slot[j]);
-        if (!any) {
-          int cur = S.a_qlen[a] > 0 ? S.a_qid[a][0] : 0, at = 0;
-          for (int j = 0; j < n; j++) if (S.t_id[S.open_slot[j]] == cur) { at = j; break; }
-          o_legal[a * MT + at] = 1;
+        for (int a = 0; a < nA; a++) {
+          const int st = __builtin_amdgcn_readlane(my_st, a), hid_ = __builtin_amdgcn_readlane(my_hid, a),
+                    aty = __builtin_amdgcn_readlane(my_ty, a);
+          const bool iscur = in_n && tid == hid_;
+          bool v = false;
+          if (in_n) {
+            if (st == 2) v = iscur;
+            else {  // _is_task_action_valid (:341-363); open rows are never status 2
+              v = iscur || (((elig >> aty) & 1u) && !saturated && !(P.capability_mask && S.a_caps[ty][a] <= 0));
+            }
+          } else if (n == 0 && j == 0) {
+            v = (st != 2) || hid_ == 0;  // single task_idle row
+          }
+          if (j < MT) lg[a * MT + j] = v;
+          // "no legal action" fallback (:401-408): current task if it is open, else row 0.  Rows beyond the
+          // first 64 exist only on the 64x128 tile; the per-agent flags then live in LDS.
+          const unsigned long long mv = __ballot(v), mc = __ballot(iscur);
+          if (MT <= WG) {
+            if (mv == 0ull && n > 0 && st != 2 && lane == 0) lg[a * MT + (mc ? __ffsll((long long)mc) - 1 : 0)] = 1;
+          } else if (lane == 0) {
+            int32_t* anyf = X.row4col;   // [A] beyond the byte staging? no: separate int scratch (T >= A)
+            int32_t* curp = X.remaining;
+            if (base == 0) { anyf[a] = 0; curp[a] = -1; }
+            if (mv) anyf[a] = 1;
+            if (curp[a] < 0 && mc) curp[a] = base + __ffsll((long long)mc) - 1;
+          }
         }
       }
+      if (MT > WG) {
+        lds_sync();
+        if (lane < nA && n > 0 && S.a_state[lane] != 2 && X.row4col[lane] == 0)
+          lg[lane * MT + (X.remaining[lane] >= 0 ? X.remaining[lane] : 0)] = 1;
+      }
+      lds_sync();
+      PROF(18);
+      stream_out(o_legal, lg, nA * MT);
+      lds_sync();
+      PROF(19);
     }
-    if (o_agents) {
-      for (int p = lane; p < nA * 9; p += WG) {
-        int a = p / 9, c = p - a * 9;
-        float v;
-        if (c == 0) v = (float)(S.a_px[a] / MAX_COORD);
-        else if (c == 1) v = (float)(S.a_py[a] / MAX_COORD);
-        else if (c < 8) v = (float)S.a_caps[c - 2][a];
-        else v = (float)head_id(a);
-        o_agents[p] = v;
-      }
+    if (o_agents && lane < nA) {
+      const int a = lane;
+      float* r = o_agents + a * 9;
+      r[0] = (float)(S.a_px[a] / MAX_COORD);
+      r[1] = (float)(S.a_py[a] / MAX_COORD);
+#pragma unroll
+      for (int c = 0; c < 6; c++) r[2 + c] = (float)S.a_caps[c][a];
+      r[8] = (float)head_id(a);
     }
     if (o_flags && lane == 0) {  // _event_flag_vector (:417-438)
       float f = 0, t = 0, r = 0;
@@ -1394,6 +1609,7 @@ struct Sim {
 
   DEV void allocate(int interval, int use_visibility) {
     __shared__ int sh_go, sh_nr, sh_nc, sh_nopen;
+    PROF(10);
     interval = interval < 1 ? 1 : interval;
     if (lane == 0) {
       S.n_calls++;
@@ -1413,7 +1629,8 @@ struct Sim {
       }
       sh_go = go; sh_nr = nfree; sh_nopen = nopen;
     }
-    __syncthreads();
+    lds_sync();
+    PROF(11);
     if (!sh_go) return;
     const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
     while (true) {
@@ -1422,7 +1639,7 @@ struct Sim {
         for (int k = 0; k < S.n_open; k++) { int s = S.open_slot[k]; if (X.resid[s] > 1e-9) X.roundT[nc++] = k; }
         sh_nc = nc;
       }
-      __syncthreads();
+      lds_sync();
       const int nr = sh_nr, nc = sh_nc;
       if (nr == 0 || nc == 0) break;
       const bool tr = nc < nr;              // scipy transposes so that rows <= cols
@@ -1451,9 +1668,11 @@ struct Sim {
         }
         X.cost[tr ? (j * Cc + i) : (i * Cc + j)] = c;
       }
-      __syncthreads();
+      lds_sync();
+      PROF(12);
+      lsap(Rr, Cc);
+      PROF(13);
       if (lane == 0) {
-        lsap(Rr, Cc);
         // accept (:182-204) in ascending agent order (scipy returns rows sorted)
         int n_acc = 0;
         for (int i = 0; i < nr; i++) {
@@ -1474,59 +1693,97 @@ struct Sim {
         for (int i = 0; i < nr; i++) if (X.freeA[i] >= 0) X.freeA[w++] = X.freeA[i];
         sh_nr = n_acc ? w : 0;  // no accept -> stop
       }
-      __syncthreads();
+      lds_sync();
+      PROF(14);
     }
     if (lane == 0) {
       S.last_plan_step = S.time_steps;
       S.n_replans++;
     }
-    __syncthreads();
+    lds_sync();
   }
 
   // scipy.optimize.linear_sum_assignment (rectangular_lsap, scipy 1.15.3) on X.cost[nr x nc], nr <= nc.
-  // Lane 0.  Tie rule kept literally: a column replaces the running minimum when strictly lower, or
-  // equal and still unassigned; the scan runs over `remaining` (filled in reverse, swap-removed).
+  // Wave-cooperative: lane `it` owns scan position `it` of scipy's `remaining` array (filled in
+  // reverse, swap-removed), so the sequential tie rule — a column replaces the running minimum when
+  // strictly lower, or when equal and still unassigned — becomes: take the LAST unassigned position
+  // among the minima if there is one, else the FIRST minimum.  One f64 wave-min + two ballots per
+  // augmenting step; duals are updated one row/column per lane.  Arithmetic order per column is
+  // scipy's: minVal + C[i][j] - u[i] - v[j].  All lanes must call this (uniform control flow).
+  DEV double wave_min(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WG));
+    return v;
+  }
   DEV void lsap(int nr, int nc) {
     const double INF = __builtin_huge_val();
-    for (int i = 0; i < nr; i++) { X.u[i] = 0; X.col4row[i] = -1; }
-    for (int j = 0; j < nc; j++) { X.v[j] = 0; X.row4col[j] = -1; X.path[j] = -1; }
+    for (int i = lane; i < nr; i += WG) { X.u[i] = 0; X.col4row[i] = -1; }
+    for (int j = lane; j < nc; j += WG) { X.v[j] = 0; X.row4col[j] = -1; X.path[j] = -1; }
+    lds_sync();
     for (int cur = 0; cur < nr; cur++) {
+      for (int it = lane; it < nc; it += WG) { X.remaining[it] = nc - it - 1; X.SC[it] = 0; X.spc[it] = INF; }
+      for (int r = lane; r < nr; r += WG) X.SR[r] = 0;
+      lds_sync();
       double minVal = 0;
-      int i = cur;
-      int num_remaining = nc;
-      for (int it = 0; it < nc; it++) { X.remaining[it] = nc - it - 1; X.SC[it] = 0; X.spc[it] = INF; }
-      for (int r = 0; r < nr; r++) X.SR[r] = 0;
-      int sink = -1;
+      int i = cur, num_remaining = nc, sink = -1;
       while (sink == -1) {
-        int index = -1;
-        double lowest = INF;
-        X.SR[i] = 1;
         const double ui = X.u[i];
         const double* crow = X.cost + i * nc;
-        for (int it = 0; it < num_remaining; it++) {
-          int j = X.remaining[it];
-          double r = minVal + crow[j] - ui - X.v[j];
-          double sp = X.spc[j];
-          if (r < sp) { X.path[j] = i; X.spc[j] = r; sp = r; }
-          if (sp < lowest || (sp == lowest && X.row4col[j] == -1)) { lowest = sp; index = it; }
+        double gmin = INF;
+        int g_first = -1, g_lastU = -1;
+        for (int base = 0; base < num_remaining; base += WG) {
+          const int it = base + lane;
+          const bool active = it < num_remaining;
+          double val = INF;
+          bool un = false;
+          if (active) {
+            const int j = X.remaining[it];
+            const double r = minVal + crow[j] - ui - X.v[j];
+            double sp = X.spc[j];
+            if (r < sp) { X.path[j] = i; X.spc[j] = r; sp = r; }
+            val = sp;
+            un = X.row4col[j] == -1;
+          }
+          const double m = wave_min(val);
+          const unsigned long long eq = __ballot(active && val == m);
+          const unsigned long long equ = __ballot(active && val == m && un);
+          if (m < gmin) {
+            gmin = m;
+            g_first = base + __ffsll((long long)eq) - 1;
+            g_lastU = equ ? base + 63 - __clzll((long long)equ) : -1;
+          } else if (m == gmin && equ) {
+            g_lastU = base + 63 - __clzll((long long)equ);
+          }
         }
-        minVal = lowest;
-        if (minVal == INF) { fail(MUAVTA_ERR_LSAP); return; }
-        int j = X.remaining[index];
-        if (X.row4col[j] == -1) sink = j; else i = X.row4col[j];
-        X.SC[j] = 1;
-        X.remaining[index] = X.remaining[--num_remaining];
+        if (gmin == INF) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }
+        minVal = gmin;
+        const int index = g_lastU >= 0 ? g_lastU : g_first;
+        const int j = X.remaining[index];
+        const int rj = X.row4col[j];
+        const int last = X.remaining[num_remaining - 1];
+        lds_sync();  // everyone has read before lane 0 rewrites `remaining`
+        if (lane == 0) { X.SR[i] = 1; X.SC[j] = 1; X.remaining[index] = last; }
+        num_remaining--;
+        if (rj == -1) sink = j; else i = rj;
+        lds_sync();
       }
-      X.u[cur] += minVal;
-      for (int r = 0; r < nr; r++) if (X.SR[r] && r != cur) X.u[r] += minVal - X.spc[X.col4row[r]];
-      for (int j = 0; j < nc; j++) if (X.SC[j]) X.v[j] -= minVal - X.spc[j];
-      int j = sink;
-      while (true) {
-        int r = X.path[j];
-        X.row4col[j] = r;
-        int t = X.col4row[r]; X.col4row[r] = j; j = t;
-        if (r == cur) break;
+      // dual updates (one row / column per lane), then the augmentation along `path`
+      for (int r = lane; r < nr; r += WG) {
+        if (r == cur) X.u[r] += minVal;
+        else if (X.SR[r]) X.u[r] += minVal - X.spc[X.col4row[r]];
       }
+      for (int j = lane; j < nc; j += WG) if (X.SC[j]) X.v[j] -= minVal - X.spc[j];
+      lds_sync();
+      if (lane == 0) {
+        int j = sink;
+        while (true) {
+          int r = X.path[j];
+          X.row4col[j] = r;
+          int t = X.col4row[r]; X.col4row[r] = j; j = t;
+          if (r == cur) break;
+        }
+      }
+      lds_sync();
     }
   }
 

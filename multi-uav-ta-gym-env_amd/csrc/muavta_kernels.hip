@@ -66,6 +66,11 @@ struct Lds {
 
 extern __shared__ __align__(16) unsigned char smem[];
 
+// Minimum waves per SIMD the register allocator must leave room for (2 => at most 256 VGPR+AGPR).
+#ifndef MUAVTA_MIN_WAVES
+#define MUAVTA_MIN_WAVES 2
+#endif
+
 template <class TL>
 __global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, ObsPtrs O) {
   const int env = blockIdx.x;
@@ -73,18 +78,18 @@ __global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
   sim.reset(seeds[env]);
   obs_for_env(sim, P, O, env);
-  __syncthreads();
+  lds_sync();
   copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
 }
 
 // act_agent == nullptr: use the actions staged in the blob by k_allocate
 template <class TL>
-__global__ __launch_bounds__(WG) void k_step(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, const int32_t* act_agent,
+__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, const int32_t* act_agent,
                                              const int32_t* act_index, int act_cap, ObsPtrs O) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
-  __syncthreads();
+  lds_sync();
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
   if (act_agent && threadIdx.x == 0) {
     EnvState<TL>& S = *L.S;
@@ -101,10 +106,10 @@ __global__ __launch_bounds__(WG) void k_step(DevParams P, EnvState<TL>* blobs, u
     }
     S.n_act = n;
   }
-  __syncthreads();
+  lds_sync();
   sim.step(true);
   obs_for_env(sim, P, O, env);
-  __syncthreads();
+  lds_sync();
   copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
 }
 
@@ -114,10 +119,10 @@ __global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blob
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
-  __syncthreads();
+  lds_sync();
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
   sim.allocate(interval, use_vis);
-  __syncthreads();
+  lds_sync();
   if (out_agent) {
     const EnvState<TL>& S = *L.S;
     for (int k = threadIdx.x; k < act_cap; k += WG) {
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blob
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_rollout(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, int n_steps,
+__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, int n_steps,
                                                 int interval, int use_vis, int write_obs, ObsPtrs O, double* metrics) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
@@ -138,18 +143,24 @@ __global__ __launch_bounds__(WG) void k_rollout(DevParams P, const uint64_t* see
     sim.reset(seeds[env]);
   } else {
     copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
-    __syncthreads();
+    lds_sync();
   }
   for (int t = 0; t < n_steps; t++) {
     if (L.S->terminated || L.S->truncated) break;  // uniform: read from LDS after a barrier
     sim.allocate(interval, use_vis);
     sim.step(true);
     if (write_obs) obs_for_env(sim, P, O, env);
-    __syncthreads();
+    lds_sync();
+#ifdef MUAVTA_PROF
+    if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sim.prof_acc[20] += t_ - sim.prof_last; sim.prof_last = t_; }
+#endif
   }
+#ifdef MUAVTA_PROF
+  sim.prof_flush();
+#endif
   if (!write_obs) obs_for_env(sim, P, O, env);
   sim.metrics(metrics + (size_t)env * MUAVTA_N_METRICS);
-  __syncthreads();
+  lds_sync();
   copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
 }
 
@@ -158,7 +169,7 @@ __global__ __launch_bounds__(WG) void k_metrics(DevParams P, EnvState<TL>* blobs
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
-  __syncthreads();
+  lds_sync();
   Sim<TL> sim(*L.S, *L.X, P, nullptr);
   sim.metrics(metrics + (size_t)env * MUAVTA_N_METRICS);
 }
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(WG) void k_observe(DevParams P, EnvState<TL>* blobs
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
-  __syncthreads();
+  lds_sync();
   Sim<TL> sim(*L.S, *L.X, P, nullptr);
   obs_for_env(sim, P, O, env);
 }
@@ -188,9 +199,9 @@ __global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc,
     L.X->cost[tr ? (j * Cc + i) : (i * Cc + j)] = c[p];
   }
   if (threadIdx.x == 0) L.S->error = 0;
-  __syncthreads();
+  lds_sync();
+  sim.lsap(Rr, Cc);
   if (threadIdx.x == 0) {
-    sim.lsap(Rr, Cc);
     int64_t* r = row + (size_t)prob * Rr;
     int64_t* cc = col + (size_t)prob * Rr;
     int n = 0;
@@ -590,7 +601,17 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   else if (ta <= Tile24::A && tt <= Tile24::T && th <= Tile24::H) e->tile = TK24;
   else if (ta <= Tile64::A && tt <= Tile64::T && th <= Tile64::H) e->tile = TK64;
   else { g_create_error = "muavta_create: requested tile exceeds 64 agents x 128 task slots x 48 threats"; delete e; return MUAVTA_E_ARG; }
-  DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->Q = TL::Q; e->state_bytes = sizeof(EnvState<TL>); });
+  size_t scratch_bytes = 0;
+  DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->Q = TL::Q; e->state_bytes = sizeof(EnvState<TL>);
+                scratch_bytes = sizeof(Scratch<TL>); });
+  {  // the observation rows are staged in the LDS scratch tile before they are streamed out
+    size_t need = (size_t)e->P.max_tasks * 84, need2 = (size_t)e->P.n_agents * e->P.max_tasks;
+    if (need > scratch_bytes || need2 > scratch_bytes) {
+      g_create_error = "muavta_create: max_tasks too large for this tile's observation staging; raise tile_agents/tile_tasks";
+      delete e;
+      return MUAVTA_E_ARG;
+    }
+  }
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); muavta_destroy(e); return MUAVTA_E_HIP; } } while (0)
   CK(hipSetDevice(device));
   CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -714,6 +735,14 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
   e->host_valid = false;
   return MUAVTA_OK;
 }
+
+#ifdef MUAVTA_PROF
+int muavta_prof_read(unsigned long long* out, int reset) {  // diagnostic build only
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return MUAVTA_E_HIP;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return MUAVTA_E_HIP; }
+  return MUAVTA_OK;
+}
+#endif
 
 int muavta_sync(MuavtaEnv* e) {
   if (!e) return MUAVTA_E_ARG;

@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares of k_rollout from in-kernel s_memtime stamps (lane 0).
+Builds a SEPARATE library with -DMUAVTA_PROF (never the shipped one); shares are meaningful, the
+absolute run time of this build is not (guide: 'In-kernel stamps')."""
+import ctypes as C, os, subprocess, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from muavta_amd import native
+so = os.path.join(ROOT, "tools", "_build", "libmuavta_prof.so")
+os.makedirs(os.path.dirname(so), exist_ok=True)
+if "--build" in sys.argv:
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + native.HIPCC_FLAGS + ["-DMUAVTA_PROF", "-o", so, os.path.join(native.CSRC, "muavta_kernels.hip")])
+    sys.exit(0)
+native.SO_PATH = so
+from muavta_amd.batched import BatchedMultiUAVEnv
+from muavta_amd.params import params_for_case
+case = sys.argv[1] if len(sys.argv) > 1 else "WPS_hard_x2"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+interval = 12 if "escort" in case else 20
+env = BatchedMultiUAVEnv(params_for_case(case), n)
+L = native.lib()
+buf = (C.c_ulonglong * 32)()
+env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, True); env.sync()
+L.muavta_prof_read(buf, 1)
+env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, True); env.sync()
+L.muavta_prof_read(buf, 1)
+names = {0: "(loop gap)", 1: "rng_refill", 2: "drain+release", 3: "actions", 4: "movement", 5: "dist", 6: "serial_b threats/arrivals/escorts",
+         7: "sense", 8: "serial_c reveals/expire/reward", 9: "finish gc+open", 10: "(pre-alloc)", 11: "alloc gate", 12: "cost build",
+         13: "lsap", 14: "accept", 15: "(pre-obs)", 16: "obs rows->LDS", 17: "obs rows stream", 18: "obs legal->LDS", 19: "obs legal stream", 20: "obs agents/flags/result"}
+v = np.array(list(buf), dtype=np.float64)
+tot = v.sum()
+print(f"{case} n={n}: kernel {env.last_kernel_ms():.2f} ms; cycles/env-step (lane 0) {tot / n / 150:.0f}")
+for i in range(21):
+    print(f"  {names.get(i, i):40s} {100 * v[i] / tot:6.2f} %   {v[i] / n / 150:9.0f} cyc/step")
