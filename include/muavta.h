@@ -103,14 +103,14 @@ typedef struct MuavtaParams {
 typedef struct MuavtaDims {
   int32_t n_envs, n_agents, tile_agents, tile_tasks, tile_threats;
   int32_t max_tasks;      /* observation pad length = n_tasks + 28 (DroneEnv.py:145-147) */
-  int32_t obs_task_width; /* 21 floats per task row */
+  int32_t obs_task_width; /* 21 features per task (leading dim of the feature-major tasks tensor) */
   int32_t obs_agent_width;/* 9 floats per agent row */
   int32_t queue_cap, event_cap, action_cap;
   int64_t state_bytes;    /* bytes of one env's device state blob */
   int32_t n_threats;      /* sum(threat_count): leading dim of the THREAT_* fields */
   int32_t known_words;    /* ceil(tile_tasks / 32) */
   int32_t lds_bytes;      /* LDS one workgroup (= one env) occupies */
-  int32_t reserved;
+  int32_t legal_words;    /* ceil(max_tasks / 64): u64 words per agent row of the legal mask */
 } MuavtaDims;
 
 /* State fields readable with muavta_get (row-major, leading dim n_envs; A = n_agents, T = tile_tasks,
@@ -201,14 +201,16 @@ int muavta_step_staged(MuavtaEnv* env); /* step with the actions muavta_allocate
 int muavta_rollout(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps, int32_t replan_interval,
                    int32_t use_visibility, int32_t write_obs);
 
-/* Batched observation of the last reset/step (DroneEnv.py:365-415,468-492):
- *   tasks   f32 [N, max_tasks, 21]: id, x, y, status(-1 pad), current_reqs[6], alloc_reqs[6], init_time,
- *                                   end_time, type_idx/6, unmet, age
- *   legal   u8  [N, A, max_tasks]   legal_mask        pad u8 [N, max_tasks]  mask
+/* Batched observation of the last reset/step (DroneEnv.py:365-415,468-492), feature-major so that
+ * the device writes it with contiguous stores (transpose on the host if a row-major view is wanted):
+ *   tasks   f32 [N, 21, max_tasks]  rows of the 21 features: id, x, y, status(-1 pad), current_reqs[6],
+ *                                   alloc_reqs[6], init_time, end_time, type_idx/6, unmet, age
+ *   legal   u64 [N, A, legal_words] legal_mask as bit rows: bit (j & 63) of word (j >> 6) <=> row j legal
+ *   pad     u8  [N, max_tasks]      mask
  *   agents  f32 [N, A, 9]           agent_position(2), agent_caps(6), alloc_task
  *   flags   f32 [N, 5]              event_flags
  * Any pointer may be NULL. */
-int muavta_observe(MuavtaEnv* env, float* tasks, uint8_t* legal, uint8_t* pad, float* agents, float* flags);
+int muavta_observe(MuavtaEnv* env, float* tasks, uint64_t* legal, uint8_t* pad, float* agents, float* flags);
 
 /* rewards / terminations / truncations of the last step: reward f64 [N] (shared by all agents of an
  * env, DroneEnv.py:1162-1178,1202), done u8 [N] (terminated | truncated << 1). */

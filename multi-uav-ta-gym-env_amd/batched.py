@@ -117,12 +117,15 @@ class BatchedMultiUAVEnv:
 
     def observe(self):
         N, A, MT = self.n_envs, self.n_agents, self.max_tasks
-        tasks = np.empty((N, MT, 21), dtype=np.float32)
-        legal = np.empty((N, A, MT), dtype=np.uint8)
+        tasks = np.empty((N, 21, MT), dtype=np.float32)  # feature-major on the device
+        legal = np.empty((N, A, self.dims.legal_words), dtype=np.uint64)  # bit rows on the device
         pad = np.empty((N, MT), dtype=np.uint8)
         agents = np.empty((N, A, 9), dtype=np.float32)
         flags = np.empty((N, 5), dtype=np.float32)
         self._ck(self.L.muavta_observe(self.h, _vp(tasks), _vp(legal), _vp(pad), _vp(agents), _vp(flags)))
+        tasks = np.ascontiguousarray(tasks.transpose(0, 2, 1))    # -> [N, max_tasks, 21] like the reference's rows
+        bits = (legal[..., :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)
+        legal = bits.reshape(N, A, -1)[:, :, :MT]
         return {"tasks": tasks, "legal_mask": legal.astype(bool), "mask": pad.astype(bool), "agents": agents, "event_flags": flags}
 
     def step_result(self):

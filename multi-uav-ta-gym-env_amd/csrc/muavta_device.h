@@ -1440,7 +1440,7 @@ struct Sim {
         const unsigned long long below = (1ull << lane) - 1ull;
         lds_sync();  // every lane has read its t_order entry before any is overwritten
         if (alive) S.t_order[w + __popcll(am & below)] = s;
-        if (open) S.open_slot[no + __popcll(om & below)] = s;
+        if (open) { const int row = no + __popcll(om & below); S.open_slot[row] = s; S.t_row[s] = (uint8_t)row; }
         w += __popcll(am);
         no += __popcll(om);
       }
@@ -1452,125 +1452,99 @@ struct Sim {
   // ====================================================================================================
   // Observation tensors (:365-415,:468-492), written straight to HBM by all lanes.
   // ====================================================================================================
-  // One task ROW per lane (21 floats built in registers, staged in LDS, streamed out 16 B per lane);
-  // legal_mask: one row per lane x a loop over agents, the "no legal action" fallback (:401-408) by ballot.
-  DEV void stream_out(void* dst, const void* lds_src, int bytes) {  // dst 4-byte aligned at least
-    const int lane_ = lane;
-    if ((((uintptr_t)dst) & 15) == 0) {
-      uint4* d = reinterpret_cast<uint4*>(dst);
-      const uint4* q = reinterpret_cast<const uint4*>(lds_src);
-      const int n16 = bytes >> 4;
-      for (int i = lane_; i < n16; i += WG) d[i] = q[i];
-      uint8_t* db = reinterpret_cast<uint8_t*>(dst);
-      const uint8_t* sb = reinterpret_cast<const uint8_t*>(lds_src);
-      for (int i = (n16 << 4) + lane_; i < bytes; i += WG) db[i] = sb[i];
-    } else if ((bytes & 3) == 0 && (((uintptr_t)dst) & 3) == 0) {
-      uint32_t* d = reinterpret_cast<uint32_t*>(dst);
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(lds_src);
-      for (int i = lane_; i < (bytes >> 2); i += WG) d[i] = q[i];
-    } else {
-      uint8_t* db = reinterpret_cast<uint8_t*>(dst);
-      const uint8_t* sb = reinterpret_cast<const uint8_t*>(lds_src);
-      for (int i = lane_; i < bytes; i += WG) db[i] = sb[i];
-    }
-  }
-  DEV void write_obs(float* o_tasks, uint8_t* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags) {
+  // Observation tensors are FEATURE-MAJOR in HBM — tasks f32 [21][max_tasks], legal bit rows u64 [A][ceil(max_tasks/64)] —
+  // so with one task row per lane every store instruction is a contiguous run across the wave: no LDS
+  // staging, no transposition.  The "no legal action" fallback (:401-408) is a ballot.
+  DEV void write_obs(float* o_tasks, unsigned long long* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags) {
     const int MT = P.max_tasks, nA = P.n_agents;
     const int n = S.n_open;
     const double mts = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1);
-    float* stage = reinterpret_cast<float*>(&X);  // >= max_tasks * 84 bytes (checked at create)
+    unsigned long long leg0 = 0ull, leg1 = 0ull;  // lane a: legal bits of agent a (rows 0..63, 64..127)
     PROF(15);
-    if (o_tasks) {
-      for (int j = lane; j < MT; j += WG) {
-        float* r = stage + j * 21;
-        if (j < n) {
-          const int s = S.open_slot[j];
-          const int ty = S.t_type[s];
-          r[0] = (float)S.t_id[s];
-          r[1] = (float)(S.t_px[s] / MAX_COORD);
-          r[2] = (float)(S.t_py[s] / MAX_COORD);
-          r[3] = (float)S.t_status[s];
+    // lane a keeps agent a's (state, head id, type); the agent loop broadcasts them with v_readlane
+    int my_st = 0, my_hid = 0, my_ty = 0;
+    if (lane < nA) { my_st = S.a_state[lane]; my_hid = head_id(lane); my_ty = S.a_type[lane]; }
+    const bool capm = P.capability_mask != 0;
+    for (int base = 0; base < MT; base += WG) {
+      const int j = base + lane;
+      const bool in_n = j < n, in_mt = j < MT;
+      int tid = -1, ty = 0, s = 0;
+      uint32_t typemask = 0;  // agent types for which this row is a valid action (before the capability mask)
+      float r[21];
 #pragma unroll
-          for (int c = 0; c < 6; c++) { r[4 + c] = (float)S.t_cur[c][s]; r[10 + c] = (float)S.t_alloc[c][s]; }
-          if (P.include_time_windows) {
-            r[16] = (float)((S.t_init[s] - (double)S.time_steps) / mts);
-            r[17] = (float)((S.t_dtime[s] - (double)S.time_steps) / mts);
-            r[18] = (float)((double)ty / 6.0);
-          } else { r[16] = 0.f; r[17] = 0.f; r[18] = 0.f; }
-          const double unmet = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
-          r[19] = (float)(unmet / fmax(S.t_org[s], 1e-6));
-          r[20] = (float)fmin(((double)S.time_steps - (double)S.t_created[s]) / mts, 1.0);
-        } else {
+      for (int c = 0; c < 21; c++) r[c] = 0.f;
+      if (in_n) {
+        s = S.open_slot[j];
+        tid = S.t_id[s];
+        ty = S.t_type[s];
+        typemask = (S.t_flags[s] & TF_ELIGIBLE) ? S.t_elig[s] : 0xffffffffu;
+        if (P.saturate_mask && S.t_alloc[ty][s] >= S.t_org[s]) typemask = 0;
+        r[0] = (float)tid;
+        r[1] = (float)(S.t_px[s] / MAX_COORD);
+        r[2] = (float)(S.t_py[s] / MAX_COORD);
+        r[3] = (float)S.t_status[s];
 #pragma unroll
-          for (int c = 0; c < 21; c++) r[c] = 0.f;
-          if (!(j == 0 && n == 0)) r[3] = -1.f;  // pad rows are {"status": -1}; with no open task row 0 is task_idle
+        for (int c = 0; c < 6; c++) { r[4 + c] = (float)S.t_cur[c][s]; r[10 + c] = (float)S.t_alloc[c][s]; }
+        if (P.include_time_windows) {
+          r[16] = (float)((S.t_init[s] - (double)S.time_steps) / mts);
+          r[17] = (float)((S.t_dtime[s] - (double)S.time_steps) / mts);
+          r[18] = (float)((double)ty / 6.0);
         }
+        const double unmet = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+        r[19] = (float)(unmet / fmax(S.t_org[s], 1e-6));
+        r[20] = (float)fmin(((double)S.time_steps - (double)S.t_created[s]) / mts, 1.0);
+      } else if (!(j == 0 && n == 0)) {
+        r[3] = -1.f;  // pad rows are {"status": -1}; with no open task row 0 is task_idle (all zeros)
       }
-      lds_sync();
+      if (o_tasks && in_mt) {
+#pragma unroll
+        for (int c = 0; c < 21; c++) o_tasks[c * MT + j] = r[c];
+      }
+      if (o_pad && in_mt) o_pad[j] = j < (n == 0 ? 1 : n);
       PROF(16);
-      stream_out(o_tasks, stage, MT * 21 * 4);
-      lds_sync();
-      PROF(17);
-    }
-    const int nrows = n == 0 ? 1 : n;
-    if (o_pad) for (int j = lane; j < MT; j += WG) o_pad[j] = j < nrows;
-    if (o_legal) {
-      uint8_t* lg = reinterpret_cast<uint8_t*>(&X);  // [nA][MT] bytes
-      // lane a keeps agent a's (state, head id, type); the agent loop broadcasts them with v_readlane
-      int my_st = 0, my_hid = 0, my_ty = 0;
-      if (lane < nA) { my_st = S.a_state[lane]; my_hid = head_id(lane); my_ty = S.a_type[lane]; }
-      for (int base = 0; base < MT; base += WG) {
-        const int j = base + lane;
-        const bool in_n = j < n;
-        int tid = -1, ty = 0;
-        uint32_t elig = 0xffffffffu;
-        bool saturated = false;
-        if (in_n) {
-          const int s = S.open_slot[j];
-          tid = S.t_id[s];
-          ty = S.t_type[s];
-          if (S.t_flags[s] & TF_ELIGIBLE) elig = S.t_elig[s];
-          saturated = P.saturate_mask && S.t_alloc[ty][s] >= S.t_org[s];
+      if (o_legal) {
+        // legal_mask without a per-agent loop: one ballot per agent TYPE gives the rows that type may take
+        // (_is_task_action_valid :341-363, eligibility + saturation); lane a then picks its type's row mask.
+        unsigned long long okm = 0ull;
+#pragma unroll
+        for (int t = 0; t <= MUAVTA_F2; t++) {
+          const unsigned long long m = __ballot(in_n && ((typemask >> t) & 1u));
+          if (my_ty == t) okm = m;
         }
-        for (int a = 0; a < nA; a++) {
-          const int st = __builtin_amdgcn_readlane(my_st, a), hid_ = __builtin_amdgcn_readlane(my_hid, a),
-                    aty = __builtin_amdgcn_readlane(my_ty, a);
-          const bool iscur = in_n && tid == hid_;
-          bool v = false;
-          if (in_n) {
-            if (st == 2) v = iscur;
-            else {  // _is_task_action_valid (:341-363); open rows are never status 2
-              v = iscur || (((elig >> aty) & 1u) && !saturated && !(P.capability_mask && S.a_caps[ty][a] <= 0));
-            }
-          } else if (n == 0 && j == 0) {
-            v = (st != 2) || hid_ == 0;  // single task_idle row
+        if (capm) {  // capability mask: rows whose task type the agent has capability for
+          unsigned long long capok = 0ull;
+#pragma unroll
+          for (int tt = 0; tt < 6; tt++) {
+            const unsigned long long m = __ballot(in_n && ty == tt);
+            if (lane < nA && S.a_caps[tt][lane] > 0) capok |= m;
           }
-          if (j < MT) lg[a * MT + j] = v;
-          // "no legal action" fallback (:401-408): current task if it is open, else row 0.  Rows beyond the
-          // first 64 exist only on the 64x128 tile; the per-agent flags then live in LDS.
-          const unsigned long long mv = __ballot(v), mc = __ballot(iscur);
-          if (MT <= WG) {
-            if (mv == 0ull && n > 0 && st != 2 && lane == 0) lg[a * MT + (mc ? __ffsll((long long)mc) - 1 : 0)] = 1;
-          } else if (lane == 0) {
-            int32_t* anyf = X.row4col;   // [A] beyond the byte staging? no: separate int scratch (T >= A)
-            int32_t* curp = X.remaining;
-            if (base == 0) { anyf[a] = 0; curp[a] = -1; }
-            if (mv) anyf[a] = 1;
-            if (curp[a] < 0 && mc) curp[a] = base + __ffsll((long long)mc) - 1;
-          }
+          okm &= capok;
         }
+        if (lane < nA) { if (base == 0) leg0 = okm; else leg1 = okm; }
       }
-      if (MT > WG) {
-        lds_sync();
-        if (lane < nA && n > 0 && S.a_state[lane] != 2 && X.row4col[lane] == 0)
-          lg[lane * MT + (X.remaining[lane] >= 0 ? X.remaining[lane] : 0)] = 1;
-      }
-      lds_sync();
       PROF(18);
-      stream_out(o_legal, lg, nA * MT);
-      lds_sync();
-      PROF(19);
     }
+    if (o_legal && lane < nA) {
+      // the agent's current task is always selectable (:346-348); in state 2 it is the ONLY legal row (:475-479)
+      unsigned long long cur0 = 0ull, cur1 = 0ull;
+      int curpos = -1;
+      if (n == 0) {
+        curpos = my_hid == 0 ? 0 : -1;   // single task_idle row
+        if (my_st != 2) { leg0 = 1ull; }
+      } else if (S.a_qlen[lane] > 0) {
+        const int hs = S.a_qslot[lane][0];
+        if (ref_valid(my_hid, hs) && S.t_status[hs] != 2) curpos = S.t_row[hs];
+      }
+      if (curpos >= 0) { if (curpos < 64) cur0 = 1ull << curpos; else cur1 = 1ull << (curpos - 64); }
+      if (my_st == 2) { leg0 = cur0; leg1 = cur1; }
+      else if (n > 0) { leg0 |= cur0; leg1 |= cur1; }
+      // "no legal action" fallback (:401-408): the current task if it is open, else row 0
+      if ((leg0 | leg1) == 0ull && n > 0 && my_st != 2) leg0 = 1ull;
+      const int KM = (MT + 63) >> 6;
+      o_legal[lane * KM] = leg0;
+      if (KM > 1) o_legal[lane * KM + 1] = leg1;
+    }
+    PROF(19);
     if (o_agents && lane < nA) {
       const int a = lane;
       float* r = o_agents + a * 9;
@@ -1710,10 +1684,25 @@ struct Sim {
   // among the minima if there is one, else the FIRST minimum.  One f64 wave-min + two ballots per
   // augmenting step; duals are updated one row/column per lane.  Arithmetic order per column is
   // scipy's: minVal + C[i][j] - u[i] - v[j].  All lanes must call this (uniform control flow).
+  // f64 min over the wave without LDS traffic: 4 DPP exchange steps inside each 16-lane row (min is
+  // idempotent, so mirrors are as good as butterflies), then the 4 row results via v_readlane.
+  DEV double dpp_xchg(double v, const int ctrl_sel) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (ctrl_sel == 0) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xf, 0xf, true); }        // quad_perm [1,0,3,2]
+    else if (ctrl_sel == 1) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xf, 0xf, true); }   // quad_perm [2,3,0,1]
+    else if (ctrl_sel == 2) { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xf, 0xf, true); } // row_half_mirror
+    else { lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xf, 0xf, true); hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xf, 0xf, true); }                    // row_mirror
+    return __hiloint2double(hi, lo);
+  }
+  DEV double readlane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+  }
   DEV double wave_min(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, WG));
-    return v;
+    v = fmin(v, dpp_xchg(v, 0));
+    v = fmin(v, dpp_xchg(v, 1));
+    v = fmin(v, dpp_xchg(v, 2));
+    v = fmin(v, dpp_xchg(v, 3));
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
   }
   DEV void lsap(int nr, int nc) {
     const double INF = __builtin_huge_val();

@@ -26,8 +26,8 @@ using namespace muavta;
 namespace {
 
 struct ObsPtrs {
-  float* tasks;    // [N, max_tasks, 21]
-  uint8_t* legal;  // [N, A, max_tasks]
+  float* tasks;    // [N, 21, max_tasks]  (feature-major)
+  unsigned long long* legal;  // [N, A, ceil(max_tasks/64)] bit rows
   uint8_t* pad;    // [N, max_tasks]
   float* agents;   // [N, A, 9]
   float* flags;    // [N, 5]
@@ -38,7 +38,7 @@ struct ObsPtrs {
 template <class TL>
 __device__ __forceinline__ void obs_for_env(Sim<TL>& sim, const DevParams& P, const ObsPtrs& O, int env) {
   const size_t mt = (size_t)P.max_tasks, nA = (size_t)P.n_agents;
-  sim.write_obs(O.tasks + (size_t)env * mt * 21, O.legal + (size_t)env * nA * mt, O.pad + (size_t)env * mt,
+  sim.write_obs(O.tasks + (size_t)env * mt * 21, O.legal + (size_t)env * nA * ((mt + 63) >> 6), O.pad + (size_t)env * mt,
                 O.agents + (size_t)env * nA * 9, O.flags + (size_t)env * 5);
   if (threadIdx.x == 0) {
     O.reward[env] = sim.S.last_reward;
@@ -604,14 +604,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   size_t scratch_bytes = 0;
   DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->Q = TL::Q; e->state_bytes = sizeof(EnvState<TL>);
                 scratch_bytes = sizeof(Scratch<TL>); });
-  {  // the observation rows are staged in the LDS scratch tile before they are streamed out
-    size_t need = (size_t)e->P.max_tasks * 84, need2 = (size_t)e->P.n_agents * e->P.max_tasks;
-    if (need > scratch_bytes || need2 > scratch_bytes) {
-      g_create_error = "muavta_create: max_tasks too large for this tile's observation staging; raise tile_agents/tile_tasks";
-      delete e;
-      return MUAVTA_E_ARG;
-    }
-  }
+  (void)scratch_bytes;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); muavta_destroy(e); return MUAVTA_E_HIP; } } while (0)
   CK(hipSetDevice(device));
   CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
@@ -626,7 +619,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   CK(hipMalloc(&e->d_act_index, N * e->A * sizeof(int32_t)));
   CK(hipMalloc(&e->d_metrics, N * MUAVTA_N_METRICS * sizeof(double)));
   CK(hipMalloc(&e->O.tasks, N * mt * 21 * sizeof(float)));
-  CK(hipMalloc(&e->O.legal, N * nA * mt));
+  CK(hipMalloc(&e->O.legal, N * nA * ((mt + 63) / 64) * sizeof(unsigned long long)));
   CK(hipMalloc(&e->O.pad, N * mt));
   CK(hipMalloc(&e->O.agents, N * nA * 9 * sizeof(float)));
   CK(hipMalloc(&e->O.flags, N * 5 * sizeof(float)));
@@ -658,7 +651,7 @@ int muavta_dims(const MuavtaEnv* e, MuavtaDims* d) {
   d->n_envs = e->n_envs; d->n_agents = e->P.n_agents; d->tile_agents = e->A; d->tile_tasks = e->T; d->tile_threats = e->H;
   d->max_tasks = e->P.max_tasks; d->obs_task_width = 21; d->obs_agent_width = 9; d->queue_cap = e->Q; d->event_cap = e->E;
   d->action_cap = e->A; d->state_bytes = (int64_t)e->state_bytes;
-  d->n_threats = e->P.n_threats; d->known_words = (e->T + 31) / 32; d->lds_bytes = (int32_t)e->lds_bytes; d->reserved = 0;
+  d->n_threats = e->P.n_threats; d->known_words = (e->T + 31) / 32; d->lds_bytes = (int32_t)e->lds_bytes; d->legal_words = (e->P.max_tasks + 63) / 64;
   return MUAVTA_OK;
 }
 
@@ -760,13 +753,13 @@ int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
   return MUAVTA_OK;
 }
 
-int muavta_observe(MuavtaEnv* e, float* tasks, uint8_t* legal, uint8_t* pad, float* agents, float* flags) {
+int muavta_observe(MuavtaEnv* e, float* tasks, uint64_t* legal, uint8_t* pad, float* agents, float* flags) {
   if (!e) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "observe before reset"; return MUAVTA_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
   const size_t N = (size_t)e->n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
   if (tasks) HIPCHK(e, hipMemcpyAsync(tasks, e->O.tasks, N * mt * 21 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-  if (legal) HIPCHK(e, hipMemcpyAsync(legal, e->O.legal, N * nA * mt, hipMemcpyDeviceToHost, e->stream));
+  if (legal) HIPCHK(e, hipMemcpyAsync(legal, e->O.legal, N * nA * ((mt + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
   if (pad) HIPCHK(e, hipMemcpyAsync(pad, e->O.pad, N * mt, hipMemcpyDeviceToHost, e->stream));
   if (agents) HIPCHK(e, hipMemcpyAsync(agents, e->O.agents, N * nA * 9 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   if (flags) HIPCHK(e, hipMemcpyAsync(flags, e->O.flags, N * 5 * sizeof(float), hipMemcpyDeviceToHost, e->stream));

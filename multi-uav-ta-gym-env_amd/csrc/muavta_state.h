@@ -90,6 +90,7 @@ struct alignas(16) EnvState {
   uint64_t t_bucket[T];               // allocation_table[id] as agent bitmask
   int32_t t_order[T];                 // live slots in ascending id (== creation) order
   int32_t open_slot[T];               // env.last_tasks_info (slots), status != 2 at last observation
+  uint8_t t_row[T];                   // inverse of open_slot: row of a slot in last_tasks_info
   uint32_t known[A][KW];              // agent_known_tasks as slot bitmask
   // ---- threats (index = Threat.id) ------------------------------------------------------------
   double h_px[H], h_py[H];

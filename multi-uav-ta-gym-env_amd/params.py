@@ -111,7 +111,7 @@ class MuavtaDims(C.Structure):
         ("tile_threats", C.c_int32), ("max_tasks", C.c_int32), ("obs_task_width", C.c_int32),
         ("obs_agent_width", C.c_int32), ("queue_cap", C.c_int32), ("event_cap", C.c_int32),
         ("action_cap", C.c_int32), ("state_bytes", C.c_int64), ("n_threats", C.c_int32), ("known_words", C.c_int32),
-        ("lds_bytes", C.c_int32), ("reserved", C.c_int32),
+        ("lds_bytes", C.c_int32), ("legal_words", C.c_int32),
     ]
 
 
