@@ -97,8 +97,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     from muavta_amd.batched import BatchedMultiUAVEnv
-    from muavta_amd.params import METRIC_KEYS, params_for_case
-    from muavta_amd.scenarios import TILES
+    from muavta_amd.params import params_for_case
 
     params = params_for_case(args.case)
     env = BatchedMultiUAVEnv(params, args.envs, device=local_rank)
@@ -123,26 +122,22 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    # metrics of the last batch: per-rank partial sums -> one RCCL all-reduce (the only collective on this path)
+    # metrics of the last batch: per-rank partials -> the one collective of this path (muavta_amd/dist.py)
+    from muavta_amd.dist import reduce_metrics
+
     m = env.rollout_metrics()
     if int(np.count_nonzero(env.get("ERROR"))):
         raise SystemExit("tile overflow in the benchmark batch: results invalid")
-    K = {k: i for i, k in enumerate(METRIC_KEYS)}
-    part = torch.tensor([m[:, K["S_WPS"]].sum(), (m[:, K["S_WPS"]] ** 2).sum(), m[:, K["n_on_time"]].sum(),
-                         m[:, K["n_missed_windows"]].sum(), m[:, K["total_distance"]].sum(), float(args.envs),
-                         float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    summary = reduce_metrics(m, device="cuda" if dist is not None else None)
+    tmax = torch.tensor([elapsed, float(np.mean(kernel_ms))], dtype=torch.float64, device="cuda")
     if dist is not None:
-        dist.all_reduce(part, op=dist.ReduceOp.SUM)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    part = part.cpu().numpy()
-    elapsed = float(tmax.item())
+    elapsed, mean_kernel_ms = float(tmax[0].item()), float(tmax[1].item())
 
     if rank == 0:
         total_envs = args.envs * world
         env_steps = total_envs * HORIZON * args.steps
         value = env_steps / elapsed
-        mean_kernel_ms = float(part[6]) / world
         B = ALGO_BYTES_PER_ENV_STEP.get(tile)
         achieved = (args.envs * HORIZON * B) / (mean_kernel_ms * 1e-3) / 1e9 if B else None
         traffic = None
@@ -164,7 +159,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "k_rollout", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_env_step": B},
-            "quality": {"mean_S_WPS": float(part[0] / part[5]), "on_time": float(part[2]), "missed": float(part[3])},
+            "quality": {"mean_S_WPS": summary["mean_S_WPS"], "std_S_WPS": summary["std_S_WPS"], "on_time_rate": summary["on_time_rate"],
+                        "n_envs": summary["n_envs"]},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.case, args.interval, args.cpu_seconds)

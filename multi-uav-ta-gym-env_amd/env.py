@@ -1,0 +1,563 @@
+"""``MultiUAVEnv`` — the reference's single-environment PettingZoo ``ParallelEnv`` surface
+(mUAV_TA/DroneEnv.py:70-323, 522-762, 774-1206, 1209-1214) on top of the batched MI355X backend.
+
+It is a *view*: every number comes from the device state through ``BatchedMultiUAVEnv.get`` /
+``observe`` (n_envs = 1); no simulation logic runs in Python.  Allocators written against the
+reference (``TaskAllocation/*``: they read ``env.agents_obj`` / ``env.tasks`` /
+``env.agent_visibility_map()`` and return ``[(agent_name, Task)]``) and the harness glue
+(``_open_tasks`` / ``_apply_assign``, experiments/paper_eval.py:85-101, wps_eval.py:55-61) work on the
+object views below: UAV / Task / Threat proxies are cached per id, so identity tests such as
+``task in env.last_tasks_info`` keep working.
+
+Not mirrored (raise ``NotImplementedError``): the reference's private mutators that tests poke
+directly (``_create_escort_for``, ``UAV.allocate`` ...) — on this path state changes only through
+``reset`` / ``step``.
+"""
+from __future__ import annotations
+
+import random
+import sys
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+
+from .params import EVENT_TAGS, METRIC_KEYS, INT_METRICS, TASK_TYPES, UAV_TYPES, params_from_config
+
+MAX_INT = sys.maxsize
+_TASK_DURATION = {"Hold": 1, "Rec": 10, "Att": 5, "Def": 5, "Int": 0, "Det": 1}   # MultiDroneEnvData.py:72-85
+_MAX_SPEED = {"F1": 20.0, "F2": 15.0, "R1": 5.0, "R2": 8.0, "E1": 5.0, "T1": 14.0, "T2": 12.0}
+_ENGAGE = {"F1": 40.0, "F2": 30.0, "R1": 0.0, "R2": 0.0, "E1": 0.0, "T1": 35.0, "T2": 25.0}
+
+
+class _Snapshot:
+    """Lazily fetched device fields of env 0, dropped after every reset / step."""
+
+    def __init__(self, backend):
+        self.b = backend
+        self.cache: Dict[str, np.ndarray] = {}
+
+    def __getitem__(self, name: str) -> np.ndarray:
+        if name not in self.cache:
+            self.cache[name] = self.b.get(name)[0]
+        return self.cache[name]
+
+    def clear(self):
+        self.cache.clear()
+
+
+class TaskView:
+    """Task (mUAV_TA/DroneEnvComponents.py:223-263).  ``hard_deadline`` is an attribute only on windowed
+    tasks, exactly like the reference (callers use ``getattr(task, 'hard_deadline', None)``)."""
+
+    def __init__(self, env, task_id: int):
+        self._env, self.id = env, int(task_id)
+        self._last: Dict[str, Any] = {}
+
+    def _slot(self) -> int:
+        ids = self._env._snap["TASK_ID"]
+        hit = np.nonzero(ids == self.id)[0]
+        return int(hit[0]) if len(hit) else -1
+
+    def _field(self, key: str, name: str, pick):
+        s = self._slot()
+        if s >= 0:
+            self._last[key] = pick(self._env._snap[name][s])
+        return self._last.get(key)
+
+    @property
+    def position(self):
+        if self.id == 0:
+            return np.array([0, 0])
+        return self._field("position", "TASK_POS", lambda r: np.array(r, dtype=np.float64))
+
+    @position.setter
+    def position(self, value):
+        s = self._slot()
+        if s < 0:
+            raise ValueError("task is retired and no longer resident on the device")
+        arr = self._env._b.get("TASK_POS")
+        arr[0, s] = np.asarray(value, dtype=np.float64)
+        self._env._b.set("TASK_POS", arr)
+        self._env._snap.clear()
+
+    @property
+    def status(self) -> int:
+        if self.id == 0:
+            return 0
+        s = self._slot()
+        if s < 0:
+            return 2  # freed slots are retired tasks
+        return int(self._env._snap["TASK_STATUS"][s])
+
+    def _meta(self, col: int, default=0):
+        v = self._field(f"meta{col}", "TASK_META", lambda r: int(r[col]))
+        return default if v is None else v
+
+    @property
+    def typeIdx(self) -> int:
+        return 0 if self.id == 0 else self._meta(0)
+
+    @property
+    def type(self) -> str:
+        return TASK_TYPES[self.typeIdx]
+
+    @property
+    def task_duration(self) -> int:
+        return _TASK_DURATION[self.type]
+
+    @property
+    def currentReqs(self):
+        if self.id == 0:
+            return np.zeros(6)
+        return self._field("cur", "TASK_CUR", lambda r: np.array(r))
+
+    @property
+    def allocatedReqs(self):
+        if self.id == 0:
+            return np.zeros(6)
+        return self._field("alloc", "TASK_ALLOC", lambda r: np.array(r))
+
+    @property
+    def orgReqs(self):
+        out = np.zeros(6)
+        if self.id != 0:
+            v = self._field("org", "TASK_ORG_DONE", lambda r: float(r[0]))
+            out[self.typeIdx] = 0.0 if v is None else v
+        return out
+
+    @property
+    def allocationDetails(self):
+        """len()-able / iterable stand-in: {agent_id: (None, time)} for the agents queuing this task."""
+        env = self._env
+        if self.id == 0 or self._slot() < 0:
+            return {}
+        q = env._snap["AGENT_QUEUE"]
+        return {int(a): (None, None) for a in range(q.shape[0]) if self.id in q[a]}
+
+    @property
+    def initTime(self):
+        v = self._field("init", "TASK_TIMES", lambda r: float(r[0]))
+        return -1 if v is None else v
+
+    @property
+    def doneTime(self):
+        v = self._field("done", "TASK_TIMES", lambda r: float(r[1]))
+        return -1 if v is None else v
+
+    @property
+    def created_at(self) -> int:
+        return self._meta(2)
+
+    @property
+    def required_agents(self) -> int:
+        return self._meta(3)
+
+    @required_agents.setter
+    def required_agents(self, value):
+        s = self._slot()
+        if s < 0:
+            raise ValueError("task is retired and no longer resident on the device")
+        arr = self._env._b.get("TASK_META")
+        arr[0, s, 3] = int(value)
+        self._env._b.set("TASK_META", arr)
+        self._env._snap.clear()
+
+    @property
+    def kind(self):
+        return "Escort" if self._meta(4) else None
+
+    @property
+    def protected_agent(self):
+        a = self._meta(6, -1)
+        return None if a < 0 else self._env.agents_obj[a]
+
+    @property
+    def eligible_agent_types(self):
+        m = self._meta(7, -1)
+        return None if m < 0 else {UAV_TYPES[t] for t in range(7) if (m >> t) & 1}
+
+    @property
+    def final_quality(self):
+        return -1
+
+    def __getattr__(self, name):
+        if name == "hard_deadline":  # only present on windowed tasks
+            d = self.__dict__.get("_last", {}).get("meta1")
+            if self._slot() >= 0:
+                d = int(self._env._snap["TASK_META"][self._slot()][1])
+                self._last["meta1"] = d
+            if d is None or d < 0:
+                raise AttributeError(name)
+            return d
+        raise AttributeError(name)
+
+    def __repr__(self):
+        return f"<Task {self.id} {self.type} status={self.status}>"
+
+
+class UAVView:
+    """UAV (mUAV_TA/DroneEnvComponents.py:7-52)."""
+
+    def __init__(self, env, agent_id: int):
+        self._env, self.id = env, int(agent_id)
+
+    @property
+    def name(self) -> str:
+        return self._env.possible_agents[int(self._env._snap["AGENT_NAME_IDX"][self.id])]
+
+    @property
+    def typeIdx(self) -> int:
+        return int(self._env._snap["AGENT_TYPE"][self.id])
+
+    @property
+    def type(self) -> str:
+        return UAV_TYPES[self.typeIdx]
+
+    @property
+    def position(self):
+        return np.array(self._env._snap["AGENT_POS"][self.id])
+
+    @position.setter
+    def position(self, value):
+        arr = self._env._b.get("AGENT_POS")
+        arr[0, self.id] = np.asarray(value, dtype=np.float64)
+        self._env._b.set("AGENT_POS", arr)
+        self._env._snap.clear()
+
+    @property
+    def state(self) -> int:
+        return int(self._env._snap["AGENT_STATE"][self.id])
+
+    @state.setter
+    def state(self, value):
+        arr = self._env._b.get("AGENT_STATE")
+        arr[0, self.id] = int(value)
+        self._env._b.set("AGENT_STATE", arr)
+        self._env._snap.clear()
+
+    @property
+    def currentCap2Task(self):
+        return np.array(self._env._snap["AGENT_CAPS"][self.id])
+
+    @property
+    def tasks(self) -> List[TaskView]:
+        q = self._env._snap["AGENT_QUEUE"][self.id]
+        return [self._env._task(int(t)) for t in q if t >= 0]
+
+    @property
+    def next_free_position(self):
+        return np.array(self._env._snap["AGENT_NFP"][self.id])
+
+    @property
+    def next_free_time(self) -> float:
+        return float(self._env._snap["AGENT_NFT"][self.id])
+
+    @property
+    def attackCap(self) -> int:
+        return int(self._env._snap["AGENT_ATTACK_CAP"][self.id])
+
+    @property
+    def task_start(self) -> int:
+        return int(self._env._snap["AGENT_MISC"][self.id][0])
+
+    @property
+    def fail_event(self) -> int:
+        return int(self._env._snap["AGENT_MISC"][self.id][1])
+
+    @property
+    def re_eval(self) -> bool:
+        return bool(self._env._snap["AGENT_MISC"][self.id][2])
+
+    @property
+    def commit_until(self) -> int:
+        return int(self._env._snap["AGENT_MISC"][self.id][4])
+
+    @commit_until.setter
+    def commit_until(self, value):  # TaskAllocation/Hybrid/AttentionCommit.py:44 writes this
+        arr = self._env._b.get("AGENT_MISC")
+        arr[0, self.id, 4] = int(value)
+        self._env._b.set("AGENT_MISC", arr)
+        self._env._snap.clear()
+
+    @property
+    def max_speed(self) -> float:
+        return _MAX_SPEED[self.type] / self._env._params.simulation_frame_rate * 0.02
+
+    @property
+    def engage_range(self) -> float:
+        return _ENGAGE[self.type]
+
+    def allocate(self, task, time_step):
+        raise NotImplementedError("state changes only through MultiUAVEnv.step on the batched path")
+
+    def __repr__(self):
+        return f"<UAV {self.name} id={self.id} state={self.state}>"
+
+
+class ThreatView:
+    def __init__(self, env, threat_id: int):
+        self._env, self.id = env, int(threat_id)
+
+    @property
+    def position(self):
+        return np.array(self._env._snap["THREAT_POS"][self.id])
+
+    def _m(self, col):
+        return int(self._env._snap["THREAT_META"][self.id][col])
+
+    @property
+    def status(self) -> int:
+        return self._m(0)
+
+    @property
+    def target_agent(self):
+        a = self._m(1)
+        return None if a < 0 else self._env.agents_obj[a]
+
+    @property
+    def mission_target_agent(self):
+        a = self._m(2)
+        return None if a < 0 else self._env.agents_obj[a]
+
+    @property
+    def attackCap(self) -> int:
+        return self._m(3)
+
+    @property
+    def relative_task(self):
+        return self._env._task(self._m(4))
+
+    @property
+    def threat_type(self) -> str:
+        return UAV_TYPES[self._m(5)]
+
+
+class MultiUAVEnv:
+    metadata = {"render_modes": ["human"], "name": "multi_agent_env_v0"}
+
+    def __init__(self, config=None, backend=None, device: int = 0, flags: Optional[dict] = None, **tiles):
+        if config is None:
+            config = {"agents": {"F1": 0, "F2": 0, "R1": 1, "R2": 1}, "tasks": {"Att": 0, "Rec": 2, "Hold": 0},
+                      "threats_list": [("T1", 4), ("T2", 2)]}
+        self.config = config
+        self._params = params_from_config(config, flags, **tiles)
+        if backend is None:
+            from .batched import BatchedMultiUAVEnv  # HIP library; raises MuavtaError when unavailable
+
+            backend = BatchedMultiUAVEnv(self._params, 1, device)
+        self._b = backend
+        self._snap = _Snapshot(backend)
+        p = self._params
+        self.area_width, self.area_height, self.max_coord = 1200, 700, 1200       # MultiDroneEnvData.py:8
+        self.bases = [np.array([400, 680])]
+        self.max_time_steps = p.max_time_steps
+        self.n_agents = p.n_agents
+        self.max_agents = max(48, self.n_agents + 8)                                 # DroneEnv.py:122
+        self.possible_agents = p.possible_agents
+        self.agents = list(self.possible_agents)
+        self.n_tasks, self.max_tasks = p.n_tasks, p.max_tasks
+        self.commit_horizon = p.commit_horizon
+        self.reassign_penalty = p.reassign_penalty
+        self.sense_radius, self.threat_delay = p.sense_radius, p.threat_delay
+        self.escort_enabled = bool(p.escort_enabled)
+        self.task_idle = TaskView(self, 0)
+        self._tasks: Dict[int, TaskView] = {0: self.task_idle}
+        self.agents_obj: List[UAVView] = []
+        self.agent_by_name: Dict[str, UAVView] = {}
+        self._threats: Dict[int, ThreatView] = {}
+        self._known: Dict[str, set] = {}
+        self._seed_stream = random.Random()
+        self._steps = 0
+        self.observations: Dict[str, dict] = {}
+        self.last_tasks_info: Optional[List[TaskView]] = None
+
+    # ------------------------------------------------------------------ helpers
+    def _task(self, tid: int) -> TaskView:
+        t = self._tasks.get(tid)
+        if t is None:
+            t = self._tasks[tid] = TaskView(self, tid)
+        return t
+
+    def _scalar(self, col: int) -> float:
+        return float(self._snap["SCALARS"][col])
+
+    def _refresh(self):
+        self._snap.clear()
+        ids = self._snap["TASK_ID"]
+        for tid in ids[ids >= 0]:
+            self._task(int(tid))
+        for tid in range(1, int(self._scalar(27)) + 1):  # tasks created and retired between two observations
+            self._task(tid)
+        # touch the cached fields of resident tasks so they survive slot recycling
+        for t in self._tasks.values():
+            if t.id and t._slot() >= 0:
+                _ = (t.position, t.typeIdx, t.currentReqs, t.allocatedReqs, t.orgReqs, t.created_at, t.required_agents,
+                     t.kind, t._meta(6, -1), t._meta(7, -1), getattr(t, "hard_deadline", None), t.initTime, t.doneTime)
+        self.last_tasks_info = [self._task(int(i)) for i in self._snap["OPEN_IDS"] if i >= 0]
+        # agent_known_tasks grows monotonically in the reference; bits of recycled slots are folded in here
+        known = self._snap["KNOWN"]
+        for a in self.agents_obj:
+            s = self._known.setdefault(a.name, set())
+            for slot, tid in enumerate(ids):
+                if tid >= 0 and (known[a.id][slot >> 5] >> (slot & 31)) & 1:
+                    s.add(int(tid))
+
+    def _build_observations(self):
+        o = self._b.observe()
+        rows = o["tasks"][0]
+        tasks_info = []
+        for r in rows:
+            if r[3] == -1.0:
+                tasks_info.append({"status": -1})
+                continue
+            d = {"id": int(r[0]), "position": np.array(r[1:3], dtype=np.float64), "status": int(r[3]),
+                 "current_reqs": np.array(r[4:10], dtype=np.float64), "alloc_reqs": np.array(r[10:16], dtype=np.float64)}
+            if int(r[0]) != 0 or len(self.last_tasks_info) > 0:
+                if self._params.include_time_windows:
+                    d.update(init_time=float(r[16]), end_time=float(r[17]), type_idx=float(r[18]))
+                d.update(unmet=float(r[19]), age=float(r[20]))
+            tasks_info.append(d)
+        mask = [bool(x) for x in o["mask"][0]]
+        self.observations = {}
+        for a in self.agents_obj:
+            self.observations[a.name] = {
+                "agent_position": np.array(o["agents"][0, a.id, 0:2], dtype=np.float64),
+                "agent_caps": np.array(o["agents"][0, a.id, 2:8], dtype=np.float64),
+                "alloc_task": int(o["agents"][0, a.id, 8]),
+                "tasks_info": tasks_info,
+                "mask": mask,
+                "legal_mask": [bool(x) for x in o["legal_mask"][0, a.id]],
+                "event_flags": np.array(o["event_flags"][0], dtype=np.float32),
+            }
+
+    # ------------------------------------------------------------------ PettingZoo surface
+    def reset(self, seed=None, return_info=True, options=None):
+        if seed is None:  # the reference draws from the global `random` module (DroneEnv.py:525-526)
+            seed = self._seed_stream.randint(0, MAX_INT)
+        self._seed = int(seed)
+        self._b.reset(np.array([self._seed], dtype=np.uint64))
+        self._steps = 0
+        self._tasks = {0: self.task_idle}
+        self._threats = {}
+        self._known = {}
+        self._snap.clear()
+        self.agents_obj = [UAVView(self, a) for a in range(self.n_agents)]
+        self.agent_by_name = {a.name: a for a in self.agents_obj}
+        self.agents = list(self.possible_agents)
+        self._refresh()
+        self._build_observations()
+        self.rewards = {a.name: 0 for a in self.agents_obj}
+        self.terminations = {a.name: False for a in self.agents_obj}
+        self.truncations = {a.name: False for a in self.agents_obj}
+        self.infos = {a.name: {} for a in self.agents_obj}
+        return self.observations, self.infos
+
+    def step(self, actions):
+        if not isinstance(actions, dict):
+            raise TypeError("actions must be a dict {agent_name: index | [indices]} (DroneEnv.py:810)")
+        items = []
+        for name, idxs in actions.items():
+            a = self.agent_by_name[name]
+            for i in (idxs if isinstance(idxs, list) else [idxs]):
+                items.append((a.id, int(i)))
+        if len(items) > self._b.A_tile:
+            raise ValueError(f"at most {self._b.A_tile} (agent, index) items per step on this tile")
+        aa, ai = self._b.pack_actions([items])
+        self._b.step(aa, ai)
+        self._steps += 1
+        self._refresh()
+        self._build_observations()
+        reward, term, trunc = self._b.step_result()
+        self.rewards = {a.name: float(reward[0]) for a in self.agents_obj}
+        self.terminations = {a.name: bool(term[0]) for a in self.agents_obj}
+        self.truncations = {a.name: bool(trunc[0]) for a in self.agents_obj}
+        self.infos = {a.name: {} for a in self.agents_obj}
+        self.infos["selected"] = self.possible_agents[self._steps % len(self.possible_agents)]  # agent_selector.next()
+        ev = self._snap["EVENTS"]
+        self.infos["events"] = [[EVENT_TAGS[int(t)], int(arg)] for t, arg in ev if t >= 0]
+        if term[0] or trunc[0]:
+            self.infos["metrics"] = self.calculate_metrics()
+        return self.observations, self.rewards, self.terminations, self.truncations, self.infos
+
+    def observe(self, agent):
+        o = self.observations[agent]
+        o["agent_id"] = agent
+        return o
+
+    # ------------------------------------------------------------------ attributes callers read
+    @property
+    def tasks(self) -> List[TaskView]:
+        return [self._tasks[k] for k in sorted(self._tasks) if k != 0]
+
+    @property
+    def threats(self) -> List[ThreatView]:
+        meta = self._snap["THREAT_META"]
+        out = []
+        for h in range(meta.shape[0]):
+            if meta[h][0] != -9:
+                out.append(self._threats.setdefault(h, ThreatView(self, h)))
+        return out
+
+    time_steps = property(lambda self: int(self._scalar(0)))
+    F_Reward = property(lambda self: self._scalar(2))
+    total_distance = property(lambda self: self._scalar(3))
+    n_on_time = property(lambda self: int(self._scalar(4)))
+    n_missed_windows = property(lambda self: int(self._scalar(5)))
+    n_windowed_tasks = property(lambda self: int(self._scalar(6)))
+    n_task_switches = property(lambda self: int(self._scalar(7)))
+    n_reallocations = property(lambda self: int(self._scalar(8)))
+    n_arrivals = property(lambda self: int(self._scalar(9)))
+    conclusion_time = property(lambda self: int(self._scalar(11)))
+    escort_requests = property(lambda self: int(self._scalar(12)))
+    escort_completed = property(lambda self: int(self._scalar(13)))
+    escort_failed = property(lambda self: int(self._scalar(14)))
+    escort_required_steps = property(lambda self: int(self._scalar(15)))
+    escort_covered_steps = property(lambda self: int(self._scalar(16)))
+    protection_breaches = property(lambda self: int(self._scalar(17)))
+    threats_intercepted = property(lambda self: int(self._scalar(18)))
+    recon_losses = property(lambda self: int(self._scalar(19)))
+    escort_losses = property(lambda self: int(self._scalar(20)))
+    mutual_support_engagements = property(lambda self: int(self._scalar(21)))
+    protected_rec_completed = property(lambda self: int(self._scalar(22)))
+    current_agent = property(lambda self: self.possible_agents[self._steps % len(self.possible_agents)])
+
+    def get_live_agents(self):  # DroneEnv.py:1484-1486
+        return [a for a in self.agents_obj if a.state != -1]
+
+    def agent_visibility_map(self):  # :1595-1599
+        if not self.sense_radius and not self.threat_delay:
+            return None
+        return {name: set(ids) for name, ids in self._known.items()}
+
+    def known_tasks_for(self, agent_name=None):  # :1582-1593
+        if agent_name is not None:
+            ids = self._known.get(agent_name, set())
+            return [t for t in self.tasks if t.id in ids or t.id == 0]
+        if not self.sense_radius and not self.threat_delay:
+            return list(self.tasks)
+        known = set().union(*self._known.values()) if self._known else set()
+        return [t for t in self.tasks if t.id in known or t.id == 0]
+
+    def calculate_metrics(self) -> Dict[str, Any]:  # :1231-1319, key order preserved
+        row = self._b.metrics()[0]
+        return {k: (int(v) if k in INT_METRICS else float(v)) for k, v in zip(METRIC_KEYS, row)}
+
+    def compute_s_wps(self) -> float:  # :1321-1337
+        return float(self._b.metrics()[0][METRIC_KEYS.index("S_WPS")])
+
+    def compute_s_esc(self) -> float:  # :2002-2011
+        return float(self._b.metrics()[0][METRIC_KEYS.index("S_ESC")])
+
+    def get_initial_state(self):
+        return {"state": self._b.get_state().copy(), "rng": self._b.get_rng().copy()}
+
+    def observation_space(self, agent):
+        raise NotImplementedError("the reference's declared space does not match what it returns (SURVEY A.2)")
+
+    def action_space(self, agent):
+        raise NotImplementedError("see observation_space")
+
+    def _create_escort_for(self, *a, **k):
+        raise NotImplementedError("private mutators are not part of the batched path; escorts appear through step()")
+
+    _sync_escorts = _retire_escort = _escort_fighters_near = _create_escort_for

@@ -1,0 +1,141 @@
+"""Test-only stand-in for BatchedMultiUAVEnv (n_envs = 1) on top of the CPU oracle, so the pure-Python
+facade (muavta_amd.env.MultiUAVEnv) can be exercised without a GPU.  Lives under tests/ on purpose:
+the product never imports the oracle.  Slot space here is simply slot == task id."""
+import numpy as np
+
+import orc
+
+
+class OracleBackend:
+    def __init__(self, params):
+        self.params = params
+        self.o = orc.OracleEnv(params)
+        self.n_envs, self.n_agents = 1, params.n_agents
+        self.A_tile = max(16, params.n_agents)
+        self.max_tasks = params.max_tasks
+        self.possible_agents = params.possible_agents
+        self._last_alloc = None
+
+    def reset(self, seeds):
+        self.o.reset(int(seeds[0]))
+
+    def pack_actions(self, per_env):
+        aa = np.full((1, self.A_tile), -1, dtype=np.int32)
+        ai = np.zeros((1, self.A_tile), dtype=np.int32)
+        for k, (a, i) in enumerate(per_env[0]):
+            aa[0, k], ai[0, k] = a, i
+        return aa, ai
+
+    def step(self, aa, ai):
+        n = int((aa[0] >= 0).sum()) if (aa[0] < 0).any() else aa.shape[1]
+        k = 0
+        while k < aa.shape[1] and aa[0, k] >= 0:
+            k += 1
+        self.o.step(aa[0, :k], ai[0, :k])
+
+    def allocate(self, interval=20, use_visibility=True, fetch=True):
+        a, i = self.o.allocate(interval, int(use_visibility))
+        aa, ai = self.pack_actions([list(zip(a.tolist(), i.tolist()))])
+        return aa, ai
+
+    def step_result(self):
+        d = self.o.dims()
+        return np.array([self.o.scalars()[1]]), np.array([bool(d["terminated"])]), np.array([bool(d["truncated"])])
+
+    def metrics(self):
+        return self.o.metrics()[None]
+
+    def observe(self):
+        ti, legal, pad, ag, fl = self.o.observe()
+        return {"tasks": ti[None], "legal_mask": legal[None], "mask": pad[None], "agents": ag[None], "event_flags": fl[None]}
+
+    def get_state(self):
+        raise NotImplementedError
+
+    get_rng = get_state
+
+    def get(self, name):
+        rows, caps, q = self.o.agents()
+        trow, reqs = self.o.tasks()
+        nt = trow.shape[0]
+        if name == "TASK_ID":
+            ids = np.arange(nt, dtype=np.int32); ids[0] = -1
+            return ids[None]
+        if name == "TASK_STATUS":
+            return trow[:, 0].astype(np.int32)[None]
+        if name == "TASK_POS":
+            return trow[:, 1:3][None].copy()
+        if name == "TASK_CUR":
+            return reqs[:, 0][None].copy()
+        if name == "TASK_ALLOC":
+            return reqs[:, 1][None].copy()
+        if name == "TASK_ORG_DONE":
+            ty = trow[:, 6].astype(int)
+            done = reqs[np.arange(nt), 2, ty]
+            org = np.where(trow[:, 6] >= 0, 0.0, 0.0)
+            return np.stack([self._org(trow, reqs), done], axis=1)[None]
+        if name == "TASK_TIMES":
+            return trow[:, 3:5][None].copy()
+        if name == "TASK_META":
+            m = np.zeros((nt, 8), dtype=np.int32)
+            m[:, 0:5] = trow[:, 6:11]; m[:, 5] = trow[:, 5]; m[:, 6] = trow[:, 11]; m[:, 7] = trow[:, 12]
+            return m[None]
+        if name == "AGENT_POS":
+            return rows[:, 0:2][None].copy()
+        if name == "AGENT_STATE":
+            return rows[:, 2].astype(np.int32)[None]
+        if name == "AGENT_HEAD":
+            return rows[:, 3].astype(np.int32)[None]
+        if name == "AGENT_QUEUE":
+            return q[None].copy()
+        if name == "AGENT_NFT":
+            return rows[:, 5][None].copy()
+        if name == "AGENT_NFP":
+            return rows[:, 6:8][None].copy()
+        if name == "AGENT_CAPS":
+            return caps[None].copy()
+        if name == "AGENT_ATTACK_CAP":
+            return rows[:, 8].astype(np.int32)[None]
+        if name == "AGENT_TYPE":
+            return rows[:, 12].astype(np.int32)[None]
+        if name == "AGENT_NAME_IDX":
+            return rows[:, 13].astype(np.int32)[None]
+        if name == "AGENT_MISC":
+            m = np.zeros((rows.shape[0], 6), dtype=np.int32)
+            m[:, 0] = rows[:, 9]; m[:, 1] = rows[:, 14]; m[:, 2] = rows[:, 10]; m[:, 3] = rows[:, 11]; m[:, 5] = rows[:, 4]
+            return m[None]
+        if name == "KNOWN":
+            k = self.o.known()
+            words = (nt + 31) // 32
+            out = np.zeros((k.shape[0], words), dtype=np.uint32)
+            for a in range(k.shape[0]):
+                for t in np.nonzero(k[a])[0]:
+                    out[a, t >> 5] |= np.uint32(1 << (t & 31))
+            return out[None]
+        if name == "THREAT_POS":
+            return self.o.threats()[:, 1:3][None].copy()
+        if name == "THREAT_META":
+            th = self.o.threats()
+            m = np.stack([th[:, 0], th[:, 3], th[:, 4], th[:, 5], th[:, 6], th[:, 7]], axis=1).astype(np.int32)
+            return m[None]
+        if name == "SCALARS":
+            d = self.o.dims()
+            s = np.concatenate([self.o.scalars(), [d["pending_reset"], d["n_reached"], d["n_pending"], d["n_task_ids"] - 1]])
+            return s[None]
+        if name == "OPEN_IDS":
+            oi = self.o.open_ids()
+            out = np.full(max(nt, 1), -1, dtype=np.int32); out[: len(oi)] = oi
+            return out[None]
+        if name == "EVENTS":
+            ev = self.o.events()
+            out = np.full((max(len(ev), 1) + 1, 2), -1, dtype=np.int32); out[: len(ev)] = ev
+            return out[None]
+        raise KeyError(name)
+
+    @staticmethod
+    def _org(trow, reqs):
+        # orgReqs[typeIdx]: static tasks 1.0, Det = its initial count, Int 2.0, escort = requirement; the oracle
+        # does not export orgReqs, so recover it as doneReqs + currentReqs at the type index when possible
+        ty = trow[:, 6].astype(int)
+        n = trow.shape[0]
+        return reqs[np.arange(n), 0, ty] + reqs[np.arange(n), 2, ty]

@@ -320,3 +320,44 @@ def test_invalid_and_out_of_range_actions():
         for i, o in enumerate(oracles):
             o.step([a for a, _ in acts[i]], [j for _, j in acts[i]])
             compare(snap, i, o, f"random actions seed {i} t={t + 1}")
+
+
+def test_facade_on_gpu_matches_reference_observations():
+    """MultiUAVEnv facade over the HIP backend: the obs dicts / infos / rewards a PettingZoo caller sees equal
+    what the reference returned (golden trace), with actions produced by the on-device allocator."""
+    from muavta_amd.env import MultiUAVEnv
+    from muavta_amd.params import EVENT_TAGS
+    from muavta_amd.scenarios import CASE_SPECS, WPS_ENV_FLAGS
+    case, seed = "WPS_hard", 2
+    g = np.load(os.path.join(GOLDEN, f"trace_{case}_s{seed}.npz"))
+    env = MultiUAVEnv(CASE_SPECS[case], flags=dict(WPS_ENV_FLAGS), tile_agents=16, tile_tasks=32, tile_threats=16)
+    obs, infos = env.reset(seed=seed)
+    T = int(g["max_tasks"])
+    for t in range(150):
+        want = g["obs_tasks"][t]
+        first = obs[env.agents_obj[0].name]
+        assert len(first["tasks_info"]) == T
+        for j, info in enumerate(first["tasks_info"]):
+            if "id" not in info:
+                assert want[j, 3] == -1
+            else:
+                assert info["id"] == int(want[j, 0]) and info["status"] == int(want[j, 3])
+                assert np.float32(info["unmet"]) == want[j, 19] and np.float32(info["age"]) == want[j, 20]
+        legal = np.unpackbits(g["obs_legal"][t], axis=-1)[:, :T].astype(bool)
+        for a in env.agents_obj:
+            assert obs[a.name]["legal_mask"] == list(legal[a.id])
+            assert np.array_equal(np.float32(obs[a.name]["agent_position"]), g["obs_agent"][t][a.id, 0:2])
+        assert np.array_equal(obs[env.agents_obj[0].name]["event_flags"], g["obs_flags"][t])
+        aa, ai = env._b.allocate(20, True)
+        actions = {env.agents_obj[int(a)].name: int(i) for a, i in zip(aa[0], ai[0]) if a >= 0}
+        obs, rew, term, trunc, infos = env.step(actions)
+        assert rew[env.agents_obj[0].name] == g["reward"][t + 1]
+        ev = g["events"][g["events"][:, 0] == t + 1][:, 1:]
+        assert infos["events"] == [[EVENT_TAGS[int(x)], int(y)] for x, y in ev]
+        vis = env.agent_visibility_map()
+        NT = int(g["n_task_ids"])
+        known = np.unpackbits(g["known"][t + 1], axis=-1)[:, :NT].astype(bool)
+        for a in env.agents_obj:
+            assert vis[a.name] == set(np.nonzero(known[a.id])[0].tolist()), f"t={t + 1} {a.name}"
+    assert all(trunc.values()) and np.array_equal(np.array([float(infos["metrics"][k]) for k in METRIC_KEYS]), g["metrics"])
+    assert len(env.tasks) == int(g["metrics"][13])
