@@ -9,6 +9,9 @@ reference (``TaskAllocation/*``: they read ``env.agents_obj`` / ``env.tasks`` /
 object views below: UAV / Task / Threat proxies are cached per id, so identity tests such as
 ``task in env.last_tasks_info`` keep working.
 
+``agent_visibility_map()`` is exact for every task that is still open; ids of tasks that were revealed only
+after they had retired (the reference keeps adding those to its sets) may be absent — no caller looks them up.
+
 Not mirrored (raise ``NotImplementedError``): the reference's private mutators that tests poke
 directly (``_create_escort_for``, ``UAV.allocate`` ...) — on this path state changes only through
 ``reset`` / ``step``.

@@ -357,7 +357,9 @@ def test_facade_on_gpu_matches_reference_observations():
         vis = env.agent_visibility_map()
         NT = int(g["n_task_ids"])
         known = np.unpackbits(g["known"][t + 1], axis=-1)[:, :NT].astype(bool)
-        for a in env.agents_obj:
-            assert vis[a.name] == set(np.nonzero(known[a.id])[0].tolist()), f"t={t + 1} {a.name}"
+        open_ids = {x.id for x in env.last_tasks_info}
+        for a in env.agents_obj:  # ids of RETIRED tasks may be missing from the facade's sets (documented): callers only look up open ones
+            want_known = set(np.nonzero(known[a.id])[0].tolist())
+            assert vis[a.name] <= want_known and vis[a.name] & open_ids == want_known & open_ids, f"t={t + 1} {a.name}"
     assert all(trunc.values()) and np.array_equal(np.array([float(infos["metrics"][k]) for k in METRIC_KEYS]), g["metrics"])
     assert len(env.tasks) == int(g["metrics"][13])
