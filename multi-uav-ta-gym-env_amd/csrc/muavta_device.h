@@ -110,6 +110,32 @@ DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
   mt[0] = 0x80000000u;
 }
 
+// The workgroup's LDS: [EnvState | Scratch].  Out-of-line (noinline) routines re-derive their view from here.
+extern __shared__ __align__(16) unsigned char muavta_smem[];
+template <class TL> DEV EnvState<TL>* lds_state() { return reinterpret_cast<EnvState<TL>*>(muavta_smem); }
+template <class TL> DEV Scratch<TL>* lds_scratch() {
+  return reinterpret_cast<Scratch<TL>*>(muavta_smem + ((sizeof(EnvState<TL>) + 15) & ~size_t(15)));
+}
+
+// Order-dependent routines that run on lane 0 can be compiled OUT OF LINE (one copy each) with
+// -DMUAVTA_OUTLINE=__noinline__: that shrinks k_rollout from 152 KB to 68 KB of code, but measured 12 %
+// SLOWER on MI355X (call ABI + 672 B/lane of scratch), so the default keeps them inlined.
+#ifndef MUAVTA_OUTLINE
+#define MUAVTA_OUTLINE __forceinline__
+#endif
+template <class TL> __device__ MUAVTA_OUTLINE void ni_release_all_tasks(const DevParams* P, uint32_t* tape, int for_type);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_handle_threat_engagement(const DevParams* P, uint32_t* tape, int h);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_generate_threat(const DevParams* P, uint32_t* tape);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_sync_escorts(const DevParams* P, uint32_t* tape);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_step_serial_c_lists(const DevParams* P, uint32_t* tape, bool any_due, bool any_exp);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_reset_serial(const DevParams* P, uint32_t* tape);
+template <class TL> __device__ MUAVTA_OUTLINE double ni_step_serial_move(const DevParams* P, uint32_t* tape, int first, int last);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_update_threats_serial(const DevParams* P, uint32_t* tape, int first, unsigned long long livemask);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_create_escort_for(const DevParams* P, uint32_t* tape, int recon, int rec_slot);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_retire_escort_for(const DevParams* P, uint32_t* tape, int recon, bool failed);
+template <class TL> __device__ MUAVTA_OUTLINE void ni_desallocate_all(const DevParams* P, uint32_t* tape, int a);
+
 #ifdef MUAVTA_PROF
 __device__ unsigned long long g_prof[32];
 #define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; } } while (0)
@@ -121,8 +147,8 @@ template <class TL>
 struct Sim {
   typedef EnvState<TL> State;
 #ifdef MUAVTA_PROF
-  unsigned long long prof_acc[24] = {0}, prof_last = 0;
-  __device__ void prof_flush() { if (threadIdx.x == 0) for (int i = 0; i < 24; i++) atomicAdd(&g_prof[i], prof_acc[i]); }
+  unsigned long long prof_acc[32] = {0}, prof_last = 0;
+  __device__ void prof_flush() { if (threadIdx.x == 0) for (int i = 0; i < 32; i++) atomicAdd(&g_prof[i], prof_acc[i]); }
 #endif
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   State& S;
@@ -140,9 +166,15 @@ struct Sim {
     uint32_t p = S.rng_idx[st];
     uint32_t blk = (p >> 16) & 1u, off = p & 0xffffu;  // high half: which block is "current"
     if (off >= 1248u) { fail(MUAVTA_ERR_POSITION); off = 1247u; }
-    uint32_t b = off >= 624u ? (blk ^ 1u) : blk;
-    uint32_t o = off >= 624u ? off - 624u : off;
-    uint32_t y = tape[st * MUAVTA_RNG_WORDS + b * 624u + o];
+    uint32_t y;
+    const uint32_t w = p - S.rng_win_at[st];  // same block marker => plain cursor difference
+    if (w < 8u) {
+      y = S.rng_win[st][w];  // prefetched into LDS at the step boundary
+    } else {
+      uint32_t b = off >= 624u ? (blk ^ 1u) : blk;
+      uint32_t o = off >= 624u ? off - 624u : off;
+      y = tape[st * MUAVTA_RNG_WORDS + b * 624u + o];
+    }
     S.rng_idx[st] = (blk << 16) | (off + 1u);
     y ^= (y >> 11);
     y ^= (y << 7) & 0x9d2c5680u;
@@ -183,6 +215,31 @@ struct Sim {
       }
     }
   }
+  // Lane (st, k) fetches raw word cursor+k of stream st at the START of the step (rng_prefetch_issue) and
+  // parks it in the LDS window just before the first consumer (rng_prefetch_commit): the HBM/L2 latency
+  // hides behind the action / movement phases, and lane 0's draws of this step come from LDS.
+  DEV uint32_t rng_prefetch_issue() {
+    uint32_t w = 0;
+    if (lane < 32) {
+      const int st = lane >> 3, k = lane & 7;
+      const uint32_t p = S.rng_idx[st];
+      const uint32_t blk = (p >> 16) & 1u, off = (p & 0xffffu) + (uint32_t)k;
+      if (off < 1248u) {
+        const uint32_t b = off >= 624u ? (blk ^ 1u) : blk;
+        const uint32_t o = off >= 624u ? off - 624u : off;
+        w = tape[st * MUAVTA_RNG_WORDS + b * 624u + o];
+      }
+    }
+    return w;
+  }
+  DEV void rng_prefetch_commit(uint32_t w) {
+    if (lane < 32) {
+      const int st = lane >> 3, k = lane & 7;
+      S.rng_win[st][k] = w;
+      if (k == 0) S.rng_win_at[st] = S.rng_idx[st];  // no draw happens between issue and commit
+    }
+    lds_sync();
+  }
   // All lanes: seed stream(s).  `scr` = LDS scratch of >= 2*624 words.
   DEV void rng_seed_pair(uint32_t* scr, int stA, uint64_t seedA, int stB, uint64_t seedB) {
     if (lane == 0) mt_seed(scr, (uint32_t)seedA, (uint32_t)(seedA >> 32), (seedA >> 32) ? 2 : 1);
@@ -196,7 +253,7 @@ struct Sim {
       mt_twist(scr + 624, bB);
       mt_twist(bB, bB + 624);
     }
-    if (lane == 0) { S.rng_idx[stA] = 0; if (stB >= 0) S.rng_idx[stB] = 0; }
+    if (lane == 0) { S.rng_idx[stA] = 0; S.rng_win_at[stA] = 0x7fffffffu; if (stB >= 0) { S.rng_idx[stB] = 0; S.rng_win_at[stB] = 0x7fffffffu; } }
     __syncthreads();
   }
 
@@ -271,7 +328,8 @@ struct Sim {
       i++;
     }
   }
-  DEV void desallocate_all(int a) { iterate_desallocate(a); S.a_commit[a] = 0; }
+  DEV void desallocate_all(int a) { ni_desallocate_all<TL>(&P, tape, a); }
+  DEV void desallocate_all_impl(int a) { iterate_desallocate(a); S.a_commit[a] = 0; }
   DEV void out_of_service(int a) { S.a_state[a] = -1; S.a_commit[a] = 0; iterate_desallocate(a); }
 
   // UAV.taskDone (DroneEnvComponents.py:143-179)
@@ -445,7 +503,8 @@ struct Sim {
     for (int k = 0; k < S.n_escorts; k++) if (S.esc_agent[k] == recon) return k;
     return -1;
   }
-  DEV void create_escort_for(int recon, int rec_slot) {  // _create_escort_for (:1888-1917)
+  DEV void create_escort_for(int recon, int rec_slot) { ni_create_escort_for<TL>(&P, tape, recon, rec_slot); }
+  DEV void create_escort_for_impl(int recon, int rec_slot) {  // _create_escort_for (:1888-1917)
     if (!P.escort_enabled) return;
     if (escort_lookup(recon) >= 0) return;
     int s = new_task(S.a_px[recon], S.a_py[recon], MUAVTA_DEF, P.escort_requirement);
@@ -498,7 +557,8 @@ struct Sim {
     if (failed) S.escort_failed++; else S.escort_completed++;
     push_event(MUAVTA_EV_ESCORT_RETIRED, id);
   }
-  DEV void retire_escort_for(int recon, bool failed) {  // :1952-1957
+  DEV void retire_escort_for(int recon, bool failed) { ni_retire_escort_for<TL>(&P, tape, recon, failed); }
+  DEV void retire_escort_for_impl(int recon, bool failed) {  // :1952-1957
     int k = escort_lookup(recon);
     if (k >= 0) retire_escort_entry(k, failed);
   }
@@ -540,7 +600,8 @@ struct Sim {
   }
 
   // ---------------------------------------------------------------- releaseAllTasks (:1442-1480)
-  DEV void release_all_tasks(int for_type) {
+  DEV void release_all_tasks(int for_type) { ni_release_all_tasks<TL>(&P, tape, for_type); }
+  DEV void release_all_tasks_impl(int for_type) {
     int ft = for_type < 0 ? for_type + 6 : for_type;  // python negative index -> caps[-1] == Det
     uint32_t avail = 0;
     for (int a = 0; a < P.n_agents; a++) {
@@ -673,7 +734,8 @@ struct Sim {
     finish_step_parallel(false);
   }
 
-  DEV void reset_serial() {
+  DEV void reset_serial() { ni_reset_serial<TL>(&P, tape); }
+  DEV void reset_serial_impl() {
     const int nA = P.n_agents;
     S.conclusion_time = P.max_time_steps + 1;
     S.next_task_id = 1;
@@ -760,9 +822,33 @@ struct Sim {
   // ====================================================================================================
   // step (:774-1206).  n_act staged actions in S.act_agent / S.act_slot (slot < 0: invalid index).
   // ====================================================================================================
+  // np.sum of n <= 128 doubles with numpy's pairwise order: 8 strided accumulators r[k] (one per lane),
+  // combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the n % 8 tail added in order; plain loop for n < 8.
+  DEV double np_sum_wave(const double* d, int n) {
+    double res;
+    if (n < 8) {
+      res = 0.;
+      for (int i = 0; i < n; i++) res += d[i];
+      return res;
+    }
+    const int body = n - (n % 8);
+    double r = 0.;
+    if (lane < 8) {
+      r = d[lane];
+      for (int i = 8 + lane; i < body; i += 8) r += d[i];
+    }
+    r = r + dpp_xchg(r, 0);   // lanes 2m, 2m+1: r[2m] + r[2m+1]
+    r = r + dpp_xchg(r, 1);   // quads: (r0+r1)+(r2+r3) | (r4+r5)+(r6+r7)
+    r = r + dpp_xchg(r, 2);   // row_half_mirror pairs the two quads of lanes 0..7
+    res = readlane_f64(r, 0);
+    for (int i = body; i < n; i++) res += d[i];
+    return res;
+  }
+
   DEV void step(bool write_obs_flag) {
     PROF(0);
     rng_refill();
+    const uint32_t rng_words = rng_prefetch_issue();
     PROF(1);
     // previous positions stay in registers of the lane that owns the agent
     double prev_x = 0, prev_y = 0;
@@ -772,21 +858,42 @@ struct Sim {
     if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
     lds_sync();
     PROF(3);
-    const int first_serial = move_parallel();
-    lds_sync();
-    if (lane == 0 && first_serial < P.n_agents) step_serial_move(first_serial, r_quality);
-    lds_sync();
-    PROF(4);
-    // distances (:1131-1138): np.linalg.norm(axis=1) == sqrt(x*x + y*y), no fma
-    if (lane < P.n_agents) {
-      double dx = S.a_px[lane] - prev_x, dy = S.a_py[lane] - prev_y;
-      double d = sqrt(dx * dx + dy * dy);
-      S.a_dist[lane] += d;
-      X.u[lane < A ? lane : 0] = d;
+    // movement (:965-1129): lanes commit every agent up to the first "event" agent, lane 0 plays that one
+    // agent exactly as the reference does, and the wave resumes behind it
+    for (int start = 0; start < P.n_agents;) {
+      const int first = move_parallel(start);
+      lds_sync();
+      PROF(26);
+      if (first >= P.n_agents) break;
+      if (lane == 0) step_serial_move(first, first + 1, r_quality);
+      lds_sync();
+      PROF(4);
+      start = first + 1;
     }
-    lds_sync();
+    // distances (:1131-1138): np.linalg.norm(axis=1) == sqrt(x*x + y*y), no fma
+    double dist_sum;
+    {
+      double d = 0.0;
+      if (lane < P.n_agents) {
+        double dx = S.a_px[lane] - prev_x, dy = S.a_py[lane] - prev_y;
+        d = sqrt(dx * dx + dy * dy);
+        S.a_dist[lane] += d;
+        X.u[lane] = d;
+      }
+      lds_sync();
+      dist_sum = np_sum_wave(X.u, P.n_agents);  // np.sum(dists) (:1138)
+    }
+    rng_prefetch_commit(rng_words);
     PROF(5);
-    if (lane == 0) step_serial_b();
+    if (lane == 0) step_serial_b(dist_sum);
+    lds_sync();
+    {
+      unsigned long long livemask;
+      const int first = update_threats_parallel(livemask);
+      lds_sync();
+      PROF(23);
+      if (lane == 0) step_serial_b2(first, livemask);
+    }
     lds_sync();
     PROF(6);
     sense_parallel();  // _wps_update_sensing (:1506-1523)
@@ -802,8 +909,10 @@ struct Sim {
       }
       const bool any_due = __ballot(due) != 0ull;
       const bool any_exp = P.hard_windows && __ballot(expiring) != 0ull;
+      PROF(28);
       if (lane == 0 && (any_due || any_exp)) step_serial_c_lists(any_due, any_exp);
       lds_sync();
+      PROF(29);
       if (lane < P.n_agents && S.a_state[lane] != -1) { idle = S.a_qlen[lane] == 0; resp = !idle; }
       for (int k = lane; k < S.n_order; k += WG) blocking |= !counts_for_mission_done(S.t_order[k]);
       const int n_idle = __popcll(__ballot(idle));
@@ -817,13 +926,6 @@ struct Sim {
     PROF(9);
   }
 
-  // Per-agent geometry of the movement state machine, one agent per lane: distance / unit direction to
-  // the current task and the resulting displacement, and the same towards the base.  Positions of an
-  // agent change only at its own turn and task positions do not change inside the loop, so the serial
-  // pass can consume these as long as the agent's current task is still the one seen here.
-  struct MovePre { double dist, nav_dx, nav_dy, base_d, rtb_dx, rtb_dy; };
-  DEV double* pre_f(int k) { return X.cost + k * A; }          // 6 arrays of A doubles in the (idle) cost tile
-  DEV int32_t* pre_id() { return X.remaining; }                // T >= A
   DEV void displacement(double px, double py, double ux, double uy, double speed, double& ddx, double& ddy) {
     double avx, avy;
     avoid_obstacles(px, py, ux, uy, avx, avy);
@@ -831,19 +933,18 @@ struct Sim {
     norm_vector(mx, my);
     ddx = mx * speed; ddy = my * speed;
   }
-  // The movement state machine (:965-1129) with one agent per lane.  An agent's turn only touches its
-  // own fields unless it (a) fails, (b) engages an Int task (rewrites the threat's target) or
-  // (c) concludes a task; those are "events".  Agents BEFORE the first event agent (agents_obj order)
-  // are therefore independent of everything later in the loop and commit their lane's result; from
-  // the first event agent on, lane 0 replays the reference's serial loop (step_serial_move), reusing the
-  // geometry the lanes left in the cost tile.  Returns the index the serial replay starts at.
-  DEV int move_parallel() {
+  // The movement state machine (:965-1129) with one agent per lane.  An agent's turn only touches its own
+  // fields unless it (a) fails, (b) engages an Int task (rewrites the threat's target) or (c) concludes a
+  // task; those are "events".  Agents in [start, first event) are independent of everything later in the
+  // loop and commit their lane's result.  An agent either heads for its current task or (idle) for the
+  // base, never both, so each lane runs ONE distance / unit-vector / displacement pipeline.
+  // Returns the index of the first event agent >= start (n_agents if none).
+  DEV int move_parallel(int start) {
     const int a = lane;
-    const bool live = a < P.n_agents && S.a_state[a] != -1;
+    const bool live = a >= start && a < P.n_agents && S.a_state[a] != -1;
     bool evt = false, pop_head = false;
     int new_st = 0, new_ts = 0, cid = 0, cs = -1;
     double px = 0, py = 0, ddx = 0.0, ddy = 0.0;
-    if (a < P.n_agents) pre_id()[a] = -2;
     if (live) {
       if (S.a_fail[a] == S.time_steps) {
         evt = true;
@@ -851,54 +952,54 @@ struct Sim {
         px = S.a_px[a]; py = S.a_py[a];
         const double speed = P.speed[S.a_type[a]];
         new_st = S.a_state[a]; new_ts = S.a_task_start[a];
-        const double base_d = norm2(px - BASE_X, py - BASE_Y);
-        pre_f(3)[a] = base_d;
-        double rdx, rdy;
-        {
-          double bx = BASE_X - px, by = BASE_Y - py;
-          norm_vector(bx, by);  // :1119
-          displacement(px, py, bx, by, speed, rdx, rdy);
-          pre_f(4)[a] = rdx; pre_f(5)[a] = rdy;
-        }
         const int qlen = S.a_qlen[a], reeval = S.a_reeval[a];
-        if (new_st == 0 && !reeval && qlen == 0 && base_d > speed + 5) new_st = 3;  // :987-993
         if (reeval) { cid = S.a_last_id[a]; cs = S.a_last_slot[a]; }
         else if (qlen > 0) { cid = S.a_qid[a][0]; cs = S.a_qslot[a][0]; }
-        if (cid != 0 && ref_retired(cid, cs)) {
-          pop_head = true;  // :1004-1007, own queue only (the task is retired: removeAgentCap is a no-op)
-        } else if (cid != 0) {
-          const int ty = S.t_type[cs];
-          const double engage = ENGAGE_RANGE[S.a_type[a]];
-          double dx = S.t_px[cs] - px, dy = S.t_py[cs] - py;
+        const bool retired = cid != 0 && ref_retired(cid, cs);
+        const bool to_task = cid != 0 && !retired;
+        const bool idle_check = new_st == 0 && !reeval && qlen == 0;    // :987-993
+        const bool to_base = !to_task && (idle_check || new_st == 3);
+        if (retired) pop_head = true;  // :1004-1007, own queue only (the task is retired: removeAgentCap is a no-op)
+        if (to_task || to_base) {
+          // vector to the target, its norm, unit vector, displacement — identical arithmetic on both paths:
+          // task: dir/dist with the EPS guard (:1014-1020); base: norm_vector(base - pos) (:1119) whose norm
+          // equals norm(pos - base) used by the distance tests (:992,:1116)
+          const double tx = to_task ? S.t_px[cs] : BASE_X, ty_ = to_task ? S.t_py[cs] : BASE_Y;
+          const double dx = tx - px, dy = ty_ - py;
           const double dist = norm2(dx, dy);
           double ux = 0, uy = 0;
-          if (!(fabs(dist) < 1e-12)) { ux = dx / dist; uy = dy / dist; }
+          const bool zero = to_task ? (fabs(dist) < 1e-12) : (dist == 0);
+          if (!zero) { ux = dx / dist; uy = dy / dist; }
           double ndx, ndy;
           displacement(px, py, ux, uy, speed, ndx, ndy);
-          pre_f(0)[a] = dist; pre_f(1)[a] = ndx; pre_f(2)[a] = ndy;
-          pre_id()[a] = cid;
-          if (new_st == 1) {
-            if (ty == MUAVTA_INT) {
-              if (dist < engage) evt = true;
+          if (to_task) {
+            const int ty = S.t_type[cs];
+            const double engage = ENGAGE_RANGE[S.a_type[a]];
+            if (new_st == 1) {
+              if (ty == MUAVTA_INT) {
+                if (dist < engage) evt = true;
+                else { ddx = ndx; ddy = ndy; }
+              } else if (dist < speed) {
+                new_st = 2; new_ts = S.time_steps;
+                px = S.t_px[cs]; py = S.t_py[cs];
+              } else { ddx = ndx; ddy = ndy; }
+            } else if (new_st == 2) {
+              if (ty == MUAVTA_INT && dist >= engage) new_st = 1;
+              if (new_ts == -1) {
+                new_ts = S.time_steps;
+                px = S.t_px[cs]; py = S.t_py[cs];
+              } else if ((S.time_steps - new_ts) >= TASK_DURATION[ty] && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
+                         ty != MUAVTA_INT && ty != MUAVTA_DET) {
+                evt = true;
+              }
+            }
+          } else {
+            if (idle_check && dist > speed + 5) new_st = 3;
+            if (new_st == 3) {  // :1114-1121
+              if (dist < speed + 5) new_st = 0;
               else { ddx = ndx; ddy = ndy; }
-            } else if (dist < speed) {
-              new_st = 2; new_ts = S.time_steps;
-              px = S.t_px[cs]; py = S.t_py[cs];
-            } else { ddx = ndx; ddy = ndy; }
-          } else if (new_st == 2) {
-            if (ty == MUAVTA_INT && dist >= engage) new_st = 1;
-            if (new_ts == -1) {
-              new_ts = S.time_steps;
-              px = S.t_px[cs]; py = S.t_py[cs];
-            } else if ((S.time_steps - new_ts) >= TASK_DURATION[ty] && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
-                       ty != MUAVTA_INT && ty != MUAVTA_DET) {
-              evt = true;
             }
           }
-        }
-        if (new_st == 3) {  // :1114-1121
-          if (base_d < speed + 5) new_st = 0;
-          else { ddx = rdx; ddy = rdy; }
         }
       }
     }
@@ -1000,8 +1101,11 @@ struct Sim {
   }
 
   // ---- movement state machine (:965-1129), agents_obj order, lane 0 ----
-  DEV void step_serial_move(int first, double& quality_reward) {
-    for (int a = first; a < P.n_agents; a++) {
+  // the reference's loop body for agents [first, last) on lane 0
+  DEV void step_serial_move(int first, int last, double& quality_reward) { quality_reward += ni_step_serial_move<TL>(&P, tape, first, last); }
+  DEV double step_serial_move_impl(int first, int last) {
+    double quality_reward = 0;
+    for (int a = first; a < last; a++) {
       if (S.a_state[a] == -1) continue;
       if (S.a_fail[a] == S.time_steps) {  // :972-981
         S.a_state[a] = -1;
@@ -1013,10 +1117,9 @@ struct Sim {
       }
       const double speed = P.speed[S.a_type[a]];
       double px = S.a_px[a], py = S.a_py[a];
-      const double base_d = pre_f(3)[a];
       double ddx = 0.0, ddy = 0.0;  // displacement of this step (movement normalised twice, times max_speed)
       if (S.a_state[a] == 0 && !S.a_reeval[a]) {  // :987-993
-        if (S.a_qlen[a] == 0 && base_d > speed + 5) S.a_state[a] = 3;
+        if (S.a_qlen[a] == 0 && norm2(px - BASE_X, py - BASE_Y) > speed + 5) S.a_state[a] = 3;
       }
       {
         // current task: last_task while re_eval, else the head (:996-1002); id 0 == task_idle
@@ -1031,16 +1134,10 @@ struct Sim {
         } else if (cid != 0) {
           const int ty = S.t_type[cs];
           const double engage = ENGAGE_RANGE[S.a_type[a]];
-          double dist, ndx, ndy;
-          if (pre_id()[a] == cid) {  // geometry computed by the agent's lane is still current
-            dist = pre_f(0)[a]; ndx = pre_f(1)[a]; ndy = pre_f(2)[a];
-          } else {                   // current task changed under an earlier agent's completion / escort retirement
-            double dx = S.t_px[cs] - px, dy = S.t_py[cs] - py;
-            dist = norm2(dx, dy);
-            double ux = 0, uy = 0;
-            if (!(fabs(dist) < 1e-12)) { ux = dx / dist; uy = dy / dist; }
-            displacement(px, py, ux, uy, speed, ndx, ndy);
-          }
+          double dx = S.t_px[cs] - px, dy = S.t_py[cs] - py;
+          const double dist = norm2(dx, dy);
+          double ux = 0, uy = 0;
+          if (!(fabs(dist) < 1e-12)) { ux = dx / dist; uy = dy / dist; }
           if (S.a_state[a] == 1) {  // navigating (:1012-1048)
             if (ty == MUAVTA_INT) {
               if (dist < engage) {
@@ -1048,14 +1145,14 @@ struct Sim {
                 S.h_target[S.t_threat[cs]] = a;
                 S.a_task_start[a] = S.time_steps;
               } else {
-                ddx = ndx; ddy = ndy;
+                displacement(px, py, ux, uy, speed, ddx, ddy);
               }
             } else if (dist < speed) {
               S.a_state[a] = 2;
               S.a_task_start[a] = S.time_steps;
               px = S.t_px[cs]; py = S.t_py[cs];
             } else {
-              ddx = ndx; ddy = ndy;
+              displacement(px, py, ux, uy, speed, ddx, ddy);
             }
           } else if (S.a_state[a] == 2) {  // in task (:1051-1110)
             if (ty == MUAVTA_INT) {
@@ -1092,48 +1189,49 @@ struct Sim {
           }
         }
       }
-      if (S.a_state[a] == 3) {  // returning to base (:1114-1121); the position is still the one the lane saw
-        if (base_d < speed + 5) S.a_state[a] = 0;
-        else { ddx = pre_f(4)[a]; ddy = pre_f(5)[a]; }
+      if (S.a_state[a] == 3) {  // returning to base (:1114-1121)
+        if (norm2(px - BASE_X, py - BASE_Y) < speed + 5) {
+          S.a_state[a] = 0;
+        } else {
+          double bx = BASE_X - px, by = BASE_Y - py;
+          norm_vector(bx, by);
+          displacement(px, py, bx, by, speed, ddx, ddy);
+        }
       }
       px = px + ddx; py = py + ddy;  // :1125-1127
       S.a_px[a] = fmin(fmax(px, 0.0), AREA_W);
       S.a_py[a] = fmin(fmax(py, 0.0), AREA_H);
     }
+    return quality_reward;
   }
 
   // total distance, threats, arrivals, escorts
-  DEV void step_serial_b() {
-    {  // np.sum(dists) (:1138): numpy pairwise summation (8 accumulators for n >= 8)
-      const int n = P.n_agents;
-      const double* d = X.u;
-      double res;
-      if (n < 8) { res = 0.; for (int i = 0; i < n; i++) res += d[i]; }
-      else {
-        double r[8];
-        for (int k = 0; k < 8; k++) r[k] = d[k];
-        int i;
-        for (i = 8; i < n - (n % 8); i += 8) for (int k = 0; k < 8; k++) r[k] += d[i + k];
-        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; i++) res += d[i];
-      }
-      S.total_distance += res;
-    }
-    // :1140-1145 — evaluated here, before this step's spawns / expiries change the counts
-    S.r_time_penalty = -(double)(P.n_tasks - S.n_reached) / (double)P.n_tasks * ((double)S.time_steps / (double)P.max_time_steps);
+  DEV void step_serial_b(double dist_sum) {
+    S.total_distance += dist_sum;
+    // :1140-1145 — evaluated here, before this step's spawns / expiries change the counts.  A term whose
+    // weight is 0 contributes +-0.0 to the reward sum whatever its value, so it is not evaluated at all.
+    S.r_time_penalty = 0;
+    if (P.rw[6] != 0) S.r_time_penalty = -(double)(P.n_tasks - S.n_reached) / (double)P.n_tasks * ((double)S.time_steps / (double)P.max_time_steps);
     S.r_alloc = 0;
-    if (S.time_steps > P.n_tasks + 1) {  // -len(unallocated_tasks()) (:1434-1440); bucket 0 (idle) is always empty
+    if (P.rw[5] != 0 && S.time_steps > P.n_tasks + 1) {  // -len(unallocated_tasks()) (:1434-1440); bucket 0 (idle) is always empty
       int n = 1 + S.n_retired_empty_buckets;
       for (int k = 0; k < S.n_order; k++) if (S.t_bucket[S.t_order[k]] == 0) n++;
       S.r_alloc = -(double)n;
     }
+    PROF(21);
     generate_threat();
-    update_threats();
+    PROF(22);
+  }
+  DEV void step_serial_b2(int first, unsigned long long livemask) {
+    if (first < S.n_active_threats) update_threats_serial(first, livemask);
+    PROF(24);
     inject_dynamic_arrivals();
+    PROF(25);
     if (P.escort_enabled) sync_escorts();
   }
 
-  DEV void generate_threat() {  // :1601-1643
+  DEV void generate_threat() { ni_generate_threat<TL>(&P, tape); }
+  DEV void generate_threat_impl() {  // :1601-1643
     for (int g = 0; g < P.n_threat_groups; g++) {
       int left = S.g_end[g] - S.g_next[g];
       if (left > 0 && S.time_steps > 40 && S.time_steps % 10 == 0) {
@@ -1191,7 +1289,8 @@ struct Sim {
     else mark_outcome(S.h_tflags[h], S.h_tdeadline[h], success);
   }
 
-  DEV void handle_threat_engagement(int h) {  // :1781-1858
+  DEV void handle_threat_engagement(int h) { ni_handle_threat_engagement<TL>(&P, tape, h); }
+  DEV void handle_threat_engagement_impl(int h) {  // :1781-1858
     int primary = S.h_target[h];
     int mission = S.h_mission[h] >= 0 ? S.h_mission[h] : primary;
     int n_def = 0;
@@ -1258,13 +1357,68 @@ struct Sim {
     }
   }
 
-  DEV void update_threats() {  // :1725-1744
+  // update_threats (:1725-1744), one active threat per lane.  A threat's turn touches only its own record
+  // (position, target, its Int task's position) unless it ENGAGES (shared RNG stream, kills) or leaves the
+  // area with an uncounted window (shared counters): those are events.  Threats before the first event
+  // (env.threats order) commit their lane's result; lane 0 replays the reference loop from the event on.
+  // Returns (first serial index, snapshot mask of threats with status != 2).
+  DEV int update_threats_parallel(unsigned long long& livemask) {
+    static_assert(H <= 64, "one threat per lane");
     const int n = S.n_active_threats;
-    // python snapshots [t for t in self.threats if t.status != 2] before the loop
-    uint64_t livemask[(H + 63) / 64] = {0};
-    for (int k = 0; k < n; k++) if (S.h_status[S.h_order[k]] != 2) livemask[k >> 6] |= 1ull << (k & 63);
-    for (int k = 0; k < n; k++) {
-      if (!((livemask[k >> 6] >> (k & 63)) & 1ull)) continue;
+    const int k = lane;
+    int h = 0;
+    bool active = false;
+    if (k < n) { h = S.h_order[k]; active = S.h_status[h] != 2; }
+    livemask = __ballot(active);  // python snapshots [t for t in self.threats if t.status != 2] before the loop
+    bool evt = false;
+    double npx = 0, npy = 0;
+    int tgt = -1, icpt = -1, slot = -1;
+    bool live_task = false;
+    if (active) {
+      const int hty = S.h_type[h];
+      const double speed = P.speed[hty];
+      const double px = S.h_px[h], py = S.h_py[h];
+      tgt = S.h_target[h]; icpt = S.h_intercept[h];
+      if (S.h_status[h] == 0 || tgt < 0) {
+        npx = px + speed * 0.0;
+        npy = py + speed * -1.0;
+      } else {
+        if (P.escort_enabled) {  // _retarget_threat_via_escort (:1766-1779): reads agents only
+          int mission = S.h_mission[h] >= 0 ? S.h_mission[h] : tgt;
+          if (mission >= 0 && S.a_state[mission] != -1 && is_recon(S.a_type[mission])) {
+            int cnt;
+            int e0 = closest_escort(mission, P.escort_intercept_radius, &cnt);
+            if (cnt == 0) { tgt = mission; icpt = -1; }
+            else { tgt = e0; icpt = e0; }
+          }
+        }
+        double dx = S.a_px[tgt] - px, dy = S.a_py[tgt] - py;
+        norm_vector(dx, dy);
+        npx = px + speed * dx;
+        npy = py + speed * dy;
+        if (norm2(S.a_px[tgt] - npx, S.a_py[tgt] - npy) < ENGAGE_RANGE[hty]) evt = true;
+      }
+      slot = S.h_task_slot[h];
+      live_task = ref_valid(S.h_task_id[h], slot);
+      if (npy <= 0) {  // leaving the area: an event only if the retirement would still change something
+        if (live_task) evt |= (S.t_status[slot] != 2) || ((S.t_flags[slot] & TF_DEADLINE) && !(S.t_flags[slot] & TF_COUNTED));
+        else evt |= (S.h_tflags[h] & TF_DEADLINE) && !(S.h_tflags[h] & TF_COUNTED);
+      }
+    }
+    const unsigned long long em = __ballot(evt);
+    const int first = em ? __ffsll((long long)em) - 1 : n;
+    if (active && k < first) {
+      S.h_px[h] = npx; S.h_py[h] = npy;
+      S.h_target[h] = tgt; S.h_intercept[h] = icpt;
+      if (live_task) { S.t_px[slot] = npx; S.t_py[slot] = npy; }
+    }
+    return first;
+  }
+  DEV void update_threats_serial(int first, unsigned long long livemask) { ni_update_threats_serial<TL>(&P, tape, first, livemask); }
+  DEV void update_threats_serial_impl(int first, unsigned long long livemask) {
+    const int n = S.n_active_threats;
+    for (int k = first; k < n; k++) {
+      if (!((livemask >> k) & 1ull)) continue;
       int h = S.h_order[k];
       const double speed = P.speed[S.h_type[h]];
       if (S.h_status[h] == 0 || S.h_target[h] < 0) {
@@ -1294,7 +1448,8 @@ struct Sim {
     }
   }
 
-  DEV void inject_dynamic_arrivals() {  // :1646-1689
+  DEV void inject_dynamic_arrivals() { ni_inject_dynamic_arrivals<TL>(&P, tape); }
+  DEV void inject_dynamic_arrivals_impl() {  // :1646-1689
     if (P.arrival_rate <= 0 || S.time_steps < 5) return;
     if (rnd(ST_TGT) >= P.arrival_rate) return;
     if (S.next_task_id - 1 >= P.max_tasks - 1) return;  // len(self.tasks) >= max_tasks - 1
@@ -1321,7 +1476,8 @@ struct Sim {
     S.pending_reset = 1;
   }
 
-  DEV void sync_escorts() {  // :1964-2000
+  DEV void sync_escorts() { ni_sync_escorts<TL>(&P, tape); }
+  DEV void sync_escorts_impl() {  // :1964-2000
     for (int a = 0; a < P.n_agents; a++) {
       if (S.a_state[a] == -1 || !is_recon(S.a_type[a])) continue;
       if (S.a_qlen[a] == 0) continue;
@@ -1352,23 +1508,45 @@ struct Sim {
     }
   }
 
-  // _wps_update_sensing (:1506-1523): agent x live-slot pairs over the wave, distance tile in registers
+  // _wps_update_sensing (:1506-1523).  First the wave compacts the slots that can be sensed at all (dynamic,
+  // open) by ballot; then lane = (agent a, candidate sub-row) with the agent's position in registers.  The
+  // test `norm(d) <= sense_radius` is done on the squared form: sqrt is monotone and correctly rounded, so
+  // it equals `fma(dy,dy,dx*dx) <= bound` with the bound precomputed on the host (no sqrt per pair).
   DEV void sense_parallel() {
     if (P.sense_radius <= 0) return;
     const int nA = P.n_agents, nO = S.n_order;
-    for (int p = lane; p < nA * nO; p += WG) {
-      int a = p / nO, s = S.t_order[p - a * nO];
-      if (S.a_state[a] == -1) continue;
-      if (S.t_status[s] == 2) continue;
+    int32_t* cand = X.roundT;  // T entries
+    int nc = 0;
+    for (int base = 0; base < nO; base += WG) {
+      const int k = base + lane;
+      int s = -1;
+      bool c = false;
+      if (k < nO) {
+        s = S.t_order[k];
+        c = S.t_status[s] != 2 && (S.t_created[s] > 0 || (S.t_flags[s] & TF_DEADLINE));
+      }
+      const unsigned long long m = __ballot(c);
+      if (c) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = s;
+      nc += __popcll(m);
+    }
+    if (nc == 0) return;
+    lds_sync();
+    int aw = 1;
+    while (aw < nA) aw <<= 1;               // 16 / 32 / 64
+    const int a = lane & (aw - 1), sub = lane / aw, stride = WG / aw;
+    if (!(a < nA && S.a_state[a] != -1)) return;
+    const double ax = S.a_px[a], ay = S.a_py[a];
+    for (int k = sub; k < nc; k += stride) {
+      const int s = cand[k];
       if ((S.known[a][s >> 5] >> (s & 31)) & 1u) continue;
-      if (S.t_created[s] <= 0 && !(S.t_flags[s] & TF_DEADLINE)) continue;
-      double d = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
-      if (d <= P.sense_radius) atomicOr(&S.known[a][s >> 5], 1u << (s & 31));
+      const double dx = ax - S.t_px[s], dy = ay - S.t_py[s];
+      if (fma(dy, dy, dx * dx) <= P.sense_sq_bound) atomicOr(&S.known[a][s >> 5], 1u << (s & 31));
     }
   }
 
   // _wps_process_reveals (:1525-1541) and _wps_expire_windows (:1557-1573); lane 0, only when due
-  DEV void step_serial_c_lists(bool any_due, bool any_exp) {
+  DEV void step_serial_c_lists(bool any_due, bool any_exp) { ni_step_serial_c_lists<TL>(&P, tape, any_due, any_exp); }
+  DEV void step_serial_c_lists_impl(bool any_due, bool any_exp) {
     if (any_due) {
       int w = 0;
       for (int k = 0; k < S.n_pending; k++) {
@@ -1805,5 +1983,20 @@ struct Sim {
     m[k++] = S.escort_requests; m[k++] = S.escort_completed; m[k++] = S.escort_failed;
   }
 };
+
+#define MUAVTA_NI_SIM Sim<TL> sim(*lds_state<TL>(), *lds_scratch<TL>(), *P, tape)
+template <class TL> __device__ MUAVTA_OUTLINE void ni_release_all_tasks(const DevParams* P, uint32_t* tape, int for_type) { MUAVTA_NI_SIM; sim.release_all_tasks_impl(for_type); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_handle_threat_engagement(const DevParams* P, uint32_t* tape, int h) { MUAVTA_NI_SIM; sim.handle_threat_engagement_impl(h); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_generate_threat(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.generate_threat_impl(); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.inject_dynamic_arrivals_impl(); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_sync_escorts(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.sync_escorts_impl(); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_step_serial_c_lists(const DevParams* P, uint32_t* tape, bool any_due, bool any_exp) { MUAVTA_NI_SIM; sim.step_serial_c_lists_impl(any_due, any_exp); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_reset_serial(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.reset_serial_impl(); }
+template <class TL> __device__ MUAVTA_OUTLINE double ni_step_serial_move(const DevParams* P, uint32_t* tape, int first, int last) { MUAVTA_NI_SIM; return sim.step_serial_move_impl(first, last); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_update_threats_serial(const DevParams* P, uint32_t* tape, int first, unsigned long long livemask) { MUAVTA_NI_SIM; sim.update_threats_serial_impl(first, livemask); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_create_escort_for(const DevParams* P, uint32_t* tape, int recon, int rec_slot) { MUAVTA_NI_SIM; sim.create_escort_for_impl(recon, rec_slot); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_retire_escort_for(const DevParams* P, uint32_t* tape, int recon, bool failed) { MUAVTA_NI_SIM; sim.retire_escort_for_impl(recon, failed); }
+template <class TL> __device__ MUAVTA_OUTLINE void ni_desallocate_all(const DevParams* P, uint32_t* tape, int a) { MUAVTA_NI_SIM; sim.desallocate_all_impl(a); }
+#undef MUAVTA_NI_SIM
 
 }  // namespace muavta

@@ -64,7 +64,7 @@ struct Lds {
   static size_t bytes() { return ((sizeof(EnvState<TL>) + 15) & ~size_t(15)) + sizeof(Scratch<TL>); }
 };
 
-extern __shared__ __align__(16) unsigned char smem[];
+#define smem muavta_smem
 
 // Minimum waves per SIMD the register allocator must leave room for (2 => at most 256 VGPR+AGPR).
 #ifndef MUAVTA_MIN_WAVES
@@ -340,6 +340,15 @@ int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
   for (int t = 0; t < 7; t++) d->speed[t] = MAX_SPEED[t] / p->simulation_frame_rate * 0.02;
   d->threat_prob = 0.7 / p->simulation_frame_rate * 0.02;
   d->reward_norm_factor = (possible * 1 + possible) / 1000;
+  {  // sqrt is correctly rounded and monotone, so `sqrt(v) <= r` is a threshold test on v; find the threshold
+    const double r = p->sense_radius;
+    double v = r * r;
+    if (r > 0) {
+      while (std::sqrt(v) > r) v = std::nextafter(v, 0.0);
+      while (std::sqrt(std::nextafter(v, INFINITY)) <= r) v = std::nextafter(v, INFINITY);
+    }
+    d->sense_sq_bound = v;
+  }
   d->fail_rate = p->fail_rate; d->arrival_rate = p->arrival_rate; d->dynamic_idle_penalty = p->dynamic_idle_penalty;
   d->sense_radius = p->sense_radius; d->miss_penalty = p->miss_penalty; d->on_time_bonus = p->on_time_bonus;
   d->reassign_penalty = p->reassign_penalty; d->escort_radius = p->escort_radius; d->escort_requirement = p->escort_requirement;
@@ -720,7 +729,8 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
     ds = e->d_seeds;
   }
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
-  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, ds, (EnvState<TL>*)e->blobs,
+  static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
+  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds, e->stream, e->P, ds, (EnvState<TL>*)e->blobs,
                                  e->tapes, n_steps, interval, use_vis, write_obs, e->O, e->d_metrics));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));

@@ -45,6 +45,7 @@ struct DevParams {
   double speed[7];          // maxSpeeds[type] / frame_rate * 0.02            (DroneEnv.py:611,725)
   double threat_prob;       // 0.7 / frame_rate * 0.02                         (:162)
   double reward_norm_factor;// (possible + possible) / 1000                    (:670-675)
+  double sense_sq_bound;    // largest v with sqrt(v) <= sense_radius (correctly rounded): d <= r  <=>  d*d-form <= bound
   double fail_rate, arrival_rate, dynamic_idle_penalty, sense_radius, miss_penalty, on_time_bonus,
       reassign_penalty, escort_radius, escort_requirement, escort_intercept_radius, mutual_support_radius;
   double rw[8];
@@ -122,7 +123,9 @@ struct alignas(16) EnvState {
   int32_t pending_reset, terminated, truncated, error, did_reset;
   int32_t last_plan_step, n_replans, n_calls;  // HungarianAllocator state
   uint32_t rng_idx[4];                // cursor into each stream's 2x624-word tape (agent, obs, tgt, mission)
-  int32_t pad_[3];
+  uint32_t rng_win[4][8];             // the next 8 raw words of each stream, prefetched at the step boundary
+  uint32_t rng_win_at[4];             // cursor value the window was filled at
+  int32_t pad_[1];
 };
 
 // Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
