@@ -42,6 +42,13 @@ __constant__ double CAP_TABLE[7][6] = {
 __constant__ double ENGAGE_RANGE[7] = {0.0, 0.0, 0.0, 40.0, 30.0, 35.0, 25.0};
 __constant__ double FAIL_MULT[7] = {1.2, 0.8, 1.5, 1.5, 0.8, 1.8, 1.0};
 __constant__ int TASK_DURATION[6] = {1, 10, 5, 5, 0, 1};
+// The same tables as select chains / packed constants: an indexed read of __constant__ (or of a kernarg
+// array) with a per-lane index is a vector memory load with hundreds of cycles of exposed latency on the
+// order-dependent paths; these cost a few VALU ops.
+DEV int task_duration(int ty) { return (int)((0x010005050A01ull >> (8 * ty)) & 0xffull); }  // Hold, Rec, Att, Def, Int, Det
+DEV double engage_range(int t) { return t == MUAVTA_F1 ? 40.0 : t == MUAVTA_F2 ? 30.0 : t == MUAVTA_T1 ? 35.0 : t == MUAVTA_T2 ? 25.0 : 0.0; }
+DEV double threat_attack(int t) { return 0.2; }                          // UavCapTable[T1/T2][Att]
+DEV double threat_defence(int t) { return t == MUAVTA_T1 ? 0.5 : 0.4; }  // UavCapTable[T1/T2][Def]
 
 DEV double norm2(double x, double y) { return sqrt(fma(y, y, x * x)); }  // np.linalg.norm of a 2-vector
 DEV bool is_recon(int t) { return t == MUAVTA_R1 || t == MUAVTA_R2; }
@@ -160,6 +167,10 @@ struct Sim {
   __device__ Sim(State& s, Scratch<TL>& x, const DevParams& p, uint32_t* t) : S(s), X(x), P(p), tape(t), lane(threadIdx.x) {}
 
   DEV void fail(int code) { if (S.error == 0) S.error = code; }
+  DEV double speed_of(int t) const {  // P.speed[t] without a memory access for a per-lane t
+    return t == 0 ? P.speed[0] : t == 1 ? P.speed[1] : t == 2 ? P.speed[2] : t == 3 ? P.speed[3] : t == 4 ? P.speed[4]
+         : t == 5 ? P.speed[5] : P.speed[6];
+  }
 
   // ---------------------------------------------------------------- RNG (lane 0 unless noted)
   DEV uint32_t next32(int st) {
@@ -284,7 +295,7 @@ struct Sim {
     S.t_ndet[s] -= 1;
     if (S.t_ndet[s] > 0) {
       const int id = S.t_id[s];
-      const double dur = (double)TASK_DURATION[S.t_type[s]];
+      const double dur = (double)task_duration(S.t_type[s]);
       bool first = true;
       double mn = 0, mx = 0;
       for (int b = 0; b < P.n_agents; b++)
@@ -360,9 +371,9 @@ struct Sim {
     S.a_reeval[a] = 0;
     S.a_last_id[a] = -1;
     S.a_last_slot[a] = -1;
-    double time_to_task = norm2(S.a_nfx[a] - S.t_px[s], S.a_nfy[a] - S.t_py[s]) / P.speed[S.a_type[a]];
+    double time_to_task = norm2(S.a_nfx[a] - S.t_px[s], S.a_nfy[a] - S.t_py[s]) / speed_of(S.a_type[a]);
     double start_time = (S.a_nft[a] - (double)S.time_steps) > 0 ? S.a_nft[a] : (double)S.time_steps;
-    double dur = (double)TASK_DURATION[S.t_type[s]];
+    double dur = (double)task_duration(S.t_type[s]);
     double end_time = start_time + time_to_task + dur;
     int n = S.a_qlen[a];
     if (n == 0) {
@@ -950,7 +961,7 @@ struct Sim {
         evt = true;
       } else {
         px = S.a_px[a]; py = S.a_py[a];
-        const double speed = P.speed[S.a_type[a]];
+        const double speed = speed_of(S.a_type[a]);
         new_st = S.a_state[a]; new_ts = S.a_task_start[a];
         const int qlen = S.a_qlen[a], reeval = S.a_reeval[a];
         if (reeval) { cid = S.a_last_id[a]; cs = S.a_last_slot[a]; }
@@ -974,7 +985,7 @@ struct Sim {
           displacement(px, py, ux, uy, speed, ndx, ndy);
           if (to_task) {
             const int ty = S.t_type[cs];
-            const double engage = ENGAGE_RANGE[S.a_type[a]];
+            const double engage = engage_range(S.a_type[a]);
             if (new_st == 1) {
               if (ty == MUAVTA_INT) {
                 if (dist < engage) evt = true;
@@ -988,7 +999,7 @@ struct Sim {
               if (new_ts == -1) {
                 new_ts = S.time_steps;
                 px = S.t_px[cs]; py = S.t_py[cs];
-              } else if ((S.time_steps - new_ts) >= TASK_DURATION[ty] && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
+              } else if ((S.time_steps - new_ts) >= task_duration(ty) && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
                          ty != MUAVTA_INT && ty != MUAVTA_DET) {
                 evt = true;
               }
@@ -1115,7 +1126,7 @@ struct Sim {
         S.pending_reset = 1;
         continue;
       }
-      const double speed = P.speed[S.a_type[a]];
+      const double speed = speed_of(S.a_type[a]);
       double px = S.a_px[a], py = S.a_py[a];
       double ddx = 0.0, ddy = 0.0;  // displacement of this step (movement normalised twice, times max_speed)
       if (S.a_state[a] == 0 && !S.a_reeval[a]) {  // :987-993
@@ -1133,7 +1144,7 @@ struct Sim {
           S.a_last_id[a] = -1; S.a_last_slot[a] = -1;
         } else if (cid != 0) {
           const int ty = S.t_type[cs];
-          const double engage = ENGAGE_RANGE[S.a_type[a]];
+          const double engage = engage_range(S.a_type[a]);
           double dx = S.t_px[cs] - px, dy = S.t_py[cs] - py;
           const double dist = norm2(dx, dy);
           double ux = 0, uy = 0;
@@ -1161,7 +1172,7 @@ struct Sim {
             if (S.a_task_start[a] == -1) {
               S.a_task_start[a] = S.time_steps;
               px = S.t_px[cs]; py = S.t_py[cs];
-            } else if ((S.time_steps - S.a_task_start[a]) >= TASK_DURATION[ty] && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
+            } else if ((S.time_steps - S.a_task_start[a]) >= task_duration(ty) && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
                        ty != MUAVTA_INT && ty != MUAVTA_DET) {
               // task concluded by this agent (:1079-1107)
               S.a_px[a] = px; S.a_py[a] = py;  // taskDone reads agent.position
@@ -1255,7 +1266,7 @@ struct Sim {
             S.h_mission[h] = tgt;
             // TaskFromThreat (:1861-1876)
             int ty = S.h_type[h];
-            double attack = CAP_TABLE[ty][2], defence = CAP_TABLE[ty][3];
+            double attack = threat_attack(ty), defence = threat_defence(ty);
             int s = new_task(S.h_px[h], S.h_py[h], MUAVTA_INT, 2.0);
             if (s >= 0) {
               S.t_cur[MUAVTA_ATT][s] = defence * 2;
@@ -1306,14 +1317,14 @@ struct Sim {
     }
     if (primary < 0) return;
     const int hty = S.h_type[h];
-    const double t_att = CAP_TABLE[hty][2], t_def = CAP_TABLE[hty][3], t_rng = ENGAGE_RANGE[hty];
+    const double t_att = threat_attack(hty), t_def = threat_defence(hty), t_rng = engage_range(hty);
     double attDiff, defDiff, engageDiff;
     if (n_def >= 2) {
       S.mutual_support_engagements++;
       double att_sum = 0, def_sum = 0, eng_sum = 0;
       for (int k = 0; k < n_def; k++) att_sum += S.a_caps[2][defs[k]];
       for (int k = 0; k < n_def; k++) def_sum += S.a_caps[3][defs[k]];
-      for (int k = 0; k < n_def; k++) eng_sum += ENGAGE_RANGE[S.a_type[defs[k]]];
+      for (int k = 0; k < n_def; k++) eng_sum += engage_range(S.a_type[defs[k]]);
       eng_sum = eng_sum / (double)n_def;
       attDiff = att_sum / fmax(t_att, 1e-6);
       defDiff = def_sum / fmax(t_def, 1e-6);
@@ -1321,7 +1332,7 @@ struct Sim {
     } else {
       attDiff = S.a_caps[2][primary] / fmax(t_att, 1e-6);
       defDiff = S.a_caps[3][primary] / fmax(t_def, 1e-6);
-      engageDiff = ENGAGE_RANGE[S.a_type[primary]] / fmax(t_rng, 1e-6);
+      engageDiff = engage_range(S.a_type[primary]) / fmax(t_rng, 1e-6);
     }
     double avg_diff = (attDiff + defDiff + engageDiff) / 3;
     double prob = avg_diff / (avg_diff + 1);
@@ -1376,7 +1387,7 @@ struct Sim {
     bool live_task = false;
     if (active) {
       const int hty = S.h_type[h];
-      const double speed = P.speed[hty];
+      const double speed = speed_of(hty);
       const double px = S.h_px[h], py = S.h_py[h];
       tgt = S.h_target[h]; icpt = S.h_intercept[h];
       if (S.h_status[h] == 0 || tgt < 0) {
@@ -1396,7 +1407,7 @@ struct Sim {
         norm_vector(dx, dy);
         npx = px + speed * dx;
         npy = py + speed * dy;
-        if (norm2(S.a_px[tgt] - npx, S.a_py[tgt] - npy) < ENGAGE_RANGE[hty]) evt = true;
+        if (norm2(S.a_px[tgt] - npx, S.a_py[tgt] - npy) < engage_range(hty)) evt = true;
       }
       slot = S.h_task_slot[h];
       live_task = ref_valid(S.h_task_id[h], slot);
@@ -1420,7 +1431,7 @@ struct Sim {
     for (int k = first; k < n; k++) {
       if (!((livemask >> k) & 1ull)) continue;
       int h = S.h_order[k];
-      const double speed = P.speed[S.h_type[h]];
+      const double speed = speed_of(S.h_type[h]);
       if (S.h_status[h] == 0 || S.h_target[h] < 0) {
         S.h_px[h] = S.h_px[h] + speed * 0.0;
         S.h_py[h] = S.h_py[h] + speed * -1.0;
@@ -1439,7 +1450,7 @@ struct Sim {
         norm_vector(dx, dy);
         S.h_px[h] = S.h_px[h] + speed * dx;
         S.h_py[h] = S.h_py[h] + speed * dy;
-        if (norm2(S.a_px[tg] - S.h_px[h], S.a_py[tg] - S.h_py[h]) < ENGAGE_RANGE[S.h_type[h]]) handle_threat_engagement(h);
+        if (norm2(S.a_px[tg] - S.h_px[h], S.a_py[tg] - S.h_py[h]) < engage_range(S.h_type[h])) handle_threat_engagement(h);
       }
       int s = S.h_task_slot[h];
       bool live = ref_valid(S.h_task_id[h], s);
