@@ -15,7 +15,8 @@ from .params import MuavtaDims, MuavtaParams
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 SO_PATH = os.environ.get("MUAVTA_SO") or os.path.join(PKG_DIR, "libmuavta.so")  # MUAVTA_SO: diagnostic builds only
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-Os",  # -Os: the rollout kernel is ~150 KB of code; smaller code measured +3.5 % over -O3
+                "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
 EXPORTS = [
     "muavta_create", "muavta_destroy", "muavta_last_error", "muavta_dims", "muavta_reset", "muavta_step",
