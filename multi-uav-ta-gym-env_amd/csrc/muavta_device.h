@@ -130,16 +130,19 @@ template <class TL> DEV Scratch<TL>* lds_scratch() {
 #ifndef MUAVTA_OUTLINE
 #define MUAVTA_OUTLINE __forceinline__
 #endif
+#ifndef MUAVTA_OUTLINE_COLD
+#define MUAVTA_OUTLINE_COLD MUAVTA_OUTLINE
+#endif
 template <class TL> __device__ MUAVTA_OUTLINE void ni_release_all_tasks(const DevParams* P, uint32_t* tape, int for_type);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_handle_threat_engagement(const DevParams* P, uint32_t* tape, int h);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_generate_threat(const DevParams* P, uint32_t* tape);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_sync_escorts(const DevParams* P, uint32_t* tape);
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_handle_threat_engagement(const DevParams* P, uint32_t* tape, int h);
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_generate_threat(const DevParams* P, uint32_t* tape);
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape);
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_sync_escorts(const DevParams* P, uint32_t* tape);
 template <class TL> __device__ MUAVTA_OUTLINE void ni_step_serial_c_lists(const DevParams* P, uint32_t* tape, bool any_due, bool any_exp);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_reset_serial(const DevParams* P, uint32_t* tape);
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_reset_serial(const DevParams* P, uint32_t* tape);
 template <class TL> __device__ MUAVTA_OUTLINE double ni_step_serial_move(const DevParams* P, uint32_t* tape, int first, int last);
 template <class TL> __device__ MUAVTA_OUTLINE void ni_update_threats_serial(const DevParams* P, uint32_t* tape, int first, unsigned long long livemask);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_create_escort_for(const DevParams* P, uint32_t* tape, int recon, int rec_slot);
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_create_escort_for(const DevParams* P, uint32_t* tape, int recon, int rec_slot);
 template <class TL> __device__ MUAVTA_OUTLINE void ni_retire_escort_for(const DevParams* P, uint32_t* tape, int recon, bool failed);
 template <class TL> __device__ MUAVTA_OUTLINE void ni_desallocate_all(const DevParams* P, uint32_t* tape, int a);
 
@@ -1833,7 +1836,7 @@ struct Sim {
       }
       lds_sync();
       PROF(12);
-      lsap(Rr, Cc);
+      if (T <= WG) lsap_reg(Rr, Cc); else lsap(Rr, Cc);
       PROF(13);
       if (lane == 0) {
         // accept (:182-204) in ascending agent order (scipy returns rows sorted)
@@ -1965,6 +1968,74 @@ struct Sim {
     }
   }
 
+  // Same algorithm with the search state in REGISTERS (nc <= 64): lane `it` carries the column sitting at
+  // scan position `it` — its id, dual v, shortest-path cost, predecessor row and assignment — and a
+  // swap-remove moves the last position's registers into the vacated lane with v_readlane.  Row duals u and
+  // col4row live in the row's lane.  Per scan step only the cost element is read from LDS.
+  DEV void lsap_reg(int nr, int nc) {
+    const double INF = __builtin_huge_val();
+    double u_r = 0;   // lane r < nr: u[r]
+    int c4r = -1;     // lane r < nr: col4row[r]
+    for (int j = lane; j < nc; j += WG) { X.v[j] = 0; X.row4col[j] = -1; }
+    lds_sync();
+    for (int cur = 0; cur < nr; cur++) {
+      int j = nc - 1 - lane;  // scipy fills `remaining` in reverse
+      const bool incol = lane < nc;
+      double vj = incol ? X.v[j] : 0.0, sp = INF;
+      int r4c = incol ? X.row4col[j] : 0, pth = -1;
+      unsigned long long SRmask = 0ull, SCmask = 0ull;
+      double minVal = 0;
+      int i = cur, nrem = nc, sink = -1;
+      while (sink == -1) {
+        SRmask |= 1ull << i;
+        const double ui = readlane_f64(u_r, i);
+        const bool active = lane < nrem;
+        double val = INF;
+        bool un = false;
+        if (active) {
+          const double r = minVal + X.cost[i * nc + j] - ui - vj;
+          if (r < sp) { sp = r; pth = i; }
+          val = sp;
+          un = r4c == -1;
+        }
+        const double m = wave_min(val);
+        const unsigned long long eq = __ballot(active && val == m);
+        const unsigned long long equ = __ballot(active && val == m && un);
+        if (m == INF) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }
+        minVal = m;
+        const int index = equ ? 63 - __clzll((long long)equ) : __ffsll((long long)eq) - 1;
+        const int jsel = __builtin_amdgcn_readlane(j, index), rj = __builtin_amdgcn_readlane(r4c, index);
+        if (lane == index) { X.spc[jsel] = sp; X.path[jsel] = pth; }  // final values of the selected column, by column id
+        SCmask |= 1ull << jsel;
+        const int last = nrem - 1;
+        const int jl = __builtin_amdgcn_readlane(j, last), r4l = __builtin_amdgcn_readlane(r4c, last), pl = __builtin_amdgcn_readlane(pth, last);
+        const double vl = readlane_f64(vj, last), spl = readlane_f64(sp, last);
+        if (lane == index) { j = jl; vj = vl; r4c = r4l; sp = spl; pth = pl; }
+        nrem--;
+        if (rj == -1) sink = jsel; else i = rj;
+      }
+      lds_sync();
+      if (lane < nr) {
+        if (lane == cur) u_r += minVal;
+        else if ((SRmask >> lane) & 1ull) u_r += minVal - X.spc[c4r];
+      }
+      if (lane < nc && ((SCmask >> lane) & 1ull)) X.v[lane] -= minVal - X.spc[lane];
+      // augmentation along `path` (uniform walk; col4row lives in the rows' lanes)
+      int jj = sink;
+      while (true) {
+        const int r = X.path[jj];
+        if (lane == 0) X.row4col[jj] = r;
+        const int t = __builtin_amdgcn_readlane(c4r, r);
+        if (lane == r) c4r = jj;
+        jj = t;
+        if (r == cur) break;
+      }
+      lds_sync();
+    }
+    if (lane < nr) X.col4row[lane] = c4r;
+    lds_sync();
+  }
+
   // calculate_metrics (:1231-1319) -> out[30]
   DEV void metrics(double* m) {
     if (lane != 0) return;
@@ -1997,15 +2068,15 @@ struct Sim {
 
 #define MUAVTA_NI_SIM Sim<TL> sim(*lds_state<TL>(), *lds_scratch<TL>(), *P, tape)
 template <class TL> __device__ MUAVTA_OUTLINE void ni_release_all_tasks(const DevParams* P, uint32_t* tape, int for_type) { MUAVTA_NI_SIM; sim.release_all_tasks_impl(for_type); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_handle_threat_engagement(const DevParams* P, uint32_t* tape, int h) { MUAVTA_NI_SIM; sim.handle_threat_engagement_impl(h); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_generate_threat(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.generate_threat_impl(); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.inject_dynamic_arrivals_impl(); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_sync_escorts(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.sync_escorts_impl(); }
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_handle_threat_engagement(const DevParams* P, uint32_t* tape, int h) { MUAVTA_NI_SIM; sim.handle_threat_engagement_impl(h); }
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_generate_threat(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.generate_threat_impl(); }
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.inject_dynamic_arrivals_impl(); }
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_sync_escorts(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.sync_escorts_impl(); }
 template <class TL> __device__ MUAVTA_OUTLINE void ni_step_serial_c_lists(const DevParams* P, uint32_t* tape, bool any_due, bool any_exp) { MUAVTA_NI_SIM; sim.step_serial_c_lists_impl(any_due, any_exp); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_reset_serial(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.reset_serial_impl(); }
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_reset_serial(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.reset_serial_impl(); }
 template <class TL> __device__ MUAVTA_OUTLINE double ni_step_serial_move(const DevParams* P, uint32_t* tape, int first, int last) { MUAVTA_NI_SIM; return sim.step_serial_move_impl(first, last); }
 template <class TL> __device__ MUAVTA_OUTLINE void ni_update_threats_serial(const DevParams* P, uint32_t* tape, int first, unsigned long long livemask) { MUAVTA_NI_SIM; sim.update_threats_serial_impl(first, livemask); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_create_escort_for(const DevParams* P, uint32_t* tape, int recon, int rec_slot) { MUAVTA_NI_SIM; sim.create_escort_for_impl(recon, rec_slot); }
+template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_create_escort_for(const DevParams* P, uint32_t* tape, int recon, int rec_slot) { MUAVTA_NI_SIM; sim.create_escort_for_impl(recon, rec_slot); }
 template <class TL> __device__ MUAVTA_OUTLINE void ni_retire_escort_for(const DevParams* P, uint32_t* tape, int recon, bool failed) { MUAVTA_NI_SIM; sim.retire_escort_for_impl(recon, failed); }
 template <class TL> __device__ MUAVTA_OUTLINE void ni_desallocate_all(const DevParams* P, uint32_t* tape, int a) { MUAVTA_NI_SIM; sim.desallocate_all_impl(a); }
 #undef MUAVTA_NI_SIM
