@@ -1774,39 +1774,33 @@ struct Sim {
   }
 
   DEV void allocate(int interval, int use_visibility) {
-    __shared__ int sh_go, sh_nr, sh_nc, sh_nopen;
     PROF(10);
     interval = interval < 1 ? 1 : interval;
-    if (lane == 0) {
-      S.n_calls++;
-      S.n_act = 0;
-      // should_replan (:27-41): every tag the env emits is in the trigger set
-      bool go = (S.time_steps - S.last_plan_step >= interval) || (S.n_dev > 0);
-      int nfree = 0, nopen = 0;
-      if (go) {
-        for (int a = 0; a < P.n_agents; a++) if (S.a_state[a] != -1) X.freeA[nfree++] = a;
-        for (int k = 0; k < S.n_open; k++) {
-          int s = S.open_slot[k];
-          double r = residual_demand(s);
-          X.resid[s] = r;
-          if (r > 0) nopen++;
-        }
-        if (nfree == 0 || nopen == 0) go = false;
+    if (lane == 0) { S.n_calls++; S.n_act = 0; }
+    // should_replan (:27-41): every tag the env emits is in the trigger set
+    bool go = (S.time_steps - S.last_plan_step >= interval) || (S.n_dev > 0);
+    int nr = 0;
+    if (go) {
+      // live agents -> free list (get_live_agents order), residual demand per open task: one lane each
+      nr = compact_to(X.freeA, P.n_agents, [&](int a) { return S.a_state[a] != -1; }, [&](int a) { return a; });
+      bool any_open = false;
+      for (int k = lane; k < S.n_open; k += WG) {
+        const int s = S.open_slot[k];
+        const double r = residual_demand(s);
+        X.resid[s] = r;
+        any_open |= r > 0;
       }
-      sh_go = go; sh_nr = nfree; sh_nopen = nopen;
+      if (nr == 0 || __ballot(any_open) == 0ull) go = false;
     }
     lds_sync();
     PROF(11);
-    if (!sh_go) return;
+    if (!go) return;
     const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
+    int n_act = 0;
     while (true) {
-      if (lane == 0) {  // round_tasks: open tasks (that had residual > 0 initially) with residual > 1e-9
-        int nc = 0;
-        for (int k = 0; k < S.n_open; k++) { int s = S.open_slot[k]; if (X.resid[s] > 1e-9) X.roundT[nc++] = k; }
-        sh_nc = nc;
-      }
+      // round_tasks: open tasks (that had residual > 0 initially) with residual > 1e-9, in last_tasks_info order
+      const int nc = compact_to(X.roundT, S.n_open, [&](int k) { return X.resid[S.open_slot[k]] > 1e-9; }, [&](int k) { return k; });
       lds_sync();
-      const int nr = sh_nr, nc = sh_nc;
       if (nr == 0 || nc == 0) break;
       const bool tr = nc < nr;              // scipy transposes so that rows <= cols
       const int Rr = tr ? nc : nr, Cc = tr ? nr : nc;
@@ -1838,35 +1832,59 @@ struct Sim {
       PROF(12);
       if (T <= WG) lsap_reg(Rr, Cc); else lsap(Rr, Cc);
       PROF(13);
-      if (lane == 0) {
-        // accept (:182-204) in ascending agent order (scipy returns rows sorted)
-        int n_acc = 0;
-        for (int i = 0; i < nr; i++) {
-          int j = tr ? X.row4col[i] : X.col4row[i];
-          if (j < 0) continue;
-          double c = X.cost[tr ? (j * Cc + i) : (i * Cc + j)];
-          if (c >= 1e5 / 2) continue;
-          int a = X.freeA[i], oi = X.roundT[j], s = S.open_slot[oi];
-          double delivered = is_escort_task(s) ? 1.0 : S.a_caps[S.t_type[s]][a];
-          int n = S.n_act;
-          S.act_agent[n] = a; S.act_slot[n] = s; S.act_index[n] = oi;
-          S.n_act = n + 1;
-          X.resid[s] = fmax(X.resid[s] - delivered, 0.0);
-          X.freeA[i] = -1;
-          n_acc++;
+      // accept (:182-204): one free agent per lane, actions appended in ascending agent order (scipy returns
+      // rows sorted); each task appears at most once per round, so the residual updates are independent
+      int n_acc = 0, n_left = 0;
+      for (int base = 0; base < nr; base += WG) {
+        const int i = base + lane;
+        bool acc = false, keep = false;
+        int a = -1, oi = 0, s = 0;
+        if (i < nr) {
+          a = X.freeA[i];
+          const int j = tr ? X.row4col[i] : X.col4row[i];
+          keep = true;
+          if (j >= 0 && X.cost[tr ? (j * Cc + i) : (i * Cc + j)] < 1e5 / 2) {
+            acc = true; keep = false;
+            oi = X.roundT[j]; s = S.open_slot[oi];
+          }
         }
-        int w = 0;
-        for (int i = 0; i < nr; i++) if (X.freeA[i] >= 0) X.freeA[w++] = X.freeA[i];
-        sh_nr = n_acc ? w : 0;  // no accept -> stop
+        const unsigned long long am = __ballot(acc), km = __ballot(keep);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        lds_sync();  // freeA fully read before it is compacted in place
+        if (acc) {
+          const int n = n_act + n_acc + __popcll(am & below);
+          S.act_agent[n] = a; S.act_slot[n] = s; S.act_index[n] = oi;
+          const double delivered = is_escort_task(s) ? 1.0 : S.a_caps[S.t_type[s]][a];
+          X.resid[s] = fmax(X.resid[s] - delivered, 0.0);
+        }
+        if (keep) X.freeA[n_left + __popcll(km & below)] = a;
+        n_acc += __popcll(am);
+        n_left += __popcll(km);
       }
+      n_act += n_acc;
+      nr = n_acc ? n_left : 0;  // no accept -> stop
       lds_sync();
       PROF(14);
     }
     if (lane == 0) {
+      S.n_act = n_act;
       S.last_plan_step = S.time_steps;
       S.n_replans++;
     }
     lds_sync();
+  }
+  // out[0..n) = f(k) for the k in [0, count) with pred(k), order preserved (ballot + popcount); returns n
+  template <class Pred, class Val>
+  DEV int compact_to(int32_t* out, int count, Pred pred, Val val) {
+    int n = 0;
+    for (int base = 0; base < count; base += WG) {
+      const int k = base + lane;
+      const bool p = k < count && pred(k);
+      const unsigned long long m = __ballot(p);
+      if (p) out[n + __popcll(m & ((1ull << lane) - 1ull))] = val(k);
+      n += __popcll(m);
+    }
+    return n;
   }
 
   // scipy.optimize.linear_sum_assignment (rectangular_lsap, scipy 1.15.3) on X.cost[nr x nc], nr <= nc.
