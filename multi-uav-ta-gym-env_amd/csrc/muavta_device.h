@@ -290,30 +290,16 @@ struct Sim {
   }
   DEV bool escort_type(int t) const { return (P.escort_mask >> t) & 1u; }
 
-  // Task.removeAgentCap (DroneEnvComponents.py:280-301); `det` = allocationDetails[agent][1].
-  // The agent's own queue entry must already be gone.
+  // Task.removeAgentCap (DroneEnvComponents.py:280-301).  The agent's own queue entry must already be gone.
+  // initTime / doneTime are NOT maintained incrementally: the reference's upkeep keeps the invariants
+  // initTime == min(details times), doneTime == max(details times) + duration (or -1, -1 when empty), and
+  // details == the agents' queue entries, so refresh_task_times() rebuilds them per step in one parallel pass.
   DEV void remove_agent_cap(int s, int a, double det) {
+    (void)det;
     if (S.t_status[s] == 2) return;
     for (int c = 0; c < 6; c++) S.t_alloc[c][s] -= S.a_caps[c][a];
     S.t_ndet[s] -= 1;
-    if (S.t_ndet[s] > 0) {
-      const int id = S.t_id[s];
-      const double dur = (double)task_duration(S.t_type[s]);
-      bool first = true;
-      double mn = 0, mx = 0;
-      for (int b = 0; b < P.n_agents; b++)
-        for (int k = 0; k < S.a_qlen[b]; k++)
-          if (S.a_qid[b][k] == id) {
-            double t = S.a_qtime[b][k];
-            if (first) { mn = mx = t; first = false; }
-            else { mn = t < mn ? t : mn; mx = t > mx ? t : mx; }
-          }
-      if (det == S.t_init[s]) S.t_init[s] = mn;
-      if (det + dur == S.t_dtime[s]) S.t_dtime[s] = mx + dur;
-    } else {
-      S.t_init[s] = -1;
-      S.t_dtime[s] = -1;
-    }
+    S.times_dirty = 1;
   }
   // UAV.desAllocate (DroneEnvComponents.py:97-113) for a task id that IS in the queue at position k.
   DEV void des_allocate_at(int a, int k) {
@@ -392,14 +378,9 @@ struct Sim {
     S.a_nfx[a] = S.t_px[s];
     S.a_nfy[a] = S.t_py[s];
     // Task.addAgentCap (DroneEnvComponents.py:306-326); status != 2 checked above
-    double time_end = time_to_task + dur;
     S.t_ndet[s] += 1;
+    S.times_dirty = 1;
     for (int c = 0; c < 6; c++) S.t_alloc[c][s] += S.a_caps[c][a];
-    if (time_to_task < S.t_init[s] || S.t_init[s] == -1) {
-      S.t_init[s] = time_to_task;
-      if (S.t_dtime[s] == -1) S.t_dtime[s] = time_end;
-    }
-    if (time_end > S.t_dtime[s]) S.t_dtime[s] = time_end;
     S.t_status[s] = 1;
     return true;
   }
@@ -1647,7 +1628,44 @@ struct Sim {
   // Observation tensors are FEATURE-MAJOR in HBM — tasks f32 [21][max_tasks], legal bit rows u64 [A][ceil(max_tasks/64)] —
   // so with one task row per lane every store instruction is a contiguous run across the wave: no LDS
   // staging, no transposition.  The "no legal action" fallback (:401-408) is a ballot.
+  // Task.initTime / doneTime of every live, non-retired slot from the agents' queue entries (== the task's
+  // allocationDetails): times are non-negative doubles, so u64 min/max on their bit patterns (LDS atomics)
+  // order them numerically.  One queue entry per lane.
+  DEV void refresh_task_times() {
+    if (!S.times_dirty) return;  // uniform: LDS word
+    lds_sync();
+    if (lane == 0) S.times_dirty = 0;
+    unsigned long long* tmin = reinterpret_cast<unsigned long long*>(X.cost);
+    unsigned long long* tmax = tmin + T;
+    for (int s = lane; s < T; s += WG) { tmin[s] = ~0ull; tmax[s] = 0ull; }
+    lds_sync();
+    const int nE = P.n_agents * Q;
+    for (int e = lane; e < nE; e += WG) {
+      const int a = e / Q, k = e - a * Q;
+      if (k < S.a_qlen[a]) {
+        const int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
+        if (ref_valid(id, slot) && S.t_status[slot] != 2) {
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(S.a_qtime[a][k]);
+          atomicMin(&tmin[slot], bits);
+          atomicMax(&tmax[slot], bits);
+        }
+      }
+    }
+    lds_sync();
+    for (int s = lane; s < T; s += WG) {
+      if (S.t_id[s] >= 0 && S.t_status[s] != 2) {
+        if (tmin[s] == ~0ull) { S.t_init[s] = -1; S.t_dtime[s] = -1; }
+        else {
+          S.t_init[s] = __longlong_as_double((long long)tmin[s]);
+          S.t_dtime[s] = __longlong_as_double((long long)tmax[s]) + (double)task_duration(S.t_type[s]);
+        }
+      }
+    }
+    lds_sync();
+  }
+
   DEV void write_obs(float* o_tasks, unsigned long long* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags) {
+    refresh_task_times();
     const int MT = P.max_tasks, nA = P.n_agents;
     const int n = S.n_open;
     const double mts = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1);

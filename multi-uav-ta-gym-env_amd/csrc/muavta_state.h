@@ -125,7 +125,7 @@ struct alignas(16) EnvState {
   uint32_t rng_idx[4];                // cursor into each stream's 2x624-word tape (agent, obs, tgt, mission)
   uint32_t rng_win[4][8];             // the next 8 raw words of each stream, prefetched at the step boundary
   uint32_t rng_win_at[4];             // cursor value the window was filled at
-  int32_t pad_[1];
+  int32_t times_dirty;                // some allocationDetails changed since initTime/doneTime were rebuilt
 };
 
 // Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
