@@ -12,6 +12,7 @@
 // named).  This file is the product path; it shares no code with oracle/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include "muavta_state.h"
 
@@ -86,6 +87,18 @@ DEV void mt_twist(const uint32_t* src, uint32_t* dst) {
   if (lane == 0) dst[623] = mt_mix(src[623], dst[0], dst[396]);
   __syncthreads();
 }
+// Same on LDS buffers of a single-wave workgroup: phases are ordered by lds_sync() (no vmcnt drain).
+DEV void mt_twist_lds(const uint32_t* src, uint32_t* dst) {
+  const int lane = threadIdx.x;
+  for (int k = lane; k < 227; k += WG) dst[k] = mt_mix(src[k], src[k + 1], src[k + 397]);
+  lds_sync();
+  for (int k = 227 + lane; k < 454; k += WG) dst[k] = mt_mix(src[k], src[k + 1], dst[k - 227]);
+  lds_sync();
+  for (int k = 454 + lane; k < 623; k += WG) dst[k] = mt_mix(src[k], src[k + 1], dst[k - 227]);
+  lds_sync();
+  if (lane == 0) dst[623] = mt_mix(src[623], dst[0], dst[396]);
+  lds_sync();
+}
 // init_by_array(key[0..len)) into mt[624] (LDS).  One lane.
 DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
   uint32_t g = 19650218u;  // init_genrand(19650218) generated on the fly
@@ -107,9 +120,26 @@ DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
     prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key + (uint32_t)j;
     mt[1] = prev;
   }
-  for (int i = 2; i < 624; i++) {
-    prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-    mt[i] = prev;
+  // second loop (i = 2..623): the recurrence is serial in `prev`, but the mt[i] operands are first-loop values
+  // whose addresses are known, so they are fetched eight at a time (one LDS wait per 8 steps, not per step)
+  {
+    int i = 2;
+    for (; i + 8 <= 624; i += 8) {
+      uint32_t m[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) m[q] = mt[i + q];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        prev = (m[q] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i + q);
+        m[q] = prev;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) mt[i + q] = m[q];
+    }
+    for (; i < 624; i++) {
+      prev = (mt[i] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+      mt[i] = prev;
+    }
   }
   mt[0] = prev;
   prev = (mt[1] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
@@ -166,8 +196,13 @@ struct Sim {
   const DevParams& P;
   uint32_t* tape;  // [4][1248] in HBM
   int lane;
+  // LDS window of prefetched raw tape words consulted by next32(): normally the 8-word window in the state
+  // blob; reset() points it at a 192-word-per-stream copy in the scratch tile (a reset draws ~100 words)
+  const uint32_t* win_ptr;
+  uint32_t win_len, win_stride;
 
-  __device__ Sim(State& s, Scratch<TL>& x, const DevParams& p, uint32_t* t) : S(s), X(x), P(p), tape(t), lane(threadIdx.x) {}
+  __device__ Sim(State& s, Scratch<TL>& x, const DevParams& p, uint32_t* t)
+      : S(s), X(x), P(p), tape(t), lane(threadIdx.x), win_ptr(&s.rng_win[0][0]), win_len(8), win_stride(8) {}
 
   DEV void fail(int code) { if (S.error == 0) S.error = code; }
   DEV double speed_of(int t) const {  // P.speed[t] without a memory access for a per-lane t
@@ -182,8 +217,8 @@ struct Sim {
     if (off >= 1248u) { fail(MUAVTA_ERR_POSITION); off = 1247u; }
     uint32_t y;
     const uint32_t w = p - S.rng_win_at[st];  // same block marker => plain cursor difference
-    if (w < 8u) {
-      y = S.rng_win[st][w];  // prefetched into LDS at the step boundary
+    if (w < win_len) {
+      y = win_ptr[st * win_stride + w];  // prefetched into LDS at the step boundary
     } else {
       uint32_t b = off >= 624u ? (blk ^ 1u) : blk;
       uint32_t o = off >= 624u ? off - 624u : off;
@@ -699,21 +734,36 @@ struct Sim {
   // ====================================================================================================
   // reset (:522-762).  All lanes enter; RNG seeding is cooperative, the rest runs on lane 0.
   // ====================================================================================================
-  DEV void reset(uint64_t seed) {
-    // zero the whole blob (all lanes)
-    {
-      uint32_t* w = reinterpret_cast<uint32_t*>(&S);
-      for (int i = lane; i < (int)(sizeof(State) / 4); i += WG) w[i] = 0;
-    }
+  // reset-time RNG setup for one stream whose seeded MT state sits in `seeded` (LDS): block0 -> `b0`,
+  // block1 -> `seeded` (in place of the consumed seed state); both go to the HBM tape with coalesced stores
+  // and the head of block0 to the reset window.  Everything is ordered by lds_sync(): no global hand-off.
+  static constexpr int RESET_WIN = 192;  // words per stream staged for the reset (it draws ~100)
+  DEV void reset_stream(int st, uint32_t* seeded, uint32_t* b0, uint32_t* win) {
+    mt_twist_lds(seeded, b0);
+    mt_twist_lds(b0, seeded);
+    uint32_t* t = tape + st * MUAVTA_RNG_WORDS;
+    for (int k = lane; k < 624; k += WG) { t[k] = b0[k]; t[624 + k] = seeded[k]; }
+    for (int k = lane; k < RESET_WIN; k += WG) win[st * RESET_WIN + k] = b0[k];
     lds_sync();
-    uint32_t* scr = reinterpret_cast<uint32_t*>(&X);
-    rng_seed_pair(scr, ST_AGENT, seed, -1, 0);
+  }
+  DEV void reset(uint64_t seed) {
+    // RNG first.  The (not yet initialised) state blob doubles as scratch for four 624-word MT buffers; the
+    // stream cursors live beyond them.
+    static_assert(offsetof(State, rng_idx) >= 4 * 624 * 4 && offsetof(State, area) >= 4 * 624 * 4, "MT buffers overlap live scalars");
+    static_assert(sizeof(Scratch<TL>) >= 4 * RESET_WIN * 4, "scratch tile too small for the reset RNG window");
+    uint32_t* T0 = reinterpret_cast<uint32_t*>(&S);
+    uint32_t *T1 = T0 + 624, *T2 = T1 + 624, *T3 = T2 + 624;
+    uint32_t* win = reinterpret_cast<uint32_t*>(&X);
+    if (lane < 4) { S.rng_idx[lane] = 0; S.rng_win_at[lane] = 0; }
+    if (lane == 0) { S.error = 0; mt_seed(T0, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1); }
+    lds_sync();
+    reset_stream(ST_AGENT, T0, T1, win);
+    win_ptr = win; win_len = RESET_WIN; win_stride = RESET_WIN;
     if (lane == 0) {  // :535-538
-      uint64_t s_obs = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);
-      uint64_t s_tgt = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);
-      uint64_t s_mis = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);
       uint64_t* sd = reinterpret_cast<uint64_t*>(&S.area[0][0]);  // parked until the areas are built
-      sd[0] = s_obs; sd[1] = s_tgt; sd[2] = s_mis;
+      sd[0] = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);   // rndObsGen
+      sd[1] = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);   // rndTgtGen
+      sd[2] = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);   // rndMissionGen
     }
     lds_sync();
     uint64_t s_obs, s_tgt, s_mis;
@@ -721,10 +771,28 @@ struct Sim {
       const uint64_t* sd = reinterpret_cast<const uint64_t*>(&S.area[0][0]);
       s_obs = sd[0]; s_tgt = sd[1]; s_mis = sd[2];
     }
+    const uint32_t agent_cursor = S.rng_idx[ST_AGENT];
+    const int err0 = S.error;
     lds_sync();
-    rng_seed_pair(scr, ST_TGT, s_tgt, ST_MISSION, s_mis);
-    if (P.num_obstacles > 0) rng_seed_pair(scr, ST_OBS, s_obs, -1, 0);
-    if (lane == 0) reset_serial();
+    if (lane == 0) mt_seed(T0, (uint32_t)s_tgt, (uint32_t)(s_tgt >> 32), (s_tgt >> 32) ? 2 : 1);
+    if (lane == 1) mt_seed(T1, (uint32_t)s_mis, (uint32_t)(s_mis >> 32), (s_mis >> 32) ? 2 : 1);
+    if (lane == 2 && P.num_obstacles > 0) mt_seed(T2, (uint32_t)s_obs, (uint32_t)(s_obs >> 32), (s_obs >> 32) ? 2 : 1);
+    lds_sync();
+    reset_stream(ST_TGT, T0, T3, win);
+    reset_stream(ST_MISSION, T1, T3, win);
+    if (P.num_obstacles > 0) reset_stream(ST_OBS, T2, T3, win);
+    // now the blob itself: zero it, restore the cursors, build the episode
+    {
+      uint32_t* w = reinterpret_cast<uint32_t*>(&S);
+      for (int i = lane; i < (int)(sizeof(State) / 4); i += WG) w[i] = 0;
+    }
+    lds_sync();
+    if (lane == 0) { S.rng_idx[ST_AGENT] = agent_cursor; S.error = err0; }
+    lds_sync();
+    if (lane == 0) reset_serial_impl();  // not through the out-of-line wrapper: it must see this object's window
+    lds_sync();
+    win_ptr = &S.rng_win[0][0]; win_len = 8; win_stride = 8;
+    if (lane < 4) S.rng_win_at[lane] = 0x7fffffffu;  // the small window is (re)filled at the next step boundary
     lds_sync();
     finish_step_parallel(false);
   }
@@ -1592,8 +1660,21 @@ struct Sim {
   // the switch penalty and expected-distance terms, :852-861,:1219-1220).  Parallel over slots.
   DEV void finish_step_parallel(bool gc) {
     if (gc) {
-      for (int s = lane; s < T; s += WG) {
-        if (S.t_id[s] >= 0 && S.t_status[s] == 2 && slot_unreferenced(S.t_id[s])) release_slot(s);
+      // fast path: no live slot is retired and every live slot is already listed as open (no task was created
+      // or retired since the lists were built) -> t_order / last_tasks_info are unchanged
+      const int n = S.n_order;
+      bool ret = false;
+      for (int k = lane; k < n; k += WG) {
+        const int s = S.t_order[k];
+        if (S.t_status[s] == 2) {
+          ret = true;
+          if (slot_unreferenced(S.t_id[s])) release_slot(s);
+        }
+      }
+      if (__ballot(ret) == 0ull && S.n_open == n) {
+        if (lane == 0) S.n_act = 0;
+        lds_sync();
+        return;
       }
       lds_sync();
     }
