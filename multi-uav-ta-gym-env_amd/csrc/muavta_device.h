@@ -389,13 +389,13 @@ struct Sim {
     return true;
   }
   // UAV.allocate (DroneEnvComponents.py:55-95) for a real task (id != 0) in slot s
-  DEV bool uav_allocate(int a, int s) {
+  DEV bool uav_allocate(int a, int s, double pre_time = -1.0) {
     int id = S.t_id[s];
     if (queue_find(a, id) >= 0 || S.t_status[s] == 2) return false;
     S.a_reeval[a] = 0;
     S.a_last_id[a] = -1;
     S.a_last_slot[a] = -1;
-    double time_to_task = norm2(S.a_nfx[a] - S.t_px[s], S.a_nfy[a] - S.t_py[s]) / speed_of(S.a_type[a]);
+    double time_to_task = pre_time >= 0 ? pre_time : norm2(S.a_nfx[a] - S.t_px[s], S.a_nfy[a] - S.t_py[s]) / speed_of(S.a_type[a]);
     double start_time = (S.a_nft[a] - (double)S.time_steps) > 0 ? S.a_nft[a] : (double)S.time_steps;
     double dur = (double)task_duration(S.t_type[s]);
     double end_time = start_time + time_to_task + dur;
@@ -663,6 +663,65 @@ struct Sim {
     }
   }
 
+  // releaseAllTasks with the whole wave: per-agent flags by the agent's lane, queue teardown (shared f64
+  // accumulators on the tasks -> agents_obj order) by lane 0 for the agents that actually queue something,
+  // then one task per lane for the status/bucket reset.  All lanes must call it.
+  DEV void release_all_tasks_coop(int for_type) {
+    const int ft = for_type < 0 ? for_type + 6 : for_type;  // python negative index -> caps[-1] == Det
+    const int a = lane;
+    bool match = false, busy = false;
+    if (a < P.n_agents && S.a_caps[ft][a] > 0 && S.a_state[a] != -1) {
+      match = true;
+      S.a_reeval[a] = 1;  // len(agent.tasks) > 0 always holds in python ([task_idle] counts)
+      if (S.a_qlen[a] > 0) { S.a_last_id[a] = S.a_qid[a][0]; S.a_last_slot[a] = S.a_qslot[a][0]; busy = true; }
+      else { S.a_last_id[a] = 0; S.a_last_slot[a] = -1; S.a_commit[a] = 0; }  // desallocateAll on [task_idle]
+    }
+    unsigned long long bm = __ballot(busy);
+    uint32_t avail = 0;
+    {  // available_agents: set of type indices of the matched agents
+      const int ty = a < P.n_agents ? S.a_type[a] : 0;
+#pragma unroll
+      for (int t = 0; t <= MUAVTA_F2; t++) if (__ballot(match && ty == t) != 0ull) avail |= 1u << t;
+    }
+    lds_sync();
+    if (lane == 0) {
+      while (bm) {
+        const int b = __ffsll((long long)bm) - 1;
+        bm &= bm - 1ull;
+        desallocate_all_impl(b);
+      }
+    }
+    lds_sync();
+    if (for_type < 0) return;  // no task has typeIdx -1
+    double cum = 0;
+    for (int ty = 0; ty < 7; ty++) if ((avail >> ty) & 1u) cum += CAP_TABLE[ty][for_type];
+    bool dead_end = false;
+    for (int k = lane; k < S.n_order; k += WG) {
+      const int s = S.t_order[k];
+      if (S.t_status[s] != 2 && S.t_type[s] == for_type) {
+        if (cum == 0) dead_end = true;
+        else { S.t_status[s] = 0; S.t_bucket[s] = 0; }
+      }
+    }
+    if (__ballot(dead_end) != 0ull) {  // nobody left who can do this type: retire the tasks, in id order (:1466-1476)
+      lds_sync();
+      if (lane == 0) {
+        for (int k = 0; k < S.n_order; k++) {
+          const int s = S.t_order[k];
+          if (S.t_status[s] != 2 && S.t_type[s] == for_type) {
+            S.t_status[s] = 2;
+            if (!(S.t_flags[s] & TF_REACHED)) {
+              S.t_flags[s] |= TF_REACHED;
+              S.n_reached++;
+              if (S.n_reached == P.n_tasks) S.conclusion_time = S.time_steps;
+            }
+          }
+        }
+      }
+    }
+    lds_sync();
+  }
+
   // ---------------------------------------------------------------- geometry helpers
   DEV void norm_vector(double& x, double& y) {  // EnvUtils.norm_vector (MultiDroneEnvUtils.py:168-177)
     double m = norm2(x, y);
@@ -918,8 +977,22 @@ struct Sim {
     if (lane < P.n_agents) { prev_x = S.a_px[lane]; prev_y = S.a_py[lane]; }
     lds_sync();
     double r_action = 0, r_distance = 0, r_quality = 0, r_squality = 0;
-    if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
-    lds_sync();
+    {
+      // drain the event queue (:800-805): infos['events'] := event_list, every Reset_Allocation in order
+      const int nev = S.n_events;
+      for (int k = lane; k < nev; k += WG) { S.dev_tag[k] = S.ev_tag[k]; S.dev_arg[k] = S.ev_arg[k]; }
+      if (lane == 0) { S.step_reward = 0; S.time_steps += 1; S.n_dev = nev; S.n_events = 0; }  // :796
+      lds_sync();
+      for (int k = 0; k < nev; k++)
+        if (S.dev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) release_all_tasks_coop(S.dev_arg[k]);
+    }
+    PROF(2);
+    if (S.n_act > 0) {
+      precompute_actions();
+      lds_sync();
+      if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
+      lds_sync();
+    }
     PROF(3);
     // movement (:965-1129): lanes commit every agent up to the first "event" agent, lane 0 plays that one
     // agent exactly as the reference does, and the wave resumes behind it
@@ -1084,17 +1157,34 @@ struct Sim {
   }
 
   // events drain, action application, movement state machine
+  // Geometry of the staged actions, one action per lane (each agent appears at most once per step on the
+  // allocator path; repeated agents fall back to the inline computation): distance to the current head and to
+  // the new task (switch penalty :859-861), time_to_task of UAV.allocate (DroneEnvComponents.py:64) and the
+  // expected-distance term (:1216-1229).  Agent / task positions do not change while actions are applied.
+  DEV double* act_f(int k) { return X.cost + k * A; }   // 4 arrays of A doubles in the idle cost tile
+  DEV void precompute_actions() {
+    const int k = lane;
+    if (k >= S.n_act) return;
+    const int a = S.act_agent[k], s = S.act_slot[k];
+    X.remaining[k] = -1;  // validity tag: agent id
+    if (a < 0 || s < 0 || S.a_state[a] == -1) return;
+    const double px = S.a_px[a], py = S.a_py[a], tx = S.t_px[s], ty = S.t_py[s];
+    double d_old = 0;
+    if (S.a_qlen[a] > 0) { const int hs = S.a_qslot[a][0]; d_old = norm2(px - S.t_px[hs], py - S.t_py[hs]); }
+    act_f(0)[k] = d_old;
+    act_f(1)[k] = norm2(px - tx, py - ty);
+    act_f(2)[k] = norm2(S.a_nfx[a] - tx, S.a_nfy[a] - ty) / speed_of(S.a_type[a]);
+    const int n = S.a_qlen[a];  // after the append the queue holds n + 1 entries; tasks[-2] is the current last one
+    double total;
+    if (n >= 1) { const int ps = S.a_qslot[a][n - 1]; total = norm2(tx - S.t_px[ps], ty - S.t_py[ps]); }
+    else total = norm2(tx - px, ty - py);
+    act_f(3)[k] = -1.0 * total / MAX_COORD;
+    bool dup = false;
+    for (int q = 0; q < k; q++) dup |= S.act_agent[q] == a;
+    if (!dup) X.remaining[k] = a;
+  }
+  // action application (:813-933), dict order, lane 0
   DEV void step_serial_a(double& action_reward, double& distance_reward, double& quality_reward, double& S_quality_reward) {
-    S.step_reward = 0;
-    S.time_steps += 1;  // :796
-    // drain the event queue (:800-805)
-    int nev = S.n_events;
-    S.n_dev = nev;
-    for (int k = 0; k < nev; k++) { S.dev_tag[k] = S.ev_tag[k]; S.dev_arg[k] = S.ev_arg[k]; }
-    S.n_events = 0;
-    for (int k = 0; k < nev; k++)
-      if (S.dev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) release_all_tasks(S.dev_arg[k]);
-    PROF(2);
     // ---- task allocation (:813-933) ----
     for (int k = 0; k < S.n_act; k++) {
       int a = S.act_agent[k];
@@ -1103,6 +1193,7 @@ struct Sim {
       int s = S.act_slot[k];
       if (s < 0) { action_reward += -1; continue; }  // index beyond last_tasks_info (:835-838)
       int tid = S.t_id[s];
+      const bool pre = P.multiple_tasks_per_agent && X.remaining[k] == a;  // lane k's geometry is valid for this action
       {
         int hid_ = head_id(a);
         if (hid_ != tid) {
@@ -1113,8 +1204,12 @@ struct Sim {
             S.n_reallocations += 1;
             S.n_task_switches += 1;
             S.a_commit[a] = 0;
-            double dist_old = norm2(S.a_px[a] - S.t_px[hs], S.a_py[a] - S.t_py[hs]);
-            double dist_new = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
+            double dist_old, dist_new;
+            if (pre) { dist_old = act_f(0)[k]; dist_new = act_f(1)[k]; }
+            else {
+              dist_old = norm2(S.a_px[a] - S.t_px[hs], S.a_py[a] - S.t_py[hs]);
+              dist_new = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
+            }
             distance_reward += (dist_old - dist_new) / MAX_COORD;
           } else {
             S_quality_reward += 0.05;
@@ -1136,7 +1231,7 @@ struct Sim {
         S.a_nfy[a] = S.a_py[a];
       }
       if (!action_valid(a, s)) { action_reward += -1; continue; }
-      if (uav_allocate(a, s)) {
+      if (uav_allocate(a, s, pre ? act_f(2)[k] : -1.0)) {
         S.t_bucket[s] |= 1ull << a;
         int ty = S.t_type[s];
         double agentCap = S.a_caps[ty][a];
@@ -1146,7 +1241,9 @@ struct Sim {
         if (addedCap <= 0) S_quality_reward -= 1.5;
         S_quality_reward += addedCap;
         S.t_status[s] = 1;
-        {  // calculate_agent_expected_reward (:1216-1229)
+        if (pre) {
+          distance_reward += act_f(3)[k];
+        } else {  // calculate_agent_expected_reward (:1216-1229)
           int n = S.a_qlen[a];
           double total;
           if (n >= 2) {
