@@ -1031,6 +1031,7 @@ struct Sim {
       if (lane == 0) step_serial_b2(first, livemask);
     }
     lds_sync();
+    if (P.escort_enabled) sync_escorts_coop();
     PROF(6);
     sense_parallel();  // _wps_update_sensing (:1506-1523)
     lds_sync();
@@ -1387,7 +1388,6 @@ struct Sim {
     PROF(24);
     inject_dynamic_arrivals();
     PROF(25);
-    if (P.escort_enabled) sync_escorts();
   }
 
   DEV void generate_threat() { ni_generate_threat<TL>(&P, tape); }
@@ -1665,6 +1665,66 @@ struct Sim {
       int cnt;
       closest_escort(recon, P.escort_radius, &cnt);
       if (cnt > 0) S.escort_covered_steps++;
+    }
+  }
+
+  // _sync_escorts (:1964-2000) with the whole wave: the per-agent / per-escort predicates are evaluated one per
+  // lane (ballots), creations and retirements (shared state, id allocation order) stay on lane 0 in the
+  // reference's order, and the coverage test "any escort fighter within radius" is a ballot over agents.
+  DEV void sync_escorts_coop() {
+    {  // recon UAVs already on a Rec task without an escort (:1967-1974)
+      const int a = lane;
+      bool need = false;
+      int cs = -1;
+      if (a < P.n_agents && S.a_state[a] != -1 && is_recon(S.a_type[a]) && S.a_qlen[a] > 0) {
+        const int cid = S.a_qid[a][0];
+        cs = S.a_qslot[a][0];
+        need = !ref_retired(cid, cs) && S.t_type[cs] == MUAVTA_REC && escort_lookup(a) < 0;
+      }
+      unsigned long long nm = __ballot(need);
+      if (nm) {
+        if (lane == 0) {
+          while (nm) {
+            const int b = __ffsll((long long)nm) - 1;
+            nm &= nm - 1ull;
+            create_escort_for_impl(b, S.a_qslot[b][0]);
+          }
+        }
+        lds_sync();
+      }
+    }
+    const int n = S.n_escorts;  // snapshot of the map (retiring pops entries)
+    int snap = lane < n ? S.esc_agent[lane] : -1;
+    for (int k = 0; k < n; k++) {
+      const int recon = __builtin_amdgcn_readlane(snap, k);
+      const unsigned long long hit = __ballot(lane < S.n_escorts && S.esc_agent[lane] == recon);
+      if (!hit) continue;
+      const int kk = __ffsll((long long)hit) - 1;
+      const int es = S.esc_slot[kk], eid = S.esc_id[kk];
+      const int rid = S.esc_pid[kk], rs = S.esc_pslot[kk];
+      const bool dead = S.a_state[recon] == -1;
+      const bool idle = S.a_qlen[recon] == 0 || S.a_state[recon] == 0 || S.a_state[recon] == 3;
+      const bool rec_done = ref_retired(rid, rs);
+      const bool wrong_task = S.a_qlen[recon] > 0 && S.a_qid[recon][0] != rid;
+      if (dead || idle || rec_done || wrong_task) {
+        if (lane == 0) retire_escort_entry(kk, dead);
+        lds_sync();
+        continue;
+      }
+      // _escort_fighters_near(recon, escort_radius) non-empty? (:1746-1764) — one agent per lane
+      bool near = false;
+      const bool esc_live = !ref_retired(eid, es);
+      if (esc_live && lane < P.n_agents && S.a_state[lane] != -1 && escort_type(S.a_type[lane]) && S.a_qlen[lane] > 0 &&
+          S.a_qid[lane][0] == eid) {
+        near = norm2(S.a_px[lane] - S.a_px[recon], S.a_py[lane] - S.a_py[recon]) <= P.escort_radius;
+      }
+      const bool covered = __ballot(near) != 0ull;
+      if (lane == 0) {
+        if (esc_live) { S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon]; }  // follow the protected UAV
+        S.escort_required_steps++;
+        if (covered) S.escort_covered_steps++;
+      }
+      lds_sync();
     }
   }
 
