@@ -442,6 +442,10 @@ struct Sim {
     if (h >= 0) { S.h_tflags[h] = S.t_flags[s] & (TF_DEADLINE | TF_COUNTED); S.h_tdeadline[h] = S.t_deadline[s]; }
     if (S.t_bucket[s] == 0) atomicAdd(&S.n_retired_empty_buckets, 1);
     S.t_id[s] = -1;
+    // leave the slot clean for its next tenant: nobody knows it, it is on the free list (atomics: several
+    // lanes release different slots of the same word in the end-of-step GC)
+    for (int a = 0; a < P.n_agents; a++) atomicAnd(&S.known[a][s >> 5], ~(1u << (s & 31)));
+    atomicOr(&S.free_slots[s >> 5], 1u << (s & 31));
   }
   DEV int reclaim_slot_serial() {
     for (int k = 0; k < S.n_order; k++) {
@@ -461,9 +465,11 @@ struct Sim {
   DEV int new_task(double x, double y, int type, double req) {
     int id = S.next_task_id++;  // _alloc_task_id (:325-328)
     int s = -1;
-    for (int k = 0; k < T; k++) if (S.t_id[k] < 0) { s = k; break; }
+    for (int w = 0; w < KW; w++) if (S.free_slots[w]) { s = (w << 5) + __ffs((int)S.free_slots[w]) - 1; break; }
+    if (s >= T) s = -1;
     if (s < 0) s = reclaim_slot_serial();  // tile full mid-step: recycle a retired slot before the end-of-step GC
     if (s < 0) { fail(MUAVTA_ERR_TASK_SLOTS); return -1; }
+    S.free_slots[s >> 5] &= ~(1u << (s & 31));
     S.t_id[s] = id;
     S.t_px[s] = x; S.t_py[s] = y;
     for (int c = 0; c < 6; c++) { S.t_cur[c][s] = 0; S.t_alloc[c][s] = 0; }
@@ -474,7 +480,6 @@ struct Sim {
     S.t_flags[s] = 0; S.t_elig[s] = 0; S.t_threat[s] = -1;
     S.t_prot_agent[s] = -1; S.t_prot_id[s] = -1; S.t_prot_slot[s] = -1;
     S.t_ndet[s] = 0; S.t_bucket[s] = 0;
-    for (int a = 0; a < A; a++) S.known[a][s >> 5] &= ~(1u << (s & 31));
     S.t_order[S.n_order++] = s;
     return s;
   }
@@ -563,7 +568,7 @@ struct Sim {
     if (ref_retired(id, s)) return;
     // _release_escort_agents (:1919-1936)
     for (int a = 0; a < P.n_agents; a++) {
-      if (S.a_state[a] == -1) continue;
+      if (S.a_state[a] == -1 || S.a_qlen[a] == 0) continue;
       if (des_allocate(a, id)) {
         if (S.a_qlen[a] == 0) {
           S.a_state[a] = 0;
@@ -863,6 +868,7 @@ struct Sim {
     S.next_task_id = 1;
     S.last_plan_step = -1000000000;
     for (int k = 0; k < T; k++) S.t_id[k] = -1;
+    for (int w = 0; w < KW; w++) S.free_slots[w] = (w == KW - 1 && (T & 31)) ? ((1u << (T & 31)) - 1u) : 0xffffffffu;
     for (int h = 0; h < H; h++) { S.h_status[h] = -9; S.h_target[h] = -1; S.h_mission[h] = -1; S.h_intercept[h] = -1; S.h_task_id[h] = -1; S.h_task_slot[h] = -1; }
     for (int a = 0; a < A; a++) { S.a_state[a] = -1; S.a_last_id[a] = -1; S.a_last_slot[a] = -1; S.a_fail[a] = -1; S.a_task_start[a] = -1; S.a_name[a] = -1; S.a_type[a] = 0; }
     // obstacles (:579-583)
@@ -2061,6 +2067,7 @@ struct Sim {
       const bool tr = nc < nr;              // scipy transposes so that rows <= cols
       const int Rr = tr ? nc : nr, Cc = tr ? nr : nc;
       // ---- cost tile (:137-179), one (agent, task) pair per lane ----
+      bool feasible = false;
       for (int p = lane; p < nr * nc; p += WG) {
         int i = p / nc, j = p - i * nc;
         int a = X.freeA[i], s = S.open_slot[X.roundT[j]];
@@ -2083,7 +2090,10 @@ struct Sim {
           }
         }
         X.cost[tr ? (j * Cc + i) : (i * Cc + j)] = c;
+        feasible |= c < 1e5 / 2;
       }
+      // no pair under the acceptance threshold -> the round accepts nothing whatever the assignment is
+      if (__ballot(feasible) == 0ull) break;
       lds_sync();
       PROF(12);
       if (T <= WG) lsap_reg(Rr, Cc); else lsap(Rr, Cc);

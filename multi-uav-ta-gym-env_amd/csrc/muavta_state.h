@@ -92,7 +92,8 @@ struct alignas(16) EnvState {
   int32_t t_order[T];                 // live slots in ascending id (== creation) order
   int32_t open_slot[T];               // env.last_tasks_info (slots), status != 2 at last observation
   uint8_t t_row[T];                   // inverse of open_slot: row of a slot in last_tasks_info
-  uint32_t known[A][KW];              // agent_known_tasks as slot bitmask
+  uint32_t known[A][KW];              // agent_known_tasks as slot bitmask (bits of free slots are kept clear)
+  uint32_t free_slots[KW];            // bit s set <=> slot s is free
   // ---- threats (index = Threat.id) ------------------------------------------------------------
   double h_px[H], h_py[H];
   int32_t h_status[H];                // -9 = still waiting in its group
