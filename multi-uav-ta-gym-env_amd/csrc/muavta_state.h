@@ -130,7 +130,7 @@ struct alignas(16) EnvState {
 };
 
 // Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
-typedef Tile<16, 32, 16, 64, 48, 8> Tile16;
+typedef Tile<16, 32, 16, 48, 40, 8> Tile16;  // events <= 16, pending reveals <= 22 measured over 4096 seeds
 typedef Tile<24, 48, 24, 128, 64, 16> Tile24;
 typedef Tile<64, 128, 48, 128, 96, 8> Tile64;
 
