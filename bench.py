@@ -122,6 +122,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
+    # secondary figure: the PettingZoo-style path, one k_allocate + one k_step launch per env step,
+    # state blob loaded from / stored to HBM by every launch; untimed w.r.t. the headline
+    step_api = None
+    if rank == 0 and world == 1:
+        env.reset(seeds)
+        env.sync()
+        t1 = time.perf_counter()
+        for _ in range(HORIZON):
+            env.allocate(args.interval, True, fetch=False)
+            env.step_staged()
+        env.sync()
+        step_api = args.envs * HORIZON / (time.perf_counter() - t1)
+        env.rollout(seeds, HORIZON, args.interval, True, write_obs)  # restore the headline batch's final state
+        env.sync()
+
     # metrics of the last batch: per-rank partials -> the one collective of this path (muavta_amd/dist.py)
     from muavta_amd.dist import reduce_metrics
 
@@ -159,6 +174,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "k_rollout", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_env_step": B},
+            "step_api_env_steps_per_s": step_api,
             "quality": {"mean_S_WPS": summary["mean_S_WPS"], "std_S_WPS": summary["std_S_WPS"], "on_time_rate": summary["on_time_rate"],
                         "n_envs": summary["n_envs"]},
         }
