@@ -1348,21 +1348,65 @@ struct Env {
     return !events.empty();  // every tag the env emits is in the allocator's trigger set
   }
   // returns number of (agent, task) actions; also fills act_agent/act_index as _apply_assign would
-  int allocate(int interval, int use_visibility, int32_t* act_agent, int32_t* act_index, int cap) {
-    n_calls++;
+  // mode 0: Local-/Global-/Coalition-Hungarian as driven by run_wps_episode / run_escort_episode.
+  // mode 1: Urgency-Pair (TaskAllocation/Hybrid/PairCostHybrid.py:31-86,520-550 + experiments/wps_eval.py:64-74,
+  //         248-254): replan gate _should_replan(env, events, 15), engineered edge scores (float32) for the
+  //         first 16 live agents x first 32 underfilled tasks, then HungarianAllocator.allocate_tasks(force=True).
+  int allocate(int interval, int use_visibility, int32_t* act_agent, int32_t* act_index, int cap, int mode = 0) {
     last_actions.clear();
     lsap_costs.clear(); lsap_shapes.clear(); lsap_rows.clear(); lsap_cols.clear();
     interval = std::max(1, interval);
     int n_out = 0;
     auto finish = [&]() { if (n_out < cap && act_agent) act_agent[n_out] = -1; return n_out; };
-    if (!should_replan(done_events, interval)) return finish();
     std::vector<int> live;  // env.get_live_agents()
     for (auto& a : agents) if (a.state != -1) live.push_back(a.id);
-    std::vector<int> open_tasks;  // _open_tasks(env) filtered again by allocate_tasks (same predicate)
-    for (size_t k = 1; k < tasks.size(); k++)
-      if (tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_tasks.push_back((int)k);
-    if (live.empty() || open_tasks.empty()) return finish();
     bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
+    std::vector<float> score;      // [agent id][task id], 0 where there is no edge
+    std::vector<char> in_list(tasks.size(), 1);
+    if (mode == 1) {
+      bool gate = time_steps == 0 || time_steps % 15 == 0;
+      for (auto& ev : done_events) gate |= (ev.tag == MUAVTA_EV_RESET_ALLOCATION || ev.tag == MUAVTA_EV_NEW_THREAT || ev.tag == MUAVTA_EV_AGENT_FAIL);
+      if (!gate) return finish();
+      // build_att_tokens: open_tasks = underfilled at the type index (AttentionRAH.py:69-73)
+      std::vector<int> att_open;
+      for (size_t k = 1; k < tasks.size(); k++) {
+        const Task& t = tasks[k];
+        bool under = t.status != 2 && t.allocatedReqs[t.type] < t.currentReqs[t.type];
+        in_list[k] = under;
+        if (under) att_open.push_back((int)k);
+      }
+      score.assign((size_t)n_agents * tasks.size(), 0.0f);
+      int n_live = std::max((int)live.size(), 1);
+      for (size_t i = 0; i < live.size() && i < 16; i++) {
+        const UAV& a = agents[live[i]];
+        for (size_t j = 0; j < att_open.size() && j < 32; j++) {
+          const Task& t = tasks[att_open[j]];
+          if (vis && !known[a.id][t.id]) continue;                                   // edge_valid (PairCostHybrid.py:42-60)
+          if (t.has_eligible && !((t.eligible_mask >> a.type) & 1u)) continue;
+          if (a.caps[t.type] <= 0) continue;
+          double urg = 0.0;
+          if (t.has_deadline) { int remaining = std::max(t.hard_deadline - time_steps, 0); urg = 1.0 - std::fmin(remaining / 40.0, 1.0); }
+          double scar = 0.0;
+          if (vis) {
+            int n_know = 0;
+            for (int b = 0; b < n_agents; b++) n_know += known[b][t.id] ? 1 : 0;
+            scar = 1.0 - std::fmin((double)n_know / std::max(n_live, 1), 1.0);
+          }
+          double dist = norm2(a.pos.x - t.pos.x, a.pos.y - t.pos.y) / std::fmax(max_coord, 1.0);
+          double v = 0.5 * urg + 0.3 * scar - 0.4 * dist;
+          v = std::fmin(std::fmax(v, -0.35), 0.35);                                   // np.clip(..., -SCORE_CLAMP, SCORE_CLAMP)
+          score[(size_t)a.id * tasks.size() + t.id] = (float)v;                      // float32 scores array
+        }
+      }
+      n_calls++;  // allocate_tasks(force=True)
+    } else {
+      n_calls++;
+      if (!should_replan(done_events, interval)) return finish();
+    }
+    std::vector<int> open_tasks;  // the list handed to allocate_tasks, filtered by its own residual test (:113-119)
+    for (size_t k = 1; k < tasks.size(); k++)
+      if (in_list[k] && tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_tasks.push_back((int)k);
+    if (live.empty() || open_tasks.empty()) return finish();
     std::vector<double> residuals(tasks.size(), 0.0);
     for (int t : open_tasks) residuals[t] = residual_demand(tasks[t]);
     std::vector<int> free_agents = live;
@@ -1393,7 +1437,8 @@ struct Env {
             double missing = std::fmax(residuals[t.id], 1e-6);
             base_cost = dist / std::fmax(max_coord, 1.0) - 0.5 * std::fmin(delivered, missing) - 0.4 * 0.0 - 0.6 * urgency;
           }
-          if (base_cost < 1e5 / 2) cost[(size_t)i * nc + j] = base_cost - 0.0;
+          if (base_cost < 1e5 / 2)
+            cost[(size_t)i * nc + j] = base_cost - (score.empty() ? 0.0 : (double)score[(size_t)a.id * tasks.size() + t.id]);
         }
       }
       int m = std::min(nr, nc);
@@ -1450,6 +1495,20 @@ int orc_step(void* h, int n_act, const int32_t* act_agent, const int32_t* act_in
 }
 int orc_allocate(void* h, int interval, int use_vis, int32_t* act_agent, int32_t* act_index, int cap) {
   return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap);
+}
+int orc_allocate_mode(void* h, int interval, int use_vis, int mode, int32_t* act_agent, int32_t* act_index, int cap) {
+  return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap, mode);
+}
+int orc_rollout_mode(void* h, uint64_t seed, int n_steps, int interval, int use_vis, int mode) {
+  Env* e = (Env*)h;
+  e->reset(seed);
+  std::vector<int32_t> aa(e->n_agents + 1), ai(e->n_agents + 1);
+  int s = 0;
+  for (; s < n_steps; s++) {
+    int n = e->allocate(interval, use_vis, aa.data(), ai.data(), e->n_agents, mode);
+    if (e->step(n, aa.data(), ai.data())) { s++; break; }
+  }
+  return s;
 }
 // reset(seed) + n_steps x (allocate -> step); returns steps executed
 int orc_rollout(void* h, uint64_t seed, int do_reset, int n_steps, int interval, int use_vis) {

@@ -67,6 +67,15 @@ class OracleEnv:
         n = self.L.orc_allocate(self.h, int(interval), int(use_vis), _p(aa), _p(ai), self.A)
         return aa[:n].copy(), ai[:n].copy()
 
+    def allocate_mode(self, interval, use_vis, mode):
+        aa = np.full(self.A + 1, -1, dtype=np.int32)
+        ai = np.zeros(self.A + 1, dtype=np.int32)
+        n = self.L.orc_allocate_mode(self.h, int(interval), int(use_vis), int(mode), _p(aa), _p(ai), self.A)
+        return aa[:n].copy(), ai[:n].copy()
+
+    def rollout_mode(self, seed, n_steps, interval, use_vis, mode):
+        return self.L.orc_rollout_mode(self.h, C.c_uint64(seed), int(n_steps), int(interval), int(use_vis), int(mode))
+
     def step(self, act_agent, act_index):
         aa = np.ascontiguousarray(act_agent, dtype=np.int32)
         ai = np.ascontiguousarray(act_index, dtype=np.int32)

@@ -191,3 +191,45 @@ def test_numpy_bit_patterns():
         d = g[f"sum{n}_in"]
         got = np.array([L.orc_np_sum(np.ascontiguousarray(r).ctypes.data_as(C.c_void_p), n) for r in d])
         assert np.array_equal(got, g[f"sum{n}_out"]), n
+
+
+# ---- next row: Urgency-Pair (engineered edge scores feeding the same Hungarian) --------------------------
+URG_TRACES = sorted(glob.glob(os.path.join(GOLDEN, "urgpair_trace_*.npz")))
+URG_METRICS = sorted(glob.glob(os.path.join(GOLDEN, "urgpair_metrics_*.npz")))
+
+
+@pytest.mark.parametrize("path", URG_TRACES, ids=[os.path.basename(p)[14:-4] for p in URG_TRACES])
+def test_urgency_pair_trace(path):
+    g = np.load(path)
+    name = os.path.basename(path)[14:-4]
+    case, seed = name.rsplit("_s", 1)
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(int(seed))
+    acts = g["actions"]
+    li = off = 0
+    for s in range(150):
+        aa, ai = e.allocate_mode(20, 1, 1)
+        ga = acts[acts[:, 0] == s]
+        assert np.array_equal(aa, ga[:, 1]) and np.array_equal(ai, ga[:, 3]), f"{name} t={s}: {aa} vs {ga[:, 1]}"
+        assert np.array_equal(e.last_actions()[:, 1], ga[:, 2])
+        shapes, costs, _, _ = e.lsap_calls()
+        o = 0
+        for k in range(len(shapes)):
+            assert int(g["lsap_step"][li]) == s and tuple(shapes[k]) == tuple(g["lsap_shape"][li])
+            n = int(shapes[k][0] * shapes[k][1])
+            assert np.array_equal(costs[o:o + n], g["lsap_cost"][off:off + n]), f"{name} t={s}: scored cost matrix"
+            o += n; off += n; li += 1
+        e.step(aa, ai)
+    assert li == len(g["lsap_step"])
+    assert np.array_equal(e.metrics(), g["metrics"]) and e.dims()["n_replans"] == int(g["n_replans"])
+
+
+@pytest.mark.parametrize("path", URG_METRICS, ids=[os.path.basename(p)[16:-4] for p in URG_METRICS])
+def test_urgency_pair_metrics(path):
+    g = np.load(path)
+    case = os.path.basename(path)[16:-4]
+    e = orc.OracleEnv(params_for_case(case))
+    for seed, want in enumerate(g["metrics"]):
+        assert e.rollout_mode(seed, 150, 20, 1, 1) == 150
+        assert np.array_equal(e.metrics(), want), f"{case} seed {seed}"
+        assert e.dims()["n_replans"] == int(g["n_replans"][seed])

@@ -367,5 +367,65 @@ def main():
         print("metrics", case, np.stack(rows)[:, 4].mean())
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--urgency-pair" not in sys.argv:
     main()
+
+
+# ------------------------------------------------------------------------------------------------
+# Next row: Urgency-Pair — engineered edge scores feeding the same Hungarian
+# (TaskAllocation/Hybrid/PairCostHybrid.py:68-86,520-550; loop = experiments/wps_eval.py:248-254)
+# ------------------------------------------------------------------------------------------------
+def run_episode_urgency_pair(case, seed, full):
+    from TaskAllocation.Hybrid.PairCostHybrid import UrgencyPair
+    from experiments.wps_eval import _apply_assign, _should_replan
+
+    env = make_env(case)
+    tap = LsapTap()
+    HA.linear_sum_assignment = tap
+    try:
+        obs, info = env.reset(seed=seed)
+        hung = HA.HungarianAllocator(replan_interval=20, max_coord=env.max_coord)
+        urg = UrgencyPair()
+        done = {a: False for a in env.agents}
+        trunc = {a: False for a in env.agents}
+        act_rows, latest = [], None
+        while not all(done.values()) and not all(trunc.values()):
+            events = _events(info)
+            actions = {}
+            tap.step = env.time_steps
+            if _should_replan(env, events):
+                result, _, _ = urg.plan(env, hung, events=events, force=True)
+                actions = _apply_assign(env, result)
+                for name, idx in actions.items():
+                    act_rows.append((env.time_steps, env.agent_by_name[name].id, env.last_tasks_info[idx].id, idx))
+            obs, reward, done, trunc, info = env.step(actions)
+            if "metrics" in info:
+                latest = info["metrics"]
+    finally:
+        HA.linear_sum_assignment = linear_sum_assignment
+    out = {"metrics": np.array([float(latest[k]) for k in METRIC_KEYS]), "n_replans": np.int64(hung.n_replans)}
+    if full:
+        out["actions"] = np.array(act_rows, dtype=np.int64).reshape(-1, 4)
+        out["lsap_step"] = np.array([c[0] for c in tap.calls], dtype=np.int64)
+        out["lsap_shape"] = np.array([c[1].shape for c in tap.calls], dtype=np.int64).reshape(-1, 2)
+        out["lsap_cost"] = np.concatenate([c[1].ravel() for c in tap.calls]) if tap.calls else np.zeros(0)
+    return out
+
+
+def gen_urgency_pair():
+    for case, full_seeds, n_metric in (("WPS_hard", (0, 1), 32), ("WPS_attn", (0,), 16), ("WPS_hard_x2", (0,), 32)):
+        for s in full_seeds:
+            tr = run_episode_urgency_pair(case, s, True)
+            np.savez_compressed(os.path.join(OUT, f"urgpair_trace_{case}_s{s}.npz"), **tr)
+            print("urgency-pair trace", case, s, tr["metrics"][4])
+        rows, reps = [], []
+        for s in range(n_metric):
+            r = run_episode_urgency_pair(case, s, False)
+            rows.append(r["metrics"]); reps.append(int(r["n_replans"]))
+        np.savez_compressed(os.path.join(OUT, f"urgpair_metrics_{case}.npz"), metrics=np.stack(rows),
+                            n_replans=np.array(reps, dtype=np.int64), keys=np.array(METRIC_KEYS))
+        print("urgency-pair metrics", case, np.stack(rows)[:, 4].mean())
+
+
+if __name__ == "__main__" and "--urgency-pair" in sys.argv:
+    gen_urgency_pair()
