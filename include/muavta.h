@@ -193,6 +193,15 @@ int muavta_allocate(MuavtaEnv* env, int32_t replan_interval, int32_t use_visibil
                     int32_t* act_agent, int32_t* act_index);
 int muavta_step_staged(MuavtaEnv* env); /* step with the actions muavta_allocate left on the device */
 
+/* Which allocator muavta_allocate / muavta_rollout run (default MUAVTA_ALLOC_HUNGARIAN):
+ *   MUAVTA_ALLOC_URGENCY_PAIR = UrgencyPair.plan(env, hung, events, force=True) under the harness gate
+ *   _should_replan(env, events, 15): engineered float32 edge scores 0.5*urgency + 0.3*scarcity - 0.4*dist, clipped
+ *   to +-0.35, on the first 16 live agents x first 32 underfilled tasks, subtracted from the Hungarian cost
+ *   (TaskAllocation/Hybrid/PairCostHybrid.py:31-86,520-550; experiments/wps_eval.py:64-74,248-254).
+ *   `replan_interval` is ignored in that mode. */
+enum { MUAVTA_ALLOC_HUNGARIAN = 0, MUAVTA_ALLOC_URGENCY_PAIR = 1 };
+int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
+
 /* The measured path: reset(seeds) followed by n_steps x (allocate -> step) fused in ONE kernel
  * launch, state resident in LDS (run_wps_episode / run_escort_episode with Local-/Coalition-
  * Hungarian, experiments/wps_eval.py:76-291, experiments/escort_eval.py:86-226).  seeds == NULL

@@ -95,6 +95,10 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_allocate(self.h, int(replan_interval), int(use_visibility), _vp(aa), _vp(ai)))
         return aa, ai
 
+    def set_allocator(self, name: str = "hungarian"):
+        """'hungarian' (Local-/Coalition-Hungarian) or 'urgency_pair' (UrgencyPair.plan under the WPS harness gate)."""
+        self._ck(self.L.muavta_set_allocator(self.h, {"hungarian": 0, "urgency_pair": 1}[name]))
+
     def step_staged(self):
         self._ck(self.L.muavta_step_staged(self.h))
 

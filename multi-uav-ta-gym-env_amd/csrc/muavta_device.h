@@ -62,6 +62,8 @@ struct alignas(16) Scratch {
   double u[A], v[T], spc[T], resid[T];
   int32_t path[T], col4row[A], row4col[T], remaining[T], freeA[A], roundT[T];
   uint8_t SR[A], SC[T];
+  uint8_t live_rank[A];                  // Urgency-Pair: rank of an agent among the live ones (255 = beyond the token pad)
+  int32_t pair_info_big[T > 64 ? T : 1]; // Urgency-Pair per-slot (rank, n_know) when `remaining` is busy (LDS LSAP, T > 64)
 };
 
 // ====================================================================================================
@@ -2035,29 +2037,69 @@ struct Sim {
     return fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
   }
 
-  DEV void allocate(int interval, int use_visibility) {
+  // mode 0 (MUAVTA_ALLOC_HUNGARIAN): Local-/Global-/Coalition-Hungarian as driven by the WPS / escort harness.
+  // mode 1 (MUAVTA_ALLOC_URGENCY_PAIR): TaskAllocation/Hybrid/PairCostHybrid.py:31-86,520-550 — engineered
+  //   float32 edge scores 0.5*urgency + 0.3*scarcity - 0.4*dist, clipped to +-0.35, for the first 16 live agents x
+  //   first 32 underfilled tasks, subtracted from the Hungarian cost; replan gate = experiments/wps_eval.py:64-74.
+  DEV int32_t* pair_info() { return T > 64 ? X.pair_info_big : X.remaining; }
+  DEV void allocate(int interval, int use_visibility, int mode = 0) {
     PROF(10);
     interval = interval < 1 ? 1 : interval;
-    if (lane == 0) { S.n_calls++; S.n_act = 0; }
-    // should_replan (:27-41): every tag the env emits is in the trigger set
-    bool go = (S.time_steps - S.last_plan_step >= interval) || (S.n_dev > 0);
-    int nr = 0;
+    if (lane == 0) S.n_act = 0;
+    bool go;
+    if (mode == 1) {  // _should_replan(env, events, 15); plan(force=True) bypasses the allocator's own gate
+      bool trig = false;
+      for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;  // Reset_Allocation, New_Threat, Agent_Fail
+      go = S.time_steps == 0 || S.time_steps % 15 == 0 || __ballot(trig) != 0ull;
+      if (go && lane == 0) S.n_calls++;
+    } else {
+      if (lane == 0) S.n_calls++;
+      // should_replan (:27-41): every tag the env emits is in the trigger set
+      go = (S.time_steps - S.last_plan_step >= interval) || (S.n_dev > 0);
+    }
+    const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
+    int nr = 0, n_live = 1;
     if (go) {
       // live agents -> free list (get_live_agents order), residual demand per open task: one lane each
       nr = compact_to(X.freeA, P.n_agents, [&](int a) { return S.a_state[a] != -1; }, [&](int a) { return a; });
+      n_live = nr > 1 ? nr : 1;
       bool any_open = false;
-      for (int k = lane; k < S.n_open; k += WG) {
-        const int s = S.open_slot[k];
-        const double r = residual_demand(s);
-        X.resid[s] = r;
-        any_open |= r > 0;
+      int n_under = 0;
+      for (int base = 0; base < S.n_open; base += WG) {
+        const int k = base + lane;
+        bool under = false;
+        int s = 0;
+        if (k < S.n_open) {
+          s = S.open_slot[k];
+          const int ty = S.t_type[s];
+          // Urgency-Pair only plans over build_att_tokens' open_tasks: underfilled at the type index (AttentionRAH.py:69-73)
+          under = mode != 1 || S.t_alloc[ty][s] < S.t_cur[ty][s];
+          const double r = under ? residual_demand(s) : 0.0;
+          X.resid[s] = r;
+          any_open |= r > 0;
+        }
+        if (mode == 1) {
+          const unsigned long long um = __ballot(under);
+          if (under) {
+            const int rank = n_under + __popcll(um & ((1ull << lane) - 1ull));
+            int n_know = 0;
+            if (vis) for (int b = 0; b < P.n_agents; b++) n_know += (S.known[b][s >> 5] >> (s & 31)) & 1u;
+            pair_info()[s] = (rank < 32 ? rank : 255) | (n_know << 8);
+          } else if (k < S.n_open) pair_info()[s] = 255;
+          n_under += __popcll(um);
+        }
+      }
+      if (mode == 1 && lane < P.n_agents) {
+        const bool lv = S.a_state[lane] != -1;
+        const unsigned long long lm = __ballot(lv);
+        const int rk = __popcll(lm & ((1ull << lane) - 1ull));
+        X.live_rank[lane] = (lv && rk < 16) ? (uint8_t)rk : (uint8_t)255;
       }
       if (nr == 0 || __ballot(any_open) == 0ull) go = false;
     }
     lds_sync();
     PROF(11);
     if (!go) return;
-    const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
     int n_act = 0;
     while (true) {
       // round_tasks: open tasks (that had residual > 0 initially) with residual > 1e-9, in last_tasks_info order
@@ -2086,7 +2128,18 @@ struct Sim {
             double dist = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
             double missing = fmax(X.resid[s], 1e-6);
             double base = dist / fmax(MAX_COORD, 1.0) - 0.5 * fmin(delivered, missing) - 0.4 * 0.0 - 0.6 * urgency;
-            if (base < 1e5 / 2) c = base - 0.0;
+            double score = 0.0;
+            if (mode == 1) {  // urgency_edge_scores (PairCostHybrid.py:68-86) on the edges build_pair_tokens keeps (:42-60)
+              const int info = pair_info()[s];
+              if ((info & 255) < 32 && X.live_rank[a] < 16 && S.a_caps[S.t_type[s]][a] > 0) {
+                double scar = 0.0;
+                if (vis) scar = 1.0 - fmin((double)(info >> 8) / (double)n_live, 1.0);
+                double v = 0.5 * urgency + 0.3 * scar - 0.4 * (dist / fmax(MAX_COORD, 1.0));
+                v = fmin(fmax(v, -0.35), 0.35);
+                score = (double)(float)v;  // the scores array is float32
+              }
+            }
+            if (base < 1e5 / 2) c = base - score;
           }
         }
         X.cost[tr ? (j * Cc + i) : (i * Cc + j)] = c;

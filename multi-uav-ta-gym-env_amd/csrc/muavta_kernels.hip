@@ -116,14 +116,14 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(DevParams P, EnvS
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, int interval, int use_vis,
+__global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, int interval, int use_vis, int mode,
                                                  int32_t* out_agent, int32_t* out_index, int act_cap) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
   lds_sync();
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
-  sim.allocate(interval, use_vis);
+  sim.allocate(interval, use_vis, mode);
   lds_sync();
   if (out_agent) {
     const EnvState<TL>& S = *L.S;
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blob
 
 template <class TL>
 __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, int n_steps,
-                                                int interval, int use_vis, int write_obs, ObsPtrs O, double* metrics) {
+                                                int interval, int use_vis, int mode, int write_obs, ObsPtrs O, double* metrics) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(DevParams P, c
   }
   for (int t = 0; t < n_steps; t++) {
     if (L.S->terminated || L.S->truncated) break;  // uniform: read from LDS after a barrier
-    sim.allocate(interval, use_vis);
+    sim.allocate(interval, use_vis, mode);
     sim.step(true);
     if (write_obs) obs_for_env(sim, P, O, env);
     lds_sync();
@@ -260,6 +260,7 @@ struct MuavtaEnv {
   DevParams P;
   MuavtaParams params;
   int tile = TK16;
+  int alloc_mode = 0;  // MUAVTA_ALLOC_*
   int n_envs = 0, device = 0;
   int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
   size_t state_bytes = 0, lds_bytes = 0;
@@ -709,7 +710,7 @@ int muavta_allocate(MuavtaEnv* e, int32_t interval, int32_t use_vis, int32_t* ac
   if (!e->did_reset) { e->err = "allocate before reset"; return MUAVTA_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
   DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs,
-                                 e->tapes, interval, use_vis, e->d_act_agent, e->d_act_index, e->A));
+                                 e->tapes, interval, use_vis, e->alloc_mode, e->d_act_agent, e->d_act_index, e->A));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   if (act_agent && act_index) {
@@ -733,7 +734,7 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
   DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds, e->stream, e->P, ds, (EnvState<TL>*)e->blobs,
-                                 e->tapes, n_steps, interval, use_vis, write_obs, e->O, e->d_metrics));
+                                 e->tapes, n_steps, interval, use_vis, e->alloc_mode, write_obs, e->O, e->d_metrics));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
   e->did_reset = true;
@@ -748,6 +749,12 @@ int muavta_prof_read(unsigned long long* out, int reset) {  // diagnostic build 
   return MUAVTA_OK;
 }
 #endif
+
+int muavta_set_allocator(MuavtaEnv* e, int32_t mode) {
+  if (!e || (mode != MUAVTA_ALLOC_HUNGARIAN && mode != MUAVTA_ALLOC_URGENCY_PAIR)) { if (e) e->err = "unknown allocator mode"; return MUAVTA_E_ARG; }
+  e->alloc_mode = mode;
+  return MUAVTA_OK;
+}
 
 int muavta_sync(MuavtaEnv* e) {
   if (!e) return MUAVTA_E_ARG;

@@ -363,3 +363,49 @@ def test_facade_on_gpu_matches_reference_observations():
             assert vis[a.name] <= want_known and vis[a.name] & open_ids == want_known & open_ids, f"t={t + 1} {a.name}"
     assert all(trunc.values()) and np.array_equal(np.array([float(infos["metrics"][k]) for k in METRIC_KEYS]), g["metrics"])
     assert len(env.tasks) == int(g["metrics"][13])
+
+
+# ---- next row: Urgency-Pair allocator (edge scores fused into the cost tile) ----------------------------------
+@pytest.mark.parametrize("case,n", [("WPS_hard", 8), ("WPS_attn", 4), ("WPS_hard_x2", 6), ("WPS_attn_AWACS", 3)])
+def test_urgency_pair_stepwise_vs_oracle(case, n):
+    env = _env(case, n)
+    env.set_allocator("urgency_pair")
+    seeds = np.arange(n, dtype=np.uint64)
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    env.reset(seeds)
+    for i, o in enumerate(oracles):
+        o.reset(i)
+    for t in range(150):
+        aa, ai = env.allocate(20, True)
+        staged = env.get("STAGED_ACTIONS")
+        for i, o in enumerate(oracles):
+            oa, oi = o.allocate_mode(20, 1, 1)
+            k = len(oa)
+            assert np.array_equal(aa[i][:k], oa) and np.all(aa[i][k:] == -1), f"{case} seed {i} t={t}: agents {aa[i]} vs {oa}"
+            assert np.array_equal(ai[i][:k], oi) and np.array_equal(staged[i][:k, 1], o.last_actions()[:, 1]), f"{case} seed {i} t={t}"
+            o.step(oa, oi)
+        env.step(aa, ai)
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"urgency-pair {case} seed {i} t={t + 1}")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "urgpair_metrics_*.npz"))),
+                         ids=lambda p: os.path.basename(p)[16:-4])
+def test_urgency_pair_fused_rollout_matches_reference(path):
+    g = np.load(path)
+    case = os.path.basename(path)[16:-4]
+    want = g["metrics"]
+    n = want.shape[0]
+    env = _env(case, n)
+    env.set_allocator("urgency_pair")
+    env.rollout(np.arange(n, dtype=np.uint64), 150, 20, True, True)
+    got = env.rollout_metrics()
+    assert np.all(env.get("ERROR") == 0)
+    assert np.array_equal(got, want), f"{case}: seeds {np.nonzero(~np.all(got == want, axis=1))[0][:8]} differ"
+    assert np.array_equal(env.get("SCALARS")[:, 23].astype(int), g["n_replans"])
+    env.set_allocator("hungarian")  # and back: the default path is untouched
+    gm = np.load(os.path.join(GOLDEN, f"metrics_{case}.npz"))
+    m = min(n, gm["metrics"].shape[0])
+    env.rollout(np.arange(n, dtype=np.uint64), 150, int(gm["interval"]), True, False)
+    assert np.array_equal(env.rollout_metrics()[:m], gm["metrics"][:m])
