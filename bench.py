@@ -91,10 +91,12 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # under torch.distributed.run the RCCL path is exercised even at N=1
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     from muavta_amd.batched import BatchedMultiUAVEnv
     from muavta_amd.params import params_for_case
@@ -102,7 +104,9 @@ def main():
     params = params_for_case(args.case)
     env = BatchedMultiUAVEnv(params, args.envs, device=local_rank)
     tile = f"{env.dims.tile_agents}x{env.dims.tile_tasks}"
-    seeds = np.arange(rank * args.envs, (rank + 1) * args.envs, dtype=np.uint64)  # seed = global env index
+    from muavta_amd.dist import shard_seeds
+
+    seeds = shard_seeds(rank, args.envs)  # seed = global env index
     write_obs = not args.no_obs
 
     def barrier():
