@@ -198,8 +198,14 @@ int muavta_step_staged(MuavtaEnv* env); /* step with the actions muavta_allocate
  *   _should_replan(env, events, 15): engineered float32 edge scores 0.5*urgency + 0.3*scarcity - 0.4*dist, clipped
  *   to +-0.35, on the first 16 live agents x first 32 underfilled tasks, subtracted from the Hungarian cost
  *   (TaskAllocation/Hybrid/PairCostHybrid.py:31-86,520-550; experiments/wps_eval.py:64-74,248-254).
- *   `replan_interval` is ignored in that mode. */
-enum { MUAVTA_ALLOC_HUNGARIAN = 0, MUAVTA_ALLOC_URGENCY_PAIR = 1 };
+ *   `replan_interval` is ignored in that mode.
+ *   MUAVTA_ALLOC_URGENCY_COALITION = UrgencyCoalition.plan(env, hung_force, events, force=True) under
+ *   escort_eval._should_replan(env, events, replan_interval): f64 edge scores clip(0.45*urgency + 0.35*threat
+ *   pressure*(0.5+0.5*is_escort) + 0.3*min(cap,1) - 0.25*dist [+0.2 role bonus], 0, 1) for every live agent x open
+ *   task, agents with commit_until > t held out of the match, assigned agents that hold a real task locked for
+ *   commit_horizon steps (TaskAllocation/Hybrid/AttentionEscort.py:32-66,714-767; AttentionCommit.py:24-44;
+ *   experiments/escort_eval.py:52-58,175-180). */
+enum { MUAVTA_ALLOC_HUNGARIAN = 0, MUAVTA_ALLOC_URGENCY_PAIR = 1, MUAVTA_ALLOC_URGENCY_COALITION = 2 };
 int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
 
 /* The measured path: reset(seeds) followed by n_steps x (allocate -> step) fused in ONE kernel

@@ -96,8 +96,9 @@ class BatchedMultiUAVEnv:
         return aa, ai
 
     def set_allocator(self, name: str = "hungarian"):
-        """'hungarian' (Local-/Coalition-Hungarian) or 'urgency_pair' (UrgencyPair.plan under the WPS harness gate)."""
-        self._ck(self.L.muavta_set_allocator(self.h, {"hungarian": 0, "urgency_pair": 1}[name]))
+        """'hungarian' (Local-/Coalition-Hungarian), 'urgency_pair' (UrgencyPair.plan under the WPS harness gate) or
+        'urgency_coalition' (UrgencyCoalition.plan under the escort harness gate, with commit locks)."""
+        self._ck(self.L.muavta_set_allocator(self.h, {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2}[name]))
 
     def step_staged(self):
         self._ck(self.L.muavta_step_staged(self.h))

@@ -2052,6 +2052,9 @@ struct Sim {
       for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;  // Reset_Allocation, New_Threat, Agent_Fail
       go = S.time_steps == 0 || S.time_steps % 15 == 0 || __ballot(trig) != 0ull;
       if (go && lane == 0) S.n_calls++;
+    } else if (mode == 2) {  // escort_eval._should_replan(env, events, interval): all five env tags are REPLAN_EVENTS
+      go = S.time_steps == 0 || S.time_steps % interval == 0 || S.n_dev > 0;
+      if (go && lane == 0) S.n_calls++;
     } else {
       if (lane == 0) S.n_calls++;
       // should_replan (:27-41): every tag the env emits is in the trigger set
@@ -2061,7 +2064,10 @@ struct Sim {
     int nr = 0, n_live = 1;
     if (go) {
       // live agents -> free list (get_live_agents order), residual demand per open task: one lane each
-      nr = compact_to(X.freeA, P.n_agents, [&](int a) { return S.a_state[a] != -1; }, [&](int a) { return a; });
+      // Urgency-Coalition holds committed agents out of the match (committed_names, AttentionCommit.py:24-30)
+      nr = compact_to(X.freeA, P.n_agents,
+                      [&](int a) { return S.a_state[a] != -1 && !(mode == 2 && S.a_commit[a] > S.time_steps); },
+                      [&](int a) { return a; });
       n_live = nr > 1 ? nr : 1;
       bool any_open = false;
       int n_under = 0;
@@ -2108,6 +2114,22 @@ struct Sim {
       if (nr == 0 || nc == 0) break;
       const bool tr = nc < nr;              // scipy transposes so that rows <= cols
       const int Rr = tr ? nc : nr, Cc = tr ? nr : nc;
+      if (mode == 2) {  // _threat_stats (AttentionEscort.py:46-66): nearest live threat to the task (escort: to its recon)
+        for (int j = lane; j < nc; j += WG) {
+          const int s = S.open_slot[X.roundT[j]];
+          const int pa = S.t_prot_agent[s];
+          const double ax = pa >= 0 ? S.a_px[pa] : S.t_px[s], ay = pa >= 0 ? S.a_py[pa] : S.t_py[s];
+          double best = MAX_COORD;
+          for (int k = 0; k < S.n_active_threats; k++) {
+            const int h = S.h_order[k];
+            if (S.h_status[h] == 2) continue;
+            const double d = norm2(S.h_px[h] - ax, S.h_py[h] - ay);
+            if (d < best) best = d;
+          }
+          X.spc[j] = 1.0 - fmin(best / MAX_COORD, 1.0);  // pressure; spc is re-initialised by the solver afterwards
+        }
+        lds_sync();
+      }
       // ---- cost tile (:137-179), one (agent, task) pair per lane ----
       bool feasible = false;
       for (int p = lane; p < nr * nc; p += WG) {
@@ -2138,6 +2160,16 @@ struct Sim {
                 v = fmin(fmax(v, -0.35), 0.35);
                 score = (double)(float)v;  // the scores array is float32
               }
+            }
+            if (mode == 2) {  // UrgencyCoalition.plan (AttentionEscort.py:729-752), left-to-right in f64
+              const int ty = S.t_type[s];
+              const bool esc = (S.t_flags[s] & TF_ESCORT) != 0;
+              const double cap = S.a_caps[ty][a] > 0 ? S.a_caps[ty][a] : 0.0;
+              double v = 0.45 * urgency + 0.35 * X.spc[j] * (0.5 + 0.5 * (esc ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
+              const bool fighter = is_fighter(S.a_type[a]);
+              if (fighter && (esc || ty == MUAVTA_INT)) v += 0.2;
+              if (!fighter && ty == MUAVTA_REC) v += 0.2;
+              score = fmin(fmax(v, 0.0), 1.0);
             }
             if (base < 1e5 / 2) c = base - score;
           }
@@ -2184,6 +2216,10 @@ struct Sim {
       nr = n_acc ? n_left : 0;  // no accept -> stop
       lds_sync();
       PROF(14);
+    }
+    if (mode == 2 && P.commit_horizon > 0 && lane < n_act) {  // apply_agent_commits (AttentionCommit.py:33-44)
+      const int a = S.act_agent[lane];
+      if (S.a_qlen[a] > 0) S.a_commit[a] = S.time_steps + P.commit_horizon;  // only agents that hold a real task now
     }
     if (lane == 0) {
       S.n_act = n_act;

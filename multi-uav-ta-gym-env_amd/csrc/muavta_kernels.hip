@@ -339,6 +339,7 @@ int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
   int need = (int)std::ceil(p->escort_requirement);
   d->escort_required_agents = need > 2 ? need : 2;
   d->escort_mask = p->escort_agent_type_mask;
+  d->commit_horizon = p->commit_horizon;
   static const double MAX_SPEED[7] = {5.0, 8.0, 5.0, 20.0, 15.0, 14.0, 12.0};  // MultiDroneEnvData.py:32-38
   for (int t = 0; t < 7; t++) d->speed[t] = MAX_SPEED[t] / p->simulation_frame_rate * 0.02;
   d->threat_prob = 0.7 / p->simulation_frame_rate * 0.02;
@@ -751,7 +752,7 @@ int muavta_prof_read(unsigned long long* out, int reset) {  // diagnostic build 
 #endif
 
 int muavta_set_allocator(MuavtaEnv* e, int32_t mode) {
-  if (!e || (mode != MUAVTA_ALLOC_HUNGARIAN && mode != MUAVTA_ALLOC_URGENCY_PAIR)) { if (e) e->err = "unknown allocator mode"; return MUAVTA_E_ARG; }
+  if (!e || (mode < MUAVTA_ALLOC_HUNGARIAN || mode > MUAVTA_ALLOC_URGENCY_COALITION)) { if (e) e->err = "unknown allocator mode"; return MUAVTA_E_ARG; }
   e->alloc_mode = mode;
   return MUAVTA_OK;
 }

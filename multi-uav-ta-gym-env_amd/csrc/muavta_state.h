@@ -40,7 +40,7 @@ struct DevParams {
   int32_t max_time_steps, multiple_tasks_per_agent, early_terminate, capability_mask, saturate_mask,
       include_time_windows, threat_delay, hard_windows, window_length, burst_mode, burst_size,
       dual_region_bursts, share_knowledge, escort_enabled, num_obstacles, random_init_pos,
-      escort_required_agents /* max(2, ceil(escort_requirement)), DroneEnv.py:1907 */;
+      escort_required_agents /* max(2, ceil(escort_requirement)), DroneEnv.py:1907 */, commit_horizon;
   uint32_t escort_mask;
   double speed[7];          // maxSpeeds[type] / frame_rate * 0.02            (DroneEnv.py:611,725)
   double threat_prob;       // 0.7 / frame_rate * 0.02                         (:162)

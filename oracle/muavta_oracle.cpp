@@ -1361,7 +1361,8 @@ struct Env {
     std::vector<int> live;  // env.get_live_agents()
     for (auto& a : agents) if (a.state != -1) live.push_back(a.id);
     bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
-    std::vector<float> score;      // [agent id][task id], 0 where there is no edge
+    std::vector<double> score;     // [agent id][task id], 0 where there is no edge
+    std::vector<char> reserved(n_agents, 0);
     std::vector<char> in_list(tasks.size(), 1);
     if (mode == 1) {
       bool gate = time_steps == 0 || time_steps % 15 == 0;
@@ -1375,7 +1376,7 @@ struct Env {
         in_list[k] = under;
         if (under) att_open.push_back((int)k);
       }
-      score.assign((size_t)n_agents * tasks.size(), 0.0f);
+      score.assign((size_t)n_agents * tasks.size(), 0.0);
       int n_live = std::max((int)live.size(), 1);
       for (size_t i = 0; i < live.size() && i < 16; i++) {
         const UAV& a = agents[live[i]];
@@ -1395,10 +1396,46 @@ struct Env {
           double dist = norm2(a.pos.x - t.pos.x, a.pos.y - t.pos.y) / std::fmax(max_coord, 1.0);
           double v = 0.5 * urg + 0.3 * scar - 0.4 * dist;
           v = std::fmin(std::fmax(v, -0.35), 0.35);                                   // np.clip(..., -SCORE_CLAMP, SCORE_CLAMP)
-          score[(size_t)a.id * tasks.size() + t.id] = (float)v;                      // float32 scores array
+          score[(size_t)a.id * tasks.size() + t.id] = (double)(float)v;              // float32 scores array
         }
       }
       n_calls++;  // allocate_tasks(force=True)
+    } else if (mode == 2) {
+      // Urgency-Coalition (TaskAllocation/Hybrid/AttentionEscort.py:714-767) under escort_eval._should_replan (:52-58)
+      bool gate = time_steps == 0 || time_steps % interval == 0 || !done_events.empty();  // all 5 env tags are REPLAN_EVENTS
+      if (!gate) return finish();
+      score.assign((size_t)n_agents * tasks.size(), 0.0);
+      for (int aid : live) {
+        const UAV& a = agents[aid];
+        for (size_t k = 1; k < tasks.size(); k++) {
+          const Task& t = tasks[k];
+          if (t.status == 2 || !(residual_demand(t) > 0)) continue;                    // _open_tasks_residual (:32-44)
+          if (t.has_eligible && !((t.eligible_mask >> a.type) & 1u)) continue;
+          double urg = 0.0;
+          if (t.has_deadline) { int remaining = std::max(t.hard_deadline - time_steps, 0); urg = 1.0 - std::fmin(remaining / 40.0, 1.0); }
+          // _threat_stats (:46-66): anchor = protected agent's position for escorts
+          Vec anchor = t.pos;
+          if (t.protected_agent >= 0) anchor = agents[t.protected_agent].pos;
+          double best = max_coord;
+          for (int hid : threats) {
+            const Threat& th = threats_all[hid];
+            if (th.status == 2) continue;
+            double d = norm2(th.pos.x - anchor.x, th.pos.y - anchor.y);
+            if (d < best) best = d;
+          }
+          double pressure = 1.0 - std::fmin(best / max_coord, 1.0);
+          double is_escort = t.escort ? 1.0 : 0.0;
+          double cap = a.caps[t.type] > 0 ? a.caps[t.type] : 0.0;
+          double dist = norm2(a.pos.x - t.pos.x, a.pos.y - t.pos.y) / max_coord;
+          double sc = 0.45 * urg + 0.35 * pressure * (0.5 + 0.5 * is_escort) + 0.3 * std::fmin(cap, 1.0) - 0.25 * dist;
+          bool fighter = !is_recon(a.type);  // type names F1/F2 vs R1/R2
+          if (fighter && (t.escort || t.type == MUAVTA_INT)) sc += 0.2;
+          if (!fighter && t.type == MUAVTA_REC) sc += 0.2;
+          score[(size_t)a.id * tasks.size() + t.id] = std::fmin(std::fmax(sc, 0.0), 1.0);
+        }
+      }
+      for (int aid : live) reserved[aid] = agents[aid].commit_until > time_steps;      // committed_names (AttentionCommit.py:24-30)
+      n_calls++;
     } else {
       n_calls++;
       if (!should_replan(done_events, interval)) return finish();
@@ -1406,10 +1443,13 @@ struct Env {
     std::vector<int> open_tasks;  // the list handed to allocate_tasks, filtered by its own residual test (:113-119)
     for (size_t k = 1; k < tasks.size(); k++)
       if (in_list[k] && tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_tasks.push_back((int)k);
-    if (live.empty() || open_tasks.empty()) return finish();
+    bool any_free = false;
+    for (int aid : live) any_free |= !reserved[aid];
+    if (!any_free || open_tasks.empty()) return finish();
     std::vector<double> residuals(tasks.size(), 0.0);
     for (int t : open_tasks) residuals[t] = residual_demand(tasks[t]);
-    std::vector<int> free_agents = live;
+    std::vector<int> free_agents;
+    for (int aid : live) if (!reserved[aid]) free_agents.push_back(aid);             // HungarianAllocator.py:91-92
     std::vector<std::pair<int, int>> actions;
     while (!free_agents.empty()) {
       std::vector<int> round_tasks;
@@ -1465,6 +1505,12 @@ struct Env {
     }
     last_plan_step = time_steps;
     n_replans++;
+    if (mode == 2 && P.commit_horizon > 0) {  // apply_agent_commits (AttentionCommit.py:33-44): pre-step queue head decides
+      for (auto& pr : actions) {
+        UAV& a = agents[pr.first];
+        if (!a.tasks.empty() && a.tasks[0] != 0) a.commit_until = time_steps + P.commit_horizon;
+      }
+    }
     // _apply_assign (experiments/wps_eval.py:55-61): first assignment per agent wins
     std::vector<char> seen(n_agents, 0);
     for (auto& pr : actions) {
@@ -1537,6 +1583,7 @@ void orc_dims(void* h, int32_t* out) {
   out[15] = (int)q;
 }
 // agents: f64 [A, 16]: x, y, state, head, qlen, nft, nfpx, nfpy, attackCap, task_start, re_eval, last_task, type, name_idx, fail_event, dist ; caps [A,6]; queue [A,Q]
+void orc_get_commit(void* h, int32_t* out) { Env* e = (Env*)h; for (auto& a : e->agents) out[a.id] = a.commit_until; }
 void orc_get_agents(void* h, double* rows, double* caps, int32_t* queue, int qcap) {
   Env* e = (Env*)h;
   for (auto& a : e->agents) {

@@ -94,6 +94,11 @@ class OracleEnv:
         self.L.orc_get_agents(self.h, _p(rows), _p(caps), _p(q), self.QCAP)
         return rows, caps, q
 
+    def agent_commit_until(self):
+        c = np.zeros(self.A, dtype=np.int32)
+        self.L.orc_get_commit(self.h, _p(c))
+        return c
+
     def tasks(self):
         nt = self.dims()["n_task_ids"]
         rows = np.zeros((nt, 14)); reqs = np.zeros((nt, 3, 6))

@@ -409,3 +409,46 @@ def test_urgency_pair_fused_rollout_matches_reference(path):
     m = min(n, gm["metrics"].shape[0])
     env.rollout(np.arange(n, dtype=np.uint64), 150, int(gm["interval"]), True, False)
     assert np.array_equal(env.rollout_metrics()[:m], gm["metrics"][:m])
+
+
+# ---- next row: Urgency-Coalition allocator (threat-pressure edge scores + commit locks) ---------------------------
+@pytest.mark.parametrize("case,n,interval", [("WPS_escort", 6, 12), ("WPS_escort24", 3, 12), ("WPS_hard", 4, 12), ("WPS_burst64", 2, 12)])
+def test_urgency_coalition_stepwise_vs_oracle(case, n, interval):
+    env = _env(case, n)
+    env.set_allocator("urgency_coalition")
+    seeds = np.arange(n, dtype=np.uint64)
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    env.reset(seeds)
+    for i, o in enumerate(oracles):
+        o.reset(i)
+    for t in range(150):
+        aa, ai = env.allocate(interval, True)
+        staged = env.get("STAGED_ACTIONS")
+        commit = env.get("AGENT_MISC")[:, :, 4]
+        for i, o in enumerate(oracles):
+            oa, oi = o.allocate_mode(interval, 1, 2)
+            k = len(oa)
+            assert np.array_equal(aa[i][:k], oa) and np.all(aa[i][k:] == -1), f"{case} seed {i} t={t}: agents {aa[i]} vs {oa}"
+            assert np.array_equal(ai[i][:k], oi) and np.array_equal(staged[i][:k, 1], o.last_actions()[:, 1]), f"{case} seed {i} t={t}"
+            assert np.array_equal(commit[i][:env.n_agents], o.agent_commit_until()), f"{case} seed {i} t={t}: commit locks"
+            o.step(oa, oi)
+        env.step(aa, ai)
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"urgency-coalition {case} seed {i} t={t + 1}")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "urgcoal_metrics_*.npz"))),
+                         ids=lambda p: os.path.basename(p)[16:-4])
+def test_urgency_coalition_fused_rollout_matches_reference(path):
+    g = np.load(path)
+    case = os.path.basename(path)[16:-4]
+    want = g["metrics"]
+    n = want.shape[0]
+    env = _env(case, n)
+    env.set_allocator("urgency_coalition")
+    env.rollout(np.arange(n, dtype=np.uint64), 150, int(g["interval"]), True, True)
+    got = env.rollout_metrics()
+    assert np.all(env.get("ERROR") == 0)
+    assert np.array_equal(got, want), f"{case}: seeds {np.nonzero(~np.all(got == want, axis=1))[0][:8]} differ"
+    assert np.array_equal(env.get("SCALARS")[:, 23].astype(int), g["n_replans"])

@@ -233,3 +233,43 @@ def test_urgency_pair_metrics(path):
         assert e.rollout_mode(seed, 150, 20, 1, 1) == 150
         assert np.array_equal(e.metrics(), want), f"{case} seed {seed}"
         assert e.dims()["n_replans"] == int(g["n_replans"][seed])
+
+
+# ---- next row: Urgency-Coalition (AttentionEscort.py:714-767 under escort_eval._should_replan) ----
+URGCOAL_TRACES = [("WPS_escort", 0), ("WPS_escort", 1), ("WPS_escort24", 0), ("WPS_hard", 0)]
+
+
+@pytest.mark.parametrize("case,seed", URGCOAL_TRACES)
+def test_urgency_coalition_stepwise_vs_reference(case, seed):
+    g = np.load(os.path.join(GOLDEN, f"urgcoal_trace_{case}_s{seed}.npz"))
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(seed)
+    interval = int(g["interval"])
+    acts = g["actions"]
+    lsap_step, lsap_shape, lsap_cost = g["lsap_step"], g["lsap_shape"], g["lsap_cost"]
+    cost_off = np.concatenate([[0], np.cumsum(lsap_shape[:, 0] * lsap_shape[:, 1])])
+    for t in range(150):
+        aa, ai = e.allocate_mode(interval, True, 2)
+        exp = acts[acts[:, 0] == t]
+        assert sorted(zip(aa.tolist(), ai.tolist())) == sorted(zip(exp[:, 1].tolist(), exp[:, 3].tolist())), (case, seed, t)
+        shapes, costs, _, _ = e.lsap_calls()
+        k = np.nonzero(lsap_step == t)[0]
+        assert len(shapes) == len(k), (case, seed, t)
+        off = 0
+        for j, kk in enumerate(k):
+            nr, nc = shapes[j]
+            assert (nr, nc) == tuple(lsap_shape[kk])
+            np.testing.assert_array_equal(costs[off:off + nr * nc], lsap_cost[cost_off[kk]:cost_off[kk + 1]])
+            off += nr * nc
+        np.testing.assert_array_equal(e.agent_commit_until(), g["commit_until"][t])
+        e.step(aa, ai)
+    np.testing.assert_array_equal(e.metrics(), g["metrics"])
+
+
+@pytest.mark.parametrize("case", ["WPS_escort", "WPS_escort24", "WPS_hard"])
+def test_urgency_coalition_metrics_vs_reference(case):
+    g = np.load(os.path.join(GOLDEN, f"urgcoal_metrics_{case}.npz"))
+    e = orc.OracleEnv(params_for_case(case))
+    for s in range(g["metrics"].shape[0]):
+        e.rollout_mode(s, 150, int(g["interval"]), True, 2)
+        np.testing.assert_array_equal(e.metrics(), g["metrics"][s], err_msg=f"{case} seed {s}")

@@ -367,7 +367,7 @@ def main():
         print("metrics", case, np.stack(rows)[:, 4].mean())
 
 
-if __name__ == "__main__" and "--urgency-pair" not in sys.argv:
+if __name__ == "__main__" and "--urgency-pair" not in sys.argv and "--urgency-coalition" not in sys.argv:
     main()
 
 
@@ -429,3 +429,69 @@ def gen_urgency_pair():
 
 if __name__ == "__main__" and "--urgency-pair" in sys.argv:
     gen_urgency_pair()
+
+
+# ------------------------------------------------------------------------------------------------
+# Next row (second half): Urgency-Coalition — hand-crafted pair scores + commit locks
+# feeding the coalition Hungarian (TaskAllocation/Hybrid/AttentionEscort.py:46-57,714-767;
+# loop = experiments/escort_eval.py:52-58,175-180)
+# ------------------------------------------------------------------------------------------------
+def run_episode_urgency_coalition(case, seed, interval, full):
+    from TaskAllocation.Hybrid.AttentionEscort import UrgencyCoalition
+    from experiments.escort_eval import _apply_assign, _should_replan
+
+    env = make_env(case)
+    tap = LsapTap()
+    HA.linear_sum_assignment = tap
+    try:
+        obs, info = env.reset(seed=seed)
+        hung_force = HA.HungarianAllocator(replan_interval=10**9, max_coord=env.max_coord)
+        urg = UrgencyCoalition()
+        done = {a: False for a in env.agents}
+        trunc = {a: False for a in env.agents}
+        act_rows, commit_rows, latest = [], [], None
+        while not all(done.values()) and not all(trunc.values()):
+            events = _events(info)
+            actions = {}
+            tap.step = env.time_steps
+            if _should_replan(env, events, interval):
+                result = urg.plan(env, hung_force, events=events, force=True)
+                actions = _apply_assign(env, result)
+                for name, idx in actions.items():
+                    act_rows.append((env.time_steps, env.agent_by_name[name].id, env.last_tasks_info[idx].id, idx))
+            if full:
+                commit_rows.append([int(a.commit_until) for a in sorted(env.agents_obj, key=lambda u: u.id)])
+            obs, reward, done, trunc, info = env.step(actions)
+            if "metrics" in info:
+                latest = info["metrics"]
+    finally:
+        HA.linear_sum_assignment = linear_sum_assignment
+    out = {"metrics": np.array([float(latest[k]) for k in METRIC_KEYS]), "n_replans": np.int64(hung_force.n_replans),
+           "interval": np.int64(interval)}
+    if full:
+        out["actions"] = np.array(act_rows, dtype=np.int64).reshape(-1, 4)
+        out["commit_until"] = np.array(commit_rows, dtype=np.int64)       # per step, after plan(), before step()
+        out["lsap_step"] = np.array([c[0] for c in tap.calls], dtype=np.int64)
+        out["lsap_shape"] = np.array([c[1].shape for c in tap.calls], dtype=np.int64).reshape(-1, 2)
+        out["lsap_cost"] = np.concatenate([c[1].ravel() for c in tap.calls]) if tap.calls else np.zeros(0)
+    return out
+
+
+def gen_urgency_coalition():
+    for case, interval, full_seeds, n_metric in (("WPS_escort", 12, (0, 1), 24), ("WPS_escort24", 12, (0,), 8),
+                                                 ("WPS_hard", 12, (0,), 8)):
+        for s in full_seeds:
+            tr = run_episode_urgency_coalition(case, s, interval, True)
+            np.savez_compressed(os.path.join(OUT, f"urgcoal_trace_{case}_s{s}.npz"), **tr)
+            print("urgency-coalition trace", case, s, tr["metrics"][4], tr["metrics"][5])
+        rows, reps = [], []
+        for s in range(n_metric):
+            r = run_episode_urgency_coalition(case, s, interval, False)
+            rows.append(r["metrics"]); reps.append(int(r["n_replans"]))
+        np.savez_compressed(os.path.join(OUT, f"urgcoal_metrics_{case}.npz"), metrics=np.stack(rows),
+                            n_replans=np.array(reps, dtype=np.int64), interval=np.int64(interval), keys=np.array(METRIC_KEYS))
+        print("urgency-coalition metrics", case, np.stack(rows)[:, 5].mean())
+
+
+if __name__ == "__main__" and "--urgency-coalition" in sys.argv:
+    gen_urgency_coalition()
