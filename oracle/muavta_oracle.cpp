@@ -1347,6 +1347,214 @@ struct Env {
     if ((long long)time_steps - last_plan_step >= interval) return true;
     return !events.empty();  // every tag the env emits is in the allocator's trigger set
   }
+
+  // ---- token builders -------------------------------------------------------
+  // kind 0/1: build_pair_tokens = build_att_tokens (TaskAllocation/Hybrid/AttentionRAH.py:50-173; 1 = raw) + edge_valid
+  //           (PairCostHybrid.py:31-65);  kind 2: build_escort_tokens (AttentionEscort.py:76-243).
+  // Rows are [max_tasks, Dt] / [max_agents, Da] float32, masks 1 = padding, ids -1 = padding.
+  static void token_dims(int kind, int* dt, int* da) { *dt = kind == 0 ? 13 : kind == 1 ? 9 : 22; *da = kind == 0 ? 12 : kind == 1 ? 11 : 16; }
+  double task_urgency(const Task& t) const {  // _urgency (AttentionRAH.py:29-34)
+    if (!t.has_deadline) return 0.0;
+    int remaining = std::max(t.hard_deadline - time_steps, 0);
+    return 1.0 - std::fmin(remaining / 40.0, 1.0);
+  }
+  void threat_stats(const Task& t, double* pressure, double* dist_n, double* fighter_pressure) const {  // AttentionEscort.py:46-66
+    Vec anchor = t.pos;
+    if (t.protected_agent >= 0) anchor = agents[t.protected_agent].pos;
+    double best = max_coord;
+    int n_near = 0;
+    for (int hid : threats) {
+      const Threat& th = threats_all[hid];
+      if (th.status == 2) continue;
+      double d = norm2(th.pos.x - anchor.x, th.pos.y - anchor.y);
+      if (d < best) best = d;
+      if (d < 150.0) n_near++;
+    }
+    *pressure = 1.0 - std::fmin(best / max_coord, 1.0);
+    *dist_n = std::fmin(best / max_coord, 1.0);
+    *fighter_pressure = std::fmin(n_near / 4.0, 1.0);
+  }
+  int tokens(int kind, int max_tasks, int max_agents, float* task_feats, uint8_t* task_mask, int32_t* task_ids,
+             float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent_out) const {
+    int Dt, Da;
+    token_dims(kind, &Dt, &Da);
+    std::fill(task_feats, task_feats + (size_t)max_tasks * Dt, 0.0f);
+    std::fill(agent_feats, agent_feats + (size_t)max_agents * Da, 0.0f);
+    std::fill(edge_valid, edge_valid + (size_t)max_agents * max_tasks, 0.0f);
+    std::fill(task_mask, task_mask + max_tasks, (uint8_t)1);
+    std::fill(agent_mask, agent_mask + max_agents, (uint8_t)1);
+    std::fill(task_ids, task_ids + max_tasks, -1);
+    std::fill(agent_ids, agent_ids + max_agents, -1);
+    const bool vis = !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is not None
+    const double horizon = (double)std::max(P.max_time_steps, 1);
+    const double mid_x = AREA_W * 0.5;
+    const double URGENT = 1.0 - 12.0 / 40.0;
+    std::vector<int> live;
+    for (auto& a : agents) if (a.state != -1) live.push_back(a.id);
+    const int n_live = std::max((int)live.size(), 1);
+    std::vector<int> specialists;
+    for (int aid : live) if (agents[aid].type == MUAVTA_F2) specialists.push_back(aid);
+    auto d_spec_of = [&](const Task& t) {
+      if (specialists.empty()) return max_coord;
+      double best = 0; bool first = true;
+      for (int aid : specialists) {
+        double d = norm2(agents[aid].pos.x - t.pos.x, agents[aid].pos.y - t.pos.y);
+        if (first || d < best) { best = d; first = false; }
+      }
+      return best;
+    };
+    auto n_know_of = [&](const Task& t) { int n = 0; for (int b = 0; b < n_agents; b++) n += known[b][t.id] ? 1 : 0; return n; };
+    int n_urgent = 0;
+    std::vector<int> kept;
+    if (kind != 2) {
+      const bool raw = kind == 1;
+      std::vector<int> open_tasks;
+      for (size_t k = 1; k < tasks.size(); k++) {
+        const Task& t = tasks[k];
+        if (t.status != 2 && t.allocatedReqs[t.type] < t.currentReqs[t.type]) open_tasks.push_back((int)k);
+      }
+      for (size_t i = 0; i < open_tasks.size() && (int)i < max_tasks; i++) {
+        const Task& t = tasks[open_tasks[i]];
+        double urg = task_urgency(t);
+        double scar = vis ? 1.0 - std::fmin((double)n_know_of(t) / std::max(n_live, 1), 1.0) : 0.0;
+        double rem = std::fmax(t.currentReqs[t.type] - t.allocatedReqs[t.type], 0.0);
+        double is_dynamic = t.has_deadline ? 1.0 : 0.0;
+        if (urg >= URGENT && t.has_deadline) n_urgent++;
+        double n_know = vis ? (double)n_know_of(t) : 1.0;  // _known_by_count
+        double d_spec = d_spec_of(t);
+        double region = t.pos.x < mid_x ? 0.0 : 1.0;
+        float* f = task_feats + i * Dt;
+        int c = 0;
+        f[c++] = (float)(t.pos.x / max_coord); f[c++] = (float)(t.pos.y / max_coord); f[c++] = (float)((double)t.type / 8.0);
+        f[c++] = t.type == MUAVTA_ATT ? 1.f : 0.f; f[c++] = t.type == MUAVTA_REC ? 1.f : 0.f; f[c++] = t.type == MUAVTA_INT ? 1.f : 0.f;
+        if (raw) {
+          double t_left = !t.has_deadline ? 1.0 : std::fmin(std::max(t.hard_deadline - time_steps, 0) / horizon, 1.0);
+          f[c++] = (float)t_left; f[c++] = (float)std::fmin(rem / 4.0, 1.0); f[c++] = (float)is_dynamic;
+        } else {
+          f[c++] = (float)urg; f[c++] = (float)scar; f[c++] = (float)std::fmin(rem / 4.0, 1.0); f[c++] = (float)is_dynamic;
+          f[c++] = (float)std::fmin(n_know / std::max(n_live, 1), 1.0); f[c++] = (float)std::fmin(d_spec / max_coord, 1.0); f[c++] = (float)region;
+        }
+        task_mask[i] = 0; task_ids[i] = t.id; kept.push_back(t.id);
+      }
+      for (size_t i = 0; i < live.size() && (int)i < max_agents; i++) {
+        const UAV& a = agents[live[i]];
+        int n_known_urgent = 0;
+        for (int tid : open_tasks) {
+          const Task& t = tasks[tid];
+          if (vis && !known[a.id][tid]) continue;
+          if (task_urgency(t) >= URGENT && t.has_deadline) n_known_urgent++;
+        }
+        bool fighter = !is_recon(a.type);
+        float* f = agent_feats + i * Da;
+        int c = 0;
+        f[c++] = (float)(a.pos.x / max_coord); f[c++] = (float)(a.pos.y / max_coord); f[c++] = fighter ? 1.f : 0.f; f[c++] = fighter ? 0.f : 1.f;
+        f[c++] = (a.tasks.empty() || a.tasks[0] == 0) ? 1.f : 0.f;
+        f[c++] = (float)std::fmin(a.caps[2] / 2.0, 1.0); f[c++] = (float)std::fmin(a.caps[3] / 2.0, 1.0); f[c++] = (float)std::fmin(a.caps[1] / 2.0, 1.0);
+        f[c++] = (float)((double)a.state / 5.0); f[c++] = (float)((double)time_steps / horizon);
+        if (!raw) f[c++] = (float)std::fmin((double)n_known_urgent / (double)std::max((int)open_tasks.size(), 1), 1.0);
+        f[c++] = a.type == MUAVTA_F2 ? 1.f : 0.f;
+        agent_mask[i] = 0; agent_ids[i] = a.id;
+        for (size_t j = 0; j < kept.size(); j++) {  // build_pair_tokens edge_valid
+          const Task& t = tasks[kept[j]];
+          if (vis && !known[a.id][t.id]) continue;
+          if (t.has_eligible && !((t.eligible_mask >> a.type) & 1u)) continue;
+          if (a.caps[t.type] <= 0) continue;
+          edge_valid[i * max_tasks + j] = 1.0f;
+        }
+      }
+    } else {
+      std::vector<int> open_all;
+      for (size_t k = 1; k < tasks.size(); k++) if (tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_all.push_back((int)k);
+      std::vector<int> open_tasks;
+      if (!vis) open_tasks = open_all;
+      else {
+        for (int tid : open_all) { bool any = false; for (int aid : live) any |= known[aid][tid] != 0; if (any) open_tasks.push_back(tid); }
+        if (open_tasks.empty()) open_tasks = open_all;
+      }
+      std::vector<double> key(tasks.size(), 0.0);
+      for (int tid : open_tasks) {  // _task_priority_key (:69-74)
+        const Task& t = tasks[tid];
+        double pr, dn, fp;
+        threat_stats(t, &pr, &dn, &fp);
+        key[tid] = -(1.5 * task_urgency(t) + 1.2 * pr + 0.8 * (t.escort ? 1.0 : 0.0) + 0.5 * (t.type == MUAVTA_INT ? 1.0 : 0.0));
+      }
+      std::stable_sort(open_tasks.begin(), open_tasks.end(), [&](int x, int y) { return key[x] < key[y]; });
+      const double c_h = (double)std::max(P.commit_horizon ? P.commit_horizon : 20, 1);
+      for (size_t i = 0; i < open_tasks.size() && (int)i < max_tasks; i++) {
+        const Task& t = tasks[open_tasks[i]];
+        double urg = task_urgency(t);
+        double scar = vis ? 1.0 - std::fmin((double)n_know_of(t) / std::max(n_live, 1), 1.0) : 0.0;
+        double rem, req_agents;
+        if (is_escort_task(t)) {
+          double required = t.required_agents ? (double)t.required_agents : 1.0;
+          rem = std::fmax(required - (double)t.allocationDetails.size(), 0.0);
+          req_agents = required;
+        } else {
+          rem = std::fmax(t.currentReqs[t.type] - t.allocatedReqs[t.type], 0.0);
+          req_agents = 1.0;
+        }
+        double n_know = vis ? (double)n_know_of(t) : 0.0;
+        double d_spec = d_spec_of(t);
+        double deficit = std::fmin(rem / 4.0, 1.0);
+        double pr, dn, fp;
+        threat_stats(t, &pr, &dn, &fp);
+        double prot_x, prot_y, prot_alive = 0.0;
+        if (t.protected_agent >= 0) {
+          const UAV& pa = agents[t.protected_agent];
+          prot_x = pa.pos.x / max_coord; prot_y = pa.pos.y / max_coord; prot_alive = pa.state == -1 ? 0.0 : 1.0;
+        } else { prot_x = t.pos.x / max_coord; prot_y = t.pos.y / max_coord; }
+        float* f = task_feats + i * Dt;
+        int c = 0;
+        f[c++] = (float)(t.pos.x / max_coord); f[c++] = (float)(t.pos.y / max_coord); f[c++] = (float)((double)t.type / 8.0);
+        f[c++] = t.type == MUAVTA_ATT ? 1.f : 0.f; f[c++] = t.type == MUAVTA_REC ? 1.f : 0.f; f[c++] = t.type == MUAVTA_INT ? 1.f : 0.f;
+        f[c++] = (float)urg; f[c++] = (float)scar; f[c++] = (float)deficit; f[c++] = t.has_deadline ? 1.f : 0.f;
+        f[c++] = (float)std::fmin(n_know / std::max(n_live, 1), 1.0); f[c++] = (float)std::fmin(d_spec / max_coord, 1.0);
+        f[c++] = t.pos.x < mid_x ? 0.f : 1.f; f[c++] = t.escort ? 1.f : 0.f; f[c++] = (float)deficit; f[c++] = (float)pr;
+        f[c++] = (float)prot_x; f[c++] = (float)prot_y; f[c++] = (float)std::fmin(req_agents / 4.0, 1.0); f[c++] = (float)dn;
+        f[c++] = (float)prot_alive; f[c++] = (float)fp;
+        task_mask[i] = 0; task_ids[i] = t.id; kept.push_back(t.id);
+      }
+      for (size_t i = 0; i < live.size() && (int)i < max_agents; i++) {
+        const UAV& a = agents[live[i]];
+        int n_known_urgent = 0, n_known_tasks = 0;
+        if (vis) for (size_t k = 0; k < tasks.size(); k++) n_known_tasks += known[a.id][k] ? 1 : 0;  // len(known_ids), retired ids included
+        for (int tid : open_all) {
+          const Task& t = tasks[tid];
+          if (vis && !known[a.id][tid]) continue;
+          if (task_urgency(t) >= URGENT && t.has_deadline) n_known_urgent++;
+        }
+        double is_escorting = 0.0, dist_prot = 1.0, near_escort = 0.0;
+        if (!a.tasks.empty() && a.tasks[0] != 0 && tasks[a.tasks[0]].escort) {
+          is_escorting = 1.0;
+          int pa = tasks[a.tasks[0]].protected_agent;
+          if (pa >= 0) {
+            dist_prot = std::fmin(norm2(a.pos.x - agents[pa].pos.x, a.pos.y - agents[pa].pos.y) / max_coord, 1.0);
+            near_escort = 1.0 - dist_prot;
+          }
+        }
+        double rem_commit = std::fmax((double)a.commit_until - (double)time_steps, 0.0);
+        bool fighter = !is_recon(a.type);
+        float* f = agent_feats + i * Da;
+        int c = 0;
+        f[c++] = (float)(a.pos.x / max_coord); f[c++] = (float)(a.pos.y / max_coord); f[c++] = fighter ? 1.f : 0.f; f[c++] = fighter ? 0.f : 1.f;
+        f[c++] = (a.tasks.empty() || a.tasks[0] == 0) ? 1.f : 0.f;
+        f[c++] = (float)std::fmin(a.caps[2] / 2.0, 1.0); f[c++] = (float)std::fmin(a.caps[3] / 2.0, 1.0); f[c++] = (float)std::fmin(a.caps[1] / 2.0, 1.0);
+        f[c++] = (float)((double)a.state / 5.0); f[c++] = (float)((double)time_steps / horizon);
+        f[c++] = (float)std::fmin(n_known_urgent / 8.0, 1.0); f[c++] = a.type == MUAVTA_F2 ? 1.f : 0.f;
+        f[c++] = (float)is_escorting; f[c++] = (float)dist_prot; f[c++] = (float)std::fmin(rem_commit / c_h, 1.0);
+        f[c++] = (float)std::fmin(near_escort + n_known_tasks / 16.0, 1.0);
+        agent_mask[i] = 0; agent_ids[i] = a.id;
+        for (size_t j = 0; j < kept.size(); j++) {
+          const Task& t = tasks[kept[j]];
+          if (vis && !known[a.id][t.id]) continue;
+          if (t.has_eligible && !((t.eligible_mask >> a.type) & 1u)) continue;
+          edge_valid[i * max_tasks + j] = 1.0f;
+        }
+      }
+    }
+    if (n_urgent_out) *n_urgent_out = n_urgent;
+    return (int)kept.size();
+  }
   // returns number of (agent, task) actions; also fills act_agent/act_index as _apply_assign would
   // mode 0: Local-/Global-/Coalition-Hungarian as driven by run_wps_episode / run_escort_episode.
   // mode 1: Urgency-Pair (TaskAllocation/Hybrid/PairCostHybrid.py:31-86,520-550 + experiments/wps_eval.py:64-74,
@@ -1541,6 +1749,10 @@ int orc_step(void* h, int n_act, const int32_t* act_agent, const int32_t* act_in
 }
 int orc_allocate(void* h, int interval, int use_vis, int32_t* act_agent, int32_t* act_index, int cap) {
   return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap);
+}
+int orc_tokens(void* h, int kind, int max_tasks, int max_agents, float* task_feats, uint8_t* task_mask, int32_t* task_ids,
+               float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent) {
+  return ((Env*)h)->tokens(kind, max_tasks, max_agents, task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent);
 }
 int orc_allocate_mode(void* h, int interval, int use_vis, int mode, int32_t* act_agent, int32_t* act_index, int cap) {
   return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap, mode);

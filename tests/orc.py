@@ -94,6 +94,20 @@ class OracleEnv:
         self.L.orc_get_agents(self.h, _p(rows), _p(caps), _p(q), self.QCAP)
         return rows, caps, q
 
+    def tokens(self, kind, max_tasks, max_agents):
+        """kind 0 pair tokens, 1 raw pair tokens, 2 escort tokens -> dict of arrays (reference layout)."""
+        dt, da = {0: (13, 12), 1: (9, 11), 2: (22, 16)}[kind]
+        out = {"task_feats": np.zeros((max_tasks, dt), np.float32), "task_mask": np.ones(max_tasks, np.uint8),
+               "task_ids": np.full(max_tasks, -1, np.int32), "agent_feats": np.zeros((max_agents, da), np.float32),
+               "agent_mask": np.ones(max_agents, np.uint8), "agent_ids": np.full(max_agents, -1, np.int32),
+               "edge_valid": np.zeros((max_agents, max_tasks), np.float32)}
+        nu = np.zeros(1, np.int32)
+        self.L.orc_tokens(self.h, int(kind), int(max_tasks), int(max_agents), _p(out["task_feats"]), _p(out["task_mask"]),
+                          _p(out["task_ids"]), _p(out["agent_feats"]), _p(out["agent_mask"]), _p(out["agent_ids"]),
+                          _p(out["edge_valid"]), _p(nu))
+        out["n_urgent"] = int(nu[0])
+        return out
+
     def agent_commit_until(self):
         c = np.zeros(self.A, dtype=np.int32)
         self.L.orc_get_commit(self.h, _p(c))

@@ -273,3 +273,39 @@ def test_urgency_coalition_metrics_vs_reference(case):
     for s in range(g["metrics"].shape[0]):
         e.rollout_mode(s, 150, int(g["interval"]), True, 2)
         np.testing.assert_array_equal(e.metrics(), g["metrics"][s], err_msg=f"{case} seed {s}")
+
+
+# ---- next row: token builders (build_pair_tokens / raw / build_escort_tokens) ----------------------------------
+TOKEN_FILES = sorted(glob.glob(os.path.join(GOLDEN, "tokens_*.npz")))
+
+
+def check_tokens(tok_of, g, k, where):
+    """tok_of(kind, max_tasks, max_agents) -> dict; compared bit for bit with the reference's arrays at sample k."""
+    p = tok_of(0, 32, 16)
+    for name, key in (("task_feats", "p_tf"), ("task_mask", "p_tm"), ("task_ids", "p_tid"), ("agent_feats", "p_af"),
+                      ("agent_mask", "p_am"), ("agent_ids", "p_aid"), ("edge_valid", "p_ev")):
+        assert np.array_equal(np.asarray(p[name]).astype(g[key].dtype), g[key][k]), f"{where}: pair {name}"
+    assert p["n_urgent"] == int(g["p_nurg"][k]), f"{where}: n_urgent"
+    r = tok_of(1, 32, 16)
+    for name, key in (("task_feats", "r_tf"), ("agent_feats", "r_af"), ("edge_valid", "r_ev")):
+        assert np.array_equal(r[name], g[key][k]), f"{where}: raw {name}"
+    e = tok_of(2, int(g["e_max_tasks"]), int(g["e_max_agents"]))
+    for name, key in (("task_feats", "e_tf"), ("task_mask", "e_tm"), ("task_ids", "e_tid"), ("agent_feats", "e_af"),
+                      ("agent_mask", "e_am"), ("agent_ids", "e_aid"), ("edge_valid", "e_ev")):
+        got, want = np.asarray(e[name]).astype(g[key].dtype), g[key][k]
+        assert np.array_equal(got, want), f"{where}: escort {name}: {np.argwhere(got != want)[:4].tolist()}"
+
+
+@pytest.mark.parametrize("path", TOKEN_FILES, ids=[os.path.basename(p)[7:-4] for p in TOKEN_FILES])
+def test_token_builders_vs_reference(path):
+    g = np.load(path)
+    case = os.path.basename(path)[7:-4]
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(int(g["seed"]))
+    mode = 2 if str(g["driver"]) == "urgcoal" else 0
+    steps = g["step"].tolist()
+    for t in range(150):
+        aa, ai = e.allocate_mode(int(g["interval"]), 1, mode)
+        if t in steps:
+            check_tokens(e.tokens, g, steps.index(t), f"{case} t={t}")
+        e.step(aa, ai)

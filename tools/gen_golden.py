@@ -367,7 +367,7 @@ def main():
         print("metrics", case, np.stack(rows)[:, 4].mean())
 
 
-if __name__ == "__main__" and "--urgency-pair" not in sys.argv and "--urgency-coalition" not in sys.argv:
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens")):
     main()
 
 
@@ -495,3 +495,73 @@ def gen_urgency_coalition():
 
 if __name__ == "__main__" and "--urgency-coalition" in sys.argv:
     gen_urgency_coalition()
+
+
+# ------------------------------------------------------------------------------------------------
+# Next row: token builders — build_pair_tokens (= build_att_tokens + edge_valid), raw variant,
+# build_escort_tokens; sampled along reference episodes (driver: Local-Hungarian, or Urgency-Coalition so that
+# commit locks are live)
+# ------------------------------------------------------------------------------------------------
+def gen_tokens():
+    from TaskAllocation.Hybrid.AttentionEscort import UrgencyCoalition, build_escort_tokens
+    from TaskAllocation.Hybrid.PairCostHybrid import build_pair_tokens
+    from experiments.escort_eval import _apply_assign as esc_apply, _should_replan as esc_should
+
+    plan = [("WPS_hard", 0, "hungarian", 20, 32, 16), ("WPS_attn", 0, "hungarian", 20, 32, 16), ("WPS_hard_x2", 1, "hungarian", 20, 32, 16),
+            ("WPS_escort", 0, "urgcoal", 12, 48, 16), ("WPS_escort24", 0, "urgcoal", 12, 48, 16), ("WPS_burst64", 0, "hungarian", 20, 32, 16),
+            ("WPS_easy", 2, "hungarian", 20, 32, 16)]
+    for case, seed, driver, interval, mt_e, ma in plan:
+        env = make_env(case)
+        obs, info = env.reset(seed=seed)
+        hung = HA.HungarianAllocator(replan_interval=interval if driver == "hungarian" else 10**9, max_coord=env.max_coord)
+        urg = UrgencyCoalition()
+        done = {a: False for a in env.agents}
+        trunc = {a: False for a in env.agents}
+        rec = {k: [] for k in ("step", "p_tf", "p_tm", "p_tid", "p_af", "p_am", "p_aid", "p_ev", "p_nurg",
+                               "r_tf", "r_af", "r_ev", "e_tf", "e_tm", "e_tid", "e_af", "e_am", "e_aid", "e_ev")}
+
+        def ids_of(tok, n):
+            out = np.full(n, -1, dtype=np.int64)
+            out[:len(tok["task_ids"])] = tok["task_ids"]
+            return out
+
+        def aids_of(tok, n):
+            out = np.full(n, -1, dtype=np.int64)
+            live = tok["live"][:n]
+            out[:len(live)] = [a.id for a in live]
+            return out
+
+        while not all(done.values()) and not all(trunc.values()):
+            events = _events(info)
+            if driver == "hungarian":
+                result = hung.allocate_tasks(env.get_live_agents(), _open_tasks(env), time_step=env.time_steps, events=events,
+                                             agent_known_ids=env.agent_visibility_map())
+                actions = {}
+                for name, task in result:
+                    if env.last_tasks_info and task in env.last_tasks_info and name not in actions:
+                        actions[name] = env.last_tasks_info.index(task)
+            else:
+                actions = {}
+                if esc_should(env, events, interval):
+                    actions = esc_apply(env, urg.plan(env, hung, events=events, force=True))
+            if env.time_steps % 3 == 0 or env.time_steps in (1, 149):  # after plan() (commit locks set), before step()
+                p = build_pair_tokens(env, 32, 16)
+                r = build_pair_tokens(env, 32, 16, raw=True)
+                e = build_escort_tokens(env, mt_e, ma)
+                rec["step"].append(env.time_steps)
+                rec["p_tf"].append(p["task_feats"]); rec["p_tm"].append(p["task_mask"]); rec["p_tid"].append(ids_of(p, 32))
+                rec["p_af"].append(p["agent_feats"]); rec["p_am"].append(p["agent_mask"]); rec["p_aid"].append(aids_of(p, 16))
+                rec["p_ev"].append(p["edge_valid"]); rec["p_nurg"].append(p["n_urgent"])
+                rec["r_tf"].append(r["task_feats"]); rec["r_af"].append(r["agent_feats"]); rec["r_ev"].append(r["edge_valid"])
+                rec["e_tf"].append(e["task_feats"]); rec["e_tm"].append(e["task_mask"]); rec["e_tid"].append(ids_of(e, mt_e))
+                rec["e_af"].append(e["agent_feats"]); rec["e_am"].append(e["agent_mask"]); rec["e_aid"].append(aids_of(e, ma))
+                rec["e_ev"].append(e["edge_valid"])
+            obs, reward, done, trunc, info = env.step(actions)
+        out = {k: np.stack([np.asarray(x) for x in v]) for k, v in rec.items()}
+        out.update(driver=np.array(driver), interval=np.int64(interval), seed=np.int64(seed), e_max_tasks=np.int64(mt_e), e_max_agents=np.int64(ma))
+        np.savez_compressed(os.path.join(OUT, f"tokens_{case}.npz"), **out)
+        print("tokens", case, out["p_tf"].shape, out["e_tf"].shape, float(out["e_af"][:, :, 15].min()), float(out["e_af"][:, :, 14].max()))
+
+
+if __name__ == "__main__" and "--tokens" in sys.argv:
+    gen_tokens()
