@@ -208,6 +208,25 @@ int muavta_step_staged(MuavtaEnv* env); /* step with the actions muavta_allocate
 enum { MUAVTA_ALLOC_HUNGARIAN = 0, MUAVTA_ALLOC_URGENCY_PAIR = 1, MUAVTA_ALLOC_URGENCY_COALITION = 2 };
 int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
 
+/* Token builders of the learned/engineered hybrids, batched over all envs straight from the device state
+ * (SURVEY §8f rank 2).  kind:
+ *   MUAVTA_TOK_PAIR      build_pair_tokens(env, max_tasks, max_agents)            task 13, agent 12 features
+ *   MUAVTA_TOK_PAIR_RAW  build_pair_tokens(env, max_tasks, max_agents, raw=True)  task  9, agent 11
+ *       (= build_att_tokens + edge_valid; TaskAllocation/Hybrid/AttentionRAH.py:50-173, PairCostHybrid.py:31-65)
+ *   MUAVTA_TOK_ESCORT    build_escort_tokens(env, max_tasks, max_agents)          task 22, agent 16
+ *       (TaskAllocation/Hybrid/AttentionEscort.py:76-243; rows sorted by _task_priority_key, :69-74)
+ * Outputs, reference layout and dtype, one block per env: task_feats f32 [N, max_tasks, Dt]; task_mask u8 [N, max_tasks]
+ * (1 = padding); task_ids i32 [N, max_tasks] (-1 = padding; tok["task_ids"]); agent_feats f32 [N, max_agents, Da];
+ * agent_mask u8 [N, max_agents]; agent_ids i32 [N, max_agents] (UAV.id of tok["live"][i], -1 = padding); edge_valid f32
+ * [N, max_agents, max_tasks]; n_urgent i32 [N] (tok["n_urgent"], 0 for MUAVTA_TOK_ESCORT; may be NULL).
+ * muavta_tokens copies into host buffers (NULL = skip that output) and synchronises; muavta_tokens_device writes to
+ * device buffers of the caller (e.g. torch tensors on the same GPU) on the handle's stream without synchronising. */
+enum { MUAVTA_TOK_PAIR = 0, MUAVTA_TOK_PAIR_RAW = 1, MUAVTA_TOK_ESCORT = 2 };
+int muavta_tokens(MuavtaEnv* env, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
+                  int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent);
+int muavta_tokens_device(MuavtaEnv* env, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
+                         int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent);
+
 /* The measured path: reset(seeds) followed by n_steps x (allocate -> step) fused in ONE kernel
  * launch, state resident in LDS (run_wps_episode / run_escort_episode with Local-/Coalition-
  * Hungarian, experiments/wps_eval.py:76-291, experiments/escort_eval.py:86-226).  seeds == NULL

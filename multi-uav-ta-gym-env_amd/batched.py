@@ -100,6 +100,34 @@ class BatchedMultiUAVEnv:
         'urgency_coalition' (UrgencyCoalition.plan under the escort harness gate, with commit locks)."""
         self._ck(self.L.muavta_set_allocator(self.h, {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2}[name]))
 
+    TOKEN_KINDS = {"pair": (0, 13, 12), "pair_raw": (1, 9, 11), "escort": (2, 22, 16)}
+
+    def tokens(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16, out=None):
+        """Batched token builders of the hybrids, from the device state: `build_pair_tokens` ('pair', 'pair_raw') /
+        `build_escort_tokens` ('escort') of the reference for every env at once (PairCostHybrid.py:31-65,
+        AttentionRAH.py:50-173, AttentionEscort.py:76-243).  Returns numpy arrays in the reference's layout, or — with
+        `out` = dict of CUDA torch tensors of the right shapes/dtypes (float32 / uint8 / int32) — fills those in place
+        on the handle's stream without a host copy."""
+        k, dt, da = self.TOKEN_KINDS[kind]
+        mt = int(max_tasks if max_tasks is not None else (48 if kind == "escort" else 32))
+        ma = int(max_agents)
+        N = self.n_envs
+        shapes = {"task_feats": ((N, mt, dt), np.float32), "task_mask": ((N, mt), np.uint8), "task_ids": ((N, mt), np.int32),
+                  "agent_feats": ((N, ma, da), np.float32), "agent_mask": ((N, ma), np.uint8), "agent_ids": ((N, ma), np.int32),
+                  "edge_valid": ((N, ma, mt), np.float32), "n_urgent": ((N,), np.int32)}
+        if out is not None:
+            ptrs = []
+            for name, (shape, dtype) in shapes.items():
+                t = out[name]
+                if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != np.dtype(dtype).itemsize:
+                    raise ValueError(f"tokens(out=...): {name} must be a contiguous CUDA tensor of shape {shape}, {np.dtype(dtype).name}")
+                ptrs.append(C.c_void_p(t.data_ptr()))
+            self._ck(self.L.muavta_tokens_device(self.h, k, mt, ma, *ptrs))
+            return out
+        arrs = {name: np.empty(shape, dtype=dtype) for name, (shape, dtype) in shapes.items()}
+        self._ck(self.L.muavta_tokens(self.h, k, mt, ma, *[_vp(a) for a in arrs.values()]))
+        return arrs
+
     def step_staged(self):
         self._ck(self.L.muavta_step_staged(self.h))
 

@@ -443,10 +443,21 @@ struct Sim {
     int h = S.t_threat[s];
     if (h >= 0) { S.h_tflags[h] = S.t_flags[s] & (TF_DEADLINE | TF_COUNTED); S.h_tdeadline[h] = S.t_deadline[s]; }
     if (S.t_bucket[s] == 0) atomicAdd(&S.n_retired_empty_buckets, 1);
+    const int id = S.t_id[s];
     S.t_id[s] = -1;
     // leave the slot clean for its next tenant: nobody knows it, it is on the free list (atomics: several
-    // lanes release different slots of the same word in the end-of-step GC)
-    for (int a = 0; a < P.n_agents; a++) atomicAnd(&S.known[a][s >> 5], ~(1u << (s & 31)));
+    // lanes release different slots of the same word in the end-of-step GC).  agent_known_tasks keeps the ids
+    // of retired tasks and the token builders read len(known_ids): count them per agent, and leave the knower
+    // set with a reveal that is still pending for this id (_wps_process_reveals adds the id to every set).
+    unsigned long long knowers = 0;
+    for (int a = 0; a < P.n_agents; a++) {
+      const uint32_t old = atomicAnd(&S.known[a][s >> 5], ~(1u << (s & 31)));
+      if ((old >> (s & 31)) & 1u) { atomicAdd(&S.a_gone[a], 1); knowers |= 1ull << a; }
+    }
+    // a reveal can only be pending while t < created_at + threat_delay (registered at creation, :1491-1501)
+    if (P.share_knowledge && S.t_created[s] > 0 && S.time_steps <= S.t_created[s] + (P.threat_delay > 0 ? P.threat_delay : 0) + 1)
+      for (int k = 0; k < S.n_pending; k++)
+        if (S.pend_slot[k] == s && S.pend_id[k] == id) S.pend_know[k] = (typename KnowMask<A>::type)knowers;
     atomicOr(&S.free_slots[s >> 5], 1u << (s & 31));
   }
   DEV int reclaim_slot_serial() {
@@ -499,7 +510,8 @@ struct Sim {
       if (n >= R) { fail(MUAVTA_ERR_PENDING); return; }
       S.pend_time[n] = S.time_steps + (P.threat_delay > 0 ? P.threat_delay : 0);
       S.pend_id[n] = S.t_id[s];
-      S.pend_slot[n] = s;
+      S.pend_slot[n] = (uint8_t)s;
+      S.pend_know[n] = 0;
       S.n_pending = n + 1;
     } else {
       know_all(s);
@@ -1779,9 +1791,13 @@ struct Sim {
       int w = 0;
       for (int k = 0; k < S.n_pending; k++) {
         if (S.time_steps >= S.pend_time[k]) {
-          if (P.share_knowledge && ref_valid(S.pend_id[k], S.pend_slot[k])) know_all(S.pend_slot[k]);
+          if (P.share_knowledge) {
+            if (ref_valid(S.pend_id[k], S.pend_slot[k])) know_all(S.pend_slot[k]);
+            else  // released before the reveal: the id still joins the set of everyone who had not sensed it
+              for (int a = 0; a < P.n_agents; a++) S.a_gone[a] += !((S.pend_know[k] >> a) & 1);
+          }
         } else {
-          S.pend_time[w] = S.pend_time[k]; S.pend_id[w] = S.pend_id[k]; S.pend_slot[w] = S.pend_slot[k];
+          S.pend_time[w] = S.pend_time[k]; S.pend_id[w] = S.pend_id[k]; S.pend_slot[w] = S.pend_slot[k]; S.pend_know[w] = S.pend_know[k];
           w++;
         }
       }
@@ -2227,6 +2243,239 @@ struct Sim {
       S.n_replans++;
     }
     lds_sync();
+  }
+
+  // ====================================================================================================
+  // Token builders: build_pair_tokens = build_att_tokens + edge_valid
+  // (TaskAllocation/Hybrid/AttentionRAH.py:50-173, PairCostHybrid.py:31-65; kind 0, kind 1 = raw) and
+  // build_escort_tokens (AttentionEscort.py:76-243; kind 2).  One token row per lane; every value is formed in
+  // f64 in the reference's order and rounded to f32 once, like `np.float32` array assignment.
+  // Rows: task_feats [max_tasks, Dt], agent_feats [max_agents, Da], edge_valid [max_agents, max_tasks]; masks 1 = pad.
+  // ====================================================================================================
+  struct TokPtrs {
+    float* task_feats; uint8_t* task_mask; int32_t* task_ids; float* agent_feats; uint8_t* agent_mask; int32_t* agent_ids;
+    float* edge_valid; int32_t* n_urgent;
+    int kind, max_tasks, max_agents;
+  };
+  DEV double slot_urgency(int s) const {  // _urgency (AttentionRAH.py:29-34)
+    if (!(S.t_flags[s] & TF_DEADLINE)) return 0.0;
+    int remaining = S.t_deadline[s] - S.time_steps;
+    remaining = remaining > 0 ? remaining : 0;
+    return 1.0 - fmin((double)remaining / 40.0, 1.0);
+  }
+  DEV void threat_stats(int s, double& pressure, double& dist_n, double& fighter_pressure) const {  // AttentionEscort.py:46-66
+    const int pa = S.t_prot_agent[s];
+    const double ax = pa >= 0 ? S.a_px[pa] : S.t_px[s], ay = pa >= 0 ? S.a_py[pa] : S.t_py[s];
+    double best = MAX_COORD;
+    int n_near = 0;
+    for (int k = 0; k < S.n_active_threats; k++) {
+      const int h = S.h_order[k];
+      if (S.h_status[h] == 2) continue;
+      const double d = norm2(S.h_px[h] - ax, S.h_py[h] - ay);
+      if (d < best) best = d;
+      n_near += d < 150.0;
+    }
+    pressure = 1.0 - fmin(best / MAX_COORD, 1.0);
+    dist_n = fmin(best / MAX_COORD, 1.0);
+    fighter_pressure = fmin((double)n_near / 4.0, 1.0);
+  }
+  DEV void tokens(const TokPtrs& K, int env) {
+    const int kind = K.kind, MT = K.max_tasks, MA = K.max_agents;
+    const int Dt = kind == 0 ? 13 : kind == 1 ? 9 : 22, Da = kind == 0 ? 12 : kind == 1 ? 11 : 16;
+    float* o_tf = K.task_feats + (size_t)env * MT * Dt;
+    uint8_t* o_tm = K.task_mask + (size_t)env * MT;
+    int32_t* o_tid = K.task_ids + (size_t)env * MT;
+    float* o_af = K.agent_feats + (size_t)env * MA * Da;
+    uint8_t* o_am = K.agent_mask + (size_t)env * MA;
+    int32_t* o_aid = K.agent_ids + (size_t)env * MA;
+    float* o_ev = K.edge_valid + (size_t)env * MA * MT;
+    const bool vis = !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is not None
+    const double horizon = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1);
+    const double mid_x = AREA_W * 0.5;
+    const double URGENT = 1.0 - 12.0 / 40.0;
+    // live agents (get_live_agents order) and the F2 specialists among them
+    const int n_live_raw = compact_to(X.freeA, P.n_agents, [&](int a) { return S.a_state[a] != -1; }, [&](int a) { return a; });
+    const int n_spec = compact_to(X.col4row, P.n_agents, [&](int a) { return S.a_state[a] != -1 && S.a_type[a] == MUAVTA_F2; }, [&](int a) { return a; });
+    const int n_live = n_live_raw > 1 ? n_live_raw : 1;
+    // open_all (env.tasks order): underfilled tasks (kind 0/1) or _open_tasks_residual (kind 2)
+    int n_all = compact_to(X.roundT, S.n_order,
+                           [&](int k) {
+                             const int s = S.t_order[k];
+                             if (S.t_status[s] == 2) return false;
+                             if (kind == 2) return residual_demand(s) > 0;
+                             const int ty = S.t_type[s];
+                             return S.t_alloc[ty][s] < S.t_cur[ty][s];
+                           },
+                           [&](int k) { return S.t_order[k]; });
+    lds_sync();
+    // per open task: urgent-and-windowed flag (for the agents' n_known_urgent), known-by count
+    for (int k = lane; k < n_all; k += WG) {
+      const int s = X.roundT[k];
+      X.SC[k] = (slot_urgency(s) >= URGENT && (S.t_flags[s] & TF_DEADLINE)) ? 1 : 0;
+    }
+    lds_sync();
+    int32_t* list = X.roundT;  // the token rows' task list
+    int n_list = n_all;
+    if (kind == 2) {
+      if (vis) {  // local task set: known by at least one live agent; all of open_all if that leaves nothing
+        const int n_loc = compact_to(X.remaining, n_all,
+                                     [&](int k) {
+                                       const int s = X.roundT[k];
+                                       bool any = false;
+                                       for (int i = 0; i < n_live_raw; i++) any |= (S.known[X.freeA[i]][s >> 5] >> (s & 31)) & 1u;
+                                       return any;
+                                     },
+                                     [&](int k) { return X.roundT[k]; });
+        lds_sync();
+        if (n_loc > 0) n_list = n_loc;
+        else for (int k = lane; k < n_all; k += WG) X.remaining[k] = X.roundT[k];
+      } else {
+        for (int k = lane; k < n_all; k += WG) X.remaining[k] = X.roundT[k];
+      }
+      lds_sync();
+      // stable sort by _task_priority_key (:69-74): rank = number of entries that sort before this one
+      for (int k = lane; k < n_list; k += WG) {
+        const int s = X.remaining[k];
+        double pr, dn, fp;
+        threat_stats(s, pr, dn, fp);
+        X.spc[k] = -(1.5 * slot_urgency(s) + 1.2 * pr + 0.8 * ((S.t_flags[s] & TF_ESCORT) ? 1.0 : 0.0) + 0.5 * (S.t_type[s] == MUAVTA_INT ? 1.0 : 0.0));
+      }
+      lds_sync();
+      for (int k = lane; k < n_list; k += WG) {
+        const double key = X.spc[k];
+        int rank = 0;
+        for (int j = 0; j < n_list; j++) rank += (X.spc[j] < key) || (X.spc[j] == key && j < k);
+        X.path[rank] = X.remaining[k];
+      }
+      lds_sync();
+      list = X.path;
+    }
+    const int n_kept = n_list < MT ? n_list : MT;
+    // ---- task rows ----
+    int n_urgent = 0;
+    for (int base = 0; base < MT; base += WG) {
+      const int i = base + lane;
+      bool urgent = false;
+      if (i < MT) {
+        float* f = o_tf + (size_t)i * Dt;
+        if (i < n_kept) {
+          const int s = list[i];
+          const int ty = S.t_type[s];
+          const double urg = slot_urgency(s);
+          int n_know_i = 0;
+          for (int b = 0; b < P.n_agents; b++) n_know_i += (S.known[b][s >> 5] >> (s & 31)) & 1u;
+          const double scar = vis ? 1.0 - fmin((double)n_know_i / (double)n_live, 1.0) : 0.0;
+          const bool dyn = (S.t_flags[s] & TF_DEADLINE) != 0;
+          double d_spec = MAX_COORD;
+          for (int q = 0; q < n_spec; q++) {
+            const int a = X.col4row[q];
+            const double d = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
+            if (q == 0 || d < d_spec) d_spec = d;
+          }
+          int c = 0;
+          f[c++] = (float)(S.t_px[s] / MAX_COORD); f[c++] = (float)(S.t_py[s] / MAX_COORD); f[c++] = (float)((double)ty / 8.0);
+          f[c++] = ty == MUAVTA_ATT ? 1.f : 0.f; f[c++] = ty == MUAVTA_REC ? 1.f : 0.f; f[c++] = ty == MUAVTA_INT ? 1.f : 0.f;
+          if (kind != 2) {
+            const double rem = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+            urgent = urg >= URGENT && dyn;
+            if (kind == 1) {
+              int left = S.t_deadline[s] - S.time_steps;
+              left = left > 0 ? left : 0;
+              f[c++] = (float)(dyn ? fmin((double)left / horizon, 1.0) : 1.0);
+              f[c++] = (float)fmin(rem / 4.0, 1.0); f[c++] = dyn ? 1.f : 0.f;
+            } else {
+              const double n_know = vis ? (double)n_know_i : 1.0;  // _known_by_count
+              f[c++] = (float)urg; f[c++] = (float)scar; f[c++] = (float)fmin(rem / 4.0, 1.0); f[c++] = dyn ? 1.f : 0.f;
+              f[c++] = (float)fmin(n_know / (double)n_live, 1.0); f[c++] = (float)fmin(d_spec / MAX_COORD, 1.0);
+              f[c++] = S.t_px[s] < mid_x ? 0.f : 1.f;
+            }
+          } else {
+            double rem, req_agents = 1.0;
+            if (is_escort_task(s)) {
+              req_agents = S.t_required[s] ? (double)S.t_required[s] : 1.0;
+              rem = fmax(req_agents - (double)S.t_ndet[s], 0.0);
+            } else rem = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+            const double n_know = vis ? (double)n_know_i : 0.0;
+            const double deficit = fmin(rem / 4.0, 1.0);
+            double pr, dn, fp;
+            threat_stats(s, pr, dn, fp);
+            const int pa = S.t_prot_agent[s];
+            const double prot_x = (pa >= 0 ? S.a_px[pa] : S.t_px[s]) / MAX_COORD, prot_y = (pa >= 0 ? S.a_py[pa] : S.t_py[s]) / MAX_COORD;
+            const float prot_alive = (pa >= 0 && S.a_state[pa] != -1) ? 1.f : 0.f;
+            f[c++] = (float)urg; f[c++] = (float)scar; f[c++] = (float)deficit; f[c++] = dyn ? 1.f : 0.f;
+            f[c++] = (float)fmin(n_know / (double)n_live, 1.0); f[c++] = (float)fmin(d_spec / MAX_COORD, 1.0);
+            f[c++] = S.t_px[s] < mid_x ? 0.f : 1.f; f[c++] = (S.t_flags[s] & TF_ESCORT) ? 1.f : 0.f; f[c++] = (float)deficit; f[c++] = (float)pr;
+            f[c++] = (float)prot_x; f[c++] = (float)prot_y; f[c++] = (float)fmin(req_agents / 4.0, 1.0); f[c++] = (float)dn;
+            f[c++] = prot_alive; f[c++] = (float)fp;
+          }
+          o_tm[i] = 0; o_tid[i] = S.t_id[s];
+        } else {
+          for (int c = 0; c < Dt; c++) f[c] = 0.f;
+          o_tm[i] = 1; o_tid[i] = -1;
+        }
+      }
+      n_urgent += __popcll(__ballot(urgent));
+    }
+    if (lane == 0 && K.n_urgent) K.n_urgent[env] = n_urgent;
+    // ---- agent rows + edge_valid ----
+    for (int i = lane; i < MA; i += WG) {
+      float* f = o_af + (size_t)i * Da;
+      float* ev = o_ev + (size_t)i * MT;
+      if (i < n_live_raw) {
+        const int a = X.freeA[i];
+        int n_known_urgent = 0;
+        for (int k = 0; k < n_all; k++) {
+          const int s = X.roundT[k];
+          if (X.SC[k] && (!vis || ((S.known[a][s >> 5] >> (s & 31)) & 1u))) n_known_urgent++;
+        }
+        const int ty = S.a_type[a];
+        const bool fighter = is_fighter(ty);
+        int c = 0;
+        f[c++] = (float)(S.a_px[a] / MAX_COORD); f[c++] = (float)(S.a_py[a] / MAX_COORD); f[c++] = fighter ? 1.f : 0.f; f[c++] = fighter ? 0.f : 1.f;
+        f[c++] = S.a_qlen[a] == 0 ? 1.f : 0.f;
+        f[c++] = (float)fmin(S.a_caps[2][a] / 2.0, 1.0); f[c++] = (float)fmin(S.a_caps[3][a] / 2.0, 1.0); f[c++] = (float)fmin(S.a_caps[1][a] / 2.0, 1.0);
+        f[c++] = (float)((double)S.a_state[a] / 5.0); f[c++] = (float)((double)S.time_steps / horizon);
+        if (kind == 0) f[c++] = (float)fmin((double)n_known_urgent / (double)(n_all > 1 ? n_all : 1), 1.0);
+        if (kind == 2) f[c++] = (float)fmin((double)n_known_urgent / 8.0, 1.0);
+        f[c++] = ty == MUAVTA_F2 ? 1.f : 0.f;
+        if (kind == 2) {
+          double is_escorting = 0.0, dist_prot = 1.0, near_escort = 0.0;
+          if (S.a_qlen[a] > 0) {
+            const int hs = S.a_qslot[a][0];
+            if (ref_valid(S.a_qid[a][0], hs) && (S.t_flags[hs] & TF_ESCORT)) {
+              is_escorting = 1.0;
+              const int pa = S.t_prot_agent[hs];
+              if (pa >= 0) {
+                dist_prot = fmin(norm2(S.a_px[a] - S.a_px[pa], S.a_py[a] - S.a_py[pa]) / MAX_COORD, 1.0);
+                near_escort = 1.0 - dist_prot;
+              }
+            }
+          }
+          int n_known_tasks = 0;  // len(known_ids): ids of released tasks are counted in a_gone
+          if (vis) { for (int w = 0; w < KW; w++) n_known_tasks += __popc(S.known[a][w]); n_known_tasks += S.a_gone[a]; }
+          const double c_h = (double)(P.commit_horizon ? (P.commit_horizon > 1 ? P.commit_horizon : 1) : 20);
+          const double rem_commit = fmax((double)S.a_commit[a] - (double)S.time_steps, 0.0);
+          f[c++] = (float)is_escorting; f[c++] = (float)dist_prot; f[c++] = (float)fmin(rem_commit / c_h, 1.0);
+          f[c++] = (float)fmin(near_escort + (double)n_known_tasks / 16.0, 1.0);
+        }
+        o_am[i] = 0; o_aid[i] = a;
+        for (int j = 0; j < MT; j++) {
+          float v = 0.f;
+          if (j < n_kept) {
+            const int s = list[j];
+            bool ok = !vis || ((S.known[a][s >> 5] >> (s & 31)) & 1u);
+            if (ok && (S.t_flags[s] & TF_ELIGIBLE) && !((S.t_elig[s] >> ty) & 1u)) ok = false;
+            if (ok && kind != 2 && !(S.a_caps[S.t_type[s]][a] > 0)) ok = false;
+            v = ok ? 1.f : 0.f;
+          }
+          ev[j] = v;
+        }
+      } else {
+        for (int c = 0; c < Da; c++) f[c] = 0.f;
+        for (int j = 0; j < MT; j++) ev[j] = 0.f;
+        o_am[i] = 1; o_aid[i] = -1;
+      }
+    }
   }
   // out[0..n) = f(k) for the k in [0, count) with pred(k), order preserved (ballot + popcount); returns n
   template <class Pred, class Val>

@@ -186,6 +186,16 @@ __global__ __launch_bounds__(WG) void k_observe(DevParams P, EnvState<TL>* blobs
   obs_for_env(sim, P, O, env);
 }
 
+template <class TL>
+__global__ __launch_bounds__(WG) void k_tokens(DevParams P, const EnvState<TL>* blobs, typename Sim<TL>::TokPtrs K) {
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  lds_sync();
+  Sim<TL> sim(*L.S, *L.X, P, nullptr);
+  sim.tokens(K, env);
+}
+
 // Stand-alone LSAP: one problem per workgroup, cost tile staged in LDS (transposed when nc < nr).
 __global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc, int64_t* row, int64_t* col) {
   typedef Tile64 TL;
@@ -261,6 +271,8 @@ struct MuavtaEnv {
   MuavtaParams params;
   int tile = TK16;
   int alloc_mode = 0;  // MUAVTA_ALLOC_*
+  void* d_tok = nullptr;  // muavta_tokens staging (host-buffer variant)
+  size_t tok_bytes = 0;
   int n_envs = 0, device = 0;
   int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
   size_t state_bytes = 0, lds_bytes = 0;
@@ -292,6 +304,7 @@ int launch_attr(MuavtaEnv* e) {
     HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_metrics<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_observe<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tokens<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   return MUAVTA_OK;
 }
@@ -302,6 +315,13 @@ int launch_attr(MuavtaEnv* e) {
     case TK24: { typedef Tile24 TL; CALL; } break; \
     default:   { typedef Tile64 TL; CALL; } break; \
   }
+
+template <class TL>
+static void launch_tokens(MuavtaEnv* e, int kind, int max_tasks, int max_agents, float* task_feats, uint8_t* task_mask, int32_t* task_ids,
+                          float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent) {
+  typename Sim<TL>::TokPtrs K{task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, kind, max_tasks, max_agents};
+  hipLaunchKernelGGL(k_tokens<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (const EnvState<TL>*)e->blobs, K);
+}
 
 int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
   memset(d, 0, sizeof(*d));
@@ -650,7 +670,7 @@ int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics);
+  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -783,6 +803,51 @@ int muavta_observe(MuavtaEnv* e, float* tasks, uint64_t* legal, uint8_t* pad, fl
   if (pad) HIPCHK(e, hipMemcpyAsync(pad, e->O.pad, N * mt, hipMemcpyDeviceToHost, e->stream));
   if (agents) HIPCHK(e, hipMemcpyAsync(agents, e->O.agents, N * nA * 9 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   if (flags) HIPCHK(e, hipMemcpyAsync(flags, e->O.flags, N * 5 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+// ---- token builders --------------------------------------------------------------------------
+static int token_dims(int kind, int* dt, int* da) {
+  if (kind == MUAVTA_TOK_PAIR) { *dt = 13; *da = 12; }
+  else if (kind == MUAVTA_TOK_PAIR_RAW) { *dt = 9; *da = 11; }
+  else if (kind == MUAVTA_TOK_ESCORT) { *dt = 22; *da = 16; }
+  else return MUAVTA_E_ARG;
+  return MUAVTA_OK;
+}
+int muavta_tokens_device(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
+                         int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent) {
+  int dt, da;
+  if (!e || token_dims(kind, &dt, &da) || max_tasks < 1 || max_agents < 1 || max_tasks > 4096 || max_agents > 4096 || !task_feats || !task_mask ||
+      !task_ids || !agent_feats || !agent_mask || !agent_ids || !edge_valid) { if (e) e->err = "muavta_tokens: bad argument"; return MUAVTA_E_ARG; }
+  if (!e->did_reset) { e->err = "tokens before reset"; return MUAVTA_E_STATE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  DISPATCH(e, launch_tokens<TL>(e, kind, max_tasks, max_agents, task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent));
+  HIPCHK(e, hipGetLastError());
+  return MUAVTA_OK;
+}
+int muavta_tokens(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
+                  int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent) {
+  int dt, da;
+  if (!e || token_dims(kind, &dt, &da) || max_tasks < 1 || max_agents < 1) { if (e) e->err = "muavta_tokens: bad argument"; return MUAVTA_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->device));
+  const size_t N = (size_t)e->n_envs, MT = (size_t)max_tasks, MA = (size_t)max_agents;
+  const size_t sz[8] = {N * MT * dt * 4, N * MT, N * MT * 4, N * MA * da * 4, N * MA, N * MA * 4, N * MA * MT * 4, N * 4};
+  size_t off[9] = {0};
+  for (int i = 0; i < 8; i++) off[i + 1] = off[i] + ((sz[i] + 255) & ~(size_t)255);
+  if (off[8] > e->tok_bytes) {
+    if (e->d_tok) hipFree(e->d_tok);
+    e->d_tok = nullptr; e->tok_bytes = 0;
+    HIPCHK(e, hipMalloc(&e->d_tok, off[8]));
+    e->tok_bytes = off[8];
+  }
+  char* b = (char*)e->d_tok;
+  int rc = muavta_tokens_device(e, kind, max_tasks, max_agents, (float*)(b + off[0]), (uint8_t*)(b + off[1]), (int32_t*)(b + off[2]),
+                                (float*)(b + off[3]), (uint8_t*)(b + off[4]), (int32_t*)(b + off[5]), (float*)(b + off[6]), (int32_t*)(b + off[7]));
+  if (rc) return rc;
+  void* host[8] = {task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent};
+  for (int i = 0; i < 8; i++)
+    if (host[i]) HIPCHK(e, hipMemcpyAsync(host[i], b + off[i], sz[i], hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
 }

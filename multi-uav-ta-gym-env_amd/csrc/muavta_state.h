@@ -62,6 +62,10 @@ struct Tile {
   static constexpr int KW = (T_ + 31) / 32;  // known-mask words per agent
 };
 
+template <int A> struct KnowMask { typedef uint64_t type; };  // one bit per agent
+template <> struct KnowMask<16> { typedef uint16_t type; };
+template <> struct KnowMask<24> { typedef uint32_t type; };
+
 template <class TL>
 struct alignas(16) EnvState {
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
@@ -77,6 +81,7 @@ struct alignas(16) EnvState {
   int32_t a_qlen[A];
   int32_t a_state[A], a_task_start[A], a_fail[A], a_acap[A], a_type[A], a_name[A];
   int32_t a_reeval[A], a_last_id[A], a_last_slot[A], a_commit[A];
+  int32_t a_gone[A];                // ids in agent_known_tasks[a] whose slot was released: len(known) = popcount(known[a]) + a_gone[a]
   // ---- task slots -----------------------------------------------------------------------------
   double t_px[T], t_py[T];
   double t_cur[6][T], t_alloc[6][T];  // currentReqs, allocatedReqs
@@ -106,7 +111,9 @@ struct alignas(16) EnvState {
   // ---- lists ------------------------------------------------------------------------------------
   int32_t ev_tag[E], ev_arg[E];       // env.event_list (generated this step)
   int32_t dev_tag[E], dev_arg[E];     // infos['events'] (drained at the start of the last step)
-  int32_t pend_time[R], pend_id[R], pend_slot[R];
+  int32_t pend_time[R], pend_id[R];
+  typename KnowMask<A>::type pend_know[R];  // who knew the task when its slot was released before the reveal came due
+  uint8_t pend_slot[R];
   int32_t esc_agent[A], esc_id[A], esc_slot[A];  // _escort_by_recon in insertion order (entries of escorts that
   int32_t esc_pid[A], esc_pslot[A];              // expired by window are never popped, as in the reference); protected Rec task
   int32_t act_agent[A], act_slot[A], act_index[A];  // actions staged by the allocator

@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import shutil
 import subprocess
 
@@ -24,7 +25,7 @@ EXPORTS = [
     "muavta_metrics", "muavta_get", "muavta_set", "muavta_get_state", "muavta_set_state", "muavta_lsap",
     "muavta_avoid_obstacles", "muavta_device_ptrs", "muavta_last_kernel_ms", "muavta_sync",
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
-    "muavta_set_allocator",
+    "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device",
 ]
 
 
@@ -67,6 +68,13 @@ def lib() -> C.CDLL:
         raise MuavtaError(
             f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+    # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64; if this library pulls in /opt/rocm's copy
+    # first, a later `import torch` in the same process finds no GPU.  Let torch's copy win when torch is installed.
+    if "torch" not in sys.modules and os.environ.get("MUAVTA_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(SO_PATH)
     vp, i32, u64p = C.c_void_p, C.c_int32, C.c_void_p
     L.muavta_create.argtypes = [C.POINTER(MuavtaParams), i32, i32, C.POINTER(vp)]
@@ -96,6 +104,8 @@ def lib() -> C.CDLL:
     L.muavta_sync.argtypes = [vp]
     L.muavta_refresh_observation.argtypes = [vp]
     L.muavta_set_allocator.argtypes = [vp, i32]
+    L.muavta_tokens.argtypes = [vp, i32, i32, i32] + [vp] * 8
+    L.muavta_tokens_device.argtypes = [vp, i32, i32, i32] + [vp] * 8
     L.muavta_abi_sizes.argtypes = [C.POINTER(i32 * 3)]
     for name in EXPORTS:
         if name != "muavta_last_error":

@@ -452,3 +452,67 @@ def test_urgency_coalition_fused_rollout_matches_reference(path):
     assert np.all(env.get("ERROR") == 0)
     assert np.array_equal(got, want), f"{case}: seeds {np.nonzero(~np.all(got == want, axis=1))[0][:8]} differ"
     assert np.array_equal(env.get("SCALARS")[:, 23].astype(int), g["n_replans"])
+
+
+# ---- next row: token builders (pair / raw / escort tokens) straight from the device state ------------------------
+TOKEN_FILES = sorted(glob.glob(os.path.join(GOLDEN, "tokens_*.npz")))
+KIND_NAME = {0: "pair", 1: "pair_raw", 2: "escort"}
+
+
+@pytest.mark.parametrize("path", TOKEN_FILES, ids=[os.path.basename(p)[7:-4] for p in TOKEN_FILES])
+def test_token_builders_vs_reference_and_oracle(path):
+    from tokcheck import check_tokens
+
+    g = np.load(path)
+    case = os.path.basename(path)[7:-4]
+    seed0, interval = int(g["seed"]), int(g["interval"])
+    n = 3
+    env = _env(case, n)
+    mode = 2 if str(g["driver"]) == "urgcoal" else 0
+    env.set_allocator("urgency_coalition" if mode == 2 else "hungarian")
+    env.reset(np.arange(seed0, seed0 + n, dtype=np.uint64))
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(seed0 + i)
+    steps = g["step"].tolist()
+    for t in range(150):
+        aa, ai = env.allocate(interval, True)
+        for o in oracles:
+            o.allocate_mode(interval, 1, mode)
+        if t in steps:
+            cache = {}
+
+            def dev_tok(i):
+                def f(kind, mt, ma):
+                    key = (kind, mt, ma)
+                    if key not in cache:
+                        cache[key] = env.tokens(KIND_NAME[kind], mt, ma)
+                    return {k: (int(v[i]) if k == "n_urgent" else v[i]) for k, v in cache[key].items()}
+                return f
+
+            check_tokens(dev_tok(0), g, steps.index(t), f"{case} t={t} (reference)")
+            for i, o in enumerate(oracles):  # the other seeds: against the oracle, same checker
+                for kind, mt, ma in ((0, 32, 16), (1, 32, 16), (2, int(g["e_max_tasks"]), int(g["e_max_agents"])), (0, 20, 6), (2, 12, 64)):
+                    want, got = o.tokens(kind, mt, ma), dev_tok(i)(kind, mt, ma)
+                    for k in want:
+                        assert np.array_equal(np.asarray(got[k]), np.asarray(want[k])), f"{case} seed {seed0 + i} t={t} kind {kind} {mt}x{ma}: {k}"
+        env.step(aa, ai)
+        for i, o in enumerate(oracles):
+            k = int(np.sum(aa[i] >= 0))
+            o.step(aa[i][:k], ai[i][:k])
+
+
+def test_tokens_into_torch_tensors_on_device():
+    import torch
+
+    env = _env("WPS_hard_x2", 64)
+    env.rollout(np.arange(64, dtype=np.uint64), 40, 20, True, False)
+    want = env.tokens("pair")
+    dt = {"task_feats": torch.float32, "task_mask": torch.uint8, "task_ids": torch.int32, "agent_feats": torch.float32,
+          "agent_mask": torch.uint8, "agent_ids": torch.int32, "edge_valid": torch.float32, "n_urgent": torch.int32}
+    out = {k: torch.empty(v.shape, dtype=dt[k], device="cuda") for k, v in want.items()}
+    env.tokens("pair", out=out)
+    env.sync()
+    for k, v in want.items():
+        assert np.array_equal(out[k].cpu().numpy(), v), k
+    assert (want["task_mask"] == 0).any() and (want["edge_valid"] > 0).any()
