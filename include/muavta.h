@@ -147,6 +147,10 @@ typedef enum MuavtaField {
   MUAVTA_F_EVENT_LIST,         /* i32 [N, E, 2]      env.event_list (generated by the last step, not yet drained)     */
   MUAVTA_F_STAGED_ACTIONS,     /* i32 [N, tile_agents, 3]  (agent, task id, open-list index) left by muavta_allocate, -1 padded */
   MUAVTA_F_ERROR,              /* i32 [N]            0 or the tile that overflowed                */
+  MUAVTA_F_RELEASE_LOG,        /* i32 [N, 1 + 3*T]   after muavta_set_release_log(h, 1): [0] = number of task slots the last step released,
+                                                       then (task id, knower mask lo, hi) rows: which agents had the id in
+                                                       agent_known_tasks when it left the device (read-only)            */
+  MUAVTA_F_KNOWN_COUNT,        /* i32 [N, A]         len(agent_known_tasks[a]) incl. ids of released tasks (read-only)  */
   MUAVTA_F_COUNT_
 } MuavtaField;
 
@@ -221,6 +225,10 @@ int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
  * [N, max_agents, max_tasks]; n_urgent i32 [N] (tok["n_urgent"], 0 for MUAVTA_TOK_ESCORT; may be NULL).
  * muavta_tokens copies into host buffers (NULL = skip that output) and synchronises; muavta_tokens_device writes to
  * device buffers of the caller (e.g. torch tensors on the same GPU) on the handle's stream without synchronising. */
+/* Per-step log of released task slots (off by default; the Python facade turns it on to keep agent_visibility_map()
+ * exact for retired ids, DroneEnv.py:1595-1599).  Costs one global atomic per released slot in muavta_step only. */
+int muavta_set_release_log(MuavtaEnv* env, int32_t enable);
+
 enum { MUAVTA_TOK_PAIR = 0, MUAVTA_TOK_PAIR_RAW = 1, MUAVTA_TOK_ESCORT = 2 };
 int muavta_tokens(MuavtaEnv* env, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
                   int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent);

@@ -20,7 +20,7 @@ F = {name: i for i, name in enumerate([
     "AGENT_POS", "AGENT_STATE", "AGENT_HEAD", "AGENT_QUEUE", "AGENT_NFT", "AGENT_NFP", "AGENT_CAPS", "AGENT_ATTACK_CAP",
     "AGENT_TYPE", "AGENT_NAME_IDX", "AGENT_DIST", "AGENT_MISC", "TASK_ID", "TASK_STATUS", "TASK_POS", "TASK_CUR",
     "TASK_ALLOC", "TASK_ORG_DONE", "TASK_META", "TASK_TIMES", "KNOWN", "THREAT_POS", "THREAT_META", "SCALARS",
-    "OPEN_IDS", "EVENTS", "EVENT_LIST", "STAGED_ACTIONS", "ERROR"])}
+    "OPEN_IDS", "EVENTS", "EVENT_LIST", "STAGED_ACTIONS", "ERROR", "RELEASE_LOG", "KNOWN_COUNT"])}
 
 
 def _vp(a: Optional[np.ndarray]):
@@ -128,6 +128,10 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_tokens(self.h, k, mt, ma, *[_vp(a) for a in arrs.values()]))
         return arrs
 
+    def set_release_log(self, enable: bool = True):
+        """Per-step log of released task slots (`get("RELEASE_LOG")`): id + knower mask; used by the facade."""
+        self._ck(self.L.muavta_set_release_log(self.h, int(bool(enable))))
+
     def step_staged(self):
         self._ck(self.L.muavta_step_staged(self.h))
 
@@ -198,6 +202,7 @@ class BatchedMultiUAVEnv:
             "THREAT_POS": ((N, H, 2), f64), "THREAT_META": ((N, H, 6), i32), "SCALARS": ((N, N_SCALARS), f64),
             "OPEN_IDS": ((N, T), i32), "EVENTS": ((N, E, 2), i32), "EVENT_LIST": ((N, E, 2), i32),
             "STAGED_ACTIONS": ((N, self.A_tile, 3), i32), "ERROR": ((N,), i32),
+            "RELEASE_LOG": ((N, 1 + 3 * T), i32), "KNOWN_COUNT": ((N, A), i32),
         }[name]
 
     def get(self, name: str) -> np.ndarray:

@@ -195,6 +195,7 @@ struct Sim {
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   State& S;
   Scratch<TL>& X;
+  int32_t* rel_log = nullptr;  // optional per-env release log in HBM (muavta_set_release_log)
   const DevParams& P;
   uint32_t* tape;  // [4][1248] in HBM
   int lane;
@@ -455,9 +456,13 @@ struct Sim {
       if ((old >> (s & 31)) & 1u) { atomicAdd(&S.a_gone[a], 1); knowers |= 1ull << a; }
     }
     // a reveal can only be pending while t < created_at + threat_delay (registered at creation, :1491-1501)
-    if (P.share_knowledge && S.t_created[s] > 0 && S.time_steps <= S.t_created[s] + (P.threat_delay > 0 ? P.threat_delay : 0) + 1)
+    if (P.share_knowledge && S.time_steps <= S.t_created[s] + (P.threat_delay > 0 ? P.threat_delay : 0) + 1)
       for (int k = 0; k < S.n_pending; k++)
         if (S.pend_slot[k] == s && S.pend_id[k] == id) S.pend_know[k] = (typename KnowMask<A>::type)knowers;
+    if (rel_log) {  // facade only: who knew the id when it left the device
+      const int k = atomicAdd(&rel_log[0], 1);
+      if (k < T) { rel_log[1 + 3 * k] = id; rel_log[2 + 3 * k] = (int32_t)(uint32_t)knowers; rel_log[3 + 3 * k] = (int32_t)(uint32_t)(knowers >> 32); }
+    }
     atomicOr(&S.free_slots[s >> 5], 1u << (s & 31));
   }
   DEV int reclaim_slot_serial() {

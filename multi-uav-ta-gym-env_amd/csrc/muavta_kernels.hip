@@ -87,12 +87,13 @@ __global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds
 // act_agent == nullptr: use the actions staged in the blob by k_allocate
 template <class TL>
 __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, const int32_t* act_agent,
-                                             const int32_t* act_index, int act_cap, ObsPtrs O) {
+                                             const int32_t* act_index, int act_cap, ObsPtrs O, int32_t* rel_log) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
   lds_sync();
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  if (rel_log) sim.rel_log = rel_log + (size_t)env * (1 + 3 * TL::T);
   if (act_agent && threadIdx.x == 0) {
     EnvState<TL>& S = *L.S;
     int n = 0;
@@ -272,6 +273,7 @@ struct MuavtaEnv {
   int tile = TK16;
   int alloc_mode = 0;  // MUAVTA_ALLOC_*
   void* d_tok = nullptr;  // muavta_tokens staging (host-buffer variant)
+  int32_t* d_rel = nullptr;  // release log [N, 1 + 3*T] (muavta_set_release_log)
   size_t tok_bytes = 0;
   int n_envs = 0, device = 0;
   int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
@@ -571,6 +573,16 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
       if (scatter) { e->err = "ERROR is read-only"; return MUAVTA_E_ARG; }
       for (int n = 0; n < N; n++) I[n] = blobs[n].error;
       break;
+    case MUAVTA_F_KNOWN_COUNT:
+      if (!chk((size_t)N * A * 4)) BAD();
+      if (scatter) { e->err = "KNOWN_COUNT is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++)
+        for (int a = 0; a < A; a++) {
+          int c = blobs[n].a_gone[a];
+          for (int w = 0; w < TL::KW; w++) c += __builtin_popcount(blobs[n].known[a][w]);
+          I[(size_t)n * A + a] = c;
+        }
+      break;
     default:
       e->err = "unknown field";
       return MUAVTA_E_ARG;
@@ -670,7 +682,7 @@ int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok);
+  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -710,8 +722,9 @@ static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
     HIPCHK(e, hipMemcpyAsync(e->d_act_index, ai, bytes, hipMemcpyHostToDevice, e->stream));
     da = e->d_act_agent; di = e->d_act_index;
   }
+  if (e->d_rel) HIPCHK(e, hipMemsetAsync(e->d_rel, 0, (size_t)e->n_envs * (1 + 3 * e->T) * sizeof(int32_t), e->stream));
   DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs,
-                                 e->tapes, da, di, e->A, e->O));
+                                 e->tapes, da, di, e->A, e->O, e->d_rel));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   return MUAVTA_OK;
@@ -852,6 +865,21 @@ int muavta_tokens(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t max_age
   return MUAVTA_OK;
 }
 
+int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
+  if (!e) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  if (enable && !e->d_rel) {
+    const size_t bytes = (size_t)e->n_envs * (1 + 3 * e->T) * sizeof(int32_t);
+    HIPCHK(e, hipMalloc((void**)&e->d_rel, bytes));
+    HIPCHK(e, hipMemset(e->d_rel, 0, bytes));
+  } else if (!enable && e->d_rel) {
+    hipFree(e->d_rel);
+    e->d_rel = nullptr;
+  }
+  return MUAVTA_OK;
+}
+
 int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from the current state (after muavta_set)
   if (!e) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
@@ -886,6 +914,14 @@ int muavta_metrics(MuavtaEnv* e, double* out) {
 int muavta_get(MuavtaEnv* e, MuavtaField field, void* dst, size_t bytes) {
   if (!e || !dst) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
+  if (field == MUAVTA_F_RELEASE_LOG) {
+    const size_t want = (size_t)e->n_envs * (1 + 3 * e->T) * sizeof(int32_t);
+    if (!e->d_rel) { e->err = "release log is off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
+    if (bytes != want) { e->err = "muavta_get(RELEASE_LOG): wrong size"; return MUAVTA_E_ARG; }
+    HIPCHK(e, hipMemcpyAsync(dst, e->d_rel, want, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return MUAVTA_OK;
+  }
   int rc = sync_host(e);
   if (rc) return rc;
   DISPATCH(e, rc = gather<TL>(e, field, dst, bytes, false));

@@ -349,6 +349,7 @@ class MultiUAVEnv:
 
             backend = BatchedMultiUAVEnv(self._params, 1, device)
         self._b = backend
+        self._b.set_release_log(True)  # keeps agent_visibility_map() exact for ids whose slot was recycled
         self._snap = _Snapshot(backend)
         p = self._params
         self.area_width, self.area_height, self.max_coord = 1200, 700, 1200       # MultiDroneEnvData.py:8
@@ -404,6 +405,30 @@ class MultiUAVEnv:
             for slot, tid in enumerate(ids):
                 if tid >= 0 and (known[a.id][slot >> 5] >> (slot & 31)) & 1:
                     s.add(int(tid))
+        # ... ids that left the device during this step, with the agents that knew them then (muavta_set_release_log)
+        if self._steps != self._log_step:
+            self._log_step = self._steps
+            log = self._snap["RELEASE_LOG"]
+            n = int(log[0])
+            if n > (len(log) - 1) // 3:
+                raise RuntimeError("release log overflow")
+            for k in range(n):
+                tid, mask = int(log[1 + 3 * k]), (int(log[2 + 3 * k]) & 0xFFFFFFFF) | ((int(log[3 + 3 * k]) & 0xFFFFFFFF) << 32)
+                for a in self.agents_obj:
+                    if (mask >> a.id) & 1:
+                        self._known[a.name].add(tid)
+        # ... and the team-wide reveal of a task whose slot was released before it came due (_register_dynamic_task /
+        # _wps_process_reveals, DroneEnv.py:1491-1541): every id joins every set at created_at + max(threat_delay, 0)
+        if self._params.share_knowledge and (self.sense_radius or self.threat_delay):
+            now, delay = self.time_steps, max(int(self.threat_delay), 0)
+            for tid, t in self._tasks.items():
+                if tid == 0 or tid in self._revealed:
+                    continue
+                born = self._born.setdefault(tid, t._last.get("meta2", now))  # never resident: created (and gone) this step
+                if now >= born + delay:
+                    self._revealed.add(tid)
+                    for s in self._known.values():
+                        s.add(tid)
 
     def _build_observations(self):
         o = self._b.observe()
@@ -443,6 +468,8 @@ class MultiUAVEnv:
         self._tasks = {0: self.task_idle}
         self._threats = {}
         self._known = {}
+        self._born, self._revealed = {}, set()
+        self._log_step = 0  # the reset itself releases nothing
         self._snap.clear()
         self.agents_obj = [UAVView(self, a) for a in range(self.n_agents)]
         self.agent_by_name = {a.name: a for a in self.agents_obj}

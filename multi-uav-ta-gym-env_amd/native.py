@@ -25,7 +25,7 @@ EXPORTS = [
     "muavta_metrics", "muavta_get", "muavta_set", "muavta_get_state", "muavta_set_state", "muavta_lsap",
     "muavta_avoid_obstacles", "muavta_device_ptrs", "muavta_last_kernel_ms", "muavta_sync",
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
-    "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device",
+    "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log",
 ]
 
 
@@ -104,6 +104,7 @@ def lib() -> C.CDLL:
     L.muavta_sync.argtypes = [vp]
     L.muavta_refresh_observation.argtypes = [vp]
     L.muavta_set_allocator.argtypes = [vp, i32]
+    L.muavta_set_release_log.argtypes = [vp, i32]
     L.muavta_tokens.argtypes = [vp, i32, i32, i32] + [vp] * 8
     L.muavta_tokens_device.argtypes = [vp, i32, i32, i32] + [vp] * 8
     L.muavta_abi_sizes.argtypes = [C.POINTER(i32 * 3)]

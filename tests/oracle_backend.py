@@ -54,7 +54,12 @@ class OracleBackend:
 
     get_rng = get_state
 
+    def set_release_log(self, enable=True):  # the oracle keeps every task id resident: nothing is ever released
+        pass
+
     def get(self, name):
+        if name == "RELEASE_LOG":
+            return np.zeros((1, 4), dtype=np.int32)
         rows, caps, q = self.o.agents()
         trow, reqs = self.o.tasks()
         nt = trow.shape[0]

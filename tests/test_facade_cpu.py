@@ -64,6 +64,11 @@ def test_facade_episode_matches_golden(case, seed):
         from muavta_amd.params import EVENT_TAGS
         assert infos["events"] == [[EVENT_TAGS[int(x)], int(y)] for x, y in ev]
         assert env.time_steps == t and env.total_distance == g["scalars"][t][1]
+        vis = env.agent_visibility_map()  # exact, ids of retired (slot-released) tasks included
+        known = np.unpackbits(g["known"][t], axis=-1)[:, :int(g["n_task_ids"])].astype(bool)
+        for a in env.agents_obj:
+            want_known = set(np.nonzero(known[a.id])[0].tolist())
+            assert vis[a.name] == want_known, f"t={t} {a.name}: {sorted(vis[a.name] ^ want_known)}"
         done = all(term.values()) or all(trunc.values())
     assert t == 150 and list(infos["metrics"].keys()) == METRIC_KEYS
     assert np.array_equal(np.array([float(infos["metrics"][k]) for k in METRIC_KEYS]), g["metrics"])
