@@ -140,16 +140,19 @@ typedef enum MuavtaField {
   MUAVTA_F_TASK_TIMES,         /* f64 [N, T, 2]      initTime, doneTime                      (rw) */
   MUAVTA_F_KNOWN,              /* u32 [N, A, ceil(T/32)]  bit s of row a: agent a knows the task in slot s (rw) */
   MUAVTA_F_THREAT_POS,         /* f64 [N, H, 2]                                              (rw) */
-  MUAVTA_F_THREAT_META,        /* i32 [N, H, 6]      status(-9 not spawned), target agent, mission target, attackCap, task id, type */
+  MUAVTA_F_THREAT_META,        /* i32 [N, H, 8]      status(-9 not spawned), target agent, mission target, attackCap, task id, type, group, intercepting agent */
   MUAVTA_F_SCALARS,            /* f64 [N, 28]        see MUAVTA_S_* below                         */
   MUAVTA_F_OPEN_IDS,           /* i32 [N, T]         env.last_tasks_info ids in order, -1 padded  */
   MUAVTA_F_EVENTS,             /* i32 [N, E, 2]      events drained by the last step (infos['events']), tag -1 padded */
   MUAVTA_F_EVENT_LIST,         /* i32 [N, E, 2]      env.event_list (generated by the last step, not yet drained)     */
   MUAVTA_F_STAGED_ACTIONS,     /* i32 [N, tile_agents, 3]  (agent, task id, open-list index) left by muavta_allocate, -1 padded */
   MUAVTA_F_ERROR,              /* i32 [N]            0 or the tile that overflowed                */
-  MUAVTA_F_RELEASE_LOG,        /* i32 [N, 1 + 3*T]   after muavta_set_release_log(h, 1): [0] = number of task slots the last step released,
-                                                       then (task id, knower mask lo, hi) rows: which agents had the id in
-                                                       agent_known_tasks when it left the device (read-only)            */
+  MUAVTA_F_RELEASE_LOG,        /* f64 [N, 1 + 29*T]  after muavta_set_release_log(h, 1): first 4 bytes of [0] = i32 number of task slots the
+                                                       last step released; then 29-double rows: id, knower mask lo32, hi32 (agents
+                                                       that had the id in agent_known_tasks), type, hard_deadline(-1), created_at,
+                                                       required_agents, escort, len(allocationDetails), protected_agent(-1),
+                                                       eligible mask(-1), x, y, orgReqs[type], doneReqs[type], initTime, doneTime,
+                                                       currentReqs[6], allocatedReqs[6]                              (read-only) */
   MUAVTA_F_KNOWN_COUNT,        /* i32 [N, A]         len(agent_known_tasks[a]) incl. ids of released tasks (read-only)  */
   MUAVTA_F_COUNT_
 } MuavtaField;

@@ -199,10 +199,10 @@ class BatchedMultiUAVEnv:
             "TASK_ID": ((N, T), i32), "TASK_STATUS": ((N, T), i32), "TASK_POS": ((N, T, 2), f64),
             "TASK_CUR": ((N, T, 6), f64), "TASK_ALLOC": ((N, T, 6), f64), "TASK_ORG_DONE": ((N, T, 2), f64),
             "TASK_META": ((N, T, 8), i32), "TASK_TIMES": ((N, T, 2), f64), "KNOWN": ((N, A, self.dims.known_words), u32),
-            "THREAT_POS": ((N, H, 2), f64), "THREAT_META": ((N, H, 6), i32), "SCALARS": ((N, N_SCALARS), f64),
+            "THREAT_POS": ((N, H, 2), f64), "THREAT_META": ((N, H, 8), i32), "SCALARS": ((N, N_SCALARS), f64),
             "OPEN_IDS": ((N, T), i32), "EVENTS": ((N, E, 2), i32), "EVENT_LIST": ((N, E, 2), i32),
             "STAGED_ACTIONS": ((N, self.A_tile, 3), i32), "ERROR": ((N,), i32),
-            "RELEASE_LOG": ((N, 1 + 3 * T), i32), "KNOWN_COUNT": ((N, A), i32),
+            "RELEASE_LOG": ((N, 1 + 29 * T), f64), "KNOWN_COUNT": ((N, A), i32),
         }[name]
 
     def get(self, name: str) -> np.ndarray:

@@ -195,7 +195,7 @@ struct Sim {
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   State& S;
   Scratch<TL>& X;
-  int32_t* rel_log = nullptr;  // optional per-env release log in HBM (muavta_set_release_log)
+  double* rel_log = nullptr;  // optional per-env release log in HBM (muavta_set_release_log)
   const DevParams& P;
   uint32_t* tape;  // [4][1248] in HBM
   int lane;
@@ -459,9 +459,18 @@ struct Sim {
     if (P.share_knowledge && S.time_steps <= S.t_created[s] + (P.threat_delay > 0 ? P.threat_delay : 0) + 1)
       for (int k = 0; k < S.n_pending; k++)
         if (S.pend_slot[k] == s && S.pend_id[k] == id) S.pend_know[k] = (typename KnowMask<A>::type)knowers;
-    if (rel_log) {  // facade only: who knew the id when it left the device
-      const int k = atomicAdd(&rel_log[0], 1);
-      if (k < T) { rel_log[1 + 3 * k] = id; rel_log[2 + 3 * k] = (int32_t)(uint32_t)knowers; rel_log[3 + 3 * k] = (int32_t)(uint32_t)(knowers >> 32); }
+    if (rel_log) {  // facade only: the task's final record and who knew the id when it left the device
+      const int k = atomicAdd(reinterpret_cast<int*>(rel_log), 1);
+      if (k < T) {
+        double* r = rel_log + 1 + (size_t)k * MUAVTA_REL_ROW;
+        const int ty = S.t_type[s];
+        r[0] = id; r[1] = (double)(uint32_t)knowers; r[2] = (double)(uint32_t)(knowers >> 32); r[3] = ty;
+        r[4] = (S.t_flags[s] & TF_DEADLINE) ? S.t_deadline[s] : -1; r[5] = S.t_created[s]; r[6] = S.t_required[s];
+        r[7] = (S.t_flags[s] & TF_ESCORT) ? 1 : 0; r[8] = S.t_ndet[s]; r[9] = S.t_prot_agent[s];
+        r[10] = (S.t_flags[s] & TF_ELIGIBLE) ? (double)S.t_elig[s] : -1.0; r[11] = S.t_px[s]; r[12] = S.t_py[s];
+        r[13] = S.t_org[s]; r[14] = S.t_done[s]; r[15] = S.t_init[s]; r[16] = S.t_dtime[s];
+        for (int c = 0; c < 6; c++) { r[17 + c] = S.t_cur[c][s]; r[23 + c] = S.t_alloc[c][s]; }
+      }
     }
     atomicOr(&S.free_slots[s >> 5], 1u << (s & 31));
   }

@@ -87,13 +87,13 @@ __global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds
 // act_agent == nullptr: use the actions staged in the blob by k_allocate
 template <class TL>
 __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, const int32_t* act_agent,
-                                             const int32_t* act_index, int act_cap, ObsPtrs O, int32_t* rel_log) {
+                                             const int32_t* act_index, int act_cap, ObsPtrs O, double* rel_log) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
   lds_sync();
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
-  if (rel_log) sim.rel_log = rel_log + (size_t)env * (1 + 3 * TL::T);
+  if (rel_log) sim.rel_log = rel_log + (size_t)env * (1 + MUAVTA_REL_ROW * TL::T);
   if (act_agent && threadIdx.x == 0) {
     EnvState<TL>& S = *L.S;
     int n = 0;
@@ -273,7 +273,7 @@ struct MuavtaEnv {
   int tile = TK16;
   int alloc_mode = 0;  // MUAVTA_ALLOC_*
   void* d_tok = nullptr;  // muavta_tokens staging (host-buffer variant)
-  int32_t* d_rel = nullptr;  // release log [N, 1 + 3*T] (muavta_set_release_log)
+  double* d_rel = nullptr;  // release log [N, 1 + MUAVTA_REL_ROW*T] (muavta_set_release_log)
   size_t tok_bytes = 0;
   int n_envs = 0, device = 0;
   int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
@@ -514,12 +514,13 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
       for (int n = 0; n < N; n++) for (int h = 0; h < H; h++) { RW(D[((size_t)n * H + h) * 2], blobs[n].h_px[h]); RW(D[((size_t)n * H + h) * 2 + 1], blobs[n].h_py[h]); }
       break;
     case MUAVTA_F_THREAT_META:
-      if (!chk((size_t)N * H * 6 * 4)) BAD();
+      if (!chk((size_t)N * H * 8 * 4)) BAD();
       if (scatter) { e->err = "THREAT_META is read-only"; return MUAVTA_E_ARG; }
       for (int n = 0; n < N; n++) for (int h = 0; h < H; h++) {
-        int32_t* r = I + ((size_t)n * H + h) * 6;
+        int32_t* r = I + ((size_t)n * H + h) * 8;
         St& b = blobs[n];
         r[0] = b.h_status[h]; r[1] = b.h_target[h]; r[2] = b.h_mission[h]; r[3] = b.h_acap[h]; r[4] = b.h_task_id[h]; r[5] = b.h_type[h];
+        r[6] = b.h_group[h]; r[7] = b.h_intercept[h];
       }
       break;
     case MUAVTA_F_SCALARS:
@@ -722,7 +723,7 @@ static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
     HIPCHK(e, hipMemcpyAsync(e->d_act_index, ai, bytes, hipMemcpyHostToDevice, e->stream));
     da = e->d_act_agent; di = e->d_act_index;
   }
-  if (e->d_rel) HIPCHK(e, hipMemsetAsync(e->d_rel, 0, (size_t)e->n_envs * (1 + 3 * e->T) * sizeof(int32_t), e->stream));
+  if (e->d_rel) HIPCHK(e, hipMemsetAsync(e->d_rel, 0, (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double), e->stream));
   DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs,
                                  e->tapes, da, di, e->A, e->O, e->d_rel));
   HIPCHK(e, hipGetLastError());
@@ -870,7 +871,7 @@ int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   if (enable && !e->d_rel) {
-    const size_t bytes = (size_t)e->n_envs * (1 + 3 * e->T) * sizeof(int32_t);
+    const size_t bytes = (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double);
     HIPCHK(e, hipMalloc((void**)&e->d_rel, bytes));
     HIPCHK(e, hipMemset(e->d_rel, 0, bytes));
   } else if (!enable && e->d_rel) {
@@ -915,7 +916,7 @@ int muavta_get(MuavtaEnv* e, MuavtaField field, void* dst, size_t bytes) {
   if (!e || !dst) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
   if (field == MUAVTA_F_RELEASE_LOG) {
-    const size_t want = (size_t)e->n_envs * (1 + 3 * e->T) * sizeof(int32_t);
+    const size_t want = (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double);
     if (!e->d_rel) { e->err = "release log is off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
     if (bytes != want) { e->err = "muavta_get(RELEASE_LOG): wrong size"; return MUAVTA_E_ARG; }
     HIPCHK(e, hipMemcpyAsync(dst, e->d_rel, want, hipMemcpyDeviceToHost, e->stream));

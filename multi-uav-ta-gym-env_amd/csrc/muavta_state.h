@@ -141,5 +141,6 @@ typedef Tile<16, 32, 16, 48, 40, 8> Tile16;  // events <= 16, pending reveals <=
 typedef Tile<24, 48, 24, 128, 64, 16> Tile24;
 typedef Tile<64, 128, 48, 128, 96, 8> Tile64;
 
+#define MUAVTA_REL_ROW 29  // doubles per release-log row (include/muavta.h: MUAVTA_F_RELEASE_LOG)
 #define MUAVTA_RNG_STREAMS 4
 #define MUAVTA_RNG_WORDS 1248  // two consecutive MT19937 blocks per stream

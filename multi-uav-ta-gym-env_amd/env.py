@@ -130,12 +130,19 @@ class TaskView:
 
     @property
     def allocationDetails(self):
-        """len()-able / iterable stand-in: {agent_id: (None, time)} for the agents queuing this task."""
+        """len()-able / `in`-able stand-in: {agent_id: (None, None)} for the agents queuing this task, padded with
+        placeholder keys up to the device's len(allocationDetails) (entries the reference leaves behind for agents
+        that no longer queue the task, DroneEnvComponents.py:98-127); the last view is kept once the slot is recycled."""
         env = self._env
-        if self.id == 0 or self._slot() < 0:
+        if self.id == 0:
             return {}
-        q = env._snap["AGENT_QUEUE"]
-        return {int(a): (None, None) for a in range(q.shape[0]) if self.id in q[a]}
+        if self._slot() >= 0:
+            q = env._snap["AGENT_QUEUE"]
+            d = {int(a): (None, None) for a in range(q.shape[0]) if self.id in q[a]}
+            for k in range(self._meta(5) - len(d)):
+                d[("stale", k)] = (None, None)
+            self._last["details"] = d
+        return self._last.get("details", {})
 
     @property
     def initTime(self):
@@ -334,6 +341,15 @@ class ThreatView:
     def threat_type(self) -> str:
         return UAV_TYPES[self._m(5)]
 
+    @property
+    def threat_group(self) -> int:
+        return self._m(6)
+
+    @property
+    def intercepting_agent(self):
+        a = self._m(7)
+        return None if a < 0 else self._env.agents_obj[a]
+
 
 class MultiUAVEnv:
     metadata = {"render_modes": ["human"], "name": "multi_agent_env_v0"}
@@ -396,8 +412,9 @@ class MultiUAVEnv:
         for t in self._tasks.values():
             if t.id and t._slot() >= 0:
                 _ = (t.position, t.typeIdx, t.currentReqs, t.allocatedReqs, t.orgReqs, t.created_at, t.required_agents,
-                     t.kind, t._meta(6, -1), t._meta(7, -1), getattr(t, "hard_deadline", None), t.initTime, t.doneTime)
+                     t.kind, t._meta(6, -1), t._meta(7, -1), getattr(t, "hard_deadline", None), t.initTime, t.doneTime, t.allocationDetails)
         self.last_tasks_info = [self._task(int(i)) for i in self._snap["OPEN_IDS"] if i >= 0]
+        _ = self.threats  # register this step's spawns now, so the order is right even if nobody looks every step
         # agent_known_tasks grows monotonically in the reference; bits of recycled slots are folded in here
         known = self._snap["KNOWN"]
         for a in self.agents_obj:
@@ -409,14 +426,27 @@ class MultiUAVEnv:
         if self._steps != self._log_step:
             self._log_step = self._steps
             log = self._snap["RELEASE_LOG"]
-            n = int(log[0])
-            if n > (len(log) - 1) // 3:
+            n = int(log[:1].view(np.int32)[0])
+            if n > (len(log) - 1) // 29:
                 raise RuntimeError("release log overflow")
-            for k in range(n):
-                tid, mask = int(log[1 + 3 * k]), (int(log[2 + 3 * k]) & 0xFFFFFFFF) | ((int(log[3 + 3 * k]) & 0xFFFFFFFF) << 32)
+            for r in log[1:1 + 29 * n].reshape(n, 29):
+                tid, mask = int(r[0]), int(r[1]) | (int(r[2]) << 32)
                 for a in self.agents_obj:
                     if (mask >> a.id) & 1:
                         self._known[a.name].add(tid)
+                # the task's final record (the last observation may predate changes of its last step, or not exist)
+                last = self._task(tid)._last
+                for col, v in zip(range(8), (r[3], r[4], r[5], r[6], r[7], r[8], r[9], r[10])):
+                    last[f"meta{col}"] = int(v)
+                last.update(position=np.array(r[11:13]), org=float(r[13]), init=float(r[15]), done=float(r[16]),
+                            cur=np.array(r[17:23]), alloc=np.array(r[23:29]),
+                            details={("stale", k): (None, None) for k in range(int(r[8]))})
+        # a threat drags its Int task along even after that task was retired (update_threats, DroneEnv.py:1725-1744)
+        tmeta, tpos = self._snap["THREAT_META"], self._snap["THREAT_POS"]
+        for h in range(tmeta.shape[0]):
+            t = self._tasks.get(int(tmeta[h][4])) if tmeta[h][0] != -9 and tmeta[h][4] > 0 else None
+            if t is not None and t._slot() < 0:
+                t._last["position"] = np.array(tpos[h], dtype=np.float64)
         # ... and the team-wide reveal of a task whose slot was released before it came due (_register_dynamic_task /
         # _wps_process_reveals, DroneEnv.py:1491-1541): every id joins every set at created_at + max(threat_delay, 0)
         if self._params.share_knowledge and (self.sense_radius or self.threat_delay):
@@ -521,12 +551,13 @@ class MultiUAVEnv:
 
     @property
     def threats(self) -> List[ThreatView]:
+        # env.threats is in spawn order (DroneEnv.py:1601-1643): groups in config order, ascending ids inside a step,
+        # so appending the newly spawned ids of each step in ascending order reproduces it (dict keeps insertion order)
         meta = self._snap["THREAT_META"]
-        out = []
         for h in range(meta.shape[0]):
-            if meta[h][0] != -9:
-                out.append(self._threats.setdefault(h, ThreatView(self, h)))
-        return out
+            if meta[h][0] != -9 and h not in self._threats:
+                self._threats[h] = ThreatView(self, h)
+        return list(self._threats.values())
 
     time_steps = property(lambda self: int(self._scalar(0)))
     F_Reward = property(lambda self: self._scalar(2))

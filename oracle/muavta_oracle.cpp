@@ -1829,10 +1829,10 @@ void orc_get_known(void* h, uint8_t* out) {  // [A, NT]
 void orc_get_threats(void* h, double* rows) {
   Env* e = (Env*)h;
   for (auto& th : e->threats_all) {
-    double* r = rows + (size_t)th.id * 8;
+    double* r = rows + (size_t)th.id * 10;
     bool active = std::find(e->threats.begin(), e->threats.end(), th.id) != e->threats.end();
     r[0] = active ? th.status : -9; r[1] = th.pos.x; r[2] = th.pos.y; r[3] = th.target_agent; r[4] = th.mission_target_agent;
-    r[5] = th.attackCap; r[6] = th.relative_task; r[7] = th.type;
+    r[5] = th.attackCap; r[6] = th.relative_task; r[7] = th.type; r[8] = th.group; r[9] = th.intercepting_agent;
   }
 }
 void orc_get_scalars(void* h, double* s) {  // MUAVTA_S_* order

@@ -33,8 +33,11 @@ class OracleBackend:
             k += 1
         self.o.step(aa[0, :k], ai[0, :k])
 
+    def set_allocator(self, name="hungarian"):
+        self._mode = {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2}[name]
+
     def allocate(self, interval=20, use_visibility=True, fetch=True):
-        a, i = self.o.allocate(interval, int(use_visibility))
+        a, i = self.o.allocate_mode(interval, int(use_visibility), getattr(self, "_mode", 0))
         aa, ai = self.pack_actions([list(zip(a.tolist(), i.tolist()))])
         return aa, ai
 
@@ -59,7 +62,7 @@ class OracleBackend:
 
     def get(self, name):
         if name == "RELEASE_LOG":
-            return np.zeros((1, 4), dtype=np.int32)
+            return np.zeros((1, 30), dtype=np.float64)
         rows, caps, q = self.o.agents()
         trow, reqs = self.o.tasks()
         nt = trow.shape[0]
@@ -107,7 +110,7 @@ class OracleBackend:
             return rows[:, 13].astype(np.int32)[None]
         if name == "AGENT_MISC":
             m = np.zeros((rows.shape[0], 6), dtype=np.int32)
-            m[:, 0] = rows[:, 9]; m[:, 1] = rows[:, 14]; m[:, 2] = rows[:, 10]; m[:, 3] = rows[:, 11]; m[:, 5] = rows[:, 4]
+            m[:, 0] = rows[:, 9]; m[:, 1] = rows[:, 14]; m[:, 2] = rows[:, 10]; m[:, 3] = rows[:, 11]; m[:, 4] = self.o.agent_commit_until(); m[:, 5] = rows[:, 4]
             return m[None]
         if name == "KNOWN":
             k = self.o.known()
@@ -121,7 +124,7 @@ class OracleBackend:
             return self.o.threats()[:, 1:3][None].copy()
         if name == "THREAT_META":
             th = self.o.threats()
-            m = np.stack([th[:, 0], th[:, 3], th[:, 4], th[:, 5], th[:, 6], th[:, 7]], axis=1).astype(np.int32)
+            m = np.stack([th[:, 0], th[:, 3], th[:, 4], th[:, 5], th[:, 6], th[:, 7], th[:, 8], th[:, 9]], axis=1).astype(np.int32)
             return m[None]
         if name == "SCALARS":
             d = self.o.dims()

@@ -126,7 +126,7 @@ class OracleEnv:
         return k.astype(bool)
 
     def threats(self):
-        rows = np.zeros((self.dims()["n_threats"], 8))
+        rows = np.zeros((self.dims()["n_threats"], 10))
         self.L.orc_get_threats(self.h, _p(rows))
         return rows
 

@@ -134,3 +134,28 @@ def test_reference_allocator_and_harness_glue_drive_the_facade(case, interval):
         got = np.array([float(info["metrics"][k]) for k in METRIC_KEYS])
         assert np.array_equal(got, g["metrics"][seed]), dict(zip(METRIC_KEYS, got - g["metrics"][seed]))
         assert hung.n_replans == int(g["n_replans"][seed])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mUAV_TA"), reason="reference checkout not present (GPU box)")
+def test_replay_document_equals_reference_generator(tmp_path):
+    """muavta_amd.replay.generate (facade + planner through the backend) writes the same dashboard document as the
+    reference's experiments/generate_simulation_replay.py for its WPS_escort / Urgency-Coalition replay."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import refshim
+    refshim.install()
+    import json
+    from experiments import generate_simulation_replay as ref
+    from muavta_amd import replay
+
+    seed = 3
+    want = ref.generate(seed, tmp_path / "ref.json", "WPS_escort")
+    env, _ = _facade("WPS_escort")
+    got = replay.generate(seed, tmp_path / "ours.json", "WPS_escort", "urgency_coalition", env=env,
+                          title="WPS_escort: protect recon with fighter coalitions")
+    assert json.loads((tmp_path / "ours.json").read_text()) == json.loads(json.dumps(got))
+    assert got["metadata"] == want["metadata"]
+    assert len(got["frames"]) == len(want["frames"]) == 151
+    for k, (a, b) in enumerate(zip(got["frames"], want["frames"])):
+        for key in ("time", "agents", "threats", "events", "decision", "metrics", "tasks"):
+            assert a[key] == b[key], f"frame {k} {key}: " + str([(x, y) for x, y in zip(a[key], b[key]) if x != y][:2] if isinstance(a[key], list) else (a[key], b[key]))
+    assert got["events"] == want["events"] and got["final_metrics"] == want["final_metrics"]

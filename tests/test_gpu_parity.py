@@ -516,3 +516,25 @@ def test_tokens_into_torch_tensors_on_device():
     for k, v in want.items():
         assert np.array_equal(out[k].cpu().numpy(), v), k
     assert (want["task_mask"] == 0).any() and (want["edge_valid"] > 0).any()
+
+
+# ---- next row: replay / frame export in the dashboard schema -----------------------------------------------------
+@pytest.mark.parametrize("case,allocator,seed", [("WPS_escort", "urgency_coalition", 3), ("WPS_hard", "urgency_pair", 1)])
+def test_replay_document_hip_backend_equals_oracle_backend(case, allocator, seed):
+    """replay.generate over the HIP backend == the same over the oracle backend (which tests/test_facade_cpu.py pins
+    to the reference's generate_simulation_replay.py document in the build container)."""
+    from muavta_amd import replay
+    from muavta_amd.env import MultiUAVEnv
+    from muavta_amd.scenarios import CASE_SPECS, TILES, WPS_ENV_FLAGS
+    from oracle_backend import OracleBackend
+
+    ta, tt, th = TILES[case]
+    hip_env = MultiUAVEnv(CASE_SPECS[case], flags=dict(WPS_ENV_FLAGS), tile_agents=ta, tile_tasks=tt, tile_threats=th)
+    got = replay.generate(seed, None, case, allocator, env=hip_env)
+    orc_env = MultiUAVEnv(CASE_SPECS[case], backend=OracleBackend(params_for_case(case)), flags=dict(WPS_ENV_FLAGS))
+    want = replay.generate(seed, None, case, allocator, env=orc_env)
+    assert got["metadata"] == want["metadata"] and len(got["frames"]) == 151
+    for k, (a, b) in enumerate(zip(got["frames"], want["frames"])):
+        for key in a:
+            assert a[key] == b[key], f"{case} frame {k} {key}"
+    assert got["events"] == want["events"] and got["final_metrics"] == want["final_metrics"]
