@@ -212,7 +212,10 @@ int muavta_step_staged(MuavtaEnv* env); /* step with the actions muavta_allocate
  *   task, agents with commit_until > t held out of the match, assigned agents that hold a real task locked for
  *   commit_horizon steps (TaskAllocation/Hybrid/AttentionEscort.py:32-66,714-767; AttentionCommit.py:24-44;
  *   experiments/escort_eval.py:52-58,175-180). */
-enum { MUAVTA_ALLOC_HUNGARIAN = 0, MUAVTA_ALLOC_URGENCY_PAIR = 1, MUAVTA_ALLOC_URGENCY_COALITION = 2 };
+/*   MUAVTA_ALLOC_HUNGARIAN_GATED = the trainers' expert / teacher: HungarianAllocator.allocate_tasks(force=True) under
+ *   _should_replan(env, events, replan_interval) with tags Reset_Allocation, New_Threat, Agent_Fail
+ *   (experiments/train_pair_cost.py:33-43,109-118); use_visibility=0 gives the Global-Hungarian expert. */
+enum { MUAVTA_ALLOC_HUNGARIAN = 0, MUAVTA_ALLOC_URGENCY_PAIR = 1, MUAVTA_ALLOC_URGENCY_COALITION = 2, MUAVTA_ALLOC_HUNGARIAN_GATED = 3 };
 int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
 
 /* Token builders of the learned/engineered hybrids, batched over all envs straight from the device state
@@ -226,6 +229,9 @@ int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
  * (1 = padding); task_ids i32 [N, max_tasks] (-1 = padding; tok["task_ids"]); agent_feats f32 [N, max_agents, Da];
  * agent_mask u8 [N, max_agents]; agent_ids i32 [N, max_agents] (UAV.id of tok["live"][i], -1 = padding); edge_valid f32
  * [N, max_agents, max_tasks]; n_urgent i32 [N] (tok["n_urgent"], 0 for MUAVTA_TOK_ESCORT; may be NULL).
+ * Imitation-learning labels (experiments/train_pair_cost.py:54-71,96-129), both may be NULL: expert_mask f32 [N, max_agents,
+ * max_tasks] = _expert_mask(tok, pairs) of the plan the last muavta_allocate staged (1 where the plan pairs agent row i
+ * with task column j on a valid edge); replanned i32 [N] = that allocate's replan gate fired at the current time step (the trainer builds a sample then).
  * muavta_tokens copies into host buffers (NULL = skip that output) and synchronises; muavta_tokens_device writes to
  * device buffers of the caller (e.g. torch tensors on the same GPU) on the handle's stream without synchronising. */
 /* Per-step log of released task slots (off by default; the Python facade turns it on to keep agent_visibility_map()
@@ -234,9 +240,11 @@ int muavta_set_release_log(MuavtaEnv* env, int32_t enable);
 
 enum { MUAVTA_TOK_PAIR = 0, MUAVTA_TOK_PAIR_RAW = 1, MUAVTA_TOK_ESCORT = 2 };
 int muavta_tokens(MuavtaEnv* env, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
-                  int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent);
+                  int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent,
+                  float* expert_mask, int32_t* replanned);
 int muavta_tokens_device(MuavtaEnv* env, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
-                         int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent);
+                         int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent,
+                         float* expert_mask, int32_t* replanned);
 
 /* The measured path: reset(seeds) followed by n_steps x (allocate -> step) fused in ONE kernel
  * launch, state resident in LDS (run_wps_episode / run_escort_episode with Local-/Coalition-

@@ -97,8 +97,9 @@ class BatchedMultiUAVEnv:
 
     def set_allocator(self, name: str = "hungarian"):
         """'hungarian' (Local-/Coalition-Hungarian), 'urgency_pair' (UrgencyPair.plan under the WPS harness gate) or
-        'urgency_coalition' (UrgencyCoalition.plan under the escort harness gate, with commit locks)."""
-        self._ck(self.L.muavta_set_allocator(self.h, {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2}[name]))
+        'urgency_coalition' (UrgencyCoalition.plan under the escort harness gate, with commit locks) or 'hungarian_gated'
+        (the trainers' expert: allocate_tasks(force=True) under _should_replan(env, events, interval), train_pair_cost.py:33-43)."""
+        self._ck(self.L.muavta_set_allocator(self.h, {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2, "hungarian_gated": 3}[name]))
 
     TOKEN_KINDS = {"pair": (0, 13, 12), "pair_raw": (1, 9, 11), "escort": (2, 22, 16)}
 
@@ -107,14 +108,16 @@ class BatchedMultiUAVEnv:
         `build_escort_tokens` ('escort') of the reference for every env at once (PairCostHybrid.py:31-65,
         AttentionRAH.py:50-173, AttentionEscort.py:76-243).  Returns numpy arrays in the reference's layout, or — with
         `out` = dict of CUDA torch tensors of the right shapes/dtypes (float32 / uint8 / int32) — fills those in place
-        on the handle's stream without a host copy."""
+        on the handle's stream without a host copy.  Also returned: `expert_mask` (= `_expert_mask(tok, pairs)` of the plan
+        the last `allocate` staged, experiments/train_pair_cost.py:54-71) and `replanned` (that allocate planned now)."""
         k, dt, da = self.TOKEN_KINDS[kind]
         mt = int(max_tasks if max_tasks is not None else (48 if kind == "escort" else 32))
         ma = int(max_agents)
         N = self.n_envs
         shapes = {"task_feats": ((N, mt, dt), np.float32), "task_mask": ((N, mt), np.uint8), "task_ids": ((N, mt), np.int32),
                   "agent_feats": ((N, ma, da), np.float32), "agent_mask": ((N, ma), np.uint8), "agent_ids": ((N, ma), np.int32),
-                  "edge_valid": ((N, ma, mt), np.float32), "n_urgent": ((N,), np.int32)}
+                  "edge_valid": ((N, ma, mt), np.float32), "n_urgent": ((N,), np.int32),
+                  "expert_mask": ((N, ma, mt), np.float32), "replanned": ((N,), np.int32)}
         if out is not None:
             ptrs = []
             for name, (shape, dtype) in shapes.items():

@@ -179,7 +179,7 @@ template <class TL> __device__ MUAVTA_OUTLINE void ni_retire_escort_for(const De
 template <class TL> __device__ MUAVTA_OUTLINE void ni_desallocate_all(const DevParams* P, uint32_t* tape, int a);
 
 #ifdef MUAVTA_PROF
-__device__ unsigned long long g_prof[32];
+__device__ unsigned long long g_prof[48];
 #define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; } } while (0)
 #else
 #define PROF(i) do { } while (0)
@@ -189,8 +189,8 @@ template <class TL>
 struct Sim {
   typedef EnvState<TL> State;
 #ifdef MUAVTA_PROF
-  unsigned long long prof_acc[32] = {0}, prof_last = 0;
-  __device__ void prof_flush() { if (threadIdx.x == 0) for (int i = 0; i < 32; i++) atomicAdd(&g_prof[i], prof_acc[i]); }
+  unsigned long long prof_acc[48] = {0}, prof_last = 0;
+  __device__ void prof_flush() { if (threadIdx.x == 0) for (int i = 0; i < 48; i++) atomicAdd(&g_prof[i], prof_acc[i]); }
 #endif
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   State& S;
@@ -1024,6 +1024,7 @@ struct Sim {
     if (S.n_act > 0) {
       precompute_actions();
       lds_sync();
+      PROF(33);
       if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
       lds_sync();
     }
@@ -1089,6 +1090,7 @@ struct Sim {
       const int n_idle = __popcll(__ballot(idle));
       const bool responding = __ballot(resp) != 0ull;
       const bool all_done_tasks = __ballot(blocking) == 0ull;
+      PROF(32);
       if (lane == 0) step_serial_c(r_action, r_distance, r_quality, r_squality, n_idle, responding, all_done_tasks);
     }
     lds_sync();
@@ -1176,6 +1178,7 @@ struct Sim {
     }
     const unsigned long long em = __ballot(evt);
     const int first = em ? __ffsll((long long)em) - 1 : P.n_agents;
+    PROF(34);
     if (live && a < first) {  // commit: own fields only
       if (pop_head) {
         des_allocate(a, cid);
@@ -1837,10 +1840,13 @@ struct Sim {
                          int idle, bool responding, bool all_done_tasks) {
     S.idle_reserve_steps += idle;
     if (S.pending_reset && responding) S.pending_reset = 0;
+    PROF(36);
     const double time_penaulty = S.r_time_penalty, alloc_reward = S.r_alloc;
     double total = P.rw[0] * action_reward + P.rw[1] * distance_reward + P.rw[2] * quality_reward + P.rw[3] * S_quality_reward +
                    P.rw[4] * (double)P.n_tasks * 0.0 + P.rw[5] * alloc_reward + P.rw[6] * time_penaulty + P.rw[7] * S.step_reward;
+    PROF(37);
     S.last_reward = total / P.reward_norm_factor / (double)P.max_time_steps;
+    PROF(38);
     bool all_done = (S.next_task_id > 1) && all_done_tasks;
     bool timed_out = (S.time_steps >= P.max_time_steps) && (P.max_time_steps > 0);
     bool done = timed_out || (P.early_terminate && all_done);
@@ -1872,6 +1878,7 @@ struct Sim {
         return;
       }
       lds_sync();
+      PROF(35);
     }
     {  // compact t_order (drop freed slots) and rebuild last_tasks_info (:492) with ballot + popcount
       const int n = S.n_order;
@@ -2082,6 +2089,11 @@ struct Sim {
       for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;  // Reset_Allocation, New_Threat, Agent_Fail
       go = S.time_steps == 0 || S.time_steps % 15 == 0 || __ballot(trig) != 0ull;
       if (go && lane == 0) S.n_calls++;
+    } else if (mode == 3) {  // trainers' expert: force=True under _should_replan(env, events, interval) (train_pair_cost.py:33-43)
+      bool trig = false;
+      for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;
+      go = S.time_steps == 0 || S.time_steps % interval == 0 || __ballot(trig) != 0ull;
+      if (go && lane == 0) S.n_calls++;
     } else if (mode == 2) {  // escort_eval._should_replan(env, events, interval): all five env tags are REPLAN_EVENTS
       go = S.time_steps == 0 || S.time_steps % interval == 0 || S.n_dev > 0;
       if (go && lane == 0) S.n_calls++;
@@ -2090,6 +2102,7 @@ struct Sim {
       // should_replan (:27-41): every tag the env emits is in the trigger set
       go = (S.time_steps - S.last_plan_step >= interval) || (S.n_dev > 0);
     }
+    if (go && lane == 0) S.gate_step = S.time_steps + 1;
     const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
     int nr = 0, n_live = 1;
     if (go) {
@@ -2269,6 +2282,8 @@ struct Sim {
   struct TokPtrs {
     float* task_feats; uint8_t* task_mask; int32_t* task_ids; float* agent_feats; uint8_t* agent_mask; int32_t* agent_ids;
     float* edge_valid; int32_t* n_urgent;
+    float* expert_mask;   // optional [N, max_agents, max_tasks]: _expert_mask of the pairs staged by the last allocate
+    int32_t* replanned;   // optional [N]: the allocator planned at this time step
     int kind, max_tasks, max_agents;
   };
   DEV double slot_urgency(int s) const {  // _urgency (AttentionRAH.py:29-34)
@@ -2431,6 +2446,8 @@ struct Sim {
       n_urgent += __popcll(__ballot(urgent));
     }
     if (lane == 0 && K.n_urgent) K.n_urgent[env] = n_urgent;
+    if (lane == 0 && K.replanned) K.replanned[env] = S.gate_step == S.time_steps + 1;
+    float* o_em = K.expert_mask ? K.expert_mask + (size_t)env * MA * MT : nullptr;
     // ---- agent rows + edge_valid ----
     for (int i = lane; i < MA; i += WG) {
       float* f = o_af + (size_t)i * Da;
@@ -2473,20 +2490,24 @@ struct Sim {
           f[c++] = (float)fmin(near_escort + (double)n_known_tasks / 16.0, 1.0);
         }
         o_am[i] = 0; o_aid[i] = a;
+        int es = -1;  // the slot the staged plan gives this agent (train_pair_cost.py:54-71: never through the visibility mask)
+        if (o_em) for (int k = 0; k < S.n_act; k++) if (S.act_agent[k] == a) es = S.act_slot[k];
         for (int j = 0; j < MT; j++) {
           float v = 0.f;
+          int s = -2;
           if (j < n_kept) {
-            const int s = list[j];
+            s = list[j];
             bool ok = !vis || ((S.known[a][s >> 5] >> (s & 31)) & 1u);
             if (ok && (S.t_flags[s] & TF_ELIGIBLE) && !((S.t_elig[s] >> ty) & 1u)) ok = false;
             if (ok && kind != 2 && !(S.a_caps[S.t_type[s]][a] > 0)) ok = false;
             v = ok ? 1.f : 0.f;
           }
           ev[j] = v;
+          if (o_em) o_em[(size_t)i * MT + j] = (s == es && v > 0.5f) ? 1.f : 0.f;
         }
       } else {
         for (int c = 0; c < Da; c++) f[c] = 0.f;
-        for (int j = 0; j < MT; j++) ev[j] = 0.f;
+        for (int j = 0; j < MT; j++) { ev[j] = 0.f; if (o_em) o_em[(size_t)i * MT + j] = 0.f; }
         o_am[i] = 1; o_aid[i] = -1;
       }
     }

@@ -320,8 +320,10 @@ int launch_attr(MuavtaEnv* e) {
 
 template <class TL>
 static void launch_tokens(MuavtaEnv* e, int kind, int max_tasks, int max_agents, float* task_feats, uint8_t* task_mask, int32_t* task_ids,
-                          float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent) {
-  typename Sim<TL>::TokPtrs K{task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, kind, max_tasks, max_agents};
+                          float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent, float* expert_mask,
+                          int32_t* replanned) {
+  typename Sim<TL>::TokPtrs K{task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned,
+                              kind, max_tasks, max_agents};
   hipLaunchKernelGGL(k_tokens<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (const EnvState<TL>*)e->blobs, K);
 }
 
@@ -779,14 +781,14 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
 
 #ifdef MUAVTA_PROF
 int muavta_prof_read(unsigned long long* out, int reset) {  // diagnostic build only
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return MUAVTA_E_HIP;
-  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return MUAVTA_E_HIP; }
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 48 * sizeof(unsigned long long)) != hipSuccess) return MUAVTA_E_HIP;
+  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return MUAVTA_E_HIP; }
   return MUAVTA_OK;
 }
 #endif
 
 int muavta_set_allocator(MuavtaEnv* e, int32_t mode) {
-  if (!e || (mode < MUAVTA_ALLOC_HUNGARIAN || mode > MUAVTA_ALLOC_URGENCY_COALITION)) { if (e) e->err = "unknown allocator mode"; return MUAVTA_E_ARG; }
+  if (!e || (mode < MUAVTA_ALLOC_HUNGARIAN || mode > MUAVTA_ALLOC_HUNGARIAN_GATED)) { if (e) e->err = "unknown allocator mode"; return MUAVTA_E_ARG; }
   e->alloc_mode = mode;
   return MUAVTA_OK;
 }
@@ -830,37 +832,40 @@ static int token_dims(int kind, int* dt, int* da) {
   return MUAVTA_OK;
 }
 int muavta_tokens_device(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
-                         int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent) {
+                         int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent,
+                         float* expert_mask, int32_t* replanned) {
   int dt, da;
   if (!e || token_dims(kind, &dt, &da) || max_tasks < 1 || max_agents < 1 || max_tasks > 4096 || max_agents > 4096 || !task_feats || !task_mask ||
       !task_ids || !agent_feats || !agent_mask || !agent_ids || !edge_valid) { if (e) e->err = "muavta_tokens: bad argument"; return MUAVTA_E_ARG; }
   if (!e->did_reset) { e->err = "tokens before reset"; return MUAVTA_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
-  DISPATCH(e, launch_tokens<TL>(e, kind, max_tasks, max_agents, task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent));
+  DISPATCH(e, launch_tokens<TL>(e, kind, max_tasks, max_agents, task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned));
   HIPCHK(e, hipGetLastError());
   return MUAVTA_OK;
 }
 int muavta_tokens(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t max_agents, float* task_feats, uint8_t* task_mask,
-                  int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent) {
+                  int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent,
+                  float* expert_mask, int32_t* replanned) {
   int dt, da;
   if (!e || token_dims(kind, &dt, &da) || max_tasks < 1 || max_agents < 1) { if (e) e->err = "muavta_tokens: bad argument"; return MUAVTA_E_ARG; }
   HIPCHK(e, hipSetDevice(e->device));
   const size_t N = (size_t)e->n_envs, MT = (size_t)max_tasks, MA = (size_t)max_agents;
-  const size_t sz[8] = {N * MT * dt * 4, N * MT, N * MT * 4, N * MA * da * 4, N * MA, N * MA * 4, N * MA * MT * 4, N * 4};
-  size_t off[9] = {0};
-  for (int i = 0; i < 8; i++) off[i + 1] = off[i] + ((sz[i] + 255) & ~(size_t)255);
-  if (off[8] > e->tok_bytes) {
+  const size_t sz[10] = {N * MT * dt * 4, N * MT, N * MT * 4, N * MA * da * 4, N * MA, N * MA * 4, N * MA * MT * 4, N * 4, N * MA * MT * 4, N * 4};
+  size_t off[11] = {0};
+  for (int i = 0; i < 10; i++) off[i + 1] = off[i] + ((sz[i] + 255) & ~(size_t)255);
+  if (off[10] > e->tok_bytes) {
     if (e->d_tok) hipFree(e->d_tok);
     e->d_tok = nullptr; e->tok_bytes = 0;
-    HIPCHK(e, hipMalloc(&e->d_tok, off[8]));
-    e->tok_bytes = off[8];
+    HIPCHK(e, hipMalloc(&e->d_tok, off[10]));
+    e->tok_bytes = off[10];
   }
   char* b = (char*)e->d_tok;
   int rc = muavta_tokens_device(e, kind, max_tasks, max_agents, (float*)(b + off[0]), (uint8_t*)(b + off[1]), (int32_t*)(b + off[2]),
-                                (float*)(b + off[3]), (uint8_t*)(b + off[4]), (int32_t*)(b + off[5]), (float*)(b + off[6]), (int32_t*)(b + off[7]));
+                                (float*)(b + off[3]), (uint8_t*)(b + off[4]), (int32_t*)(b + off[5]), (float*)(b + off[6]), (int32_t*)(b + off[7]),
+                                expert_mask ? (float*)(b + off[8]) : nullptr, replanned ? (int32_t*)(b + off[9]) : nullptr);
   if (rc) return rc;
-  void* host[8] = {task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent};
-  for (int i = 0; i < 8; i++)
+  void* host[10] = {task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned};
+  for (int i = 0; i < 10; i++)
     if (host[i]) HIPCHK(e, hipMemcpyAsync(host[i], b + off[i], sz[i], hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;

@@ -130,6 +130,7 @@ struct alignas(16) EnvState {
       escort_losses, mutual_support_engagements, protected_rec_completed;
   int32_t pending_reset, terminated, truncated, error, did_reset;
   int32_t last_plan_step, n_replans, n_calls;  // HungarianAllocator state
+  int32_t gate_step;                           // time step + 1 at which the replan gate last fired (0 = never)
   uint32_t rng_idx[4];                // cursor into each stream's 2x624-word tape (agent, obs, tgt, mission)
   uint32_t rng_win[4][8];             // the next 8 raw words of each stream, prefetched at the step boundary
   uint32_t rng_win_at[4];             // cursor value the window was filled at

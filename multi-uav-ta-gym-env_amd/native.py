@@ -105,8 +105,8 @@ def lib() -> C.CDLL:
     L.muavta_refresh_observation.argtypes = [vp]
     L.muavta_set_allocator.argtypes = [vp, i32]
     L.muavta_set_release_log.argtypes = [vp, i32]
-    L.muavta_tokens.argtypes = [vp, i32, i32, i32] + [vp] * 8
-    L.muavta_tokens_device.argtypes = [vp, i32, i32, i32] + [vp] * 8
+    L.muavta_tokens.argtypes = [vp, i32, i32, i32] + [vp] * 10
+    L.muavta_tokens_device.argtypes = [vp, i32, i32, i32] + [vp] * 10
     L.muavta_abi_sizes.argtypes = [C.POINTER(i32 * 3)]
     for name in EXPORTS:
         if name != "muavta_last_error":

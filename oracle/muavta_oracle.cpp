@@ -290,6 +290,7 @@ struct Env {
   std::vector<std::vector<char>> known;  // [agent][task id]
   std::vector<std::pair<int, int>> escort_by_recon;  // insertion-ordered dict recon agent id -> escort task id
   std::vector<int> last_tasks_info;
+  std::vector<std::pair<int, int>> last_pairs;  // every (agent, task) pair of the last allocate_tasks result
   std::vector<double> agent_distances;
   int time_steps = 0, conclusion_time = 0;
   double F_Reward = 0, step_reward = 0, total_distance = 0, reward_norm_factor = 1, last_reward = 0;
@@ -300,7 +301,7 @@ struct Env {
       escort_losses = 0, mutual_support_engagements = 0, protected_rec_completed = 0, n_reached = 0;
   bool pending_reset = false, terminated = false, truncated = false, did_reset = false;
   // HungarianAllocator state (HungarianAllocator.py:20-25)
-  long long last_plan_step = -1000000000LL;
+  long long last_plan_step = -1000000000LL, gate_step = -1;
   int n_replans = 0, n_calls = 0;
   std::vector<std::pair<int, int>> last_actions;  // (agent id, task id) chosen by the last allocate
   // capture of every LSAP call of the last allocate (tests)
@@ -550,7 +551,7 @@ struct Env {
     escort_requests = escort_completed = escort_failed = escort_required_steps = escort_covered_steps = 0;
     protection_breaches = threats_intercepted = recon_losses = escort_losses = mutual_support_engagements = 0;
     protected_rec_completed = 0; n_reached = 0;
-    last_plan_step = -1000000000LL; n_replans = 0; n_calls = 0; last_actions.clear();
+    last_plan_step = -1000000000LL; gate_step = -1; n_replans = 0; n_calls = 0; last_actions.clear();
     terminated = truncated = false; last_reward = 0;
 
     // obstacles (:579-583)
@@ -1375,7 +1376,8 @@ struct Env {
     *fighter_pressure = std::fmin(n_near / 4.0, 1.0);
   }
   int tokens(int kind, int max_tasks, int max_agents, float* task_feats, uint8_t* task_mask, int32_t* task_ids,
-             float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent_out) const {
+             float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent_out,
+             float* expert_mask = nullptr) const {
     int Dt, Da;
     token_dims(kind, &Dt, &Da);
     std::fill(task_feats, task_feats + (size_t)max_tasks * Dt, 0.0f);
@@ -1552,6 +1554,16 @@ struct Env {
         }
       }
     }
+    if (expert_mask) {  // _expert_mask (experiments/train_pair_cost.py:54-71) of the pairs the last allocate() returned
+      std::fill(expert_mask, expert_mask + (size_t)max_agents * max_tasks, 0.0f);
+      for (auto& pr : last_pairs) {
+        int i = -1, j = -1;
+        for (size_t q = 0; q < live.size() && (int)q < max_agents; q++) if (live[q] == pr.first) i = (int)q;
+        for (size_t q = 0; q < kept.size(); q++) if (kept[q] == pr.second) j = (int)q;
+        if (i < 0 || j < 0 || edge_valid[(size_t)i * max_tasks + j] < 0.5f) continue;
+        expert_mask[(size_t)i * max_tasks + j] = 1.0f;
+      }
+    }
     if (n_urgent_out) *n_urgent_out = n_urgent;
     return (int)kept.size();
   }
@@ -1561,7 +1573,7 @@ struct Env {
   //         248-254): replan gate _should_replan(env, events, 15), engineered edge scores (float32) for the
   //         first 16 live agents x first 32 underfilled tasks, then HungarianAllocator.allocate_tasks(force=True).
   int allocate(int interval, int use_visibility, int32_t* act_agent, int32_t* act_index, int cap, int mode = 0) {
-    last_actions.clear();
+    last_actions.clear(); last_pairs.clear();
     lsap_costs.clear(); lsap_shapes.clear(); lsap_rows.clear(); lsap_cols.clear();
     interval = std::max(1, interval);
     int n_out = 0;
@@ -1608,6 +1620,13 @@ struct Env {
         }
       }
       n_calls++;  // allocate_tasks(force=True)
+    } else if (mode == 3) {
+      // the trainers' expert: allocate_tasks(force=True) under _should_replan(env, events, interval)
+      // (experiments/train_pair_cost.py:33-43,109-118): tags Reset_Allocation, New_Threat, Agent_Fail
+      bool gate = time_steps == 0 || time_steps % interval == 0;
+      for (auto& ev : done_events) gate |= (ev.tag == MUAVTA_EV_RESET_ALLOCATION || ev.tag == MUAVTA_EV_NEW_THREAT || ev.tag == MUAVTA_EV_AGENT_FAIL);
+      if (!gate) return finish();
+      n_calls++;
     } else if (mode == 2) {
       // Urgency-Coalition (TaskAllocation/Hybrid/AttentionEscort.py:714-767) under escort_eval._should_replan (:52-58)
       bool gate = time_steps == 0 || time_steps % interval == 0 || !done_events.empty();  // all 5 env tags are REPLAN_EVENTS
@@ -1648,6 +1667,7 @@ struct Env {
       n_calls++;
       if (!should_replan(done_events, interval)) return finish();
     }
+    gate_step = time_steps;
     std::vector<int> open_tasks;  // the list handed to allocate_tasks, filtered by its own residual test (:113-119)
     for (size_t k = 1; k < tasks.size(); k++)
       if (in_list[k] && tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_tasks.push_back((int)k);
@@ -1713,6 +1733,7 @@ struct Env {
     }
     last_plan_step = time_steps;
     n_replans++;
+    last_pairs = actions;
     if (mode == 2 && P.commit_horizon > 0) {  // apply_agent_commits (AttentionCommit.py:33-44): pre-step queue head decides
       for (auto& pr : actions) {
         UAV& a = agents[pr.first];
@@ -1753,6 +1774,10 @@ int orc_allocate(void* h, int interval, int use_vis, int32_t* act_agent, int32_t
 int orc_tokens(void* h, int kind, int max_tasks, int max_agents, float* task_feats, uint8_t* task_mask, int32_t* task_ids,
                float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent) {
   return ((Env*)h)->tokens(kind, max_tasks, max_agents, task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent);
+}
+int orc_tokens_expert(void* h, int kind, int max_tasks, int max_agents, float* task_feats, uint8_t* task_mask, int32_t* task_ids,
+                      float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent, float* expert_mask) {
+  return ((Env*)h)->tokens(kind, max_tasks, max_agents, task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask);
 }
 int orc_allocate_mode(void* h, int interval, int use_vis, int mode, int32_t* act_agent, int32_t* act_index, int cap) {
   return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap, mode);
@@ -1795,6 +1820,7 @@ void orc_dims(void* h, int32_t* out) {
   out[15] = (int)q;
 }
 // agents: f64 [A, 16]: x, y, state, head, qlen, nft, nfpx, nfpy, attackCap, task_start, re_eval, last_task, type, name_idx, fail_event, dist ; caps [A,6]; queue [A,Q]
+long long orc_last_plan_step(void* h) { return ((Env*)h)->gate_step; }  // step at which the replan gate last fired
 void orc_get_commit(void* h, int32_t* out) { Env* e = (Env*)h; for (auto& a : e->agents) out[a.id] = a.commit_until; }
 void orc_get_agents(void* h, double* rows, double* caps, int32_t* queue, int qcap) {
   Env* e = (Env*)h;

@@ -34,7 +34,7 @@ class OracleBackend:
         self.o.step(aa[0, :k], ai[0, :k])
 
     def set_allocator(self, name="hungarian"):
-        self._mode = {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2}[name]
+        self._mode = {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2, "hungarian_gated": 3}[name]
 
     def allocate(self, interval=20, use_visibility=True, fetch=True):
         a, i = self.o.allocate_mode(interval, int(use_visibility), getattr(self, "_mode", 0))

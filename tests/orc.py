@@ -102,11 +102,16 @@ class OracleEnv:
                "agent_mask": np.ones(max_agents, np.uint8), "agent_ids": np.full(max_agents, -1, np.int32),
                "edge_valid": np.zeros((max_agents, max_tasks), np.float32)}
         nu = np.zeros(1, np.int32)
-        self.L.orc_tokens(self.h, int(kind), int(max_tasks), int(max_agents), _p(out["task_feats"]), _p(out["task_mask"]),
-                          _p(out["task_ids"]), _p(out["agent_feats"]), _p(out["agent_mask"]), _p(out["agent_ids"]),
-                          _p(out["edge_valid"]), _p(nu))
+        out["expert_mask"] = np.zeros((max_agents, max_tasks), np.float32)
+        self.L.orc_tokens_expert(self.h, int(kind), int(max_tasks), int(max_agents), _p(out["task_feats"]), _p(out["task_mask"]),
+                                 _p(out["task_ids"]), _p(out["agent_feats"]), _p(out["agent_mask"]), _p(out["agent_ids"]),
+                                 _p(out["edge_valid"]), _p(nu), _p(out["expert_mask"]))
         out["n_urgent"] = int(nu[0])
         return out
+
+    def scalars_last_plan(self):
+        self.L.orc_last_plan_step.restype = C.c_longlong
+        return int(self.L.orc_last_plan_step(self.h))
 
     def agent_commit_until(self):
         c = np.zeros(self.A, dtype=np.int32)

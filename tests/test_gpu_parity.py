@@ -509,7 +509,8 @@ def test_tokens_into_torch_tensors_on_device():
     env.rollout(np.arange(64, dtype=np.uint64), 40, 20, True, False)
     want = env.tokens("pair")
     dt = {"task_feats": torch.float32, "task_mask": torch.uint8, "task_ids": torch.int32, "agent_feats": torch.float32,
-          "agent_mask": torch.uint8, "agent_ids": torch.int32, "edge_valid": torch.float32, "n_urgent": torch.int32}
+          "agent_mask": torch.uint8, "agent_ids": torch.int32, "edge_valid": torch.float32, "n_urgent": torch.int32,
+          "expert_mask": torch.float32, "replanned": torch.int32}
     out = {k: torch.empty(v.shape, dtype=dt[k], device="cuda") for k, v in want.items()}
     env.tokens("pair", out=out)
     env.sync()
@@ -538,3 +539,45 @@ def test_replay_document_hip_backend_equals_oracle_backend(case, allocator, seed
         for key in a:
             assert a[key] == b[key], f"{case} frame {k} {key}"
     assert got["events"] == want["events"] and got["final_metrics"] == want["final_metrics"]
+
+
+# ---- next row: the trainers' imitation-learning data loop, batched ----------------------------------------------
+IL_FILES = sorted(glob.glob(os.path.join(GOLDEN, "il_*.npz")))
+
+
+@pytest.mark.parametrize("path", IL_FILES, ids=[os.path.basename(p)[3:-4] for p in IL_FILES])
+def test_il_stream_vs_reference_and_oracle(path):
+    from muavta_amd.il import il_stream
+
+    g = np.load(path)
+    case = os.path.basename(path)[3:-4]
+    seed0, n = int(g["seed"]), 3
+    env = _env(case, n)
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(seed0 + i)
+    steps, k = g["step"].tolist(), 0
+    for t, b in il_stream(env, np.arange(seed0, seed0 + n), 150, 20, "pair", 32, 16, with_reward=True):
+        # env 0: the reference's own samples
+        assert int(b["replanned"][0]) == int(g["replanned"][t]), f"{case} t={t}"
+        if g["replanned"][t]:
+            assert t == steps[k]
+            assert np.array_equal(b["expert_mask"][0], g["mask"][k]), f"{case} t={t}: expert mask"
+            assert np.array_equal(b["task_feats"][0], g["tf"][k]) and np.array_equal(b["agent_feats"][0], g["af"][k])
+            assert np.array_equal(b["edge_valid"][0], g["ev"][k]) and np.array_equal(b["task_ids"][0], g["tid"][k])
+            k += 1
+        else:
+            assert not b["expert_mask"][0].any()
+        assert b["step_reward"][0] == ((g["s_wps"][t] - g["s_wps"][t - 1]) / 20.0 if t else 0.0)
+        # the other seeds: the oracle playing the same loop
+        for i, o in enumerate(oracles):
+            aa, ai = o.allocate_mode(20, 0, 3)
+            tok = o.tokens(0, 32, 16)
+            for key in ("expert_mask", "task_feats", "agent_feats", "edge_valid", "task_ids", "agent_ids", "task_mask", "agent_mask"):
+                assert np.array_equal(b[key][i], tok[key]), f"{case} seed {seed0 + i} t={t}: {key}"
+            assert int(b["replanned"][i]) == int(o.dims()["time_steps"] == o.scalars_last_plan()), f"{case} seed {seed0 + i} t={t}"
+            o.step(aa, ai)
+    assert k == len(steps)
+    assert np.array_equal(env.metrics()[0], g["metrics"])
+    for i, o in enumerate(oracles):
+        assert np.array_equal(env.metrics()[i], o.metrics())

@@ -295,3 +295,33 @@ def test_token_builders_vs_reference(path):
         if t in steps:
             check_tokens(e.tokens, g, steps.index(t), f"{case} t={t}")
         e.step(aa, ai)
+
+
+# ---- next row: the trainers' imitation-learning data loop (expert pairs, tokens, _expert_mask, RL step reward) ----
+IL_FILES = sorted(glob.glob(os.path.join(GOLDEN, "il_*.npz")))
+
+
+@pytest.mark.parametrize("path", IL_FILES, ids=[os.path.basename(p)[3:-4] for p in IL_FILES])
+def test_il_loop_vs_reference(path):
+    g = np.load(path)
+    case = os.path.basename(path)[3:-4]
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(int(g["seed"]))
+    steps, k = g["step"].tolist(), 0
+    assert e.metrics()[4] == g["s_wps"][0]
+    for t in range(150):
+        aa, ai = e.allocate_mode(20, 0, 3)  # Global-Hungarian expert, force=True, under the trainer's gate
+        want_pairs = g["pairs"][g["pairs"][:, 0] == t][:, 1:]
+        if g["replanned"][t]:
+            assert t == steps[k]
+            tok = e.tokens(0, 32, 16)
+            assert np.array_equal(tok["expert_mask"], g["mask"][k]), f"{case} t={t}: expert mask"
+            assert np.array_equal(tok["task_feats"], g["tf"][k]) and np.array_equal(tok["agent_feats"], g["af"][k])
+            assert np.array_equal(tok["edge_valid"], g["ev"][k]) and np.array_equal(tok["task_ids"], g["tid"][k]) and np.array_equal(tok["agent_ids"], g["aid"][k])
+            k += 1
+        else:
+            assert len(aa) == 0
+        assert sorted(map(tuple, e.last_actions().tolist())) == sorted(map(tuple, want_pairs.tolist())), f"{case} t={t}: expert pairs"
+        e.step(aa, ai)
+        assert e.metrics()[4] == g["s_wps"][t + 1]  # RL step reward = (s_wps[t+1] - s_wps[t]) / 20
+    assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"])

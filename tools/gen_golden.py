@@ -367,7 +367,7 @@ def main():
         print("metrics", case, np.stack(rows)[:, 4].mean())
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens", "--il")):
     main()
 
 
@@ -565,3 +565,52 @@ def gen_tokens():
 
 if __name__ == "__main__" and "--tokens" in sys.argv:
     gen_tokens()
+
+
+# ------------------------------------------------------------------------------------------------
+# Next row: the imitation-learning data loop of experiments/train_pair_cost.py:96-129 — expert =
+# Global-Hungarian (force=True) under the trainer's _should_replan(interval 20), tokens = build_pair_tokens, label =
+# _expert_mask (never through the visibility mask); the episode follows the expert.  Plus the RL step reward
+# (S_WPS_now - S_WPS_prev) / 20 of :132-156.
+# ------------------------------------------------------------------------------------------------
+def gen_il():
+    import experiments.train_pair_cost as T
+    from TaskAllocation.Hybrid.PairCostHybrid import build_pair_tokens
+
+    for case, seed in (("WPS_hard", 0), ("WPS_hard_x2", 1), ("WPS_attn", 0), ("WPS_burst64", 0)):
+        env = make_env(case)
+        obs, info = env.reset(seed=seed)
+        hung_g = HA.HungarianAllocator(replan_interval=20, max_coord=env.max_coord)
+        done = {a: False for a in env.agents}
+        trunc = {a: False for a in env.agents}
+        rec = {k: [] for k in ("step", "mask", "tf", "af", "ev", "tid", "aid")}
+        pairs, replanned, s_wps = [], [], [float(env.compute_s_wps())]
+        while not all(done.values()) and not all(trunc.values()):
+            events = _events(info)
+            actions = {}
+            rp = T._should_replan(env, events)
+            replanned.append(int(rp))
+            if rp:
+                expert = hung_g.allocate_tasks(env.get_live_agents(), _open_tasks(env), time_step=env.time_steps, events=events, force=True)
+                tok = build_pair_tokens(env, 32, 16)
+                mask = T._expert_mask(tok, expert)
+                rec["step"].append(env.time_steps); rec["mask"].append(mask); rec["tf"].append(tok["task_feats"]); rec["af"].append(tok["agent_feats"])
+                rec["ev"].append(tok["edge_valid"])
+                tid = np.full(32, -1, dtype=np.int64); tid[:len(tok["task_ids"])] = tok["task_ids"]
+                aid = np.full(16, -1, dtype=np.int64); live = tok["live"][:16]; aid[:len(live)] = [a.id for a in live]
+                rec["tid"].append(tid); rec["aid"].append(aid)
+                for name, task in expert:
+                    pairs.append((env.time_steps, env.agent_by_name[name].id, task.id))
+                actions = T._apply_assign(env, expert)
+            obs, reward, done, trunc, info = env.step(actions)
+            s_wps.append(float(env.compute_s_wps()))
+        out = {k: np.stack(v) for k, v in rec.items()}
+        out.update(pairs=np.array(pairs, dtype=np.int64).reshape(-1, 3), replanned=np.array(replanned, dtype=np.int64),
+                   s_wps=np.array(s_wps), seed=np.int64(seed),
+                   metrics=np.array([float(info["metrics"][k]) for k in METRIC_KEYS]))
+        np.savez_compressed(os.path.join(OUT, f"il_{case}.npz"), **out)
+        print("il", case, out["mask"].shape, int(out["mask"].sum()), out["metrics"][4])
+
+
+if __name__ == "__main__" and "--il" in sys.argv:
+    gen_il()
