@@ -581,3 +581,51 @@ def test_il_stream_vs_reference_and_oracle(path):
     assert np.array_equal(env.metrics()[0], g["metrics"])
     for i, o in enumerate(oracles):
         assert np.array_equal(env.metrics()[i], o.metrics())
+
+
+# ---- fuzzed configurations (knob combinations no registry case has); reference traces in tests/golden/trace_FUZZ* ----
+FUZZ_TRACES = sorted(glob.glob(os.path.join(GOLDEN, "trace_FUZZ*.npz")))
+
+
+@pytest.mark.parametrize("path", FUZZ_TRACES, ids=[os.path.basename(p)[6:-4] for p in FUZZ_TRACES])
+def test_fuzzed_config_stepwise_vs_oracle_and_reference_metrics(path):
+    from cases import params_of
+    from muavta_amd.batched import BatchedMultiUAVEnv
+
+    g = np.load(path)
+    case, seed0 = os.path.basename(path)[6:-4].rsplit("_s", 1)
+    seed0, interval, n = int(seed0), int(g["interval"]), 4
+    small = int(g["n_task_ids"]) <= 40  # few task objects: also run on the tightest tile that fits the fleet
+    for tiles in ([dict(tile_agents=16, tile_tasks=128, tile_threats=16)] + ([dict(tile_agents=16, tile_tasks=48, tile_threats=16)] if small else [])):
+        p = params_of(case, **tiles)
+        env = BatchedMultiUAVEnv(p, n)
+        seeds = np.arange(seed0, seed0 + n, dtype=np.uint64)
+        oracles = [orc.OracleEnv(p) for _ in range(n)]
+        env.reset(seeds)
+        for i, o in enumerate(oracles):
+            o.reset(int(seeds[i]))
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"{case} seed {seeds[i]} after reset")
+        for t in range(p.max_time_steps):
+            aa, ai = env.allocate(interval, True)
+            for i, o in enumerate(oracles):
+                if o.dims()["terminated"] or o.dims()["truncated"]:
+                    continue
+                oa, oi = o.allocate(interval, 1)
+                k = len(oa)
+                assert np.array_equal(aa[i][:k], oa) and np.all(aa[i][k:] == -1) and np.array_equal(ai[i][:k], oi), f"{case} seed {seeds[i]} t={t}"
+                o.step(oa, oi)
+            live = [i for i, o in enumerate(oracles)]
+            env.step(aa, ai)
+            snap = Snapshot(env)
+            done_all = True
+            for i, o in enumerate(oracles):
+                d = o.dims()
+                if not (d["terminated"] or d["truncated"]) or d["time_steps"] == t + 1:
+                    compare(snap, i, o, f"{case} seed {seeds[i]} t={t + 1}")
+                done_all &= bool(d["terminated"] or d["truncated"])
+            if done_all or (oracles[0].dims()["terminated"] or oracles[0].dims()["truncated"]):
+                break
+        assert np.array_equal(env.metrics()[0], g["metrics"]), f"{case}: reference metrics"
+        assert np.all(env.get("ERROR") == 0)

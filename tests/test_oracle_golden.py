@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import orc
+from cases import params_of
 from muavta_amd.params import METRIC_KEYS, params_for_case
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -89,7 +90,7 @@ def test_trace_bit_exact(path):
     case, seed = name.rsplit("_s", 1)
     seed = int(seed)
     interval = int(g["interval"])
-    e = orc.OracleEnv(params_for_case(case))
+    e = orc.OracleEnv(params_of(case))
     e.reset(seed)
     rows, _, _ = e.agents()
     assert np.array_equal(rows[:, 12].astype(int), g["agent_type"])

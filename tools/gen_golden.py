@@ -367,7 +367,7 @@ def main():
         print("metrics", case, np.stack(rows)[:, 4].mean())
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens", "--il")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens", "--il", "--fuzz")):
     main()
 
 
@@ -614,3 +614,79 @@ def gen_il():
 
 if __name__ == "__main__" and "--il" in sys.argv:
     gen_il()
+
+
+# ------------------------------------------------------------------------------------------------
+# Fuzzed configurations: knob combinations no registry case has (share_knowledge off, dual-front bursts, windows
+# without delay, odd horizons, escort variants, masks, reward weights, obstacles, ...).  Full traces, same format as
+# trace_<case>_s<seed>.npz; the configs themselves are committed as tests/golden/fuzz_configs.json.
+# ------------------------------------------------------------------------------------------------
+def fuzz_config(k: int) -> dict:
+    r = random.Random(977 + k)
+    pick = r.choice
+    agents = {"F1": r.randint(0, 3), "F2": r.randint(0, 3), "R1": r.randint(0, 3), "R2": r.randint(0, 3)}
+    if agents["F1"] + agents["F2"] == 0:
+        agents["F1"] = 1
+    if agents["R1"] + agents["R2"] == 0:
+        agents["R2"] = 1
+    threats = []
+    if r.random() < 0.85:
+        threats.append(("T1", r.randint(1, 5)))
+    if r.random() < 0.7:
+        threats.append(("T2", r.randint(1, 4)))
+    cfg = {
+        "agents": agents, "tasks": {"Att": r.randint(0, 4), "Rec": r.randint(1, 5), "Hold": pick([0, 0, 1])},
+        "threats_list": threats, "max_time_steps": pick([60, 150, 150, 200]), "simulation_frame_rate": pick([0.01, 0.01, 0.02]),
+        "multiple_tasks_per_agent": pick([True, True, False]), "random_init_pos": pick([False, False, True]),
+        "num_obstacles": pick([0, 0, 0, 2]), "fail_rate": pick([0.0, 0.05, 0.2]), "early_terminate": pick([False, False, True]),
+        "capability_mask": pick([False, True]), "saturate_mask": pick([False, True]),
+        "reward_weights": pick([None, {"action": 0.5, "distance": 1.0, "quality": 0.7, "s_quality": 1.0, "time": 0.1, "alloc": 0.2,
+                                       "time_penaulty": 0.25, "step": 0.3}]),
+        "arrival_rate": pick([0.0, 0.08, 0.2]), "include_time_windows": pick([False, True]), "dynamic_idle_penalty": pick([0.0, 0.05]),
+        "sense_radius": pick([0.0, 90.0, 250.0]), "threat_delay": pick([0, 6, 20]), "hard_windows": pick([False, True, True]),
+        "window_length": pick([12, 25, 40]), "burst_mode": pick([False, True]), "burst_size": pick([1, 2, 4]),
+        "miss_penalty": pick([0.0, 25.0, 30.0]), "on_time_bonus": pick([0.0, 10.0, 12.0]), "dual_region_bursts": pick([False, True]),
+        "share_knowledge": pick([True, True, False]), "commit_horizon": pick([0, 10]), "reassign_penalty": pick([0.0, 2.0]),
+        "escort_enabled": pick([False, True]), "escort_radius": pick([70.0, 120.0]), "escort_requirement": pick([1.2, 2.5]),
+        "escort_intercept_radius": pick([100.0, 60.0]), "mutual_support_radius": pick([80.0, 150.0]),
+        "escort_agent_types": pick([("F1", "F2"), ("F2",), ("F1", "F2", "R2")]),
+    }
+    if cfg["reward_weights"] is None:
+        del cfg["reward_weights"]
+    return cfg
+
+
+def gen_fuzz(n_cfg=14):
+    import json
+    from mUAV_TA.MultiDroneEnvUtils import agentEnvOptions
+
+    global make_env
+    configs, k = {}, 0
+    base_make_env = make_env
+    while len(configs) < n_cfg and k < 60:
+        cfg = fuzz_config(k)
+        name = f"FUZZ{len(configs):02d}"
+
+        def make_env(case, _cfg=cfg):  # noqa: F811  (run_episode resolves make_env at call time)
+            kw = dict(_cfg)
+            kw["threats_list"] = [tuple(x) for x in kw["threats_list"]]
+            return MultiUAVEnv(agentEnvOptions(render_speed=-1, action_mode="TaskAssign", multiple_agents_per_task=True, fixed_seed=-1, **kw))
+
+        try:
+            interval = 12 if cfg["escort_enabled"] else 20
+            tr = run_episode(name, k % 5, interval, True)
+        except Exception as exc:  # a combination the reference itself cannot run
+            print("skip", k, type(exc).__name__, exc)
+            k += 1
+            continue
+        np.savez_compressed(os.path.join(OUT, f"trace_{name}_s{k % 5}.npz"), **tr)
+        configs[name] = cfg
+        print(name, "k", k, "S_WPS", tr["metrics"][4], "steps", tr["pos"].shape[0] - 1, "tasks", int(tr["n_task_ids"]))
+        k += 1
+    make_env = base_make_env
+    with open(os.path.join(OUT, "fuzz_configs.json"), "w") as f:
+        json.dump(configs, f, indent=1)  # key order is semantic: groups are created in dict order
+
+
+if __name__ == "__main__" and "--fuzz" in sys.argv:
+    gen_fuzz()
