@@ -440,23 +440,22 @@ struct Sim {
     }
     return true;
   }
-  DEV void release_slot(int s) {
+  // Everything a released slot leaves behind except its column of known bits: the caller clears those (serially
+  // below, or one agent per lane in the end-of-step GC) AFTER this has read them.  agent_known_tasks keeps the ids
+  // of retired tasks and the token builders read len(known_ids): a reveal that is still pending for the id gets the
+  // knower set (_wps_process_reveals adds the id to every set).
+  DEV void release_slot_record(int s) {
     int h = S.t_threat[s];
     if (h >= 0) { S.h_tflags[h] = S.t_flags[s] & (TF_DEADLINE | TF_COUNTED); S.h_tdeadline[h] = S.t_deadline[s]; }
     if (S.t_bucket[s] == 0) atomicAdd(&S.n_retired_empty_buckets, 1);
     const int id = S.t_id[s];
     S.t_id[s] = -1;
-    // leave the slot clean for its next tenant: nobody knows it, it is on the free list (atomics: several
-    // lanes release different slots of the same word in the end-of-step GC).  agent_known_tasks keeps the ids
-    // of retired tasks and the token builders read len(known_ids): count them per agent, and leave the knower
-    // set with a reveal that is still pending for this id (_wps_process_reveals adds the id to every set).
-    unsigned long long knowers = 0;
-    for (int a = 0; a < P.n_agents; a++) {
-      const uint32_t old = atomicAnd(&S.known[a][s >> 5], ~(1u << (s & 31)));
-      if ((old >> (s & 31)) & 1u) { atomicAdd(&S.a_gone[a], 1); knowers |= 1ull << a; }
-    }
     // a reveal can only be pending while t < created_at + threat_delay (registered at creation, :1491-1501)
-    if (P.share_knowledge && S.time_steps <= S.t_created[s] + (P.threat_delay > 0 ? P.threat_delay : 0) + 1)
+    const bool pending = P.share_knowledge && S.time_steps <= S.t_created[s] + (P.threat_delay > 0 ? P.threat_delay : 0) + 1;
+    if (!pending && !rel_log) return;
+    unsigned long long knowers = 0;
+    for (int a = 0; a < P.n_agents; a++) knowers |= (unsigned long long)((S.known[a][s >> 5] >> (s & 31)) & 1u) << a;
+    if (pending)
       for (int k = 0; k < S.n_pending; k++)
         if (S.pend_slot[k] == s && S.pend_id[k] == id) S.pend_know[k] = (typename KnowMask<A>::type)knowers;
     if (rel_log) {  // facade only: the task's final record and who knew the id when it left the device
@@ -472,7 +471,16 @@ struct Sim {
         for (int c = 0; c < 6; c++) { r[17 + c] = S.t_cur[c][s]; r[23 + c] = S.t_alloc[c][s]; }
       }
     }
-    atomicOr(&S.free_slots[s >> 5], 1u << (s & 31));
+  }
+  DEV void release_slot(int s) {  // serial form (lane 0, on-demand reclaim)
+    release_slot_record(s);
+    // leave the slot clean for its next tenant: nobody knows it, it is on the free list
+    const uint32_t bit = 1u << (s & 31);
+    for (int a = 0; a < P.n_agents; a++) {
+      const uint32_t old = S.known[a][s >> 5];
+      if (old & bit) { S.known[a][s >> 5] = old & ~bit; S.a_gone[a] += 1; }
+    }
+    S.free_slots[s >> 5] |= bit;
   }
   DEV int reclaim_slot_serial() {
     for (int k = 0; k < S.n_order; k++) {
@@ -1865,19 +1873,48 @@ struct Sim {
       // or retired since the lists were built) -> t_order / last_tasks_info are unchanged
       const int n = S.n_order;
       bool ret = false;
-      for (int k = lane; k < n; k += WG) {
-        const int s = S.t_order[k];
-        if (S.t_status[s] == 2) {
-          ret = true;
-          if (slot_unreferenced(S.t_id[s])) release_slot(s);
-        }
-      }
-      if (__ballot(ret) == 0ull && S.n_open == n) {
+      for (int k = lane; k < n; k += WG) ret |= S.t_status[S.t_order[k]] == 2;
+      const bool any_ret = __ballot(ret) != 0ull;
+      if (!any_ret && S.n_open == n) {
         if (lane == 0) S.n_act = 0;
         lds_sync();
         return;
       }
-      lds_sync();
+      if (any_ret) {
+        // slots still queued by a live agent (one agent per lane marks its queue entries), then the retired and
+        // unreferenced ones are released (one slot per lane), then every agent lane drops the released columns
+        // from its known mask and counts them into a_gone
+        uint32_t* refmask = reinterpret_cast<uint32_t*>(X.path);
+        uint32_t* relmask = refmask + KW;
+        if (lane < 2 * KW) refmask[lane] = 0;
+        lds_sync();
+        if (lane < P.n_agents && S.a_state[lane] != -1) {
+          const int ql = S.a_qlen[lane];
+          for (int k = 0; k < ql; k++) {
+            const int qs = S.a_qslot[lane][k];
+            if (ref_valid(S.a_qid[lane][k], qs)) atomicOr(&refmask[qs >> 5], 1u << (qs & 31));
+          }
+        }
+        lds_sync();
+        for (int k = lane; k < n; k += WG) {
+          const int s = S.t_order[k];
+          if (S.t_status[s] == 2 && !((refmask[s >> 5] >> (s & 31)) & 1u)) {
+            release_slot_record(s);
+            atomicOr(&relmask[s >> 5], 1u << (s & 31));
+          }
+        }
+        lds_sync();
+        if (lane < P.n_agents) {
+          int gone = 0;
+          for (int w = 0; w < KW; w++) {
+            const uint32_t m = relmask[w];
+            if (m) { const uint32_t old = S.known[lane][w]; gone += __popc(old & m); S.known[lane][w] = old & ~m; }
+          }
+          if (gone) S.a_gone[lane] += gone;
+        }
+        if (lane < KW) S.free_slots[lane] |= relmask[lane];
+        lds_sync();
+      }
       PROF(35);
     }
     {  // compact t_order (drop freed slots) and rebuild last_tasks_info (:492) with ballot + popcount
