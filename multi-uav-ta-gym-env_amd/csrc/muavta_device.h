@@ -707,15 +707,21 @@ struct Sim {
   // releaseAllTasks with the whole wave: per-agent flags by the agent's lane, queue teardown (shared f64
   // accumulators on the tasks -> agents_obj order) by lane 0 for the agents that actually queue something,
   // then one task per lane for the status/bucket reset.  All lanes must call it.
-  DEV void release_all_tasks_coop(int for_type) {
+  // returns whether the call changed any state: a repeat of the same event right after a call that changed nothing
+  // is a no-op (f(S) == S), which the drain loop uses to skip the tail of a burst's identical Reset_Allocation events
+  DEV bool release_all_tasks_coop(int for_type) {
     const int ft = for_type < 0 ? for_type + 6 : for_type;  // python negative index -> caps[-1] == Det
     const int a = lane;
-    bool match = false, busy = false;
+    bool match = false, busy = false, chg = false;
     if (a < P.n_agents && S.a_caps[ft][a] > 0 && S.a_state[a] != -1) {
       match = true;
+      chg = S.a_reeval[a] != 1;
       S.a_reeval[a] = 1;  // len(agent.tasks) > 0 always holds in python ([task_idle] counts)
-      if (S.a_qlen[a] > 0) { S.a_last_id[a] = S.a_qid[a][0]; S.a_last_slot[a] = S.a_qslot[a][0]; busy = true; }
-      else { S.a_last_id[a] = 0; S.a_last_slot[a] = -1; S.a_commit[a] = 0; }  // desallocateAll on [task_idle]
+      if (S.a_qlen[a] > 0) { S.a_last_id[a] = S.a_qid[a][0]; S.a_last_slot[a] = S.a_qslot[a][0]; busy = true; chg = true; }
+      else {  // desallocateAll on [task_idle]
+        chg |= S.a_last_id[a] != 0 || S.a_last_slot[a] != -1 || S.a_commit[a] != 0;
+        S.a_last_id[a] = 0; S.a_last_slot[a] = -1; S.a_commit[a] = 0;
+      }
     }
     unsigned long long bm = __ballot(busy);
     uint32_t avail = 0;
@@ -733,7 +739,7 @@ struct Sim {
       }
     }
     lds_sync();
-    if (for_type < 0) return;  // no task has typeIdx -1
+    if (for_type < 0) return __ballot(chg) != 0ull;  // no task has typeIdx -1
     double cum = 0;
     for (int ty = 0; ty < 7; ty++) if ((avail >> ty) & 1u) cum += CAP_TABLE[ty][for_type];
     bool dead_end = false;
@@ -741,9 +747,10 @@ struct Sim {
       const int s = S.t_order[k];
       if (S.t_status[s] != 2 && S.t_type[s] == for_type) {
         if (cum == 0) dead_end = true;
-        else { S.t_status[s] = 0; S.t_bucket[s] = 0; }
+        else { chg |= S.t_status[s] != 0 || S.t_bucket[s] != 0; S.t_status[s] = 0; S.t_bucket[s] = 0; }
       }
     }
+    chg |= dead_end;
     if (__ballot(dead_end) != 0ull) {  // nobody left who can do this type: retire the tasks, in id order (:1466-1476)
       lds_sync();
       if (lane == 0) {
@@ -761,6 +768,7 @@ struct Sim {
       }
     }
     lds_sync();
+    return __ballot(chg) != 0ull;
   }
 
   // ---------------------------------------------------------------- geometry helpers
@@ -1025,8 +1033,15 @@ struct Sim {
       for (int k = lane; k < nev; k += WG) { S.dev_tag[k] = S.ev_tag[k]; S.dev_arg[k] = S.ev_arg[k]; }
       if (lane == 0) { S.step_reward = 0; S.time_steps += 1; S.n_dev = nev; S.n_events = 0; }  // :796
       lds_sync();
+      int last_arg = -1000;
+      bool last_changed = true;
       for (int k = 0; k < nev; k++)
-        if (S.dev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) release_all_tasks_coop(S.dev_arg[k]);
+        if (S.dev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) {
+          const int arg = S.dev_arg[k];
+          if (arg == last_arg && !last_changed) continue;  // same call on unchanged state: nothing to do
+          last_changed = release_all_tasks_coop(arg);
+          last_arg = arg;
+        }
     }
     PROF(2);
     if (S.n_act > 0) {
@@ -1064,6 +1079,7 @@ struct Sim {
     }
     rng_prefetch_commit(rng_words);
     PROF(5);
+    precompute_threat_targets();
     if (lane == 0) step_serial_b(dist_sum);
     lds_sync();
     {
@@ -1435,11 +1451,45 @@ struct Sim {
     PROF(25);
   }
 
+  // get_closest_agent (:1691-1723) for every threat that can spawn this step, one (threat, agent) pair per lane, so
+  // that lane 0's generate_threat only looks the answer up.  Spawn positions are fixed at reset unless
+  // dual_region_bursts redraws x (then generate_threat searches itself).  Result: X.roundT[threat id].
+  DEV bool threat_spawn_step() const { return S.time_steps > 40 && S.time_steps % 10 == 0; }
+  DEV void precompute_threat_targets() {
+    if (!threat_spawn_step() || P.dual_region_bursts) return;  // uniform
+    const int nA = P.n_agents;
+    for (int g = 0; g < P.n_threat_groups; g++) {
+      const int start = S.g_next[g], left = S.g_end[g] - start;
+      int cnt = P.burst_mode ? (P.burst_size < left ? P.burst_size : left) : (left > 0 ? 1 : 0);
+      if (cnt <= 0) continue;
+      if (cnt * nA > A * T) cnt = (A * T) / nA;  // scratch bound (never binding: burst_size <= T)
+      for (int p = lane; p < cnt * nA; p += WG) {
+        const int c = p / nA, a = p - c * nA, h = start + c;
+        const int st = S.a_state[a];
+        X.cost[p] = (h < H && st != -1 && st != 4) ? norm2(S.a_px[a] - S.h_px[h], S.a_py[a] - S.h_py[h]) : __builtin_huge_val();
+      }
+      lds_sync();
+      for (int c = lane; c < cnt; c += WG) {
+        double minF = __builtin_huge_val(), minW = __builtin_huge_val();
+        int cF = -1, cW = -1;
+        for (int a = 0; a < nA; a++) {
+          const double d = X.cost[c * nA + a];
+          const int st = S.a_state[a];
+          if (st != -1 && st != 4) {
+            if (is_fighter(S.a_type[a])) { if (d < minF) { minF = d; cF = a; } }
+            else { if (d < minW) { minW = d; cW = a; } }
+          }
+        }
+        if (start + c < H) X.roundT[start + c] = cW >= 0 ? cW : cF;
+      }
+      lds_sync();
+    }
+  }
   DEV void generate_threat() { ni_generate_threat<TL>(&P, tape); }
   DEV void generate_threat_impl() {  // :1601-1643
     for (int g = 0; g < P.n_threat_groups; g++) {
       int left = S.g_end[g] - S.g_next[g];
-      if (left > 0 && S.time_steps > 40 && S.time_steps % 10 == 0) {
+      if (left > 0 && threat_spawn_step()) {
         if (rnd(ST_AGENT) < P.threat_prob) {
           int n_spawn = 1;
           if (P.burst_mode) n_spawn = P.burst_size < left ? P.burst_size : left;
@@ -1455,7 +1505,7 @@ struct Sim {
               else x = uniform(ST_AGENT, mid + wide, AREA_W - wide);
               S.h_px[h] = x;
             }
-            int tgt = closest_agent(S.h_px[h], S.h_py[h]);
+            const int tgt = P.dual_region_bursts ? closest_agent(S.h_px[h], S.h_py[h]) : X.roundT[h];
             S.h_target[h] = tgt;
             S.h_mission[h] = tgt;
             // TaskFromThreat (:1861-1876)
