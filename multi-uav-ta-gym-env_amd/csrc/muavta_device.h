@@ -1044,7 +1044,7 @@ struct Sim {
         }
     }
     PROF(2);
-    if (S.n_act > 0) {
+    if (S.n_act > 0 && !apply_actions_parallel(r_action, r_distance, r_squality)) {
       precompute_actions();
       lds_sync();
       PROF(33);
@@ -1244,6 +1244,140 @@ struct Sim {
     bool dup = false;
     for (int q = 0; q < k; q++) dup |= S.act_agent[q] == a;
     if (!dup) X.remaining[k] = a;
+  }
+
+  // ---------------------------------------------------------------------------------------------------------
+  // Action application (:813-933) with ONE ACTION PER LANE.  Legal when every staged action names a different
+  // agent (always true on the allocator path), several tasks per agent are allowed, and neither the escort
+  // subsystem (creates tasks while applying) nor the saturation mask (reads other actions' allocations) is on;
+  // otherwise the caller uses precompute_actions + step_serial_a.  What is order dependent is kept in order:
+  //  * the four reward accumulators get the same addends in the same sequence (replayed from lane registers);
+  //  * allocatedReqs of a task taken by several agents this step is summed in action order (same-slot prefix).
+  // Returns false (nothing touched) when the fast path does not apply.
+  // ---------------------------------------------------------------------------------------------------------
+  DEV bool apply_actions_parallel(double& action_reward, double& distance_reward, double& S_quality_reward) {
+    const int n_act = S.n_act;
+    if (!P.multiple_tasks_per_agent || P.escort_enabled || P.saturate_mask || n_act > WG) return false;
+    const int k = lane;
+    const bool mine = k < n_act;
+    const int a = mine ? S.act_agent[k] : -1, s = mine ? S.act_slot[k] : -1;
+    {  // uniform bail-outs: a terminator inside the list, or an agent named twice
+      bool bad = mine && a < 0;
+      for (int q = 0; q < n_act; q++) bad |= mine && q < k && S.act_agent[q] == a;
+      if (__ballot(bad) != 0ull) return false;
+    }
+    // ---- per-action part: own agent + read-only task data ----
+    double q0 = 0, q1 = 0, q2 = 0, q3 = 0, d0 = 0, d1 = 0;  // addends in program order (S_quality x4, distance x2)
+    int nq01 = 0, nq23 = 0, nd0 = 0, nd1 = 0, n_pen = 0;
+    bool realloc = false, succ = false;
+    double caps[6] = {0, 0, 0, 0, 0, 0};
+    int ty = 0;
+    if (mine && S.a_state[a] != -1) {
+      if (s < 0) n_pen = 1;  // index beyond last_tasks_info (:835-838)
+      else {
+        const int tid = S.t_id[s];
+        const int qlen = S.a_qlen[a];
+        const int hid = qlen > 0 ? S.a_qid[a][0] : 0;
+        const double px = S.a_px[a], py = S.a_py[a], tx = S.t_px[s], ty_ = S.t_py[s];
+        bool cont = false;
+        if (hid != tid) {
+          if (hid != 0) {
+            const int hs = S.a_qslot[a][0];  // kept alive by the GC while it heads a live agent's queue
+            q0 = -0.1; q1 = -S.a_caps[S.t_type[hs]][a]; nq01 = 2;
+            realloc = true;
+            S.a_commit[a] = 0;
+            const double dist_old = norm2(px - S.t_px[hs], py - S.t_py[hs]);
+            const double dist_new = norm2(px - tx, py - ty_);
+            d0 = (dist_old - dist_new) / MAX_COORD; nd0 = 1;
+          } else {
+            q0 = 0.05; nq01 = 1;
+            if (S.pending_reset && P.dynamic_idle_penalty != 0) { q1 = -P.dynamic_idle_penalty; nq01 = 2; }
+          }
+        } else { q0 = 0.05; nq01 = 1; cont = true; }  // head is a real task (idle can never be indexed)
+        if (!cont) {
+          if (!action_valid(a, s)) n_pen = 1;
+          else if (!(queue_find(a, tid) >= 0 || S.t_status[s] == 2)) {  // UAV.allocate (DroneEnvComponents.py:55-96)
+            S.a_reeval[a] = 0; S.a_last_id[a] = -1; S.a_last_slot[a] = -1;
+            const double time_to_task = norm2(S.a_nfx[a] - tx, S.a_nfy[a] - ty_) / speed_of(S.a_type[a]);
+            const double start_time = (S.a_nft[a] - (double)S.time_steps) > 0 ? S.a_nft[a] : (double)S.time_steps;
+            ty = S.t_type[s];
+            const double end_time = start_time + time_to_task + (double)task_duration(ty);
+            if (qlen == 0) { S.a_task_start[a] = -1; S.a_state[a] = 1; }
+            if (qlen >= Q) fail(MUAVTA_ERR_QUEUE);
+            else {
+              // expected-distance term (:1216-1229): from the task back to the previous queue tail (or the agent)
+              double total;
+              if (qlen >= 1) { const int ps = S.a_qslot[a][qlen - 1]; total = norm2(tx - S.t_px[ps], ty_ - S.t_py[ps]); }
+              else total = norm2(tx - px, ty_ - py);
+              d1 = -1.0 * total / MAX_COORD; nd1 = 1;
+              S.a_qid[a][qlen] = tid; S.a_qslot[a][qlen] = s; S.a_qtime[a][qlen] = time_to_task; S.a_qlen[a] = qlen + 1;
+              S.a_nft[a] = end_time; S.a_nfx[a] = tx; S.a_nfy[a] = ty_;
+              if (S.a_state[a] != 1 && S.a_state[a] != -1) S.a_state[a] = 1;
+#pragma unroll
+              for (int c = 0; c < 6; c++) caps[c] = S.a_caps[c][a];
+              succ = true;
+            }
+          }
+        }
+      }
+    }
+    // ---- task side: Task.addAgentCap in action order over the lanes that share a slot ----
+    const unsigned long long sm = __ballot(succ);
+    if (sm) {
+      double pre[6] = {0, 0, 0, 0, 0, 0};
+      if (succ) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) pre[c] = S.t_alloc[c][s];
+      }
+      unsigned long long same = 0ull;  // successful lanes on my slot
+      for (unsigned long long m = sm; m; m &= m - 1ull) {
+        const int j = __ffsll((long long)m) - 1;
+        const int sj = __builtin_amdgcn_readlane(s, j);
+        const int aj = __builtin_amdgcn_readlane(a, j);
+        if (succ && sj == s) {
+          same |= 1ull << j;
+          if (j < k) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) pre[c] += S.a_caps[c][aj];
+          }
+        }
+      }
+      lds_sync();  // every lane has read allocatedReqs before the last one of each slot writes it back
+      if (succ) {
+        double after[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) after[c] = pre[c] + caps[c];
+        const double agentCap = caps[ty];
+        double missing = S.t_cur[ty][s] - (after[ty] - agentCap);
+        missing = missing > 0 ? missing : 0;
+        const double addedCap = missing - fmax(missing - agentCap, 0.0);
+        if (addedCap <= 0) { q2 = -1.5; q3 = addedCap; nq23 = 2; } else { q2 = addedCap; nq23 = 1; }
+        atomicOr(&S.t_bucket[s], 1ull << a);
+        if ((same >> k) >> 1 == 0ull) {  // last successful lane on this slot
+#pragma unroll
+          for (int c = 0; c < 6; c++) S.t_alloc[c][s] = after[c];
+          S.t_ndet[s] += __popcll(same);
+          S.t_status[s] = 1;
+        }
+      }
+      if (lane == 0) S.times_dirty = 1;
+    }
+    const int n_re = __popcll(__ballot(realloc));
+    if (lane == 0 && n_re) { S.n_reallocations += n_re; S.n_task_switches += n_re; }
+    // ---- rewards: the reference's additions, in its order (uniform loop, operands broadcast with v_readlane) ----
+    for (int j = 0; j < n_act; j++) {
+      const int c01 = __builtin_amdgcn_readlane(nq01, j), c23 = __builtin_amdgcn_readlane(nq23, j);
+      if (__builtin_amdgcn_readlane(n_pen, j) && c01 == 0) action_reward += -1;          // s < 0: nothing else happened
+      if (c01 >= 1) S_quality_reward += readlane_f64(q0, j);
+      if (c01 >= 2) S_quality_reward += readlane_f64(q1, j);
+      if (__builtin_amdgcn_readlane(nd0, j)) distance_reward += readlane_f64(d0, j);
+      if (__builtin_amdgcn_readlane(n_pen, j) && c01 != 0) action_reward += -1;          // invalid action (:878-880)
+      if (c23 >= 1) S_quality_reward += readlane_f64(q2, j);
+      if (c23 >= 2) S_quality_reward += readlane_f64(q3, j);
+      if (__builtin_amdgcn_readlane(nd1, j)) distance_reward += readlane_f64(d1, j);
+    }
+    lds_sync();
+    return true;
   }
   // action application (:813-933), dict order, lane 0
   DEV void step_serial_a(double& action_reward, double& distance_reward, double& quality_reward, double& S_quality_reward) {
