@@ -731,7 +731,59 @@ struct Sim {
       for (int t = 0; t <= MUAVTA_F2; t++) if (__ballot(match && ty == t) != 0ull) avail |= 1u << t;
     }
     lds_sync();
-    if (lane == 0) {
+    if (Q <= 8) {
+      // desallocateAll of every busy agent at once.  `for task in self.tasks: self.desAllocate(task)` over the list
+      // being mutated drops the queue entries at even positions and keeps the odd ones (iterate_desallocate).
+      // Agent side (lane = agent): own queue compaction + next-free fields.  Task side (lane = slot): Task.removeAgentCap
+      // of the dropped entries in the reference's order (agents ascending), so allocatedReqs sees the same f64 sequence.
+      int rid[4] = {-1, -1, -1, -1}, rsl[4] = {-1, -1, -1, -1};  // dropped (task id, slot) of this lane's agent
+      if (busy) {
+        const int n = S.a_qlen[a];
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (2 * i < n) { rid[i] = S.a_qid[a][2 * i]; rsl[i] = S.a_qslot[a][2 * i]; }
+        int kid[4], ksl[4]; double ktm[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (2 * i + 1 < n) { kid[i] = S.a_qid[a][2 * i + 1]; ksl[i] = S.a_qslot[a][2 * i + 1]; ktm[i] = S.a_qtime[a][2 * i + 1]; }
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (2 * i + 1 < n) { S.a_qid[a][i] = kid[i]; S.a_qslot[a][i] = ksl[i]; S.a_qtime[a][i] = ktm[i]; }
+        S.a_qlen[a] = n >> 1;
+        S.a_nft[a] = (double)S.time_steps; S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
+        S.a_commit[a] = 0;
+      }
+      for (int base = 0; base < T; base += WG) {
+        const int sl = base + lane;
+        const bool live_slot = sl < T && S.t_id[sl] >= 0 && S.t_status[sl] != 2;  // removeAgentCap ignores concluded tasks
+        const int my_id = sl < T ? S.t_id[sl] : -1;
+        double al[6];
+        int nd = 0;
+        bool touched = false;
+        for (unsigned long long m = bm; m; m &= m - 1ull) {
+          const int b = __ffsll((long long)m) - 1;
+          bool hit = false;
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int bs = __builtin_amdgcn_readlane(rsl[i], b), bi = __builtin_amdgcn_readlane(rid[i], b);
+            hit |= live_slot && bs == sl && bi == my_id;
+          }
+          if (hit) {
+            if (!touched) {
+#pragma unroll
+              for (int c = 0; c < 6; c++) al[c] = S.t_alloc[c][sl];
+              touched = true;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) al[c] -= S.a_caps[c][b];
+            nd++;
+          }
+        }
+        if (touched) {
+#pragma unroll
+          for (int c = 0; c < 6; c++) S.t_alloc[c][sl] = al[c];
+          S.t_ndet[sl] -= nd;
+          S.times_dirty = 1;
+        }
+      }
+    } else if (lane == 0) {
       while (bm) {
         const int b = __ffsll((long long)bm) - 1;
         bm &= bm - 1ull;
