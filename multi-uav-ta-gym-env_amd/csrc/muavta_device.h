@@ -518,7 +518,7 @@ struct Sim {
     S.t_order[S.n_order++] = s;
     return s;
   }
-  DEV void know_all(int s) { for (int a = 0; a < P.n_agents; a++) S.known[a][s >> 5] |= 1u << (s & 31); }
+  DEV void know_all(int s) { for (int a = 0; a < P.n_agents; a++) S.known[a][s >> 5] |= 1u << (s & 31); S.t_flags[s] |= TF_KNOWN_ALL; }
 
   // _register_dynamic_task (:1491-1504)
   DEV void register_dynamic(int s) {
@@ -2024,7 +2024,8 @@ struct Sim {
       bool c = false;
       if (k < nO) {
         s = S.t_order[k];
-        c = S.t_status[s] != 2 && (S.t_created[s] > 0 || (S.t_flags[s] & TF_DEADLINE));
+        const int fl = S.t_flags[s];
+        c = S.t_status[s] != 2 && !(fl & TF_KNOWN_ALL) && (S.t_created[s] > 0 || (fl & TF_DEADLINE));
       }
       const unsigned long long m = __ballot(c);
       if (c) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = s;

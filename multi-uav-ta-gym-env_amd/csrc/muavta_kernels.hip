@@ -510,6 +510,7 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
     case MUAVTA_F_KNOWN:
       if (!chk((size_t)N * A * KW * 4)) BAD();
       for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) for (int w = 0; w < KW; w++) RW(U[((size_t)n * A + a) * KW + w], blobs[n].known[a][w]);
+      if (scatter) for (int n = 0; n < N; n++) for (int sl = 0; sl < T; sl++) blobs[n].t_flags[sl] &= ~TF_KNOWN_ALL;  // caller-written masks: sense again
       break;
     case MUAVTA_F_THREAT_POS:
       if (!chk((size_t)N * H * 2 * 8)) BAD();

@@ -28,7 +28,8 @@ enum {
 };
 
 // Task flag bits.
-enum { TF_ESCORT = 1, TF_COUNTED = 2, TF_REACHED = 4, TF_ELIGIBLE = 8, TF_DEADLINE = 16 };
+enum { TF_ESCORT = 1, TF_COUNTED = 2, TF_REACHED = 4, TF_ELIGIBLE = 8, TF_DEADLINE = 16,
+       TF_KNOWN_ALL = 32 /* the team-wide reveal happened: every agent's known bit is set, sensing has nothing to add */ };
 
 // Kernel-argument block: config + host-derived constants (all computed with the reference's
 // operation order on the host so device and oracle agree bit for bit).
