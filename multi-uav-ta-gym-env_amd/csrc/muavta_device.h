@@ -1110,6 +1110,9 @@ struct Sim {
       const int first = move_parallel(start);
       lds_sync();
       PROF(26);
+#ifdef MUAVTA_PROF
+      if (threadIdx.x == 0) { prof_acc[40] += 1000; if (first < P.n_agents) prof_acc[41] += 1000; }
+#endif
       if (first >= P.n_agents) break;
       if (lane == 0) step_serial_move(first, first + 1, r_quality);
       lds_sync();
