@@ -731,21 +731,24 @@ struct Sim {
       for (int t = 0; t <= MUAVTA_F2; t++) if (__ballot(match && ty == t) != 0ull) avail |= 1u << t;
     }
     lds_sync();
-    if (Q <= 8) {
+    if (Q <= 16) {
+      constexpr int HQ = (Q + 1) / 2;
       // desallocateAll of every busy agent at once.  `for task in self.tasks: self.desAllocate(task)` over the list
       // being mutated drops the queue entries at even positions and keeps the odd ones (iterate_desallocate).
       // Agent side (lane = agent): own queue compaction + next-free fields.  Task side (lane = slot): Task.removeAgentCap
       // of the dropped entries in the reference's order (agents ascending), so allocatedReqs sees the same f64 sequence.
-      int rid[4] = {-1, -1, -1, -1}, rsl[4] = {-1, -1, -1, -1};  // dropped (task id, slot) of this lane's agent
+      int rid[HQ], rsl[HQ];
+#pragma unroll
+      for (int i = 0; i < HQ; i++) { rid[i] = -1; rsl[i] = -1; }  // dropped (task id, slot) of this lane's agent
       if (busy) {
         const int n = S.a_qlen[a];
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (2 * i < n) { rid[i] = S.a_qid[a][2 * i]; rsl[i] = S.a_qslot[a][2 * i]; }
-        int kid[4], ksl[4]; double ktm[4];
+        for (int i = 0; i < HQ; i++) if (2 * i < n) { rid[i] = S.a_qid[a][2 * i]; rsl[i] = S.a_qslot[a][2 * i]; }
+        int kid[HQ], ksl[HQ]; double ktm[HQ];
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (2 * i + 1 < n) { kid[i] = S.a_qid[a][2 * i + 1]; ksl[i] = S.a_qslot[a][2 * i + 1]; ktm[i] = S.a_qtime[a][2 * i + 1]; }
+        for (int i = 0; i < HQ; i++) if (2 * i + 1 < n) { kid[i] = S.a_qid[a][2 * i + 1]; ksl[i] = S.a_qslot[a][2 * i + 1]; ktm[i] = S.a_qtime[a][2 * i + 1]; }
 #pragma unroll
-        for (int i = 0; i < 4; i++) if (2 * i + 1 < n) { S.a_qid[a][i] = kid[i]; S.a_qslot[a][i] = ksl[i]; S.a_qtime[a][i] = ktm[i]; }
+        for (int i = 0; i < HQ; i++) if (2 * i + 1 < n) { S.a_qid[a][i] = kid[i]; S.a_qslot[a][i] = ksl[i]; S.a_qtime[a][i] = ktm[i]; }
         S.a_qlen[a] = n >> 1;
         S.a_nft[a] = (double)S.time_steps; S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
         S.a_commit[a] = 0;
@@ -761,7 +764,7 @@ struct Sim {
           const int b = __ffsll((long long)m) - 1;
           bool hit = false;
 #pragma unroll
-          for (int i = 0; i < 4; i++) {
+          for (int i = 0; i < HQ; i++) {
             const int bs = __builtin_amdgcn_readlane(rsl[i], b), bi = __builtin_amdgcn_readlane(rid[i], b);
             hit |= live_slot && bs == sl && bi == my_id;
           }
@@ -1303,16 +1306,17 @@ struct Sim {
 
   // ---------------------------------------------------------------------------------------------------------
   // Action application (:813-933) with ONE ACTION PER LANE.  Legal when every staged action names a different
-  // agent (always true on the allocator path), several tasks per agent are allowed, and neither the escort
-  // subsystem (creates tasks while applying) nor the saturation mask (reads other actions' allocations) is on;
+  // agent (always true on the allocator path), several tasks per agent are allowed, and the saturation mask (reads
+  // other actions' allocations) is off;
   // otherwise the caller uses precompute_actions + step_serial_a.  What is order dependent is kept in order:
   //  * the four reward accumulators get the same addends in the same sequence (replayed from lane registers);
-  //  * allocatedReqs of a task taken by several agents this step is summed in action order (same-slot prefix).
+  //  * allocatedReqs of a task taken by several agents this step is summed in action order (same-slot prefix);
+  //  * escort creation (new task ids, events) runs on lane 0 afterwards, in action order.
   // Returns false (nothing touched) when the fast path does not apply.
   // ---------------------------------------------------------------------------------------------------------
   DEV bool apply_actions_parallel(double& action_reward, double& distance_reward, double& S_quality_reward) {
     const int n_act = S.n_act;
-    if (!P.multiple_tasks_per_agent || P.escort_enabled || P.saturate_mask || n_act > WG) return false;
+    if (!P.multiple_tasks_per_agent || P.saturate_mask || n_act > WG) return false;
     const int k = lane;
     const bool mine = k < n_act;
     const int a = mine ? S.act_agent[k] : -1, s = mine ? S.act_slot[k] : -1;
@@ -1324,7 +1328,8 @@ struct Sim {
     // ---- per-action part: own agent + read-only task data ----
     double q0 = 0, q1 = 0, q2 = 0, q3 = 0, d0 = 0, d1 = 0;  // addends in program order (S_quality x4, distance x2)
     int nq01 = 0, nq23 = 0, nd0 = 0, nd1 = 0, n_pen = 0;
-    bool realloc = false, succ = false;
+    bool realloc = false, succ = false, idle_br = false;
+    const int pending0 = S.pending_reset;
     double caps[6] = {0, 0, 0, 0, 0, 0};
     int ty = 0;
     if (mine && S.a_state[a] != -1) {
@@ -1346,7 +1351,7 @@ struct Sim {
             d0 = (dist_old - dist_new) / MAX_COORD; nd0 = 1;
           } else {
             q0 = 0.05; nq01 = 1;
-            if (S.pending_reset && P.dynamic_idle_penalty != 0) { q1 = -P.dynamic_idle_penalty; nq01 = 2; }
+            idle_br = true;  // the idle penalty (:866-868) looks at pending_reset, which an earlier action's escort creation sets
           }
         } else { q0 = 0.05; nq01 = 1; cont = true; }  // head is a real task (idle can never be indexed)
         if (!cont) {
@@ -1376,6 +1381,10 @@ struct Sim {
         }
       }
     }
+    // actions that will create an escort (and with it set pending_reset) further down, in action order
+    const bool creates = P.escort_enabled && succ && ty == MUAVTA_REC && is_recon(S.a_type[a]) && escort_lookup(a) < 0;
+    const unsigned long long cm = __ballot(creates);
+    if (idle_br && P.dynamic_idle_penalty != 0 && (pending0 || (cm & ((1ull << k) - 1ull)) != 0ull)) { q1 = -P.dynamic_idle_penalty; nq01 = 2; }
     // ---- task side: Task.addAgentCap in action order over the lanes that share a slot ----
     const unsigned long long sm = __ballot(succ);
     if (sm) {
@@ -1419,6 +1428,14 @@ struct Sim {
     }
     const int n_re = __popcll(__ballot(realloc));
     if (lane == 0 && n_re) { S.n_reallocations += n_re; S.n_task_switches += n_re; }
+    if (P.escort_enabled) {  // _create_escort_for (:923-929) creates tasks and events: lane 0, in action order
+      lds_sync();
+      for (unsigned long long m = cm; m; m &= m - 1ull) {
+        const int j = __ffsll((long long)m) - 1;
+        const int aj = __builtin_amdgcn_readlane(a, j), sj = __builtin_amdgcn_readlane(s, j);
+        if (lane == 0) create_escort_for(aj, sj);
+      }
+    }
     // ---- rewards: the reference's additions, in its order (uniform loop, operands broadcast with v_readlane) ----
     for (int j = 0; j < n_act; j++) {
       const int c01 = __builtin_amdgcn_readlane(nq01, j), c23 = __builtin_amdgcn_readlane(nq23, j);
