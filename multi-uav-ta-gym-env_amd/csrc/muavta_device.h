@@ -2518,7 +2518,7 @@ struct Sim {
       if (__ballot(feasible) == 0ull) break;
       lds_sync();
       PROF(12);
-      if (T <= WG) lsap_reg(Rr, Cc); else lsap(Rr, Cc);
+      if constexpr (T <= WG && A <= 32) lsap_reg(Rr, Cc); else lsap(Rr, Cc);
       PROF(13);
       // accept (:182-204): one free agent per lane, actions appended in ascending agent order (scipy returns
       // rows sorted); each task appears at most once per round, so the residual updates are independent
@@ -2923,67 +2923,98 @@ struct Sim {
   // scan position `it` — its id, dual v, shortest-path cost, predecessor row and assignment — and a
   // swap-remove moves the last position's registers into the vacated lane with v_readlane.  Row duals u and
   // col4row live in the row's lane.  Per scan step only the cost element is read from LDS.
+  // Register-resident variant for A <= 32, T <= 64: lane j owns COLUMN j for the whole solve — its cost column
+  // (one uniform-indexed register per row: s_set_gpr_idx), v[j], row4col[j], the shortest-path cost and predecessor —
+  // and lane r owns row r's u[r] / col4row[r]; no LDS traffic inside the solve.  scipy's `remaining` array is kept
+  // only as each column's POSITION in it (filled in reverse, swap-removed), which is all its tie rule looks at:
+  // among the minima take the unassigned column at the LAST position if there is one, else the FIRST position.
+  typedef double cost_vec __attribute__((ext_vector_type(16)));
   DEV void lsap_reg(int nr, int nc) {
     const double INF = __builtin_huge_val();
-    double u_r = 0;   // lane r < nr: u[r]
-    int c4r = -1;     // lane r < nr: col4row[r]
-    for (int j = lane; j < nc; j += WG) { X.v[j] = 0; X.row4col[j] = -1; }
-    lds_sync();
+    cost_vec c0, c1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { c0[i] = (i < nr && lane < nc) ? X.cost[i * nc + lane] : 0.0; }
+    if (A > 16) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) { c1[i] = (16 + i < nr && lane < nc) ? X.cost[(16 + i) * nc + lane] : 0.0; }
+    }
+    double u_r = 0, vj = 0;  // lane r < nr: u[r];  lane j < nc: v[j]
+    int c4r = -1, r4c = -1;  // lane r: col4row[r];  lane j: row4col[j]
+    const bool incol = lane < nc;
     for (int cur = 0; cur < nr; cur++) {
-      int j = nc - 1 - lane;  // scipy fills `remaining` in reverse
-      const bool incol = lane < nc;
-      double vj = incol ? X.v[j] : 0.0, sp = INF;
-      int r4c = incol ? X.row4col[j] : 0, pth = -1;
+      int pos = nc - 1 - lane;  // scipy fills `remaining` in reverse: column j sits at position nc-1-j
+      double sp = INF;
+      int pth = -1;
+      bool active = incol;
       unsigned long long SRmask = 0ull, SCmask = 0ull;
       double minVal = 0;
       int i = cur, nrem = nc, sink = -1;
       while (sink == -1) {
         SRmask |= 1ull << i;
         const double ui = readlane_f64(u_r, i);
-        const bool active = lane < nrem;
+        const double ci = (A > 16 && i >= 16) ? c1[i - 16] : c0[i];
         double val = INF;
         bool un = false;
         if (active) {
-          const double r = minVal + X.cost[i * nc + j] - ui - vj;
+          const double r = minVal + ci - ui - vj;
           if (r < sp) { sp = r; pth = i; }
           val = sp;
           un = r4c == -1;
         }
         const double m = wave_min(val);
+        if (m == INF) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }
         const unsigned long long eq = __ballot(active && val == m);
         const unsigned long long equ = __ballot(active && val == m && un);
-        if (m == INF) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }
+        int sel;
+        if (equ) {
+          sel = 63 - __clzll((long long)equ);
+          if (equ & (equ - 1ull)) {  // several unassigned minima: the one at the last position
+            int best = -1;
+            for (unsigned long long t = equ; t; t &= t - 1ull) {
+              const int b = __ffsll((long long)t) - 1;
+              const int pb = __builtin_amdgcn_readlane(pos, b);
+              if (pb > best) { best = pb; sel = b; }
+            }
+          }
+        } else {
+          sel = __ffsll((long long)eq) - 1;
+          if (eq & (eq - 1ull)) {    // several (assigned) minima: the one at the first position
+            int best = 1 << 30;
+            for (unsigned long long t = eq; t; t &= t - 1ull) {
+              const int b = __ffsll((long long)t) - 1;
+              const int pb = __builtin_amdgcn_readlane(pos, b);
+              if (pb < best) { best = pb; sel = b; }
+            }
+          }
+        }
         minVal = m;
-        const int index = equ ? 63 - __clzll((long long)equ) : __ffsll((long long)eq) - 1;
-        const int jsel = __builtin_amdgcn_readlane(j, index), rj = __builtin_amdgcn_readlane(r4c, index);
-        if (lane == index) { X.spc[jsel] = sp; X.path[jsel] = pth; }  // final values of the selected column, by column id
-        SCmask |= 1ull << jsel;
-        const int last = nrem - 1;
-        const int jl = __builtin_amdgcn_readlane(j, last), r4l = __builtin_amdgcn_readlane(r4c, last), pl = __builtin_amdgcn_readlane(pth, last);
-        const double vl = readlane_f64(vj, last), spl = readlane_f64(sp, last);
-        if (lane == index) { j = jl; vj = vl; r4c = r4l; sp = spl; pth = pl; }
+        const int rj = __builtin_amdgcn_readlane(r4c, sel), psel = __builtin_amdgcn_readlane(pos, sel);
+        SCmask |= 1ull << sel;
+        if (pos == nrem - 1) pos = psel;  // remaining[index] = remaining[--num_remaining]
+        if (lane == sel) active = false;
         nrem--;
-        if (rj == -1) sink = jsel; else i = rj;
+        if (rj == -1) sink = sel; else i = rj;
       }
-      lds_sync();
+      // dual updates (u over the scanned rows, v over the scanned columns)
+      const double spc_of_my_col = __shfl(sp, c4r < 0 ? 0 : c4r);  // rows in SR other than cur are assigned
       if (lane < nr) {
         if (lane == cur) u_r += minVal;
-        else if ((SRmask >> lane) & 1ull) u_r += minVal - X.spc[c4r];
+        else if ((SRmask >> lane) & 1ull) u_r += minVal - spc_of_my_col;
       }
-      if (lane < nc && ((SCmask >> lane) & 1ull)) X.v[lane] -= minVal - X.spc[lane];
-      // augmentation along `path` (uniform walk; col4row lives in the rows' lanes)
+      if (incol && ((SCmask >> lane) & 1ull)) vj -= minVal - sp;
+      // augmentation along `path` (uniform walk)
       int jj = sink;
       while (true) {
-        const int r = X.path[jj];
-        if (lane == 0) X.row4col[jj] = r;
+        const int r = __builtin_amdgcn_readlane(pth, jj);
+        if (lane == jj) r4c = r;
         const int t = __builtin_amdgcn_readlane(c4r, r);
         if (lane == r) c4r = jj;
         jj = t;
         if (r == cur) break;
       }
-      lds_sync();
     }
     if (lane < nr) X.col4row[lane] = c4r;
+    if (incol) X.row4col[lane] = r4c;
     lds_sync();
   }
 
