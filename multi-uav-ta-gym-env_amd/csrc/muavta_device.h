@@ -1140,12 +1140,19 @@ struct Sim {
     precompute_threat_targets();
     if (lane == 0) step_serial_b(dist_sum);
     lds_sync();
-    {
-      unsigned long long livemask;
-      const int first = update_threats_parallel(livemask);
-      lds_sync();
-      PROF(23);
-      if (lane == 0) step_serial_b2(first, livemask);
+    {  // update_threats (:1725-1744): lanes advance every threat up to the first one that engages or leaves the area,
+       // lane 0 plays that one as the reference does, and the wave resumes behind it
+      unsigned long long livemask = 0ull;
+      for (int start = 0;;) {
+        const int first = update_threats_parallel(start, livemask);
+        lds_sync();
+        PROF(23);
+        if (first >= S.n_active_threats) break;
+        if (lane == 0) update_threats_serial(first, livemask);
+        lds_sync();
+        start = first + 1;
+      }
+      if (lane == 0) step_serial_b2();
     }
     lds_sync();
     if (P.escort_enabled) sync_escorts_coop();
@@ -1650,8 +1657,7 @@ struct Sim {
     generate_threat();
     PROF(22);
   }
-  DEV void step_serial_b2(int first, unsigned long long livemask) {
-    if (first < S.n_active_threats) update_threats_serial(first, livemask);
+  DEV void step_serial_b2() {
     PROF(24);
     inject_dynamic_arrivals();
     PROF(25);
@@ -1823,14 +1829,16 @@ struct Sim {
   // area with an uncounted window (shared counters): those are events.  Threats before the first event
   // (env.threats order) commit their lane's result; lane 0 replays the reference loop from the event on.
   // Returns (first serial index, snapshot mask of threats with status != 2).
-  DEV int update_threats_parallel(unsigned long long& livemask) {
+  // lanes [start, n): the threats behind the last serially replayed one; `livemask` is taken once, at start == 0
+  DEV int update_threats_parallel(int start, unsigned long long& livemask) {
     static_assert(H <= 64, "one threat per lane");
     const int n = S.n_active_threats;
     const int k = lane;
     int h = 0;
     bool active = false;
     if (k < n) { h = S.h_order[k]; active = S.h_status[h] != 2; }
-    livemask = __ballot(active);  // python snapshots [t for t in self.threats if t.status != 2] before the loop
+    if (start == 0) livemask = __ballot(active);  // python snapshots [t for t in self.threats if t.status != 2] before the loop
+    active = k >= start && k < n && ((livemask >> k) & 1ull);
     bool evt = false;
     double npx = 0, npy = 0;
     int tgt = -1, icpt = -1, slot = -1;
@@ -1876,8 +1884,8 @@ struct Sim {
     return first;
   }
   DEV void update_threats_serial(int first, unsigned long long livemask) { ni_update_threats_serial<TL>(&P, tape, first, livemask); }
-  DEV void update_threats_serial_impl(int first, unsigned long long livemask) {
-    const int n = S.n_active_threats;
+  DEV void update_threats_serial_impl(int first, unsigned long long livemask) {  // the reference's loop body for ONE threat
+    const int n = first + 1 < S.n_active_threats ? first + 1 : S.n_active_threats;
     for (int k = first; k < n; k++) {
       if (!((livemask >> k) & 1ull)) continue;
       int h = S.h_order[k];
