@@ -2002,38 +2002,58 @@ struct Sim {
         lds_sync();
       }
     }
-    const int n = S.n_escorts;  // snapshot of the map (retiring pops entries)
-    int snap = lane < n ? S.esc_agent[lane] : -1;
-    for (int k = 0; k < n; k++) {
-      const int recon = __builtin_amdgcn_readlane(snap, k);
-      const unsigned long long hit = __ballot(lane < S.n_escorts && S.esc_agent[lane] == recon);
-      if (!hit) continue;
-      const int kk = __ffsll((long long)hit) - 1;
-      const int es = S.esc_slot[kk], eid = S.esc_id[kk];
-      const int rid = S.esc_pid[kk], rs = S.esc_pslot[kk];
-      const bool dead = S.a_state[recon] == -1;
+    // Snapshot of the map, one entry per lane (retiring pops entries).  Whether an entry retires depends only on its
+    // recon UAV and Rec task, which no other entry's retirement touches, so that is decided up front; coverage of
+    // the entries BETWEEN two retirements is then evaluated in one pass (fighters' queues only change at a
+    // retirement), one fighter per lane, instead of one map entry at a time.
+    const int n = S.n_escorts;
+    if (n == 0) return;
+    int recon = -1, es = -1, eid = -1;
+    bool retire = false, dead = false, esc_live = false;
+    if (lane < n) {
+      recon = S.esc_agent[lane]; es = S.esc_slot[lane]; eid = S.esc_id[lane];
+      const int rid = S.esc_pid[lane], rs = S.esc_pslot[lane];
+      dead = S.a_state[recon] == -1;
       const bool idle = S.a_qlen[recon] == 0 || S.a_state[recon] == 0 || S.a_state[recon] == 3;
       const bool rec_done = ref_retired(rid, rs);
       const bool wrong_task = S.a_qlen[recon] > 0 && S.a_qid[recon][0] != rid;
-      if (dead || idle || rec_done || wrong_task) {
-        if (lane == 0) retire_escort_entry(kk, dead);
+      retire = dead || idle || rec_done || wrong_task;
+      esc_live = !ref_retired(eid, es);
+    }
+    const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    unsigned long long rm = __ballot(retire), todo = all;
+    while (todo) {
+      const unsigned long long low = todo & (0ull - todo);                 // lowest pending entry
+      const unsigned long long nextr = rm & todo;                         // pending retirements
+      const unsigned long long seg = nextr ? (todo & ((nextr & (0ull - nextr)) - 1ull)) : todo;  // entries before the next one
+      if (seg) {
+        // _escort_fighters_near(recon, escort_radius) non-empty? (:1746-1764) for every entry of the segment
+        const bool fighter = lane < P.n_agents && S.a_state[lane] != -1 && escort_type(S.a_type[lane]) && S.a_qlen[lane] > 0;
+        const int head = fighter ? S.a_qid[lane][0] : -1;
+        const double fx = fighter ? S.a_px[lane] : 0.0, fy = fighter ? S.a_py[lane] : 0.0;
+        unsigned long long cov = 0ull;
+        for (unsigned long long m = seg; m; m &= m - 1ull) {
+          const int k = __ffsll((long long)m) - 1;
+          const int ek = __builtin_amdgcn_readlane(eid, k), rk = __builtin_amdgcn_readlane(recon, k);
+          const bool lv = (__ballot(esc_live) >> k) & 1ull;
+          bool near = false;
+          if (lv && fighter && head == ek) near = norm2(fx - S.a_px[rk], fy - S.a_py[rk]) <= P.escort_radius;
+          if (__ballot(near) != 0ull) cov |= 1ull << k;
+        }
+        if ((seg >> lane) & 1ull) {
+          if (esc_live) { S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon]; }  // follow the protected UAV
+        }
+        if (lane == 0) { S.escort_required_steps += __popcll(seg); S.escort_covered_steps += __popcll(cov); }
+        todo &= ~seg;
         lds_sync();
-        continue;
+      } else {
+        const int k = __ffsll((long long)low) - 1;
+        const int rk = __builtin_amdgcn_readlane(recon, k);
+        const bool dk = (__ballot(dead) >> k) & 1ull;
+        if (lane == 0) { const int kk = escort_lookup(rk); if (kk >= 0) retire_escort_entry(kk, dk); }
+        todo &= ~low;
+        lds_sync();
       }
-      // _escort_fighters_near(recon, escort_radius) non-empty? (:1746-1764) — one agent per lane
-      bool near = false;
-      const bool esc_live = !ref_retired(eid, es);
-      if (esc_live && lane < P.n_agents && S.a_state[lane] != -1 && escort_type(S.a_type[lane]) && S.a_qlen[lane] > 0 &&
-          S.a_qid[lane][0] == eid) {
-        near = norm2(S.a_px[lane] - S.a_px[recon], S.a_py[lane] - S.a_py[recon]) <= P.escort_radius;
-      }
-      const bool covered = __ballot(near) != 0ull;
-      if (lane == 0) {
-        if (esc_live) { S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon]; }  // follow the protected UAV
-        S.escort_required_steps++;
-        if (covered) S.escort_covered_steps++;
-      }
-      lds_sync();
     }
   }
 
