@@ -598,12 +598,15 @@ struct Sim {
     push_event(MUAVTA_EV_RESET_ALLOCATION, MUAVTA_DEF);
     S.pending_reset = 1;
   }
-  DEV void retire_escort_entry(int k, bool failed) {  // _retire_escort (:1938-1950) for map entry k
+  // `holders`: superset of the agents that queue the escort task (callers that ran a wave-wide queue scan pass the
+  // exact set; the default visits every agent, as the reference does)
+  DEV void retire_escort_entry(int k, bool failed, unsigned long long holders = ~0ull) {  // _retire_escort (:1938-1950) for map entry k
     int s = S.esc_slot[k], id = S.esc_id[k];
     // an escort that expired by its hard window keeps its map entry forever (status == 2 -> early return)
     if (ref_retired(id, s)) return;
     // _release_escort_agents (:1919-1936)
     for (int a = 0; a < P.n_agents; a++) {
+      if (!((holders >> a) & 1ull)) continue;
       if (S.a_state[a] == -1 || S.a_qlen[a] == 0) continue;
       if (des_allocate(a, id)) {
         if (S.a_qlen[a] == 0) {
@@ -2048,9 +2051,10 @@ struct Sim {
         lds_sync();
       } else {
         const int k = __ffsll((long long)low) - 1;
-        const int rk = __builtin_amdgcn_readlane(recon, k);
+        const int rk = __builtin_amdgcn_readlane(recon, k), ek = __builtin_amdgcn_readlane(eid, k);
         const bool dk = (__ballot(dead) >> k) & 1ull;
-        if (lane == 0) { const int kk = escort_lookup(rk); if (kk >= 0) retire_escort_entry(kk, dk); }
+        const unsigned long long holders = __ballot(lane < P.n_agents && S.a_state[lane] != -1 && queue_find(lane, ek) >= 0);
+        if (lane == 0) { const int kk = escort_lookup(rk); if (kk >= 0) retire_escort_entry(kk, dk, holders); }
         todo &= ~low;
         lds_sync();
       }
