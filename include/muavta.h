@@ -284,6 +284,12 @@ int muavta_set_state(MuavtaEnv* env, const void* src, size_t bytes);
  * (call site HungarianAllocator.py:181): `n` problems, each cost f64 [nr, nc] row-major (nr, nc <= 64
  * x 128); row/col i64 [n, min(nr, nc)].  Runs on HIP device `device`. */
 int muavta_lsap(int32_t device, const double* cost, int32_t n, int32_t nr, int32_t nc, int64_t* row, int64_t* col);
+/* Same, with the solver named: the allocator path uses MUAVTA_LSAP_REGISTERS (rows <= 32, columns <= 64 after scipy's
+ * transpose; no LDS traffic inside the solve) and MUAVTA_LSAP_LDS beyond that (64 x 128); MUAVTA_LSAP_AUTO picks by size.
+ * Both are the same algorithm with the same tie rule; the entry point exists so that tests can pin each one. */
+enum { MUAVTA_LSAP_AUTO = 0, MUAVTA_LSAP_LDS = 1, MUAVTA_LSAP_REGISTERS = 2 };
+int muavta_lsap_impl(int32_t device, const double* cost, int32_t n_problems, int32_t n_rows, int32_t n_cols, int64_t* row_ind,
+                     int64_t* col_ind, int32_t impl);
 
 /* core_sim.SimCore.avoid_obstacles (core_sim/src/sim_core.rs:25-59) for n (position, movement)
  * pairs against one obstacle list, evaluated on the device. */

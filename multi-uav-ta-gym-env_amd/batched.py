@@ -246,8 +246,9 @@ class BatchedMultiUAVEnv:
         return {k: p.value for k, p in zip(keys, ptrs)}
 
 
-def lsap(cost: np.ndarray, device: int = 0):
-    """Batched scipy-compatible linear_sum_assignment on the GPU: cost [n, nr, nc] (or [nr, nc])."""
+def lsap(cost: np.ndarray, device: int = 0, impl: str = "auto"):
+    """Batched scipy-compatible linear_sum_assignment on the GPU: cost [n, nr, nc] (or [nr, nc]).
+    impl: 'auto' | 'lds' (64 x 128 solver) | 'registers' (the allocator path's solver, up to 32 x 64)."""
     c = np.ascontiguousarray(cost, dtype=np.float64)
     single = c.ndim == 2
     if single:
@@ -257,7 +258,7 @@ def lsap(cost: np.ndarray, device: int = 0):
     row = np.empty((n, m), dtype=np.int64)
     col = np.empty((n, m), dtype=np.int64)
     L = native.lib()
-    rc = L.muavta_lsap(int(device), _vp(c), n, nr, nc, _vp(row), _vp(col))
+    rc = L.muavta_lsap_impl(int(device), _vp(c), n, nr, nc, _vp(row), _vp(col), {"auto": 0, "lds": 1, "registers": 2}[impl])
     if rc != 0:
         raise MuavtaError(f"muavta_lsap failed ({rc}): {L.muavta_last_error(None).decode()}")
     return (row[0], col[0]) if single else (row, col)

@@ -198,8 +198,10 @@ __global__ __launch_bounds__(WG) void k_tokens(DevParams P, const EnvState<TL>* 
 }
 
 // Stand-alone LSAP: one problem per workgroup, cost tile staged in LDS (transposed when nc < nr).
+// REG: the register-resident solver of the allocator path (rows <= 32, columns <= 64); else the LDS solver (64 x 128).
+typedef Tile<32, 64, 16, 16, 16, 8> TileLsapReg;
+template <class TL, bool REG>
 __global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc, int64_t* row, int64_t* col) {
-  typedef Tile64 TL;
   Lds<TL> L(smem);
   DevParams dummy;
   Sim<TL> sim(*L.S, *L.X, dummy, nullptr);
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc,
   }
   if (threadIdx.x == 0) L.S->error = 0;
   lds_sync();
-  sim.lsap(Rr, Cc);
+  if constexpr (REG) sim.lsap_reg(Rr, Cc); else sim.lsap(Rr, Cc);
   if (threadIdx.x == 0) {
     int64_t* r = row + (size_t)prob * Rr;
     int64_t* cc = col + (size_t)prob * Rr;
@@ -1000,20 +1002,34 @@ int muavta_rollout_metrics(MuavtaEnv* e, double* out) {  // metrics written by t
 }
 
 int muavta_lsap(int32_t device, const double* cost, int32_t n, int32_t nr, int32_t nc, int64_t* row, int64_t* col) {
+  return muavta_lsap_impl(device, cost, n, nr, nc, row, col, MUAVTA_LSAP_AUTO);
+}
+int muavta_lsap_impl(int32_t device, const double* cost, int32_t n, int32_t nr, int32_t nc, int64_t* row, int64_t* col, int32_t impl) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "muavta_lsap: no HIP device"; return MUAVTA_E_NO_DEVICE; }
   if (!cost || !row || !col || n < 1 || nr < 1 || nc < 1) { g_create_error = "muavta_lsap: bad arguments"; return MUAVTA_E_ARG; }
   int mn = nr < nc ? nr : nc, mx = nr < nc ? nc : nr;
   if (mn > Tile64::A || mx > Tile64::T) { g_create_error = "muavta_lsap: at most 64 x 128"; return MUAVTA_E_ARG; }
+  const bool fits_reg = mn <= TileLsapReg::A && mx <= TileLsapReg::T;
+  if (impl < MUAVTA_LSAP_AUTO || impl > MUAVTA_LSAP_REGISTERS || (impl == MUAVTA_LSAP_REGISTERS && !fits_reg)) {
+    g_create_error = "muavta_lsap_impl: unknown solver, or problem beyond 32 x 64 for the register solver"; return MUAVTA_E_ARG;
+  }
+  const bool use_reg = impl == MUAVTA_LSAP_REGISTERS || (impl == MUAVTA_LSAP_AUTO && fits_reg);
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); hipFree(dc); hipFree(dr); hipFree(dcl); return MUAVTA_E_HIP; } } while (0)
   double* dc = nullptr; int64_t *dr = nullptr, *dcl = nullptr;
   CK(hipSetDevice(device));
   size_t cb = (size_t)n * nr * nc * sizeof(double), rb = (size_t)n * mn * sizeof(int64_t);
   CK(hipMalloc(&dc, cb)); CK(hipMalloc(&dr, rb)); CK(hipMalloc(&dcl, rb));
   CK(hipMemcpy(dc, cost, cb, hipMemcpyHostToDevice));
-  size_t lds = Lds<Tile64>::bytes();
-  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_lsap, dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
+  if (use_reg) {
+    size_t lds = Lds<TileLsapReg>::bytes();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap<TileLsapReg, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_lsap<TileLsapReg, true>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
+  } else {
+    size_t lds = Lds<Tile64>::bytes();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap<Tile64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_lsap<Tile64, false>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
+  }
   CK(hipGetLastError());
   CK(hipMemcpy(row, dr, rb, hipMemcpyDeviceToHost));
   CK(hipMemcpy(col, dcl, rb, hipMemcpyDeviceToHost));

@@ -25,7 +25,7 @@ EXPORTS = [
     "muavta_metrics", "muavta_get", "muavta_set", "muavta_get_state", "muavta_set_state", "muavta_lsap",
     "muavta_avoid_obstacles", "muavta_device_ptrs", "muavta_last_kernel_ms", "muavta_sync",
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
-    "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log",
+    "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
 ]
 
 
@@ -98,6 +98,7 @@ def lib() -> C.CDLL:
     L.muavta_get_rng.argtypes = [vp, vp, C.c_size_t]
     L.muavta_set_rng.argtypes = [vp, vp, C.c_size_t]
     L.muavta_lsap.argtypes = [i32, vp, i32, i32, i32, vp, vp]
+    L.muavta_lsap_impl.argtypes = [i32, vp, i32, i32, i32, vp, vp, i32]
     L.muavta_avoid_obstacles.argtypes = [i32, vp, vp, i32, vp, i32, vp]
     L.muavta_device_ptrs.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.muavta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]

@@ -230,8 +230,9 @@ def test_lsap_known_answers_and_ties():
     for nr, nc in g["shape"]:
         c = g["cost"][off:off + nr * nc].reshape(nr, nc)
         m = min(nr, nc)
-        r, cc = lsap(c)
-        assert np.array_equal(r, g["row"][ro:ro + m]) and np.array_equal(cc, g["col"][ro:ro + m]), (nr, nc)
+        for impl in ("lds", "registers"):  # both solvers against scipy's answers (tie-heavy, 1e6-masked, wide and tall)
+            r, cc = lsap(c, impl=impl)
+            assert np.array_equal(r, g["row"][ro:ro + m]) and np.array_equal(cc, g["col"][ro:ro + m]), (nr, nc, impl)
         off += nr * nc; ro += m
     rng = np.random.default_rng(5)
     batch = rng.integers(0, 3, (64, 64, 128)).astype(np.float64)  # maximum tile, tie-heavy
@@ -239,6 +240,15 @@ def test_lsap_known_answers_and_ties():
     for k in range(0, 64, 8):
         orow, ocol = orc.lsap(batch[k])
         assert np.array_equal(r[k], orow) and np.array_equal(c[k], ocol)
+    for shape in ((96, 32, 64), (96, 64, 32), (64, 24, 24), (64, 1, 64), (64, 32, 1)):  # register solver at its limits, ties everywhere
+        batch = rng.integers(0, 3, shape).astype(np.float64)
+        batch[rng.random(shape) < 0.3] = 1e6
+        r, c = lsap(batch, impl="registers")
+        r2, c2 = lsap(batch, impl="lds")
+        assert np.array_equal(r, r2) and np.array_equal(c, c2)
+        for k in range(0, shape[0], 6):
+            orow, ocol = orc.lsap(batch[k])
+            assert np.array_equal(r[k], orow) and np.array_equal(c[k], ocol), shape
 
 
 def test_avoid_obstacles_vs_oracle():
