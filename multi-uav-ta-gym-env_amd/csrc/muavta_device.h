@@ -1174,7 +1174,7 @@ struct Sim {
       const bool any_due = __ballot(due) != 0ull;
       const bool any_exp = P.hard_windows && __ballot(expiring) != 0ull;
       PROF(28);
-      if (lane == 0 && (any_due || any_exp)) step_serial_c_lists(any_due, any_exp);
+      if (any_due || any_exp) process_lists_coop(any_due, any_exp);
       lds_sync();
       PROF(29);
       if (lane < P.n_agents && S.a_state[lane] != -1) { idle = S.a_qlen[lane] == 0; resp = !idle; }
@@ -2098,6 +2098,72 @@ struct Sim {
     }
   }
 
+
+  // _wps_process_reveals (:1525-1541) and _wps_expire_windows (:1557-1573), wave-cooperative: due reveals and expired
+  // windows are found by ballot and handled in list order; a reveal sets one known bit per agent lane, an expiry
+  // frees the agents heading the task (found by ballot, desallocateAll on lane 0 in agent order — the f64 order of
+  // removeAgentCap and the list-mutation quirk stay the reference's).
+  DEV void process_lists_coop(bool any_due, bool any_exp) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (any_due) {
+      const int n = S.n_pending;
+      int w = 0;
+      for (int base = 0; base < n; base += WG) {
+        const int k = base + lane;
+        int pt = 0, pid = -1, psl = 0;
+        typename KnowMask<A>::type pk = 0;
+        if (k < n) { pt = S.pend_time[k]; pid = S.pend_id[k]; psl = S.pend_slot[k]; pk = S.pend_know[k]; }
+        const bool due = k < n && S.time_steps >= pt;
+        const unsigned long long dm = __ballot(due), km = __ballot(k < n && !due);
+        if (P.share_knowledge) {
+          for (unsigned long long m = dm; m; m &= m - 1ull) {
+            const int b = __ffsll((long long)m) - 1;
+            const int id = __builtin_amdgcn_readlane(pid, b), sl = __builtin_amdgcn_readlane(psl, b);
+            if (ref_valid(id, sl)) {
+              if (lane < P.n_agents) S.known[lane][sl >> 5] |= 1u << (sl & 31);
+              if (lane == 0) S.t_flags[sl] |= TF_KNOWN_ALL;
+            } else if (lane < P.n_agents) {  // released before the reveal: the id still joins the set of everyone who had not sensed it
+              const unsigned long long kn = (unsigned long long)S.pend_know[base + b];
+              S.a_gone[lane] += !((kn >> lane) & 1ull);
+            }
+          }
+        }
+        lds_sync();  // every lane holds its entry before the survivors are packed to the front
+        if (k < n && !due) {
+          const int d = w + __popcll(km & below);
+          S.pend_time[d] = pt; S.pend_id[d] = pid; S.pend_slot[d] = (uint8_t)psl; S.pend_know[d] = pk;
+        }
+        w += __popcll(km);
+      }
+      if (lane == 0) S.n_pending = w;
+      lds_sync();
+    }
+    if (any_exp) {
+      const int n = S.n_order;
+      for (int base = 0; base < n; base += WG) {
+        const int k = base + lane;
+        int sl = -1;
+        bool ex = false;
+        if (k < n) {
+          sl = S.t_order[k];
+          ex = (S.t_flags[sl] & TF_DEADLINE) && S.t_status[sl] != 2 && S.time_steps > S.t_deadline[sl];
+        }
+        for (unsigned long long m = __ballot(ex); m; m &= m - 1ull) {
+          const int b = __ffsll((long long)m) - 1;
+          const int s_ = __builtin_amdgcn_readlane(sl, b);
+          const int id = S.t_id[s_];
+          const unsigned long long hm = __ballot(lane < P.n_agents && S.a_qlen[lane] > 0 && S.a_qid[lane][0] == id);
+          if (lane == 0) {
+            S.t_status[s_] = 2;
+            mark_outcome_slot(s_, false);
+            if (!(S.t_flags[s_] & TF_REACHED)) { S.t_flags[s_] |= TF_REACHED; S.n_reached++; }
+            for (unsigned long long h = hm; h; h &= h - 1ull) desallocate_all(__ffsll((long long)h) - 1);
+          }
+          lds_sync();  // the next expiry looks at the queues this one just changed
+        }
+      }
+    }
+  }
   // _wps_process_reveals (:1525-1541) and _wps_expire_windows (:1557-1573); lane 0, only when due
   DEV void step_serial_c_lists(bool any_due, bool any_exp) { ni_step_serial_c_lists<TL>(&P, tape, any_due, any_exp); }
   DEV void step_serial_c_lists_impl(bool any_due, bool any_exp) {
