@@ -912,7 +912,9 @@ struct Sim {
     for (int k = lane; k < RESET_WIN; k += WG) win[st * RESET_WIN + k] = b0[k];
     lds_sync();
   }
-  DEV void reset(uint64_t seed) {
+  // `seeded`: this env's four init_by_array states [4][624] from k_seed_master / k_seed_streams (one LANE per stream
+  // there, instead of one wave per env here: the recurrence is serial), or nullptr to seed in this kernel.
+  DEV void reset(uint64_t seed, const uint32_t* seeded = nullptr) {
     // RNG first.  The (not yet initialised) state blob doubles as scratch for four 624-word MT buffers; the
     // stream cursors live beyond them.
     static_assert(offsetof(State, rng_idx) >= 4 * 624 * 4 && offsetof(State, area) >= 4 * 624 * 4, "MT buffers overlap live scalars");
@@ -921,9 +923,14 @@ struct Sim {
     uint32_t *T1 = T0 + 624, *T2 = T1 + 624, *T3 = T2 + 624;
     uint32_t* win = reinterpret_cast<uint32_t*>(&X);
     if (lane < 4) { S.rng_idx[lane] = 0; S.rng_win_at[lane] = 0; }
-    if (lane == 0) { S.error = 0; mt_seed(T0, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1); }
+    PROF(39);
+    if (lane == 0) S.error = 0;
+    if (seeded) { for (int k = lane; k < 624; k += WG) T0[k] = seeded[ST_AGENT * 624 + k]; }
+    else if (lane == 0) mt_seed(T0, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1);
     lds_sync();
+    PROF(42);
     reset_stream(ST_AGENT, T0, T1, win);
+    PROF(43);
     win_ptr = win; win_len = RESET_WIN; win_stride = RESET_WIN;
     if (lane == 0) {  // :535-538
       uint64_t* sd = reinterpret_cast<uint64_t*>(&S.area[0][0]);  // parked until the areas are built
@@ -940,13 +947,21 @@ struct Sim {
     const uint32_t agent_cursor = S.rng_idx[ST_AGENT];
     const int err0 = S.error;
     lds_sync();
-    if (lane == 0) mt_seed(T0, (uint32_t)s_tgt, (uint32_t)(s_tgt >> 32), (s_tgt >> 32) ? 2 : 1);
-    if (lane == 1) mt_seed(T1, (uint32_t)s_mis, (uint32_t)(s_mis >> 32), (s_mis >> 32) ? 2 : 1);
-    if (lane == 2 && P.num_obstacles > 0) mt_seed(T2, (uint32_t)s_obs, (uint32_t)(s_obs >> 32), (s_obs >> 32) ? 2 : 1);
+    if (seeded) {
+      for (int k = lane; k < 624; k += WG) {
+        T0[k] = seeded[ST_TGT * 624 + k]; T1[k] = seeded[ST_MISSION * 624 + k];
+        if (P.num_obstacles > 0) T2[k] = seeded[ST_OBS * 624 + k];
+      }
+    } else if (lane < 3 && (lane != 2 || P.num_obstacles > 0)) {  // three lanes, one init_by_array each, side by side
+      const uint64_t sd_ = lane == 0 ? s_tgt : lane == 1 ? s_mis : s_obs;
+      mt_seed(lane == 0 ? T0 : lane == 1 ? T1 : T2, (uint32_t)sd_, (uint32_t)(sd_ >> 32), (sd_ >> 32) ? 2 : 1);
+    }
     lds_sync();
+    PROF(44);
     reset_stream(ST_TGT, T0, T3, win);
     reset_stream(ST_MISSION, T1, T3, win);
     if (P.num_obstacles > 0) reset_stream(ST_OBS, T2, T3, win);
+    PROF(45);
     // now the blob itself: zero it, restore the cursors, build the episode
     {
       uint32_t* w = reinterpret_cast<uint32_t*>(&S);
@@ -955,8 +970,10 @@ struct Sim {
     lds_sync();
     if (lane == 0) { S.rng_idx[ST_AGENT] = agent_cursor; S.error = err0; }
     lds_sync();
+    PROF(46);
     if (lane == 0) reset_serial_impl();  // not through the out-of-line wrapper: it must see this object's window
     lds_sync();
+    PROF(47);
     win_ptr = &S.rng_win[0][0]; win_len = 8; win_stride = 8;
     if (lane < 4) S.rng_win_at[lane] = 0x7fffffffu;  // the small window is (re)filled at the next step boundary
     lds_sync();

@@ -73,12 +73,53 @@ static_assert(((sizeof(EnvState<Tile16>) + 15) & ~size_t(15)) + sizeof(Scratch<T
 #define MUAVTA_MIN_WAVES 2
 #endif
 
+// ---- RNG seeding, one LANE per stream --------------------------------------------------------------------------
+// CPython's init_by_array is a serial recurrence of 2 x 624 dependent steps; inside k_reset / k_rollout one lane of
+// the env's wave would walk it while 63 idle (it was 65 % of a reset).  Here 64 envs share a wave: k_seed_master
+// seeds every env's agent stream (Random(seed), DroneEnv.py:531-533) and draws the three stream seeds from it
+// (randint(0, 2^63-1) x 3, :535-538); k_seed_streams then seeds obs / tgt / mission.  The reset kernels only load
+// the four 624-word states.  Layout: seedbuf [N][4][624] u32 (per-env block contiguous for the coalesced load there).
+DEV uint32_t seed_next32(const uint32_t* mt, int& i) {  // i-th output of the first block after seeding (i < 227)
+  const uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+  uint32_t v = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  i++;
+  v ^= (v >> 11); v ^= (v << 7) & 0x9d2c5680u; v ^= (v << 15) & 0xefc60000u; v ^= (v >> 18);
+  return v;
+}
+__global__ __launch_bounds__(WG) void k_seed_master(const uint64_t* seeds, int n, uint32_t* seedbuf, uint64_t* derived) {
+  const int e = blockIdx.x * WG + threadIdx.x;
+  if (e >= n) return;
+  uint32_t* mt = seedbuf + ((size_t)e * 4 + ST_AGENT) * 624;
+  const uint64_t seed = seeds[e];
+  mt_seed(mt, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1);
+  __threadfence_block();
+  int i = 0;
+  for (int j = 0; j < 3; j++) {  // Random.randint(0, 2^63-1) == _randbelow(2^63): getrandbits(64) until < 2^63
+    uint64_t r;
+    do {
+      if (i > 220) { r = 0; break; }  // 110 rejections in a row: not in this universe
+      const uint64_t lo = seed_next32(mt, i), hi = seed_next32(mt, i);
+      r = lo | (hi << 32);
+    } while (r >= (1ull << 63));
+    derived[(size_t)e * 3 + j] = r;
+  }
+}
+__global__ __launch_bounds__(WG) void k_seed_streams(const uint64_t* derived, int n, int with_obs, uint32_t* seedbuf) {
+  const int idx = blockIdx.x * WG + threadIdx.x;
+  const int e = idx / 3, j = idx - e * 3;  // j: 0 obs, 1 tgt, 2 mission (the order the seeds are drawn in)
+  if (e >= n || (j == 0 && !with_obs)) return;
+  const int st = j == 0 ? ST_OBS : j == 1 ? ST_TGT : ST_MISSION;
+  const uint64_t sd = derived[(size_t)e * 3 + j];
+  mt_seed(seedbuf + ((size_t)e * 4 + st) * 624, (uint32_t)sd, (uint32_t)(sd >> 32), (sd >> 32) ? 2 : 1);
+}
+
 template <class TL>
-__global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, ObsPtrs O) {
+__global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, ObsPtrs O,
+                                              const uint32_t* seedbuf) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
-  sim.reset(seeds[env]);
+  sim.reset(seeds[env], seedbuf ? seedbuf + (size_t)env * 4 * 624 : nullptr);
   obs_for_env(sim, P, O, env);
   lds_sync();
   copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
@@ -138,12 +179,13 @@ __global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blob
 
 template <class TL>
 __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, int n_steps,
-                                                int interval, int use_vis, int mode, int write_obs, ObsPtrs O, double* metrics) {
+                                                int interval, int use_vis, int mode, int write_obs, ObsPtrs O, double* metrics,
+                                                const uint32_t* seedbuf) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
   if (seeds) {
-    sim.reset(seeds[env]);
+    sim.reset(seeds[env], seedbuf ? seedbuf + (size_t)env * 4 * 624 : nullptr);
   } else {
     copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
     lds_sync();
@@ -276,6 +318,8 @@ struct MuavtaEnv {
   int alloc_mode = 0;  // MUAVTA_ALLOC_*
   void* d_tok = nullptr;  // muavta_tokens staging (host-buffer variant)
   double* d_rel = nullptr;  // release log [N, 1 + MUAVTA_REL_ROW*T] (muavta_set_release_log)
+  uint32_t* d_seedbuf = nullptr;  // [N][4][624] init_by_array states (k_seed_master / k_seed_streams)
+  uint64_t* d_derived = nullptr;  // [N][3] obs / tgt / mission stream seeds
   size_t tok_bytes = 0;
   int n_envs = 0, device = 0;
   int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
@@ -688,7 +732,7 @@ int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
+  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf); if (e->d_derived) hipFree(e->d_derived);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -706,12 +750,34 @@ int muavta_dims(const MuavtaEnv* e, MuavtaDims* d) {
   return MUAVTA_OK;
 }
 
+// seeds are in e->d_seeds: run the two seeding kernels on the handle's stream (MUAVTA_SEED_IN_KERNEL=1: leave it to the
+// reset kernel, the pre-existing path kept for A/B runs)
+static int seed_streams(MuavtaEnv* e, const uint32_t** out) {
+  static const bool in_kernel = getenv("MUAVTA_SEED_IN_KERNEL") && atoi(getenv("MUAVTA_SEED_IN_KERNEL")) != 0;
+  *out = nullptr;
+  if (in_kernel) return MUAVTA_OK;
+  const size_t N = (size_t)e->n_envs;
+  if (!e->d_seedbuf) {
+    HIPCHK(e, hipMalloc((void**)&e->d_seedbuf, N * 4 * 624 * sizeof(uint32_t)));
+    HIPCHK(e, hipMalloc((void**)&e->d_derived, N * 3 * sizeof(uint64_t)));
+  }
+  hipLaunchKernelGGL(k_seed_master, dim3((unsigned)((N + WG - 1) / WG)), dim3(WG), 0, e->stream, (const uint64_t*)e->d_seeds, (int)N, e->d_seedbuf, e->d_derived);
+  HIPCHK(e, hipGetLastError());
+  hipLaunchKernelGGL(k_seed_streams, dim3((unsigned)((3 * N + WG - 1) / WG)), dim3(WG), 0, e->stream, (const uint64_t*)e->d_derived, (int)N,
+                     (int)(e->P.num_obstacles > 0), e->d_seedbuf);
+  HIPCHK(e, hipGetLastError());
+  *out = e->d_seedbuf;
+  return MUAVTA_OK;
+}
+
 int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
   if (!e || !seeds) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
   HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  const uint32_t* sb = nullptr;
+  { int rc = seed_streams(e, &sb); if (rc) return rc; }
   DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, e->d_seeds,
-                                 (EnvState<TL>*)e->blobs, e->tapes, e->O));
+                                 (EnvState<TL>*)e->blobs, e->tapes, e->O, sb));
   HIPCHK(e, hipGetLastError());
   e->did_reset = true;
   e->host_valid = false;
@@ -771,10 +837,12 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
     HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
     ds = e->d_seeds;
   }
+  const uint32_t* sb = nullptr;
+  if (ds) { int rc = seed_streams(e, &sb); if (rc) return rc; }
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
   DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds, e->stream, e->P, ds, (EnvState<TL>*)e->blobs,
-                                 e->tapes, n_steps, interval, use_vis, e->alloc_mode, write_obs, e->O, e->d_metrics));
+                                 e->tapes, n_steps, interval, use_vis, e->alloc_mode, write_obs, e->O, e->d_metrics, sb));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
   e->did_reset = true;
