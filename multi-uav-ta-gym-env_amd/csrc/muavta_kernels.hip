@@ -75,42 +75,93 @@ static_assert(((sizeof(EnvState<Tile16>) + 15) & ~size_t(15)) + sizeof(Scratch<T
 
 // ---- RNG seeding, one LANE per stream --------------------------------------------------------------------------
 // CPython's init_by_array is a serial recurrence of 2 x 624 dependent steps; inside k_reset / k_rollout one lane of
-// the env's wave would walk it while 63 idle (it was 65 % of a reset).  Here 64 envs share a wave: k_seed_master
+// the env's wave would walk it while 63 idle (it was 65 % of a reset).  Here 16 envs x 4 streams share a wave: k_seed
 // seeds every env's agent stream (Random(seed), DroneEnv.py:531-533) and draws the three stream seeds from it
-// (randint(0, 2^63-1) x 3, :535-538); k_seed_streams then seeds obs / tgt / mission.  The reset kernels only load
+// (randint(0, 2^63-1) x 3, :535-538), then the obs / tgt / mission lanes seed theirs.  The reset kernels only load
 // the four 624-word states.  Layout: seedbuf [N][4][624] u32 (per-env block contiguous for the coalesced load there).
-DEV uint32_t seed_next32(const uint32_t* mt, int& i) {  // i-th output of the first block after seeding (i < 227)
-  const uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
-  uint32_t v = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+#define SEED_LD 65  // LDS row stride in words: column c of row i sits in bank (i + c) % 32, so both the per-lane
+                    // recurrence (fixed c, running i) and the transposed write-out (fixed c per pass, 64 i's) are conflict-free
+DEV uint32_t seed_next32(const uint32_t* col, int& i) {  // i-th output of the first block after seeding (i < 227)
+  const uint32_t y = (col[i * SEED_LD] & 0x80000000u) | (col[(i + 1) * SEED_LD] & 0x7fffffffu);
+  uint32_t v = col[(i + 397) * SEED_LD] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
   i++;
   v ^= (v >> 11); v ^= (v << 7) & 0x9d2c5680u; v ^= (v << 15) & 0xefc60000u; v ^= (v >> 18);
   return v;
 }
-__global__ __launch_bounds__(WG) void k_seed_master(const uint64_t* seeds, int n, uint32_t* seedbuf, uint64_t* derived) {
-  const int e = blockIdx.x * WG + threadIdx.x;
-  if (e >= n) return;
-  uint32_t* mt = seedbuf + ((size_t)e * 4 + ST_AGENT) * 624;
-  const uint64_t seed = seeds[e];
-  mt_seed(mt, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1);
-  __threadfence_block();
-  int i = 0;
-  for (int j = 0; j < 3; j++) {  // Random.randint(0, 2^63-1) == _randbelow(2^63): getrandbits(64) until < 2^63
-    uint64_t r;
-    do {
-      if (i > 220) { r = 0; break; }  // 110 rejections in a row: not in this universe
-      const uint64_t lo = seed_next32(mt, i), hi = seed_next32(mt, i);
-      r = lo | (hi << 32);
-    } while (r >= (1ull << 63));
-    derived[(size_t)e * 3 + j] = r;
+// init_genrand(19650218), the key-independent half of init_by_array: a compile-time table read through the scalar cache
+struct GenrandTable {
+  uint32_t v[624];
+  constexpr GenrandTable() : v{} {
+    uint32_t g = 19650218u;
+    v[0] = g;
+    for (int i = 1; i < 624; i++) { g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i; v[i] = g; }
   }
+};
+__constant__ GenrandTable G_TAB = GenrandTable();
+// init_by_array(key[0..len)) into column `col` of the [624][SEED_LD] LDS tile (same recurrence as mt_seed).  len is 1 or 2
+// (seeds below / from 2^32): key[j] + j alternates k0, k1 + 1 for len 2 and is k0 for len 1.
+DEV void seed_column(uint32_t* col, uint32_t k0, uint32_t k1, int len) {
+  uint32_t prev = 19650218u;
+  const uint32_t add_even = k0, add_odd = len == 2 ? k1 + 1u : k0;  // first loop step i uses j = (i - 1) % len
+#pragma unroll 4
+  for (int i = 1; i < 624; i++) {
+    prev = (G_TAB.v[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (((i - 1) & 1) ? add_odd : add_even);
+    col[i * SEED_LD] = prev;
+  }
+  col[0] = prev;
+  {  // 624th step of the first loop: i wrapped to 1 (mt[0] = mt[623]), j = 623 % len
+    prev = (col[SEED_LD] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (len == 2 ? add_odd : add_even);
+    col[SEED_LD] = prev;
+  }
+  int i = 2;
+  for (; i + 8 <= 624; i += 8) {
+    uint32_t m[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) m[q] = col[(i + q) * SEED_LD];
+#pragma unroll
+    for (int q = 0; q < 8; q++) { prev = (m[q] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i + q); m[q] = prev; }
+#pragma unroll
+    for (int q = 0; q < 8; q++) col[(i + q) * SEED_LD] = m[q];
+  }
+  for (; i < 624; i++) { prev = (col[i * SEED_LD] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i; col[i * SEED_LD] = prev; }
+  col[0] = prev;  // 623rd iteration of the second loop: i wrapped to 1 with mt[0] = mt[623]
+  prev = (col[SEED_LD] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+  col[SEED_LD] = prev;
+  col[0] = 0x80000000u;
 }
-__global__ __launch_bounds__(WG) void k_seed_streams(const uint64_t* derived, int n, int with_obs, uint32_t* seedbuf) {
-  const int idx = blockIdx.x * WG + threadIdx.x;
-  const int e = idx / 3, j = idx - e * 3;  // j: 0 obs, 1 tgt, 2 mission (the order the seeds are drawn in)
-  if (e >= n || (j == 0 && !with_obs)) return;
-  const int st = j == 0 ? ST_OBS : j == 1 ? ST_TGT : ST_MISSION;
-  const uint64_t sd = derived[(size_t)e * 3 + j];
-  mt_seed(seedbuf + ((size_t)e * 4 + st) * 624, (uint32_t)sd, (uint32_t)(sd >> 32), (sd >> 32) ? 2 : 1);
+// One workgroup = 16 envs x 4 streams, one lane each.  Phase 1: the agent-stream lanes run init_by_array(seed) and draw
+// the three stream seeds; phase 2: the obs / tgt / mission lanes run theirs.  Then the tile is written out transposed.
+__global__ __launch_bounds__(WG) void k_seed(const uint64_t* seeds, int n, int with_obs, uint32_t* seedbuf) {
+  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);                       // [624][SEED_LD]
+  uint64_t* derived = reinterpret_cast<uint64_t*>(tile + 624 * SEED_LD);   // [16][3]
+  const int lane = threadIdx.x, el = lane >> 2, st = lane & 3;
+  const int e = blockIdx.x * 16 + el;
+  uint32_t* col = tile + lane;
+  if (e < n && st == ST_AGENT) {
+    const uint64_t seed = seeds[e];
+    seed_column(col, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1);
+    int i = 0;
+    for (int j = 0; j < 3; j++) {  // Random.randint(0, 2^63-1) == _randbelow(2^63): getrandbits(64) until < 2^63
+      uint64_t r;
+      do {
+        if (i > 220) { r = 0; break; }  // 110 rejections in a row
+        const uint64_t lo = seed_next32(col, i), hi = seed_next32(col, i);
+        r = lo | (hi << 32);
+      } while (r >= (1ull << 63));
+      derived[el * 3 + j] = r;  // drawn in the order obs, tgt, mission (DroneEnv.py:535-538)
+    }
+  }
+  __syncthreads();
+  if (e < n && st != ST_AGENT && (st != ST_OBS || with_obs)) {
+    const uint64_t sd = derived[el * 3 + (st == ST_OBS ? 0 : st == ST_TGT ? 1 : 2)];
+    seed_column(col, (uint32_t)sd, (uint32_t)(sd >> 32), (sd >> 32) ? 2 : 1);
+  }
+  __syncthreads();
+  for (int c = 0; c < WG; c++) {  // column c -> seedbuf[(block * 64 + c)][0..624), 64 consecutive words per store
+    if (blockIdx.x * 16 + (c >> 2) >= n) break;
+    uint32_t* dst = seedbuf + ((size_t)blockIdx.x * WG + c) * 624;
+    for (int i = lane; i < 624; i += WG) dst[i] = tile[i * SEED_LD + c];
+  }
 }
 
 template <class TL>
@@ -318,8 +369,7 @@ struct MuavtaEnv {
   int alloc_mode = 0;  // MUAVTA_ALLOC_*
   void* d_tok = nullptr;  // muavta_tokens staging (host-buffer variant)
   double* d_rel = nullptr;  // release log [N, 1 + MUAVTA_REL_ROW*T] (muavta_set_release_log)
-  uint32_t* d_seedbuf = nullptr;  // [N][4][624] init_by_array states (k_seed_master / k_seed_streams)
-  uint64_t* d_derived = nullptr;  // [N][3] obs / tgt / mission stream seeds
+  uint32_t* d_seedbuf = nullptr;  // [N][4][624] init_by_array states (k_seed)
   size_t tok_bytes = 0;
   int n_envs = 0, device = 0;
   int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
@@ -732,7 +782,7 @@ int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf); if (e->d_derived) hipFree(e->d_derived);
+  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -759,11 +809,14 @@ static int seed_streams(MuavtaEnv* e, const uint32_t** out) {
   const size_t N = (size_t)e->n_envs;
   if (!e->d_seedbuf) {
     HIPCHK(e, hipMalloc((void**)&e->d_seedbuf, N * 4 * 624 * sizeof(uint32_t)));
-    HIPCHK(e, hipMalloc((void**)&e->d_derived, N * 3 * sizeof(uint64_t)));
   }
-  hipLaunchKernelGGL(k_seed_master, dim3((unsigned)((N + WG - 1) / WG)), dim3(WG), 0, e->stream, (const uint64_t*)e->d_seeds, (int)N, e->d_seedbuf, e->d_derived);
-  HIPCHK(e, hipGetLastError());
-  hipLaunchKernelGGL(k_seed_streams, dim3((unsigned)((3 * N + WG - 1) / WG)), dim3(WG), 0, e->stream, (const uint64_t*)e->d_derived, (int)N,
+  static const size_t seed_lds = (size_t)624 * SEED_LD * 4 + 16 * 3 * 8;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seed_lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_seed, dim3((unsigned)((N + 15) / 16)), dim3(WG), seed_lds, e->stream, (const uint64_t*)e->d_seeds, (int)N,
                      (int)(e->P.num_obstacles > 0), e->d_seedbuf);
   HIPCHK(e, hipGetLastError());
   *out = e->d_seedbuf;

@@ -639,3 +639,27 @@ def test_fuzzed_config_stepwise_vs_oracle_and_reference_metrics(path):
                 break
         assert np.array_equal(env.metrics()[0], g["metrics"]), f"{case}: reference metrics"
         assert np.all(env.get("ERROR") == 0)
+
+
+def test_seeds_beyond_32_bits():
+    """init_by_array with a two-word key (seed >= 2^32): the batched seeding kernel against the oracle's CPython restatement."""
+    case = "WPS_hard"
+    seeds = np.array([2**32, 2**40 + 12345, 2**63 - 1, 2**62 + 7, 2**32 - 1, 0], dtype=np.uint64)
+    env = _env(case, len(seeds))
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in seeds]
+    env.reset(seeds)
+    for o, sd in zip(oracles, seeds):
+        o.reset(int(sd))
+    snap = Snapshot(env)
+    for i, o in enumerate(oracles):
+        compare(snap, i, o, f"seed {seeds[i]} after reset")
+    for t in range(60):
+        aa, ai = env.allocate(20, True)
+        for i, o in enumerate(oracles):
+            oa, oi = o.allocate(20, 1)
+            assert np.array_equal(aa[i][:len(oa)], oa) and np.array_equal(ai[i][:len(oa)], oi)
+            o.step(oa, oi)
+        env.step(aa, ai)
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"seed {seeds[i]} t={t + 1}")
