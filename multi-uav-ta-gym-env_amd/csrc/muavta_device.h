@@ -196,6 +196,7 @@ struct Sim {
   State& S;
   Scratch<TL>& X;
   double* rel_log = nullptr;  // optional per-env release log in HBM (muavta_set_release_log)
+  int tnow;                   // env.time_steps in a (uniform) register: it changes once per step, and every LDS read of it is ~100 cycles of latency
   const DevParams& P;
   uint32_t* tape;  // [4][1248] in HBM
   int lane;
@@ -205,7 +206,8 @@ struct Sim {
   uint32_t win_len, win_stride;
 
   __device__ Sim(State& s, Scratch<TL>& x, const DevParams& p, uint32_t* t)
-      : S(s), X(x), P(p), tape(t), lane(threadIdx.x), win_ptr(&s.rng_win[0][0]), win_len(8), win_stride(8) {}
+      : S(s), X(x), P(p), tape(t), lane(threadIdx.x), win_ptr(&s.rng_win[0][0]), win_len(8), win_stride(8), tnow(s.time_steps) {}
+  DEV void sync_clock() { tnow = S.time_steps; }  // after the blob was (re)loaded or reset behind this object's back
 
   DEV void fail(int code) { if (S.error == 0) S.error = code; }
   DEV double speed_of(int t) const {  // P.speed[t] without a memory access for a per-lane t
@@ -344,7 +346,7 @@ struct Sim {
     int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
     double det = S.a_qtime[a][k];
     queue_erase(a, k);
-    S.a_nft[a] = (double)S.time_steps;
+    S.a_nft[a] = (double)tnow;
     S.a_nfx[a] = S.a_px[a];
     S.a_nfy[a] = S.a_py[a];
     S.a_commit[a] = 0;
@@ -399,7 +401,7 @@ struct Sim {
     S.a_last_id[a] = -1;
     S.a_last_slot[a] = -1;
     double time_to_task = pre_time >= 0 ? pre_time : norm2(S.a_nfx[a] - S.t_px[s], S.a_nfy[a] - S.t_py[s]) / speed_of(S.a_type[a]);
-    double start_time = (S.a_nft[a] - (double)S.time_steps) > 0 ? S.a_nft[a] : (double)S.time_steps;
+    double start_time = (S.a_nft[a] - (double)tnow) > 0 ? S.a_nft[a] : (double)tnow;
     double dur = (double)task_duration(S.t_type[s]);
     double end_time = start_time + time_to_task + dur;
     int n = S.a_qlen[a];
@@ -451,7 +453,7 @@ struct Sim {
     const int id = S.t_id[s];
     S.t_id[s] = -1;
     // a reveal can only be pending while t < created_at + threat_delay (registered at creation, :1491-1501)
-    const bool pending = P.share_knowledge && S.time_steps <= S.t_created[s] + (P.threat_delay > 0 ? P.threat_delay : 0) + 1;
+    const bool pending = P.share_knowledge && tnow <= S.t_created[s] + (P.threat_delay > 0 ? P.threat_delay : 0) + 1;
     if (!pending && !rel_log) return;
     unsigned long long knowers = 0;
     for (int a = 0; a < P.n_agents; a++) knowers |= (unsigned long long)((S.known[a][s >> 5] >> (s & 31)) & 1u) << a;
@@ -524,13 +526,13 @@ struct Sim {
   DEV void register_dynamic(int s) {
     if (P.hard_windows && !(S.t_flags[s] & TF_DEADLINE)) {
       S.t_flags[s] |= TF_DEADLINE;
-      S.t_deadline[s] = S.time_steps + P.window_length;
+      S.t_deadline[s] = tnow + P.window_length;
       S.n_windowed_tasks++;
     }
     if (P.threat_delay > 0 || P.sense_radius > 0) {
       int n = S.n_pending;
       if (n >= R) { fail(MUAVTA_ERR_PENDING); return; }
-      S.pend_time[n] = S.time_steps + (P.threat_delay > 0 ? P.threat_delay : 0);
+      S.pend_time[n] = tnow + (P.threat_delay > 0 ? P.threat_delay : 0);
       S.pend_id[n] = S.t_id[s];
       S.pend_slot[n] = (uint8_t)s;
       S.pend_know[n] = 0;
@@ -544,7 +546,7 @@ struct Sim {
     if (!(flags & TF_DEADLINE)) return;
     if (flags & TF_COUNTED) return;
     flags |= TF_COUNTED;
-    if (success && S.time_steps <= deadline) { S.n_on_time++; S.F_Reward += P.on_time_bonus; }
+    if (success && tnow <= deadline) { S.n_on_time++; S.F_Reward += P.on_time_bonus; }
     else { S.n_missed_windows++; S.F_Reward -= P.miss_penalty; }
   }
   DEV void mark_outcome_slot(int s, bool success) { mark_outcome(S.t_flags[s], S.t_deadline[s], success); }
@@ -586,7 +588,7 @@ struct Sim {
     S.t_prot_id[s] = S.t_id[rec_slot];
     S.t_prot_slot[s] = rec_slot;
     S.t_required[s] = P.escort_required_agents;
-    S.t_created[s] = S.time_steps;
+    S.t_created[s] = tnow;
     register_dynamic(s);
     int n = S.n_escorts;
     if (n >= A) { fail(MUAVTA_ERR_ESCORTS); return; }
@@ -612,7 +614,7 @@ struct Sim {
         if (S.a_qlen[a] == 0) {
           S.a_state[a] = 0;
           S.a_commit[a] = 0;
-          S.a_nft[a] = (double)S.time_steps;
+          S.a_nft[a] = (double)tnow;
           S.a_nfx[a] = S.a_px[a];
           S.a_nfy[a] = S.a_py[a];
         }
@@ -697,7 +699,7 @@ struct Sim {
           if (!(S.t_flags[s] & TF_REACHED)) {
             S.t_flags[s] |= TF_REACHED;
             S.n_reached++;
-            if (S.n_reached == P.n_tasks) S.conclusion_time = S.time_steps;
+            if (S.n_reached == P.n_tasks) S.conclusion_time = tnow;
           }
         } else {
           S.t_status[s] = 0;
@@ -753,7 +755,7 @@ struct Sim {
 #pragma unroll
         for (int i = 0; i < HQ; i++) if (2 * i + 1 < n) { S.a_qid[a][i] = kid[i]; S.a_qslot[a][i] = ksl[i]; S.a_qtime[a][i] = ktm[i]; }
         S.a_qlen[a] = n >> 1;
-        S.a_nft[a] = (double)S.time_steps; S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
+        S.a_nft[a] = (double)tnow; S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
         S.a_commit[a] = 0;
       }
       for (int base = 0; base < T; base += WG) {
@@ -819,7 +821,7 @@ struct Sim {
             if (!(S.t_flags[s] & TF_REACHED)) {
               S.t_flags[s] |= TF_REACHED;
               S.n_reached++;
-              if (S.n_reached == P.n_tasks) S.conclusion_time = S.time_steps;
+              if (S.n_reached == P.n_tasks) S.conclusion_time = tnow;
             }
           }
         }
@@ -919,6 +921,7 @@ struct Sim {
     // stream cursors live beyond them.
     static_assert(offsetof(State, rng_idx) >= 4 * 624 * 4 && offsetof(State, area) >= 4 * 624 * 4, "MT buffers overlap live scalars");
     static_assert(sizeof(Scratch<TL>) >= 4 * RESET_WIN * 4, "scratch tile too small for the reset RNG window");
+    tnow = 0;
     uint32_t* T0 = reinterpret_cast<uint32_t*>(&S);
     uint32_t *T1 = T0 + 624, *T2 = T1 + 624, *T3 = T2 + 624;
     uint32_t* win = reinterpret_cast<uint32_t*>(&X);
@@ -1106,7 +1109,8 @@ struct Sim {
       // drain the event queue (:800-805): infos['events'] := event_list, every Reset_Allocation in order
       const int nev = S.n_events;
       for (int k = lane; k < nev; k += WG) { S.dev_tag[k] = S.ev_tag[k]; S.dev_arg[k] = S.ev_arg[k]; }
-      if (lane == 0) { S.step_reward = 0; S.time_steps += 1; S.n_dev = nev; S.n_events = 0; }  // :796
+      tnow += 1;
+      if (lane == 0) { S.step_reward = 0; S.time_steps = tnow; S.n_dev = nev; S.n_events = 0; }  // :796
       lds_sync();
       int last_arg = -1000;
       bool last_changed = true;
@@ -1183,10 +1187,10 @@ struct Sim {
     {
       // wave-wide pre-checks so that lane 0 only walks the lists when something is due this step
       bool due = false, expiring = false, idle = false, resp = false, blocking = false;
-      for (int k = lane; k < S.n_pending; k += WG) due |= S.time_steps >= S.pend_time[k];
+      for (int k = lane; k < S.n_pending; k += WG) due |= tnow >= S.pend_time[k];
       for (int k = lane; k < S.n_order; k += WG) {
         const int s = S.t_order[k];
-        expiring |= (S.t_flags[s] & TF_DEADLINE) && S.t_status[s] != 2 && S.time_steps > S.t_deadline[s];
+        expiring |= (S.t_flags[s] & TF_DEADLINE) && S.t_status[s] != 2 && tnow > S.t_deadline[s];
       }
       const bool any_due = __ballot(due) != 0ull;
       const bool any_exp = P.hard_windows && __ballot(expiring) != 0ull;
@@ -1228,7 +1232,7 @@ struct Sim {
     int new_st = 0, new_ts = 0, cid = 0, cs = -1;
     double px = 0, py = 0, ddx = 0.0, ddy = 0.0;
     if (live) {
-      if (S.a_fail[a] == S.time_steps) {
+      if (S.a_fail[a] == tnow) {
         evt = true;
       } else {
         px = S.a_px[a]; py = S.a_py[a];
@@ -1262,15 +1266,15 @@ struct Sim {
                 if (dist < engage) evt = true;
                 else { ddx = ndx; ddy = ndy; }
               } else if (dist < speed) {
-                new_st = 2; new_ts = S.time_steps;
+                new_st = 2; new_ts = tnow;
                 px = S.t_px[cs]; py = S.t_py[cs];
               } else { ddx = ndx; ddy = ndy; }
             } else if (new_st == 2) {
               if (ty == MUAVTA_INT && dist >= engage) new_st = 1;
               if (new_ts == -1) {
-                new_ts = S.time_steps;
+                new_ts = tnow;
                 px = S.t_px[cs]; py = S.t_py[cs];
-              } else if ((S.time_steps - new_ts) >= task_duration(ty) && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
+              } else if ((tnow - new_ts) >= task_duration(ty) && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
                          ty != MUAVTA_INT && ty != MUAVTA_DET) {
                 evt = true;
               }
@@ -1386,7 +1390,7 @@ struct Sim {
           else if (!(queue_find(a, tid) >= 0 || S.t_status[s] == 2)) {  // UAV.allocate (DroneEnvComponents.py:55-96)
             S.a_reeval[a] = 0; S.a_last_id[a] = -1; S.a_last_slot[a] = -1;
             const double time_to_task = norm2(S.a_nfx[a] - tx, S.a_nfy[a] - ty_) / speed_of(S.a_type[a]);
-            const double start_time = (S.a_nft[a] - (double)S.time_steps) > 0 ? S.a_nft[a] : (double)S.time_steps;
+            const double start_time = (S.a_nft[a] - (double)tnow) > 0 ? S.a_nft[a] : (double)tnow;
             ty = S.t_type[s];
             const double end_time = start_time + time_to_task + (double)task_duration(ty);
             if (qlen == 0) { S.a_task_start[a] = -1; S.a_state[a] = 1; }
@@ -1521,7 +1525,7 @@ struct Sim {
           des_allocate_at(a, 0);
           if (ref_valid(qi, qs)) S.t_bucket[qs] &= ~(1ull << a);
         }
-        S.a_nft[a] = (double)S.time_steps;
+        S.a_nft[a] = (double)tnow;
         S.a_nfx[a] = S.a_px[a];
         S.a_nfy[a] = S.a_py[a];
       }
@@ -1562,7 +1566,7 @@ struct Sim {
     double quality_reward = 0;
     for (int a = first; a < last; a++) {
       if (S.a_state[a] == -1) continue;
-      if (S.a_fail[a] == S.time_steps) {  // :972-981
+      if (S.a_fail[a] == tnow) {  // :972-981
         S.a_state[a] = -1;
         desallocate_all(a);
         push_event(MUAVTA_EV_RESET_ALLOCATION, -1);
@@ -1598,13 +1602,13 @@ struct Sim {
               if (dist < engage) {
                 S.a_state[a] = 2;
                 S.h_target[S.t_threat[cs]] = a;
-                S.a_task_start[a] = S.time_steps;
+                S.a_task_start[a] = tnow;
               } else {
                 displacement(px, py, ux, uy, speed, ddx, ddy);
               }
             } else if (dist < speed) {
               S.a_state[a] = 2;
-              S.a_task_start[a] = S.time_steps;
+              S.a_task_start[a] = tnow;
               px = S.t_px[cs]; py = S.t_py[cs];
             } else {
               displacement(px, py, ux, uy, speed, ddx, ddy);
@@ -1614,9 +1618,9 @@ struct Sim {
               if (dist >= engage) S.a_state[a] = 1;
             }
             if (S.a_task_start[a] == -1) {
-              S.a_task_start[a] = S.time_steps;
+              S.a_task_start[a] = tnow;
               px = S.t_px[cs]; py = S.t_py[cs];
-            } else if ((S.time_steps - S.a_task_start[a]) >= task_duration(ty) && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
+            } else if ((tnow - S.a_task_start[a]) >= task_duration(ty) && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
                        ty != MUAVTA_INT && ty != MUAVTA_DET) {
               // task concluded by this agent (:1079-1107)
               S.a_px[a] = px; S.a_py[a] = py;  // taskDone reads agent.position
@@ -1636,7 +1640,7 @@ struct Sim {
                   S.protected_rec_completed++;
                   retire_escort_for(a, false);
                 }
-                if (all_mission_done()) S.conclusion_time = S.time_steps;
+                if (all_mission_done()) S.conclusion_time = tnow;
               } else {
                 quality_reward += S.a_caps[ty][a];
               }
@@ -1666,9 +1670,9 @@ struct Sim {
     // :1140-1145 — evaluated here, before this step's spawns / expiries change the counts.  A term whose
     // weight is 0 contributes +-0.0 to the reward sum whatever its value, so it is not evaluated at all.
     S.r_time_penalty = 0;
-    if (P.rw[6] != 0) S.r_time_penalty = -(double)(P.n_tasks - S.n_reached) / (double)P.n_tasks * ((double)S.time_steps / (double)P.max_time_steps);
+    if (P.rw[6] != 0) S.r_time_penalty = -(double)(P.n_tasks - S.n_reached) / (double)P.n_tasks * ((double)tnow / (double)P.max_time_steps);
     S.r_alloc = 0;
-    if (P.rw[5] != 0 && S.time_steps > P.n_tasks + 1) {  // -len(unallocated_tasks()) (:1434-1440); bucket 0 (idle) is always empty
+    if (P.rw[5] != 0 && tnow > P.n_tasks + 1) {  // -len(unallocated_tasks()) (:1434-1440); bucket 0 (idle) is always empty
       int n = 1 + S.n_retired_empty_buckets;
       for (int k = 0; k < S.n_order; k++) if (S.t_bucket[S.t_order[k]] == 0) n++;
       S.r_alloc = -(double)n;
@@ -1686,7 +1690,7 @@ struct Sim {
   // get_closest_agent (:1691-1723) for every threat that can spawn this step, one (threat, agent) pair per lane, so
   // that lane 0's generate_threat only looks the answer up.  Spawn positions are fixed at reset unless
   // dual_region_bursts redraws x (then generate_threat searches itself).  Result: X.roundT[threat id].
-  DEV bool threat_spawn_step() const { return S.time_steps > 40 && S.time_steps % 10 == 0; }
+  DEV bool threat_spawn_step() const { return tnow > 40 && tnow % 10 == 0; }
   DEV void precompute_threat_targets() {
     if (!threat_spawn_step() || P.dual_region_bursts) return;  // uniform
     const int nA = P.n_agents;
@@ -1748,7 +1752,7 @@ struct Sim {
               S.t_cur[MUAVTA_ATT][s] = defence * 2;
               S.t_cur[MUAVTA_DEF][s] = attack * 2;
               S.t_threat[s] = h;
-              S.t_created[s] = S.time_steps;
+              S.t_created[s] = tnow;
               if (ty == MUAVTA_T1) { S.t_required[s] = 2; S.t_flags[s] |= TF_ELIGIBLE; S.t_elig[s] = P.escort_mask; }
               S.h_task_id[h] = S.t_id[s];
               S.h_task_slot[h] = s;
@@ -1939,7 +1943,7 @@ struct Sim {
 
   DEV void inject_dynamic_arrivals() { ni_inject_dynamic_arrivals<TL>(&P, tape); }
   DEV void inject_dynamic_arrivals_impl() {  // :1646-1689
-    if (P.arrival_rate <= 0 || S.time_steps < 5) return;
+    if (P.arrival_rate <= 0 || tnow < 5) return;
     if (rnd(ST_TGT) >= P.arrival_rate) return;
     if (S.next_task_id - 1 >= P.max_tasks - 1) return;  // len(self.tasks) >= max_tasks - 1
     int ty = randbelow(ST_TGT, 2) == 0 ? MUAVTA_ATT : MUAVTA_REC;
@@ -1957,7 +1961,7 @@ struct Sim {
     int s = new_task(x, y, ty, 1.0);
     S.n_arrivals++;
     if (s >= 0) {
-      S.t_created[s] = S.time_steps;
+      S.t_created[s] = tnow;
       register_dynamic(s);
       push_event(MUAVTA_EV_NEW_THREAT, S.t_id[s]);
     }
@@ -2130,7 +2134,7 @@ struct Sim {
         int pt = 0, pid = -1, psl = 0;
         typename KnowMask<A>::type pk = 0;
         if (k < n) { pt = S.pend_time[k]; pid = S.pend_id[k]; psl = S.pend_slot[k]; pk = S.pend_know[k]; }
-        const bool due = k < n && S.time_steps >= pt;
+        const bool due = k < n && tnow >= pt;
         const unsigned long long dm = __ballot(due), km = __ballot(k < n && !due);
         if (P.share_knowledge) {
           for (unsigned long long m = dm; m; m &= m - 1ull) {
@@ -2163,7 +2167,7 @@ struct Sim {
         bool ex = false;
         if (k < n) {
           sl = S.t_order[k];
-          ex = (S.t_flags[sl] & TF_DEADLINE) && S.t_status[sl] != 2 && S.time_steps > S.t_deadline[sl];
+          ex = (S.t_flags[sl] & TF_DEADLINE) && S.t_status[sl] != 2 && tnow > S.t_deadline[sl];
         }
         for (unsigned long long m = __ballot(ex); m; m &= m - 1ull) {
           const int b = __ffsll((long long)m) - 1;
@@ -2187,7 +2191,7 @@ struct Sim {
     if (any_due) {
       int w = 0;
       for (int k = 0; k < S.n_pending; k++) {
-        if (S.time_steps >= S.pend_time[k]) {
+        if (tnow >= S.pend_time[k]) {
           if (P.share_knowledge) {
             if (ref_valid(S.pend_id[k], S.pend_slot[k])) know_all(S.pend_slot[k]);
             else  // released before the reveal: the id still joins the set of everyone who had not sensed it
@@ -2204,7 +2208,7 @@ struct Sim {
       for (int k = 0; k < S.n_order; k++) {
         int s = S.t_order[k];
         if (!(S.t_flags[s] & TF_DEADLINE) || S.t_status[s] == 2) continue;
-        if (S.time_steps > S.t_deadline[s]) {
+        if (tnow > S.t_deadline[s]) {
           S.t_status[s] = 2;
           mark_outcome_slot(s, false);
           if (!(S.t_flags[s] & TF_REACHED)) { S.t_flags[s] |= TF_REACHED; S.n_reached++; }
@@ -2228,9 +2232,9 @@ struct Sim {
     S.last_reward = total / P.reward_norm_factor / (double)P.max_time_steps;
     PROF(38);
     bool all_done = (S.next_task_id > 1) && all_done_tasks;
-    bool timed_out = (S.time_steps >= P.max_time_steps) && (P.max_time_steps > 0);
+    bool timed_out = (tnow >= P.max_time_steps) && (P.max_time_steps > 0);
     bool done = timed_out || (P.early_terminate && all_done);
-    if (all_done && S.conclusion_time > P.max_time_steps) S.conclusion_time = S.time_steps;
+    if (all_done && S.conclusion_time > P.max_time_steps) S.conclusion_time = tnow;
     S.terminated = P.early_terminate && all_done && !timed_out;
     S.truncated = timed_out;
     if (done) S.last_reward = S.F_Reward;  // :1202
@@ -2388,13 +2392,13 @@ struct Sim {
 #pragma unroll
         for (int c = 0; c < 6; c++) { r[4 + c] = (float)S.t_cur[c][s]; r[10 + c] = (float)S.t_alloc[c][s]; }
         if (P.include_time_windows) {
-          r[16] = (float)((S.t_init[s] - (double)S.time_steps) / mts);
-          r[17] = (float)((S.t_dtime[s] - (double)S.time_steps) / mts);
+          r[16] = (float)((S.t_init[s] - (double)tnow) / mts);
+          r[17] = (float)((S.t_dtime[s] - (double)tnow) / mts);
           r[18] = (float)((double)ty / 6.0);
         }
         const double unmet = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
         r[19] = (float)(unmet / fmax(S.t_org[s], 1e-6));
-        r[20] = (float)fmin(((double)S.time_steps - (double)S.t_created[s]) / mts, 1.0);
+        r[20] = (float)fmin(((double)tnow - (double)S.t_created[s]) / mts, 1.0);
       } else if (!(j == 0 && n == 0)) {
         r[3] = -1.f;  // pad rows are {"status": -1}; with no open task row 0 is task_idle (all zeros)
       }
@@ -2463,7 +2467,7 @@ struct Sim {
         else if (S.ev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) r = 1;
       }
       o_flags[0] = f; o_flags[1] = t; o_flags[2] = r;
-      o_flags[3] = (float)((double)S.time_steps / mts);
+      o_flags[3] = (float)((double)tnow / mts);
       o_flags[4] = (float)((double)n / (double)(P.max_tasks > 1 ? P.max_tasks : 1));
     }
   }
@@ -2496,29 +2500,29 @@ struct Sim {
     if (mode == 1) {  // _should_replan(env, events, 15); plan(force=True) bypasses the allocator's own gate
       bool trig = false;
       for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;  // Reset_Allocation, New_Threat, Agent_Fail
-      go = S.time_steps == 0 || S.time_steps % 15 == 0 || __ballot(trig) != 0ull;
+      go = tnow == 0 || tnow % 15 == 0 || __ballot(trig) != 0ull;
       if (go && lane == 0) S.n_calls++;
     } else if (mode == 3) {  // trainers' expert: force=True under _should_replan(env, events, interval) (train_pair_cost.py:33-43)
       bool trig = false;
       for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;
-      go = S.time_steps == 0 || S.time_steps % interval == 0 || __ballot(trig) != 0ull;
+      go = tnow == 0 || tnow % interval == 0 || __ballot(trig) != 0ull;
       if (go && lane == 0) S.n_calls++;
     } else if (mode == 2) {  // escort_eval._should_replan(env, events, interval): all five env tags are REPLAN_EVENTS
-      go = S.time_steps == 0 || S.time_steps % interval == 0 || S.n_dev > 0;
+      go = tnow == 0 || tnow % interval == 0 || S.n_dev > 0;
       if (go && lane == 0) S.n_calls++;
     } else {
       if (lane == 0) S.n_calls++;
       // should_replan (:27-41): every tag the env emits is in the trigger set
-      go = (S.time_steps - S.last_plan_step >= interval) || (S.n_dev > 0);
+      go = (tnow - S.last_plan_step >= interval) || (S.n_dev > 0);
     }
-    if (go && lane == 0) S.gate_step = S.time_steps + 1;
+    if (go && lane == 0) S.gate_step = tnow + 1;
     const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
     int nr = 0, n_live = 1;
     if (go) {
       // live agents -> free list (get_live_agents order), residual demand per open task: one lane each
       // Urgency-Coalition holds committed agents out of the match (committed_names, AttentionCommit.py:24-30)
       nr = compact_to(X.freeA, P.n_agents,
-                      [&](int a) { return S.a_state[a] != -1 && !(mode == 2 && S.a_commit[a] > S.time_steps); },
+                      [&](int a) { return S.a_state[a] != -1 && !(mode == 2 && S.a_commit[a] > tnow); },
                       [&](int a) { return a; });
       n_live = nr > 1 ? nr : 1;
       bool any_open = false;
@@ -2593,7 +2597,7 @@ struct Sim {
         if (ok) {
           double urgency = 0.0;
           if (S.t_flags[s] & TF_DEADLINE) {
-            int remaining = S.t_deadline[s] - S.time_steps;
+            int remaining = S.t_deadline[s] - tnow;
             remaining = remaining > 0 ? remaining : 0;
             urgency = 1.0 - fmin((double)remaining / 40.0, 1.0);
           }
@@ -2671,11 +2675,11 @@ struct Sim {
     }
     if (mode == 2 && P.commit_horizon > 0 && lane < n_act) {  // apply_agent_commits (AttentionCommit.py:33-44)
       const int a = S.act_agent[lane];
-      if (S.a_qlen[a] > 0) S.a_commit[a] = S.time_steps + P.commit_horizon;  // only agents that hold a real task now
+      if (S.a_qlen[a] > 0) S.a_commit[a] = tnow + P.commit_horizon;  // only agents that hold a real task now
     }
     if (lane == 0) {
       S.n_act = n_act;
-      S.last_plan_step = S.time_steps;
+      S.last_plan_step = tnow;
       S.n_replans++;
     }
     lds_sync();
@@ -2697,7 +2701,7 @@ struct Sim {
   };
   DEV double slot_urgency(int s) const {  // _urgency (AttentionRAH.py:29-34)
     if (!(S.t_flags[s] & TF_DEADLINE)) return 0.0;
-    int remaining = S.t_deadline[s] - S.time_steps;
+    int remaining = S.t_deadline[s] - tnow;
     remaining = remaining > 0 ? remaining : 0;
     return 1.0 - fmin((double)remaining / 40.0, 1.0);
   }
@@ -2817,7 +2821,7 @@ struct Sim {
             const double rem = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
             urgent = urg >= URGENT && dyn;
             if (kind == 1) {
-              int left = S.t_deadline[s] - S.time_steps;
+              int left = S.t_deadline[s] - tnow;
               left = left > 0 ? left : 0;
               f[c++] = (float)(dyn ? fmin((double)left / horizon, 1.0) : 1.0);
               f[c++] = (float)fmin(rem / 4.0, 1.0); f[c++] = dyn ? 1.f : 0.f;
@@ -2855,7 +2859,7 @@ struct Sim {
       n_urgent += __popcll(__ballot(urgent));
     }
     if (lane == 0 && K.n_urgent) K.n_urgent[env] = n_urgent;
-    if (lane == 0 && K.replanned) K.replanned[env] = S.gate_step == S.time_steps + 1;
+    if (lane == 0 && K.replanned) K.replanned[env] = S.gate_step == tnow + 1;
     float* o_em = K.expert_mask ? K.expert_mask + (size_t)env * MA * MT : nullptr;
     // ---- agent rows + edge_valid ----
     for (int i = lane; i < MA; i += WG) {
@@ -2874,7 +2878,7 @@ struct Sim {
         f[c++] = (float)(S.a_px[a] / MAX_COORD); f[c++] = (float)(S.a_py[a] / MAX_COORD); f[c++] = fighter ? 1.f : 0.f; f[c++] = fighter ? 0.f : 1.f;
         f[c++] = S.a_qlen[a] == 0 ? 1.f : 0.f;
         f[c++] = (float)fmin(S.a_caps[2][a] / 2.0, 1.0); f[c++] = (float)fmin(S.a_caps[3][a] / 2.0, 1.0); f[c++] = (float)fmin(S.a_caps[1][a] / 2.0, 1.0);
-        f[c++] = (float)((double)S.a_state[a] / 5.0); f[c++] = (float)((double)S.time_steps / horizon);
+        f[c++] = (float)((double)S.a_state[a] / 5.0); f[c++] = (float)((double)tnow / horizon);
         if (kind == 0) f[c++] = (float)fmin((double)n_known_urgent / (double)(n_all > 1 ? n_all : 1), 1.0);
         if (kind == 2) f[c++] = (float)fmin((double)n_known_urgent / 8.0, 1.0);
         f[c++] = ty == MUAVTA_F2 ? 1.f : 0.f;
@@ -2894,7 +2898,7 @@ struct Sim {
           int n_known_tasks = 0;  // len(known_ids): ids of released tasks are counted in a_gone
           if (vis) { for (int w = 0; w < KW; w++) n_known_tasks += __popc(S.known[a][w]); n_known_tasks += S.a_gone[a]; }
           const double c_h = (double)(P.commit_horizon ? (P.commit_horizon > 1 ? P.commit_horizon : 1) : 20);
-          const double rem_commit = fmax((double)S.a_commit[a] - (double)S.time_steps, 0.0);
+          const double rem_commit = fmax((double)S.a_commit[a] - (double)tnow, 0.0);
           f[c++] = (float)is_escorting; f[c++] = (float)dist_prot; f[c++] = (float)fmin(rem_commit / c_h, 1.0);
           f[c++] = (float)fmin(near_escort + (double)n_known_tasks / 16.0, 1.0);
         }
@@ -3155,7 +3159,7 @@ struct Sim {
     m[k++] = S.n_missed_windows; m[k++] = S.n_on_time; m[k++] = S.n_windowed_tasks;
     int den = S.n_on_time + S.n_missed_windows; den = den > 1 ? den : 1;
     m[k++] = (double)S.n_on_time / (double)den;
-    int den2 = S.time_steps * (P.n_agents > 1 ? P.n_agents : 1); den2 = den2 > 1 ? den2 : 1;
+    int den2 = tnow * (P.n_agents > 1 ? P.n_agents : 1); den2 = den2 > 1 ? den2 : 1;
     m[k++] = (double)S.idle_reserve_steps / (double)den2;
     m[k++] = escort_cov; m[k++] = S.protected_rec_completed; m[k++] = S.recon_losses; m[k++] = S.escort_losses;
     m[k++] = S.threats_intercepted; m[k++] = S.mutual_support_engagements; m[k++] = S.protection_breaches;

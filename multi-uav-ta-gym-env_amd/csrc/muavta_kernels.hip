@@ -240,6 +240,7 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(DevParams P, c
   } else {
     copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
     lds_sync();
+    sim.sync_clock();
   }
   for (int t = 0; t < n_steps; t++) {
     if (L.S->terminated || L.S->truncated) break;  // uniform: read from LDS after a barrier
