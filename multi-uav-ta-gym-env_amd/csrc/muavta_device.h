@@ -2222,22 +2222,24 @@ struct Sim {
   // reserve tracking (:1575-1580), pending-reset latch (:1156-1160), shared reward (:1162-1178), done flags
   DEV void step_serial_c(double action_reward, double distance_reward, double quality_reward, double S_quality_reward,
                          int idle, bool responding, bool all_done_tasks) {
-    S.idle_reserve_steps += idle;
-    if (S.pending_reset && responding) S.pending_reset = 0;
+    // every LDS operand first (one wait), then arithmetic, then the stores
+    const int irs = S.idle_reserve_steps, pr = S.pending_reset, ntid = S.next_task_id, ct = S.conclusion_time;
+    const double time_penaulty = S.r_time_penalty, alloc_reward = S.r_alloc, step_reward = S.step_reward, FR = S.F_Reward;
     PROF(36);
-    const double time_penaulty = S.r_time_penalty, alloc_reward = S.r_alloc;
     double total = P.rw[0] * action_reward + P.rw[1] * distance_reward + P.rw[2] * quality_reward + P.rw[3] * S_quality_reward +
-                   P.rw[4] * (double)P.n_tasks * 0.0 + P.rw[5] * alloc_reward + P.rw[6] * time_penaulty + P.rw[7] * S.step_reward;
+                   P.rw[4] * (double)P.n_tasks * 0.0 + P.rw[5] * alloc_reward + P.rw[6] * time_penaulty + P.rw[7] * step_reward;
     PROF(37);
-    S.last_reward = total / P.reward_norm_factor / (double)P.max_time_steps;
+    const double shared = total / P.reward_norm_factor / (double)P.max_time_steps;
     PROF(38);
-    bool all_done = (S.next_task_id > 1) && all_done_tasks;
-    bool timed_out = (tnow >= P.max_time_steps) && (P.max_time_steps > 0);
-    bool done = timed_out || (P.early_terminate && all_done);
-    if (all_done && S.conclusion_time > P.max_time_steps) S.conclusion_time = tnow;
+    const bool all_done = (ntid > 1) && all_done_tasks;
+    const bool timed_out = (tnow >= P.max_time_steps) && (P.max_time_steps > 0);
+    const bool done = timed_out || (P.early_terminate && all_done);
+    S.idle_reserve_steps = irs + idle;
+    if (pr && responding) S.pending_reset = 0;
+    if (all_done && ct > P.max_time_steps) S.conclusion_time = tnow;
     S.terminated = P.early_terminate && all_done && !timed_out;
     S.truncated = timed_out;
-    if (done) S.last_reward = S.F_Reward;  // :1202
+    S.last_reward = done ? FR : shared;  // :1202
   }
 
   // ---------------------------------------------------------------- end of step: slot GC + open list
