@@ -1442,8 +1442,11 @@ struct Sim {
         double after[6];
 #pragma unroll
         for (int c = 0; c < 6; c++) after[c] = pre[c] + caps[c];
-        const double agentCap = caps[ty];
-        double missing = S.t_cur[ty][s] - (after[ty] - agentCap);
+        // (selects, not caps[ty] / after[ty]: a dynamically indexed local array would live in scratch memory)
+        double agentCap = caps[0], after_ty = after[0];
+#pragma unroll
+        for (int c = 1; c < 6; c++) if (ty == c) { agentCap = caps[c]; after_ty = after[c]; }
+        double missing = S.t_cur[ty][s] - (after_ty - agentCap);
         missing = missing > 0 ? missing : 0;
         const double addedCap = missing - fmax(missing - agentCap, 0.0);
         if (addedCap <= 0) { q2 = -1.5; q3 = addedCap; nq23 = 2; } else { q2 = addedCap; nq23 = 1; }
