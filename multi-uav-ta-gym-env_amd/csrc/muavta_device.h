@@ -170,7 +170,6 @@ template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_handle_threat_engagem
 template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_generate_threat(const DevParams* P, uint32_t* tape);
 template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape);
 template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_sync_escorts(const DevParams* P, uint32_t* tape);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_step_serial_c_lists(const DevParams* P, uint32_t* tape, bool any_due, bool any_exp);
 template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_reset_serial(const DevParams* P, uint32_t* tape);
 template <class TL> __device__ MUAVTA_OUTLINE double ni_step_serial_move(const DevParams* P, uint32_t* tape, int first, int last);
 template <class TL> __device__ MUAVTA_OUTLINE void ni_update_threats_serial(const DevParams* P, uint32_t* tape, int first, unsigned long long livemask);
@@ -976,6 +975,16 @@ struct Sim {
     PROF(46);
     if (lane == 0) reset_serial_impl();  // not through the out-of-line wrapper: it must see this object's window
     lds_sync();
+    {  // static / initial tasks are known to everyone (:757-758): every agent lane ORs the slots' mask into its row
+      const int no = S.n_order;
+      for (int w = 0; w < KW; w++) {
+        uint32_t m = 0;
+        for (int k = 0; k < no; k++) { const int sl = S.t_order[k]; if ((sl >> 5) == w) m |= 1u << (sl & 31); }
+        if (lane < P.n_agents) S.known[lane][w] |= m;
+      }
+      for (int k = lane; k < no; k += WG) S.t_flags[S.t_order[k]] |= TF_KNOWN_ALL;
+    }
+    lds_sync();
     PROF(47);
     win_ptr = &S.rng_win[0][0]; win_len = 8; win_stride = 8;
     if (lane < 4) S.rng_win_at[lane] = 0x7fffffffu;  // the small window is (re)filled at the next step boundary
@@ -1064,9 +1073,7 @@ struct Sim {
       }
       S.g_end[g] = hid;
     }
-    // static / initial tasks are known to everyone (:757-758)
-    for (int k = 0; k < S.n_order; k++) know_all(S.t_order[k]);
-    S.did_reset = 1;
+    S.did_reset = 1;  // (the initial tasks become known to everyone in reset(), one agent per lane)
   }
 
   // ====================================================================================================
@@ -2188,40 +2195,6 @@ struct Sim {
       }
     }
   }
-  // _wps_process_reveals (:1525-1541) and _wps_expire_windows (:1557-1573); lane 0, only when due
-  DEV void step_serial_c_lists(bool any_due, bool any_exp) { ni_step_serial_c_lists<TL>(&P, tape, any_due, any_exp); }
-  DEV void step_serial_c_lists_impl(bool any_due, bool any_exp) {
-    if (any_due) {
-      int w = 0;
-      for (int k = 0; k < S.n_pending; k++) {
-        if (tnow >= S.pend_time[k]) {
-          if (P.share_knowledge) {
-            if (ref_valid(S.pend_id[k], S.pend_slot[k])) know_all(S.pend_slot[k]);
-            else  // released before the reveal: the id still joins the set of everyone who had not sensed it
-              for (int a = 0; a < P.n_agents; a++) S.a_gone[a] += !((S.pend_know[k] >> a) & 1);
-          }
-        } else {
-          S.pend_time[w] = S.pend_time[k]; S.pend_id[w] = S.pend_id[k]; S.pend_slot[w] = S.pend_slot[k]; S.pend_know[w] = S.pend_know[k];
-          w++;
-        }
-      }
-      S.n_pending = w;
-    }
-    if (any_exp) {
-      for (int k = 0; k < S.n_order; k++) {
-        int s = S.t_order[k];
-        if (!(S.t_flags[s] & TF_DEADLINE) || S.t_status[s] == 2) continue;
-        if (tnow > S.t_deadline[s]) {
-          S.t_status[s] = 2;
-          mark_outcome_slot(s, false);
-          if (!(S.t_flags[s] & TF_REACHED)) { S.t_flags[s] |= TF_REACHED; S.n_reached++; }
-          int id = S.t_id[s];
-          for (int a = 0; a < P.n_agents; a++)
-            if (S.a_qlen[a] > 0 && S.a_qid[a][0] == id) desallocate_all(a);
-        }
-      }
-    }
-  }
   // reserve tracking (:1575-1580), pending-reset latch (:1156-1160), shared reward (:1162-1178), done flags
   DEV void step_serial_c(double action_reward, double distance_reward, double quality_reward, double S_quality_reward,
                          int idle, bool responding, bool all_done_tasks) {
@@ -3178,7 +3151,6 @@ template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_handle_threat_engagem
 template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_generate_threat(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.generate_threat_impl(); }
 template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.inject_dynamic_arrivals_impl(); }
 template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_sync_escorts(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.sync_escorts_impl(); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_step_serial_c_lists(const DevParams* P, uint32_t* tape, bool any_due, bool any_exp) { MUAVTA_NI_SIM; sim.step_serial_c_lists_impl(any_due, any_exp); }
 template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_reset_serial(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.reset_serial_impl(); }
 template <class TL> __device__ MUAVTA_OUTLINE double ni_step_serial_move(const DevParams* P, uint32_t* tape, int first, int last) { MUAVTA_NI_SIM; return sim.step_serial_move_impl(first, last); }
 template <class TL> __device__ MUAVTA_OUTLINE void ni_update_threats_serial(const DevParams* P, uint32_t* tape, int first, unsigned long long livemask) { MUAVTA_NI_SIM; sim.update_threats_serial_impl(first, livemask); }
