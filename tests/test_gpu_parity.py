@@ -269,6 +269,11 @@ def test_avoid_obstacles_vs_oracle():
         want[i] = out
     assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
     assert np.array_equal(avoid_obstacles(pos, np.zeros((0, 3)), mov), np.zeros_like(pos))  # K=0: the live configs
+    from muavta_amd.core_sim import SimCore  # the reference's call shape: lists in, [dx, dy] out (DroneEnv.py:1033)
+    sc = SimCore()
+    one = sc.avoid_obstacles(list(pos[5]), [list(o) for o in obst], list(mov[5]))
+    assert isinstance(one, list) and len(one) == 2 and np.allclose(one, want[5], rtol=1e-9, atol=1e-9)
+    assert sc.avoid_obstacles([1.0, 2.0], [], [0.5, 0.5]) == [0.0, 0.0]
 
 
 def test_obstacles_random_init_and_single_task_mode():
