@@ -1,12 +1,17 @@
 // muavta_device.h — device-side simulation of ONE env instance by ONE workgroup (gfx950, wave64).
 //
-// Execution model: the env's state blob sits in LDS (EnvState).  A step is a sequence of phases;
-// phases whose iterations are independent (pairwise sensing, the agent x task cost tile, distance
-// bookkeeping, slot GC, observation rows, MT19937 regeneration) are spread over the 64 lanes, and
-// the order-dependent bookkeeping of the reference (action application in dict order, the per-agent
-// state machine in agents_obj order, threat engagements that consume the shared RNG stream, the
-// shortest-augmenting-path LSAP) runs on lane 0 against LDS.  Phases are separated by workgroup
-// barriers.  Everything is f64 with -ffp-contract=off; FMAs are explicit where numpy emits them.
+// Execution model: the env's state blob sits in LDS (EnvState).  A step is a sequence of phases separated
+// by lds_sync().  Phases whose iterations are independent (pairwise sensing, the agent x task cost tile,
+// distances, slot GC, observation rows, MT19937 regeneration) are spread over the 64 lanes.  The
+// order-dependent bookkeeping of the reference is parallelised where its order can be kept exactly:
+//   * "everything up to the first event, then lane 0 replays that one entity as the reference does, then the
+//     wave resumes behind it" — the per-agent state machine and the threat update;
+//   * "one entity per lane, order-dependent sums replayed in order" — action application (reward addends via
+//     v_readlane, allocatedReqs of a shared task via a same-slot prefix), releaseAllTasks (agent lanes compact
+//     their queues, slot lanes replay removeAgentCap in agent order), reveals / window expiry;
+//   * the LSAP keeps scipy's scan order as per-column positions and never touches LDS inside the solve.
+// What is left on lane 0 is entity creation (arrivals, threat spawns, escorts), engagements, task completion.
+// Everything is f64 with -ffp-contract=off; FMAs are explicit where numpy emits them.
 //
 // Every routine cites the reference lines it restates (mUAV_TA/DroneEnv.py unless another file is
 // named).  This file is the product path; it shares no code with oracle/.
