@@ -668,3 +668,37 @@ def test_seeds_beyond_32_bits():
         snap = Snapshot(env)
         for i, o in enumerate(oracles):
             compare(snap, i, o, f"seed {seeds[i]} t={t + 1}")
+
+
+@pytest.mark.parametrize("mode,name", [(1, "urgency_pair"), (2, "urgency_coalition"), (3, "hungarian_gated")])
+def test_allocator_modes_on_fuzzed_configs_vs_oracle(mode, name):
+    """The hybrid / trainer allocator modes under knob combinations no registry case has: device vs oracle, stepwise."""
+    from cases import fuzz_configs, params_of
+    from muavta_amd.batched import BatchedMultiUAVEnv
+
+    for case in sorted(fuzz_configs()):
+        p = params_of(case)
+        n = 2
+        env = BatchedMultiUAVEnv(p, n)
+        env.set_allocator(name)
+        seeds = np.arange(7, 7 + n, dtype=np.uint64)
+        oracles = [orc.OracleEnv(p) for _ in range(n)]
+        env.reset(seeds)
+        for i, o in enumerate(oracles):
+            o.reset(int(seeds[i]))
+        interval = 12 if p.escort_enabled else 20
+        for t in range(min(p.max_time_steps, 90)):
+            aa, ai = env.allocate(interval, True)
+            done = [bool(o.dims()["terminated"] or o.dims()["truncated"]) for o in oracles]
+            if any(done):
+                break
+            for i, o in enumerate(oracles):
+                oa, oi = o.allocate_mode(interval, 1, mode)
+                k = len(oa)
+                assert np.array_equal(aa[i][:k], oa) and np.all(aa[i][k:] == -1) and np.array_equal(ai[i][:k], oi), f"{case} {name} seed {seeds[i]} t={t}"
+                o.step(oa, oi)
+            env.step(aa, ai)
+            snap = Snapshot(env)
+            for i, o in enumerate(oracles):
+                compare(snap, i, o, f"{case} {name} seed {seeds[i]} t={t + 1}")
+        assert np.all(env.get("ERROR") == 0)
