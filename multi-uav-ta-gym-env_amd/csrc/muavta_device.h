@@ -62,9 +62,10 @@ DEV bool is_fighter(int t) { return t == MUAVTA_F1 || t == MUAVTA_F2; }
 
 template <class TL>
 struct alignas(16) Scratch {
-  enum { A = TL::A, T = TL::T };
-  double cost[A * T];  // LSAP cost tile, R x C row-major with R = min(nr, nc)
-  double u[A], v[T], spc[T], resid[T];
+  enum { A = TL::A, T = TL::T,
+         COSTN = TL::REGC ? (4 * A > 2 * T ? 4 * A : 2 * T) : A * T };  // REGC: only small staging arrays live here
+  double cost[COSTN];  // LSAP cost tile, R x C row-major with R = min(nr, nc) (unless TL::REGC)
+  double u[A], v[T], spc[T], resid[T];  // (the register-resident LSAP leaves u/v/spc to their other users)
   int32_t path[T], col4row[A], row4col[T], remaining[T], freeA[A], roundT[T];
   uint8_t SR[A], SC[T];
   uint8_t live_rank[A];                  // Urgency-Pair: rank of an agent among the live ones (255 = beyond the token pad)
@@ -1713,7 +1714,7 @@ struct Sim {
       const int start = S.g_next[g], left = S.g_end[g] - start;
       int cnt = P.burst_mode ? (P.burst_size < left ? P.burst_size : left) : (left > 0 ? 1 : 0);
       if (cnt <= 0) continue;
-      if (cnt * nA > A * T) cnt = (A * T) / nA;  // scratch bound (never binding: burst_size <= T)
+      if (cnt * nA > Scratch<TL>::COSTN) cnt = Scratch<TL>::COSTN / nA;  // scratch bound
       for (int p = lane; p < cnt * nA; p += WG) {
         const int c = p / nA, a = p - c * nA, h = start + c;
         const int st = S.a_state[a];
@@ -2565,15 +2566,12 @@ struct Sim {
             const double d = norm2(S.h_px[h] - ax, S.h_py[h] - ay);
             if (d < best) best = d;
           }
-          X.spc[j] = 1.0 - fmin(best / MAX_COORD, 1.0);  // pressure; spc is re-initialised by the solver afterwards
+          X.spc[j] = 1.0 - fmin(best / MAX_COORD, 1.0);  // threat pressure of round task j (the LDS solver re-initialises spc afterwards; the register solver leaves it)
         }
         lds_sync();
       }
-      // ---- cost tile (:137-179), one (agent, task) pair per lane ----
-      bool feasible = false;
-      for (int p = lane; p < nr * nc; p += WG) {
-        int i = p / nc, j = p - i * nc;
-        int a = X.freeA[i], s = S.open_slot[X.roundT[j]];
+      // ---- cost (:137-179) of agent a for the task in slot s (jr: its index among the round's tasks) ----
+      auto pair_cost = [&](int a, int s, int jr) -> double {
         double c = 1e6;
         bool ok = !(vis && !((S.known[a][s >> 5] >> (s & 31)) & 1u));
         if (ok && (S.t_flags[s] & TF_ELIGIBLE) && !((S.t_elig[s] >> S.a_type[a]) & 1u)) ok = false;
@@ -2604,7 +2602,7 @@ struct Sim {
               const int ty = S.t_type[s];
               const bool esc = (S.t_flags[s] & TF_ESCORT) != 0;
               const double cap = S.a_caps[ty][a] > 0 ? S.a_caps[ty][a] : 0.0;
-              double v = 0.45 * urgency + 0.35 * X.spc[j] * (0.5 + 0.5 * (esc ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
+              double v = 0.45 * urgency + 0.35 * X.spc[jr] * (0.5 + 0.5 * (esc ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
               const bool fighter = is_fighter(S.a_type[a]);
               if (fighter && (esc || ty == MUAVTA_INT)) v += 0.2;
               if (!fighter && ty == MUAVTA_REC) v += 0.2;
@@ -2613,14 +2611,40 @@ struct Sim {
             if (base < 1e5 / 2) c = base - score;
           }
         }
-        X.cost[tr ? (j * Cc + i) : (i * Cc + j)] = c;
-        feasible |= c < 1e5 / 2;
+        return c;
+      };
+      bool feasible = false;
+      cost_vec c0, c1;
+      if constexpr (TL::REGC) {
+        // lane = LSAP column (a task, or an agent when scipy transposes): its whole cost column goes straight into
+        // uniformly indexed registers, one row per iteration — no A x T tile in LDS
+        const bool incol = lane < Cc;
+        const int my_a = (tr && incol) ? X.freeA[lane] : -1;
+        const int my_s = (!tr && incol) ? S.open_slot[X.roundT[lane]] : -1;
+        for (int i = 0; i < Rr; i++) {
+          double c = 0.0;
+          if (incol) {
+            if (tr) c = pair_cost(my_a, S.open_slot[X.roundT[i]], i);
+            else c = pair_cost(X.freeA[i], my_s, lane);
+            feasible |= c < 1e5 / 2;
+          }
+          if (i < 16) c0[i] = c; else c1[i - 16] = c;
+        }
+      } else {
+        for (int p = lane; p < nr * nc; p += WG) {  // one (agent, task) pair per lane
+          const int i = p / nc, j = p - i * nc;
+          const double c = pair_cost(X.freeA[i], S.open_slot[X.roundT[j]], j);
+          X.cost[tr ? (j * Cc + i) : (i * Cc + j)] = c;
+          feasible |= c < 1e5 / 2;
+        }
       }
       // no pair under the acceptance threshold -> the round accepts nothing whatever the assignment is
       if (__ballot(feasible) == 0ull) break;
       lds_sync();
       PROF(12);
-      if constexpr (T <= WG && A <= 32) lsap_reg(Rr, Cc); else lsap(Rr, Cc);
+      if constexpr (TL::REGC) lsap_reg_core(Rr, Cc, c0, c1);
+      else if constexpr (T <= WG && A <= 32) lsap_reg(Rr, Cc);
+      else lsap(Rr, Cc);
       PROF(13);
       // accept (:182-204): one free agent per lane, actions appended in ascending agent order (scipy returns
       // rows sorted); each task appears at most once per round, so the residual updates are independent
@@ -2633,9 +2657,14 @@ struct Sim {
           a = X.freeA[i];
           const int j = tr ? X.row4col[i] : X.col4row[i];
           keep = true;
-          if (j >= 0 && X.cost[tr ? (j * Cc + i) : (i * Cc + j)] < 1e5 / 2) {
-            acc = true; keep = false;
-            oi = X.roundT[j]; s = S.open_slot[oi];
+          if (j >= 0) {
+            double cij;
+            if constexpr (TL::REGC) cij = pair_cost(a, S.open_slot[X.roundT[j]], j);  // same value the solver saw
+            else cij = X.cost[tr ? (j * Cc + i) : (i * Cc + j)];
+            if (cij < 1e5 / 2) {
+              acc = true; keep = false;
+              oi = X.roundT[j]; s = S.open_slot[oi];
+            }
           }
         }
         const unsigned long long am = __ballot(acc), km = __ballot(keep);
@@ -3031,8 +3060,7 @@ struct Sim {
   // only as each column's POSITION in it (filled in reverse, swap-removed), which is all its tie rule looks at:
   // among the minima take the unassigned column at the LAST position if there is one, else the FIRST position.
   typedef double cost_vec __attribute__((ext_vector_type(16)));
-  DEV void lsap_reg(int nr, int nc) {
-    const double INF = __builtin_huge_val();
+  DEV void lsap_reg(int nr, int nc) {  // cost tile staged in X.cost (R x C row-major)
     cost_vec c0, c1;
 #pragma unroll
     for (int i = 0; i < 16; i++) { c0[i] = (i < nr && lane < nc) ? X.cost[i * nc + lane] : 0.0; }
@@ -3040,6 +3068,10 @@ struct Sim {
 #pragma unroll
       for (int i = 0; i < 16; i++) { c1[i] = (16 + i < nr && lane < nc) ? X.cost[(16 + i) * nc + lane] : 0.0; }
     }
+    lsap_reg_core(nr, nc, c0, c1);
+  }
+  DEV void lsap_reg_core(int nr, int nc, const cost_vec& c0, const cost_vec& c1) {
+    const double INF = __builtin_huge_val();
     double u_r = 0, vj = 0;  // lane r < nr: u[r];  lane j < nc: v[j]
     int c4r = -1, r4c = -1;  // lane r: col4row[r];  lane j: row4col[j]
     const bool incol = lane < nc;

@@ -67,6 +67,7 @@ struct Lds {
 #define smem muavta_smem
 // 8 workgroups per CU need <= 160 KiB / 8 = 20480 B of LDS each on the 16x32 tile (BASELINE config 2)
 static_assert(((sizeof(EnvState<Tile16>) + 15) & ~size_t(15)) + sizeof(Scratch<Tile16>) <= 20480, "Tile16 no longer fits 8 workgroups per CU");
+static_assert(((sizeof(EnvState<Tile24>) + 15) & ~size_t(15)) + sizeof(Scratch<Tile24>) <= 26624, "Tile24 no longer fits 6 workgroups per CU (27,200 B measured at 5: the LDS granule is 1 KB)");
 
 // Minimum waves per SIMD the register allocator must leave room for (2 => at most 256 VGPR+AGPR).
 #ifndef MUAVTA_MIN_WAVES

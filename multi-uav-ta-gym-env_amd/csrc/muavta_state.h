@@ -52,8 +52,9 @@ struct DevParams {
   double rw[8];
 };
 
-template <int A_, int T_, int H_, int R_, int E_, int Q_>
+template <int A_, int T_, int H_, int R_, int E_, int Q_, bool REGC_ = false>
 struct Tile {
+  static constexpr bool REGC = REGC_;  // the allocator builds the LSAP cost columns in registers: no A x T cost tile in LDS
   static constexpr int A = A_;  // agents
   static constexpr int T = T_;  // live task slots
   static constexpr int H = H_;  // threats
@@ -140,7 +141,7 @@ struct alignas(16) EnvState {
 
 // Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
 typedef Tile<16, 32, 16, 48, 40, 8> Tile16;  // events <= 16, pending reveals <= 22 measured over 4096 seeds
-typedef Tile<24, 48, 24, 128, 64, 16> Tile24;
+typedef Tile<24, 48, 24, 88, 40, 12, true> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
 typedef Tile<64, 128, 48, 128, 96, 8> Tile64;
 
 #define MUAVTA_REL_ROW 29  // doubles per release-log row (include/muavta.h: MUAVTA_F_RELEASE_LOG)
