@@ -63,9 +63,10 @@ DEV bool is_fighter(int t) { return t == MUAVTA_F1 || t == MUAVTA_F2; }
 template <class TL>
 struct alignas(16) Scratch {
   enum { A = TL::A, T = TL::T,
-         COSTN = TL::REGC ? (4 * A > 2 * T ? 4 * A : 2 * T) : A * T };  // REGC: only small staging arrays live here
+         COSTN = TL::NO_COST_TILE ? (4 * A > 2 * T ? 4 * A : 2 * T) : A * T };  // REGC / OTFC: only small staging arrays live here
   double cost[COSTN];  // LSAP cost tile, R x C row-major with R = min(nr, nc) (unless TL::REGC)
   double u[A], v[T], spc[T], resid[T];  // (the register-resident LSAP leaves u/v/spc to their other users)
+  double press[TL::OTFC ? T : 1];       // Urgency-Coalition threat pressure per round task where the LDS solver (which owns spc) evaluates costs on the fly
   int32_t path[T], col4row[A], row4col[T], remaining[T], freeA[A], roundT[T];
   uint8_t SR[A], SC[T];
   uint8_t live_rank[A];                  // Urgency-Pair: rank of an agent among the live ones (255 = beyond the token pad)
@@ -2566,7 +2567,7 @@ struct Sim {
             const double d = norm2(S.h_px[h] - ax, S.h_py[h] - ay);
             if (d < best) best = d;
           }
-          X.spc[j] = 1.0 - fmin(best / MAX_COORD, 1.0);  // threat pressure of round task j (the LDS solver re-initialises spc afterwards; the register solver leaves it)
+          (TL::OTFC ? X.press : X.spc)[j] = 1.0 - fmin(best / MAX_COORD, 1.0);  // threat pressure of round task j (a cost-tile LDS solve may clobber spc afterwards; the register solver leaves it)
         }
         lds_sync();
       }
@@ -2602,7 +2603,7 @@ struct Sim {
               const int ty = S.t_type[s];
               const bool esc = (S.t_flags[s] & TF_ESCORT) != 0;
               const double cap = S.a_caps[ty][a] > 0 ? S.a_caps[ty][a] : 0.0;
-              double v = 0.45 * urgency + 0.35 * X.spc[jr] * (0.5 + 0.5 * (esc ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
+              double v = 0.45 * urgency + 0.35 * (TL::OTFC ? X.press : X.spc)[jr] * (0.5 + 0.5 * (esc ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
               const bool fighter = is_fighter(S.a_type[a]);
               if (fighter && (esc || ty == MUAVTA_INT)) v += 0.2;
               if (!fighter && ty == MUAVTA_REC) v += 0.2;
@@ -2634,7 +2635,7 @@ struct Sim {
         for (int p = lane; p < nr * nc; p += WG) {  // one (agent, task) pair per lane
           const int i = p / nc, j = p - i * nc;
           const double c = pair_cost(X.freeA[i], S.open_slot[X.roundT[j]], j);
-          X.cost[tr ? (j * Cc + i) : (i * Cc + j)] = c;
+          if constexpr (!TL::OTFC) X.cost[tr ? (j * Cc + i) : (i * Cc + j)] = c;  // OTFC: this pass only answers "any feasible pair?"
           feasible |= c < 1e5 / 2;
         }
       }
@@ -2643,6 +2644,8 @@ struct Sim {
       lds_sync();
       PROF(12);
       if constexpr (TL::REGC) lsap_reg_core(Rr, Cc, c0, c1);
+      else if constexpr (TL::OTFC)  // element (row i, column j) of scipy's (possibly transposed) matrix, evaluated when scanned
+        lsap(Rr, Cc, [&](int i, int j) { return tr ? pair_cost(X.freeA[j], S.open_slot[X.roundT[i]], i) : pair_cost(X.freeA[i], S.open_slot[X.roundT[j]], j); });
       else if constexpr (T <= WG && A <= 32) lsap_reg(Rr, Cc);
       else lsap(Rr, Cc);
       PROF(13);
@@ -2659,7 +2662,7 @@ struct Sim {
           keep = true;
           if (j >= 0) {
             double cij;
-            if constexpr (TL::REGC) cij = pair_cost(a, S.open_slot[X.roundT[j]], j);  // same value the solver saw
+            if constexpr (TL::NO_COST_TILE) cij = pair_cost(a, S.open_slot[X.roundT[j]], j);  // same value the solver saw
             else cij = X.cost[tr ? (j * Cc + i) : (i * Cc + j)];
             if (cij < 1e5 / 2) {
               acc = true; keep = false;
@@ -2978,7 +2981,9 @@ struct Sim {
     v = fmin(v, dpp_xchg(v, 3));
     return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
   }
-  DEV void lsap(int nr, int nc) {
+  DEV void lsap(int nr, int nc) { const double* c = X.cost; lsap(nr, nc, [c, nc](int i, int j) { return c[i * nc + j]; }); }
+  template <class CostAt>
+  DEV void lsap(int nr, int nc, CostAt cost_at) {
     const double INF = __builtin_huge_val();
     for (int i = lane; i < nr; i += WG) { X.u[i] = 0; X.col4row[i] = -1; }
     for (int j = lane; j < nc; j += WG) { X.v[j] = 0; X.row4col[j] = -1; X.path[j] = -1; }
@@ -2991,7 +2996,6 @@ struct Sim {
       int i = cur, num_remaining = nc, sink = -1;
       while (sink == -1) {
         const double ui = X.u[i];
-        const double* crow = X.cost + i * nc;
         double gmin = INF;
         int g_first = -1, g_lastU = -1;
         for (int base = 0; base < num_remaining; base += WG) {
@@ -3001,7 +3005,7 @@ struct Sim {
           bool un = false;
           if (active) {
             const int j = X.remaining[it];
-            const double r = minVal + crow[j] - ui - X.v[j];
+            const double r = minVal + cost_at(i, j) - ui - X.v[j];
             double sp = X.spc[j];
             if (r < sp) { X.path[j] = i; X.spc[j] = r; sp = r; }
             val = sp;

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(WG) void k_tokens(DevParams P, const EnvState<TL>* 
 // Stand-alone LSAP: one problem per workgroup, cost tile staged in LDS (transposed when nc < nr).
 // REG: the register-resident solver of the allocator path (rows <= 32, columns <= 64); else the LDS solver (64 x 128).
 typedef Tile<32, 64, 16, 16, 16, 8> TileLsapReg;
+typedef Tile<64, 128, 16, 16, 16, 8> TileLsapLds;  // keeps the full cost tile in LDS (the env's 64x128 tile evaluates costs on the fly)
 template <class TL, bool REG>
 __global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc, int64_t* row, int64_t* col) {
   Lds<TL> L(smem);
@@ -1149,9 +1150,9 @@ int muavta_lsap_impl(int32_t device, const double* cost, int32_t n, int32_t nr, 
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap<TileLsapReg, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL((k_lsap<TileLsapReg, true>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
   } else {
-    size_t lds = Lds<Tile64>::bytes();
-    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap<Tile64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_lsap<Tile64, false>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
+    size_t lds = Lds<TileLsapLds>::bytes();
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap<TileLsapLds, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_lsap<TileLsapLds, false>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
   }
   CK(hipGetLastError());
   CK(hipMemcpy(row, dr, rb, hipMemcpyDeviceToHost));

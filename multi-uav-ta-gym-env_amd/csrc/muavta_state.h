@@ -52,9 +52,11 @@ struct DevParams {
   double rw[8];
 };
 
-template <int A_, int T_, int H_, int R_, int E_, int Q_, bool REGC_ = false>
+template <int A_, int T_, int H_, int R_, int E_, int Q_, bool REGC_ = false, bool OTFC_ = false>
 struct Tile {
   static constexpr bool REGC = REGC_;  // the allocator builds the LSAP cost columns in registers: no A x T cost tile in LDS
+  static constexpr bool OTFC = OTFC_;  // the (LDS) solver evaluates cost elements on the fly: no A x T cost tile either
+  static constexpr bool NO_COST_TILE = REGC_ || OTFC_;
   static constexpr int A = A_;  // agents
   static constexpr int T = T_;  // live task slots
   static constexpr int H = H_;  // threats
@@ -142,7 +144,7 @@ struct alignas(16) EnvState {
 // Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
 typedef Tile<16, 32, 16, 48, 40, 8> Tile16;  // events <= 16, pending reveals <= 22 measured over 4096 seeds
 typedef Tile<24, 48, 24, 88, 40, 12, true> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
-typedef Tile<64, 128, 48, 128, 96, 8> Tile64;
+typedef Tile<64, 128, 48, 128, 96, 8, false, true> Tile64;
 
 #define MUAVTA_REL_ROW 29  // doubles per release-log row (include/muavta.h: MUAVTA_F_RELEASE_LOG)
 #define MUAVTA_RNG_STREAMS 4
