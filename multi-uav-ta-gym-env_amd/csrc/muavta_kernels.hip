@@ -104,7 +104,7 @@ __constant__ GenrandTable G_TAB = GenrandTable();
 DEV void seed_column(uint32_t* col, uint32_t k0, uint32_t k1, int len) {
   uint32_t prev = 19650218u;
   const uint32_t add_even = k0, add_odd = len == 2 ? k1 + 1u : k0;  // first loop step i uses j = (i - 1) % len
-#pragma unroll 4
+#pragma unroll 32
   for (int i = 1; i < 624; i++) {
     prev = (G_TAB.v[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (((i - 1) & 1) ? add_odd : add_even);
     col[i * SEED_LD] = prev;
@@ -115,14 +115,14 @@ DEV void seed_column(uint32_t* col, uint32_t k0, uint32_t k1, int len) {
     col[SEED_LD] = prev;
   }
   int i = 2;
-  for (; i + 8 <= 624; i += 8) {
-    uint32_t m[8];
+  for (; i + 16 <= 624; i += 16) {
+    uint32_t m[16];
 #pragma unroll
-    for (int q = 0; q < 8; q++) m[q] = col[(i + q) * SEED_LD];
+    for (int q = 0; q < 16; q++) m[q] = col[(i + q) * SEED_LD];
 #pragma unroll
-    for (int q = 0; q < 8; q++) { prev = (m[q] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i + q); m[q] = prev; }
+    for (int q = 0; q < 16; q++) { prev = (m[q] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i + q); m[q] = prev; }
 #pragma unroll
-    for (int q = 0; q < 8; q++) col[(i + q) * SEED_LD] = m[q];
+    for (int q = 0; q < 16; q++) col[(i + q) * SEED_LD] = m[q];
   }
   for (; i < 624; i++) { prev = (col[i * SEED_LD] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i; col[i * SEED_LD] = prev; }
   col[0] = prev;  // 623rd iteration of the second loop: i wrapped to 1 with mt[0] = mt[623]
