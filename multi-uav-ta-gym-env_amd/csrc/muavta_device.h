@@ -1715,27 +1715,30 @@ struct Sim {
       const int start = S.g_next[g], left = S.g_end[g] - start;
       int cnt = P.burst_mode ? (P.burst_size < left ? P.burst_size : left) : (left > 0 ? 1 : 0);
       if (cnt <= 0) continue;
-      if (cnt * nA > Scratch<TL>::COSTN) cnt = Scratch<TL>::COSTN / nA;  // scratch bound
-      for (int p = lane; p < cnt * nA; p += WG) {
-        const int c = p / nA, a = p - c * nA, h = start + c;
-        const int st = S.a_state[a];
-        X.cost[p] = (h < H && st != -1 && st != 4) ? norm2(S.a_px[a] - S.h_px[h], S.a_py[a] - S.h_py[h]) : __builtin_huge_val();
-      }
-      lds_sync();
-      for (int c = lane; c < cnt; c += WG) {
-        double minF = __builtin_huge_val(), minW = __builtin_huge_val();
-        int cF = -1, cW = -1;
-        for (int a = 0; a < nA; a++) {
-          const double d = X.cost[c * nA + a];
+      const int chunk = Scratch<TL>::COSTN / nA;  // threats per pass of the distance scratch (>= 1: COSTN >= 4 * A)
+      for (int c0 = 0; c0 < cnt; c0 += chunk) {
+        const int cn = cnt - c0 < chunk ? cnt - c0 : chunk;
+        for (int p = lane; p < cn * nA; p += WG) {
+          const int c = p / nA, a = p - c * nA, h = start + c0 + c;
           const int st = S.a_state[a];
-          if (st != -1 && st != 4) {
-            if (is_fighter(S.a_type[a])) { if (d < minF) { minF = d; cF = a; } }
-            else { if (d < minW) { minW = d; cW = a; } }
-          }
+          X.cost[p] = (h < H && st != -1 && st != 4) ? norm2(S.a_px[a] - S.h_px[h], S.a_py[a] - S.h_py[h]) : __builtin_huge_val();
         }
-        if (start + c < H) X.roundT[start + c] = cW >= 0 ? cW : cF;
+        lds_sync();
+        for (int c = lane; c < cn; c += WG) {
+          double minF = __builtin_huge_val(), minW = __builtin_huge_val();
+          int cF = -1, cW = -1;
+          for (int a = 0; a < nA; a++) {
+            const double d = X.cost[c * nA + a];
+            const int st = S.a_state[a];
+            if (st != -1 && st != 4) {
+              if (is_fighter(S.a_type[a])) { if (d < minF) { minF = d; cF = a; } }
+              else { if (d < minW) { minW = d; cW = a; } }
+            }
+          }
+          if (start + c0 + c < H) X.roundT[start + c0 + c] = cW >= 0 ? cW : cF;
+        }
+        lds_sync();
       }
-      lds_sync();
     }
   }
   DEV void generate_threat() { ni_generate_threat<TL>(&P, tape); }

@@ -702,3 +702,30 @@ def test_allocator_modes_on_fuzzed_configs_vs_oracle(mode, name):
             for i, o in enumerate(oracles):
                 compare(snap, i, o, f"{case} {name} seed {seeds[i]} t={t + 1}")
         assert np.all(env.get("ERROR") == 0)
+
+
+def test_large_bursts_on_the_64_agent_tile():
+    """burst_size x n_agents beyond one pass of the closest-agent scratch (64 agents x 6 threats): chunked precompute."""
+    from muavta_amd.batched import BatchedMultiUAVEnv
+    from muavta_amd.params import params_from_config
+    from muavta_amd.scenarios import CASE_SPECS, TILES, WPS_ENV_FLAGS
+
+    spec = dict(CASE_SPECS["WPS_burst64"]); spec["burst_size"] = 6
+    ta, tt, th = TILES["WPS_burst64"]
+    p = params_from_config(spec, dict(WPS_ENV_FLAGS), tile_agents=ta, tile_tasks=tt, tile_threats=th)
+    n = 2
+    env = BatchedMultiUAVEnv(p, n)
+    oracles = [orc.OracleEnv(p) for _ in range(n)]
+    env.reset(np.arange(n, dtype=np.uint64))
+    for i, o in enumerate(oracles):
+        o.reset(i)
+    for t in range(100):
+        aa, ai = env.allocate(20, True)
+        for i, o in enumerate(oracles):
+            oa, oi = o.allocate(20, 1)
+            assert np.array_equal(aa[i][:len(oa)], oa) and np.array_equal(ai[i][:len(oa)], oi), f"seed {i} t={t}"
+            o.step(oa, oi)
+        env.step(aa, ai)
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"burst 6 seed {i} t={t + 1}")
