@@ -63,7 +63,9 @@ DEV bool is_fighter(int t) { return t == MUAVTA_F1 || t == MUAVTA_F2; }
 template <class TL>
 struct alignas(16) Scratch {
   enum { A = TL::A, T = TL::T,
-         COSTN = TL::NO_COST_TILE ? (4 * A > 2 * T ? 4 * A : 2 * T) : A * T };  // REGC / OTFC: only small staging arrays live here
+         COSTN_MIN = 4 * A > 2 * T ? 4 * A : 2 * T,  // act_f: 4 x A doubles; refresh_task_times: 2 x T u64
+         COSTN = !TL::NO_COST_TILE ? A * T           // REGC / OTFC: only small staging arrays live here ...
+               : (A <= 16 && COSTN_MIN < 144) ? 144 : COSTN_MIN };  // ... and the scratch still has to hold the 3 KB reset RNG window
   double cost[COSTN];  // LSAP cost tile, R x C row-major with R = min(nr, nc) (unless TL::REGC)
   double u[A], v[T], spc[T], resid[T];  // (the register-resident LSAP leaves u/v/spc to their other users)
   double press[TL::OTFC ? T : 1];       // Urgency-Coalition threat pressure per round task where the LDS solver (which owns spc) evaluates costs on the fly
@@ -1018,7 +1020,7 @@ struct Sim {
       S.obst[o][0] = x; S.obst[o][1] = y; S.obst[o][2] = size;
     }
     // agents (:591-612): shuffle ids, create in config order
-    int32_t* ids = X.path;  // scratch (T >= A)
+    int32_t* ids = S.act_agent;  // scratch: A ints in the blob, idle during a reset (the Scratch tile holds the reset RNG windows)
     for (int i = 0; i < nA; i++) ids[i] = i;
     for (int i = nA - 1; i >= 1; i--) {
       int j = (int)randbelow(ST_AGENT, (uint64_t)i + 1);
@@ -1039,6 +1041,7 @@ struct Sim {
         S.a_state[a] = 0;
         S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
       }
+    for (int i = 0; i < nA; i++) ids[i] = 0;
     // fail events (:616-618)
     for (int a = 0; a < nA; a++)
       if (rnd(ST_AGENT) < P.fail_rate * FAIL_MULT[S.a_type[a]])
@@ -2632,7 +2635,7 @@ struct Sim {
             else c = pair_cost(X.freeA[i], my_s, lane);
             feasible |= c < 1e5 / 2;
           }
-          if (i < 16) c0[i] = c; else c1[i - 16] = c;
+          if constexpr (A > 16) { if (i < 16) c0[i] = c; else c1[i - 16] = c; } else c0[i] = c;
         }
       } else {
         for (int p = lane; p < nr * nc; p += WG) {  // one (agent, task) pair per lane

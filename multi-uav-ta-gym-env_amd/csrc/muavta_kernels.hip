@@ -67,6 +67,7 @@ struct Lds {
 #define smem muavta_smem
 // 8 workgroups per CU need <= 160 KiB / 8 = 20480 B of LDS each on the 16x32 tile (BASELINE config 2)
 static_assert(((sizeof(EnvState<Tile16>) + 15) & ~size_t(15)) + sizeof(Scratch<Tile16>) <= 20480, "Tile16 no longer fits 8 workgroups per CU");
+static_assert(((sizeof(EnvState<Tile16L>) + 15) & ~size_t(15)) + sizeof(Scratch<Tile16L>) <= 20480, "Tile16L no longer fits 8 workgroups per CU");
 static_assert(((sizeof(EnvState<Tile24>) + 15) & ~size_t(15)) + sizeof(Scratch<Tile24>) <= 26624, "Tile24 no longer fits 6 workgroups per CU (27,200 B measured at 5: the LDS granule is 1 KB)");
 
 // Minimum waves per SIMD the register allocator must leave room for (2 => at most 256 VGPR+AGPR).
@@ -361,7 +362,7 @@ thread_local std::string g_create_error;
     }                                                                                             \
   } while (0)
 
-enum TileKind { TK16 = 0, TK24 = 1, TK64 = 2 };
+enum TileKind { TK16 = 0, TK24 = 1, TK64 = 2, TK16L = 3 };
 
 }  // namespace
 
@@ -413,6 +414,7 @@ int launch_attr(MuavtaEnv* e) {
 #define DISPATCH(e, CALL)                    \
   switch ((e)->tile) {                       \
     case TK16: { typedef Tile16 TL; CALL; } break; \
+    case TK16L: { typedef Tile16L TL; CALL; } break; \
     case TK24: { typedef Tile24 TL; CALL; } break; \
     default:   { typedef Tile64 TL; CALL; } break; \
   }
@@ -746,6 +748,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   int tt = params->tile_tasks > 0 ? params->tile_tasks : 32;
   int th = params->tile_threats > e->P.n_threats ? params->tile_threats : e->P.n_threats;
   if (ta <= Tile16::A && tt <= Tile16::T && th <= Tile16::H) e->tile = TK16;
+  else if (ta <= Tile16L::A && tt <= Tile16L::T && th <= Tile16L::H) e->tile = TK16L;
   else if (ta <= Tile24::A && tt <= Tile24::T && th <= Tile24::H) e->tile = TK24;
   else if (ta <= Tile64::A && tt <= Tile64::T && th <= Tile64::H) e->tile = TK64;
   else { g_create_error = "muavta_create: requested tile exceeds 64 agents x 128 task slots x 48 threats"; delete e; return MUAVTA_E_ARG; }

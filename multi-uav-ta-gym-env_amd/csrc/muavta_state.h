@@ -143,6 +143,10 @@ struct alignas(16) EnvState {
 
 // Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
 typedef Tile<16, 32, 16, 48, 40, 8> Tile16;  // events <= 16, pending reveals <= 22 measured over 4096 seeds
+// Same fleet as Tile16 with head-room: 40 task slots (the reference stops creating arrivals at max_tasks - 1 = 40 tasks for
+// the 16-UAV configs) and queues of 10; the cost tile gives way to register-built cost columns so that it still fits
+// 8 workgroups per CU.  Chosen with tile_tasks in (32, 40]: ~1 in 16,000 seeds of WPS_hard_x2 needs more than 32 slots.
+typedef Tile<16, 40, 16, 48, 40, 10, true> Tile16L;
 typedef Tile<24, 48, 24, 88, 40, 12, true> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
 typedef Tile<64, 128, 48, 128, 96, 8, false, true> Tile64;
 

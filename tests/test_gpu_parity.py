@@ -161,8 +161,9 @@ def test_fused_rollout_matches_reference_metrics(path):
     assert np.array_equal(env.metrics(), want)
 
 
-@pytest.mark.parametrize("case,interval,n", [("WPS_hard_x2", 20, 384), ("WPS_escort24", 12, 96), ("WPS_burst64", 20, 48)],
-                         ids=["cfg2b", "cfg4b", "cfg5"])
+@pytest.mark.parametrize("case,interval,n", [("WPS_hard_x2", 20, 4096), ("WPS_escort24", 12, 1024), ("WPS_burst64", 20, 256), ("WPS_escort", 12, 1024),
+                                              ("WPS_hard", 20, 2048), ("WPS_attn", 20, 512)],
+                         ids=["cfg2b", "cfg4b", "cfg5", "escort", "hard", "attn"])
 def test_fused_rollout_vs_oracle_many_seeds(case, interval, n):
     env = _env(case, n)
     seeds = np.arange(1000, 1000 + n, dtype=np.uint64)
@@ -729,3 +730,55 @@ def test_large_bursts_on_the_64_agent_tile():
         snap = Snapshot(env)
         for i, o in enumerate(oracles):
             compare(snap, i, o, f"burst 6 seed {i} t={t + 1}")
+
+
+@pytest.mark.parametrize("case,name,mode,interval,vis,n", [("WPS_hard_x2", "urgency_pair", 1, 20, 1, 2048), ("WPS_escort24", "urgency_coalition", 2, 12, 1, 512),
+                                                            ("WPS_escort", "urgency_coalition", 2, 12, 1, 1024), ("WPS_hard_x2", "hungarian_gated", 3, 20, 0, 2048),
+                                                            ("WPS_burst64", "urgency_coalition", 2, 12, 1, 128)])
+def test_fused_rollout_allocator_modes_vs_oracle_many_seeds(case, name, mode, interval, vis, n):
+    # Urgency-Pair keeps more tasks open on the 16-UAV workload: 5 of 8192 seeds need more than 32 slots / 8 queue entries
+    env = _env(case, n, **({"tile_tasks": 40} if (case, name) == ("WPS_hard_x2", "urgency_pair") else {}))
+    env.set_allocator(name)
+    seeds = np.arange(5000, 5000 + n, dtype=np.uint64)
+    env.rollout(seeds, 150, interval, bool(vis), False)
+    got = env.rollout_metrics()
+    assert np.all(env.get("ERROR") == 0)
+    o = orc.OracleEnv(params_for_case(case))
+    for i, s in enumerate(seeds):
+        o.rollout_mode(int(s), 150, interval, vis, mode)
+        assert np.array_equal(got[i], o.metrics()), f"{case} {name} seed {s}"
+
+
+def test_roomier_16_agent_tile_runs_the_seeds_that_overflow_32_slots():
+    """tile_tasks=40 selects the 16x40 tile (register-built cost columns, queue 10): stepwise parity, and the seeds that
+    need more than 32 task slots / 8 queue entries (flagged MUAVTA_E_CAPACITY on the 16x32 tile) match the oracle."""
+    case = "WPS_hard_x2"
+    env = _env(case, 4, tile_tasks=40)
+    assert env.T == 40 and env.Q == 10
+    seeds = np.array([9649, 6231, 0, 1], dtype=np.uint64)  # 9649: 34 slots under Local-Hungarian
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in seeds]
+    env.reset(seeds)
+    for o, sd in zip(oracles, seeds):
+        o.reset(int(sd))
+    for t in range(150):
+        aa, ai = env.allocate(20, True)
+        for i, o in enumerate(oracles):
+            oa, oi = o.allocate(20, 1)
+            assert np.array_equal(aa[i][:len(oa)], oa) and np.array_equal(ai[i][:len(oa)], oi), f"seed {seeds[i]} t={t}"
+            o.step(oa, oi)
+        env.step(aa, ai)
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"16x40 tile seed {seeds[i]} t={t + 1}")
+    small = _env(case, 1)
+    small.rollout(np.array([9649], dtype=np.uint64), 150, 20, True, False)
+    assert small.get("ERROR")[0] == 1  # the 16x32 tile says so instead of returning a wrong episode
+    for name, mode, sd in (("urgency_pair", 1, [6231, 8273, 9649, 11430, 11656]),):
+        big = _env(case, len(sd), tile_tasks=40)
+        big.set_allocator(name)
+        big.rollout(np.array(sd, dtype=np.uint64), 150, 20, True, False)
+        assert not big.get("ERROR").any()
+        o = orc.OracleEnv(params_for_case(case))
+        for i, s_ in enumerate(sd):
+            o.rollout_mode(int(s_), 150, 20, 1, mode)
+            assert np.array_equal(big.rollout_metrics()[i], o.metrics()), f"{name} seed {s_}"
