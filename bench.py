@@ -126,9 +126,10 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
 
-    # secondary figure: the PettingZoo-style path, one k_allocate + one k_step launch per env step,
-    # state blob loaded from / stored to HBM by every launch; untimed w.r.t. the headline
-    step_api = None
+    # secondary figures: the per-step paths, state blob loaded from / stored to HBM by every launch; untimed
+    # w.r.t. the headline.  step_api: one k_allocate + one k_step launch per env step (a caller that looks at the plan);
+    # fused_step_api: muavta_rollout(h, NULL, 1, ...) = allocate + step + observe in ONE launch per env step.
+    step_api = fused_step_api = None
     if rank == 0 and world == 1:
         env.reset(seeds)
         env.sync()
@@ -138,6 +139,13 @@ def main():
             env.step_staged()
         env.sync()
         step_api = args.envs * HORIZON / (time.perf_counter() - t1)
+        env.reset(seeds)
+        env.sync()
+        t1 = time.perf_counter()
+        for _ in range(HORIZON):
+            env.rollout(None, 1, args.interval, True, write_obs)
+        env.sync()
+        fused_step_api = args.envs * HORIZON / (time.perf_counter() - t1)
         env.rollout(seeds, HORIZON, args.interval, True, write_obs)  # restore the headline batch's final state
         env.sync()
 
@@ -178,7 +186,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                          "kernel": "k_rollout", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_env_step": B},
-            "step_api_env_steps_per_s": step_api,
+            "step_api_env_steps_per_s": step_api, "fused_step_api_env_steps_per_s": fused_step_api,
             "quality": {"mean_S_WPS": summary["mean_S_WPS"], "std_S_WPS": summary["std_S_WPS"], "on_time_rate": summary["on_time_rate"],
                         "n_envs": summary["n_envs"]},
         }
