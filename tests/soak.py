@@ -3,8 +3,8 @@
 reports mismatching seeds and tile-capacity overflows (flagged envs are skipped in the comparison)."""
 import sys, os, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # tests/soak.py: lives under tests/ because it uses the oracle as its checker
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import orc
 from muavta_amd.batched import BatchedMultiUAVEnv
 from muavta_amd.params import params_for_case
