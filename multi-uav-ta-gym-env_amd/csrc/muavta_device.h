@@ -2247,6 +2247,9 @@ struct Sim {
         lds_sync();
         return;
       }
+#ifdef MUAVTA_PROF
+      if (threadIdx.x == 0) { prof_acc[30] += 1000; if (any_ret) prof_acc[31] += 1000; }
+#endif
       if (any_ret) {
         // slots still queued by a live agent (one agent per lane marks its queue entries), then the retired and
         // unreferenced ones are released (one slot per lane), then every agent lane drops the released columns
