@@ -4,20 +4,26 @@
 One bench "step" = one pass of the hot path over one batch: reset(seeds) + 150 x (Local-Hungarian
 allocate -> env.step incl. observation write) for `--envs` independent env instances per GPU, in ONE
 kernel launch (muavta_rollout).  Workload = BASELINE config 2b: WPS_hard knobs on 16 UAVs
-(`WPS_hard_x2`), 4096 envs per GPU, 16x32 tile, seeds = global env index.
+(`WPS_hard_x2`), 4096 envs per GPU, the 16-agent tile, seeds = global env index.
 
     python bench.py [--gpus N --steps K --warmup W]          # N>1: launched by torch.distributed.run
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29533 \
+        bench.py --gpus 8 --case WPS_burst64 --envs 1024       # BASELINE config 5 (8192 envs, 64x128 tile)
 
 Prints ONE JSON line on rank 0.  `value` is whole-job env-steps/s (all ranks), inputs (seeds) already
 resident on the device, timed region bracketed by barrier + torch.cuda.synchronize() on both sides,
 max over ranks.  `roofline.achieved` = SURVEY §8(d) algorithmic bytes per env-step x env-steps per
-launch / mean kernel duration, the latter measured with HIP events on the library's own stream.
-`cpu_baseline` = the CPU oracle (oracle/, a restatement of the reference: kind "port") timed on this
+launch / mean k_rollout duration, the latter measured with HIP events on the library's own stream; the
+kernel keeps the env state in LDS, so this is an algorithmic-equivalent rate, NOT measured HBM traffic —
+`roofline.traffic` / `roofline.measured_hbm_GBs` are the PMC-measured bytes (see `roofline.note`).
+`cpu_baseline` = the CPU oracle (oracle/, a restatement of the reference: kind "port") timed on ALL of this
 box's host cores over a bounded sample of the same workload (rank 0, N=1 only).
+`other_tiles` (N=1 only) = the same measurement for BASELINE configs 4 and 5 (24x48 escort, 64x128 burst).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -29,16 +35,58 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HORIZON = 150
-# algorithmic bytes per env-step B(A,T,H) = 2*S_state + S_obs + S_act
-ALGO_BYTES_PER_ENV_STEP = {"16x32": 39.9e3, "24x48": 65.7e3, "64x128": 255e3}
+# algorithmic bytes per env-step B(A,T,H) = 2*S_state + S_obs + S_act, by agent count of the tile
+ALGO_BYTES_PER_ENV_STEP = {16: 39.9e3, 24: 65.7e3, 64: 255e3}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+# BASELINE.json configs 4 and 5 (per-GPU size): (case, envs, replan interval)
+OTHER_TILES = (("WPS_escort24", 4096, 12), ("WPS_burst64", 1024, 20))
+
+
+def source_hash() -> str:
+    """Hash of the kernel sources: PMC traffic figures under profiles/ are only reused for the build they were taken on."""
+    from muavta_amd import native
+
+    h = hashlib.sha256()
+    for p in native.sources():
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(case: str, envs: int):
+    """HBM bytes per k_rollout launch from the rocprofv3 --pmc passes (tools/collect_profiles.sh), or None when the
+    committed figure was taken on other kernel sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return None
+    e = d.get(f"{case}:{envs}")
+    if isinstance(e, dict) and e.get("source_hash") == source_hash():
+        return e.get("bytes_per_launch")
+    return None
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return model, max(1, cores)
 
 
 def cpu_baseline(case: str, interval: int, seconds: float):
-    """Oracle (CPU restatement, test infrastructure) on the host cores: bounded sample, multi-process."""
+    """Oracle (CPU restatement, test infrastructure) on every host core this process may use: bounded sample."""
     import multiprocessing as mp
 
-    cores = max(1, min(os.cpu_count() or 1, 16))
+    model, cores = host_cpu()
     with mp.get_context("spawn").Pool(cores) as pool:
         t0 = time.perf_counter()
         res = pool.starmap(_cpu_worker, [(case, interval, seconds, 10_000_000 + 4096 * r) for r in range(cores)])
@@ -46,9 +94,9 @@ def cpu_baseline(case: str, interval: int, seconds: float):
     steps = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
     return {
-        "value": steps / busy, "unit": "env-steps/s", "cores": cores, "kind": "port",
+        "value": steps / busy, "unit": "env-steps/s", "cores": cores, "cpu_model": model, "kind": "port",
         "sample": f"{steps // HORIZON} episodes of {case} (150 steps each, Local-Hungarian interval {interval}) "
-                  f"split over {cores} processes, {busy:.1f} s of work each ({wall:.1f} s wall incl. spawn)",
+                  f"split over {cores} processes (one per usable host core), {busy:.1f} s of work each ({wall:.1f} s wall incl. spawn)",
     }
 
 
@@ -67,6 +115,35 @@ def _cpu_worker(case, interval, seconds, seed0):
     return steps, time.perf_counter() - t0
 
 
+def roofline(case, envs, n_agents_tile, kernel_ms):
+    B = ALGO_BYTES_PER_ENV_STEP.get(n_agents_tile)
+    achieved = (envs * HORIZON * B) / (kernel_ms * 1e-3) / 1e9 if B else None
+    traffic = measured_traffic(case, envs)
+    return {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
+        "kernel": "k_rollout", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": B,
+        "achieved_is": "algorithmic bytes (SURVEY 8d) / kernel time, not HBM traffic",
+        "measured_hbm_GBs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+        "limiter": "latency / issue: env state is LDS-resident for the whole rollout, order-dependent phases run on one lane",
+    }
+
+
+def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
+    for _ in range(warmup):
+        env.rollout(seeds, HORIZON, interval, True, write_obs)
+        env.sync()
+    kernel_ms, seed_ms = [], []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        env.rollout(seeds, HORIZON, interval, True, write_obs)
+        kernel_ms.append(env.last_kernel_ms())  # HIP events on the library's stream; waits for the launch
+        seed_ms.append(env.last_seed_ms())
+    barrier()
+    return time.perf_counter() - t0, float(np.mean(kernel_ms)), float(np.mean(seed_ms))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,12 +151,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
     ap.add_argument("--case", default="WPS_hard_x2")
-    ap.add_argument("--interval", type=int, default=20)
+    ap.add_argument("--interval", type=int, default=None, help="replan interval (default 20; 12 for the escort cases)")
     ap.add_argument("--no-obs", action="store_true", help="skip the per-step observation write (NOT the headline)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the step-API / other-tile / IL figures (profiling runs)")
     ap.add_argument("--seed-base", type=int, default=0, help="first global env index (default 0: seeds = global env index)")
     args = ap.parse_args()
+    if args.interval is None:
+        args.interval = 12 if "escort" in args.case else 20
 
     import torch
 
@@ -100,13 +180,11 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     from muavta_amd.batched import BatchedMultiUAVEnv
+    from muavta_amd.dist import reduce_metrics, shard_seeds
     from muavta_amd.params import params_for_case
 
-    params = params_for_case(args.case)
-    env = BatchedMultiUAVEnv(params, args.envs, device=local_rank)
+    env = BatchedMultiUAVEnv(params_for_case(args.case), args.envs, device=local_rank)
     tile = f"{env.dims.tile_agents}x{env.dims.tile_tasks}"
-    from muavta_amd.dist import shard_seeds
-
     seeds = shard_seeds(rank, args.envs, args.seed_base)  # seed = global env index
     write_obs = not args.no_obs
 
@@ -115,72 +193,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        env.rollout(seeds, HORIZON, args.interval, True, write_obs)
-        env.sync()
-    kernel_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        env.rollout(seeds, HORIZON, args.interval, True, write_obs)
-        kernel_ms.append(env.last_kernel_ms())  # HIP events on the library's stream; waits for the launch
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, mean_kernel_ms, mean_seed_ms = time_rollouts(env, seeds, args.interval, write_obs, args.steps, args.warmup, barrier)
 
-    # secondary figures: the per-step paths, state blob loaded from / stored to HBM by every launch; untimed
-    # w.r.t. the headline.  step_api: one k_allocate + one k_step launch per env step (a caller that looks at the plan);
-    # fused_step_api: muavta_rollout(h, NULL, 1, ...) = allocate + step + observe in ONE launch per env step.
-    step_api = fused_step_api = None
-    if rank == 0 and world == 1:
-        env.reset(seeds)
-        env.sync()
-        t1 = time.perf_counter()
-        for _ in range(HORIZON):
-            env.allocate(args.interval, True, fetch=False)
-            env.step_staged()
-        env.sync()
-        step_api = args.envs * HORIZON / (time.perf_counter() - t1)
-        env.reset(seeds)
-        env.sync()
-        t1 = time.perf_counter()
-        for _ in range(HORIZON):
-            env.rollout(None, 1, args.interval, True, write_obs)
-        env.sync()
-        fused_step_api = args.envs * HORIZON / (time.perf_counter() - t1)
-        env.rollout(seeds, HORIZON, args.interval, True, write_obs)  # restore the headline batch's final state
-        env.sync()
-
-    # metrics of the last batch: per-rank partials -> the one collective of this path (muavta_amd/dist.py)
-    from muavta_amd.dist import reduce_metrics
-
+    # metrics of the last batch: per-rank partials -> the one collective of this path (muavta_amd/dist.py).  Every env has
+    # to produce a result: a capacity-flagged env (ERROR != 0) fails the run, on every rank alike (the count is reduced
+    # before anybody decides).
     m = env.rollout_metrics()
-    # An env that needs more than its tile holds (task slots / queue depth) says so instead of returning a wrong episode
-    # (about 1 in 10,000 seeds on the 16x32 tile, e.g. global index 9649).  It ran its 150 steps like the
-    # others, so the throughput stands; its metrics are left out of the quality summary and it is counted below.
-    flagged = env.get("ERROR") != 0
-    n_flagged = int(np.count_nonzero(flagged))
-    if n_flagged > max(1, args.envs // 1000):
-        raise SystemExit(f"{n_flagged} of {args.envs} envs overflowed the tile: pick a larger one (tile_tasks / tile_agents)")
-    summary = reduce_metrics(m[~flagged], device="cuda" if dist is not None else None)
-    tmax = torch.tensor([elapsed, float(np.mean(kernel_ms)), float(n_flagged)], dtype=torch.float64, device="cuda")
+    n_flagged = int(np.count_nonzero(env.get("ERROR")))
+    tmax = torch.tensor([elapsed, mean_kernel_ms, mean_seed_ms, float(n_flagged)], dtype=torch.float64, device="cuda")
     if dist is not None:
-        dist.all_reduce(tmax[:2], op=dist.ReduceOp.MAX)
-        dist.all_reduce(tmax[2:], op=dist.ReduceOp.SUM)
-    elapsed, mean_kernel_ms, n_flagged = float(tmax[0].item()), float(tmax[1].item()), int(tmax[2].item())
+        dist.all_reduce(tmax[:3], op=dist.ReduceOp.MAX)
+        dist.all_reduce(tmax[3:], op=dist.ReduceOp.SUM)
+    elapsed, mean_kernel_ms, mean_seed_ms, n_flagged = float(tmax[0]), float(tmax[1]), float(tmax[2]), int(tmax[3])
+    if n_flagged:
+        if dist is not None:
+            dist.destroy_process_group()
+        raise SystemExit(f"{n_flagged} env(s) overflowed the {tile} tile (muavta_get ERROR): results would be incomplete")
+    summary = reduce_metrics(m, device="cuda" if dist is not None else None)
+
+    # secondary figures (rank 0 at N=1 only, outside the timed region)
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = secondary_figures(env, seeds, args, write_obs, barrier)
 
     if rank == 0:
         total_envs = args.envs * world
-        env_steps = total_envs * HORIZON * args.steps
-        value = env_steps / elapsed
-        B = ALGO_BYTES_PER_ENV_STEP.get(tile)
-        achieved = (args.envs * HORIZON * B) / (mean_kernel_ms * 1e-3) / 1e9 if B else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")  # written from the rocprofv3 --pmc passes
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"{args.case}:{args.envs}")
-            except Exception:
-                traffic = None
+        value = total_envs * HORIZON * args.steps / elapsed
         out = {
             "metric": "env-steps/sec at N parallel envs, WPS_hard 16x32; 1/2/4/8 GPU",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -189,20 +227,61 @@ def main():
             "config": {"workload": f"{args.case}: reset + 150 fused steps, Local-Hungarian interval {args.interval}, visibility on, "
                                    f"obs write {'on' if write_obs else 'off'}",
                        "envs_per_gpu": args.envs, "total_envs": total_envs, "tile": tile, "n_agents": env.n_agents,
+                       "lds_bytes_per_env": int(env.dims.lds_bytes),
                        "horizon": HORIZON, "parallelism": f"env-sharded x{world}, RCCL all-reduce of the metric vector only"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_rollout", "kernel_ms": mean_kernel_ms, "algorithmic_bytes_per_env_step": B},
-            "step_api_env_steps_per_s": step_api, "fused_step_api_env_steps_per_s": fused_step_api,
+            "roofline": roofline(args.case, args.envs, env.dims.tile_agents, mean_kernel_ms),
+            "seed_kernel_ms": mean_seed_ms,
             "quality": {"mean_S_WPS": summary["mean_S_WPS"], "std_S_WPS": summary["std_S_WPS"], "on_time_rate": summary["on_time_rate"],
-                        "n_envs": summary["n_envs"], "capacity_flagged_envs": n_flagged},
+                        "n_envs": summary["n_envs"], "capacity_flagged_envs": 0},
         }
+        out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.case, args.interval, args.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_figures(env, seeds, args, write_obs, barrier):
+    """Per-step paths of the headline case, BASELINE configs 4 and 5 on their tiles, the IL data loop."""
+    from muavta_amd.batched import BatchedMultiUAVEnv
+    from muavta_amd.params import params_for_case
+
+    out = {}
+    # step_api: one k_allocate + one k_step launch per env step (a caller that looks at the plan);
+    # fused_step_api: muavta_rollout(h, NULL, 1, ...) = allocate + step + observe in ONE launch per env step.
+    env.reset(seeds)
+    env.sync()
+    t1 = time.perf_counter()
+    for _ in range(HORIZON):
+        env.allocate(args.interval, True, fetch=False)
+        env.step_staged()
+    env.sync()
+    out["step_api_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
+    env.reset(seeds)
+    env.sync()
+    t1 = time.perf_counter()
+    for _ in range(HORIZON):
+        env.rollout(None, 1, args.interval, True, write_obs)
+    env.sync()
+    out["fused_step_api_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
+    env.rollout(seeds, HORIZON, args.interval, True, write_obs)  # restore the headline batch's final state
+    env.sync()
+    if args.case == "WPS_hard_x2":
+        tiles = {}
+        for case, n, interval in OTHER_TILES:
+            e2 = BatchedMultiUAVEnv(params_for_case(case), n, device=0)
+            s2 = np.arange(n, dtype=np.uint64)
+            el, kms, sms = time_rollouts(e2, s2, interval, True, 5, 2, barrier)
+            flagged = int(np.count_nonzero(e2.get("ERROR")))
+            tiles[case] = {"env_steps_per_s": n * HORIZON * 5 / el, "envs": n, "tile": f"{e2.dims.tile_agents}x{e2.dims.tile_tasks}",
+                           "interval": interval, "ms_per_step": el / 5 * 1e3, "lds_bytes_per_env": int(e2.dims.lds_bytes),
+                           "capacity_flagged_envs": flagged, "seed_kernel_ms": sms,
+                           "roofline": roofline(case, n, e2.dims.tile_agents, kms)}
+            e2.close()
+        out["other_tiles"] = tiles
+    return out
 
 
 if __name__ == "__main__":

@@ -303,6 +303,9 @@ int muavta_device_ptrs(MuavtaEnv* env, void** state, void** obs_tasks, void** ob
 /* Duration of the last muavta_rollout launch, measured with HIP events recorded on the handle's own
  * stream around the kernel (ms).  Blocks until that launch has finished. */
 int muavta_last_kernel_ms(MuavtaEnv* env, float* ms);
+/* Same for the RNG seeding kernel (CPython init_by_array of the four random.Random streams per env,
+ * DroneEnv.py:531-538) that ran in front of that rollout; 0 when the rollout continued without seeds. */
+int muavta_last_seed_ms(MuavtaEnv* env, float* ms);
 /* Block until everything queued on the handle's stream has finished. */
 int muavta_sync(MuavtaEnv* env);
 /* Metrics written by the last muavta_rollout itself (f64 [N, 30]); no extra launch. */

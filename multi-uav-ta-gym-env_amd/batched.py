@@ -155,6 +155,11 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_last_kernel_ms(self.h, C.byref(ms)))
         return float(ms.value)
 
+    def last_seed_ms(self) -> float:
+        ms = C.c_float()
+        self._ck(self.L.muavta_last_seed_ms(self.h, C.byref(ms)))
+        return float(ms.value)
+
     def observe(self):
         N, A, MT = self.n_envs, self.n_agents, self.max_tasks
         tasks = np.empty((N, 21, MT), dtype=np.float32)  # feature-major on the device

@@ -35,6 +35,14 @@ struct ObsPtrs {
   uint8_t* done;   // [N]
 };
 
+// Launch-invariant context in device memory (one copy per handle): every kernel gets a pointer to it, so the ~600 B of
+// parameters are read on demand through the scalar cache and can be handed to the out-of-line step body by pointer.
+struct DevCtx {
+  DevParams P;
+  ObsPtrs O;
+  uint32_t* tapes;  // [N][4][1248] MT19937 tapes
+};
+
 template <class TL>
 __device__ __forceinline__ void obs_for_env(Sim<TL>& sim, const DevParams& P, const ObsPtrs& O, int env) {
   const size_t mt = (size_t)P.max_tasks, nA = (size_t)P.n_agents;
@@ -167,8 +175,9 @@ __global__ __launch_bounds__(WG) void k_seed(const uint64_t* seeds, int n, int w
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, ObsPtrs O,
+__global__ __launch_bounds__(WG) void k_reset(const DevCtx* __restrict__ ctx, const uint64_t* seeds, EnvState<TL>* blobs,
                                               const uint32_t* seedbuf) {
+  const DevParams& P = ctx->P; const ObsPtrs& O = ctx->O; uint32_t* const tapes = ctx->tapes;
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
@@ -180,8 +189,9 @@ __global__ __launch_bounds__(WG) void k_reset(DevParams P, const uint64_t* seeds
 
 // act_agent == nullptr: use the actions staged in the blob by k_allocate
 template <class TL>
-__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, const int32_t* act_agent,
-                                             const int32_t* act_index, int act_cap, ObsPtrs O, double* rel_log) {
+__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(const DevCtx* __restrict__ ctx, EnvState<TL>* blobs, const int32_t* act_agent,
+                                             const int32_t* act_index, int act_cap, double* rel_log) {
+  const DevParams& P = ctx->P; const ObsPtrs& O = ctx->O; uint32_t* const tapes = ctx->tapes;
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
@@ -211,8 +221,9 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(DevParams P, EnvS
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blobs, uint32_t* tapes, int interval, int use_vis, int mode,
+__global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctx, EnvState<TL>* blobs, int interval, int use_vis, int mode,
                                                  int32_t* out_agent, int32_t* out_index, int act_cap) {
+  const DevParams& P = ctx->P; uint32_t* const tapes = ctx->tapes;
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
@@ -230,41 +241,52 @@ __global__ __launch_bounds__(WG) void k_allocate(DevParams P, EnvState<TL>* blob
   copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
 }
 
+// One env step of the fused rollout: allocate -> step -> observation write.  OUT OF LINE on purpose: inlined into the
+// 150-step loop of k_rollout the compiler hoists loop invariants across the whole body and the kernel needs 255 VGPRs
+// (+188 B/lane of scratch); as a function of its own the body fits the 128 VGPRs of four waves per SIMD, the call costs
+// one entry/exit sequence per ~3,500 instructions.
 template <class TL>
-__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(DevParams P, const uint64_t* seeds, EnvState<TL>* blobs, uint32_t* tapes, int n_steps,
-                                                int interval, int use_vis, int mode, int write_obs, ObsPtrs O, double* metrics,
-                                                const uint32_t* seedbuf) {
+__device__ __noinline__ void rollout_step(const DevCtx* __restrict__ ctx, int interval, int use_vis, int mode, int write_obs) {
   const int env = blockIdx.x;
   Lds<TL> L(smem);
-  Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  Sim<TL> sim(*L.S, *L.X, ctx->P, ctx->tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  sim.allocate(interval, use_vis, mode);
+  sim.step(true);
+  if (write_obs) obs_for_env(sim, ctx->P, ctx->O, env);
+  lds_sync();
+#ifdef MUAVTA_PROF
+  if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sim.prof_acc[20] += t_ - sim.prof_last; sim.prof_last = t_; }
+  sim.prof_flush();
+#endif
+}
+
+template <class TL>
+__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* __restrict__ ctx, const uint64_t* seeds, EnvState<TL>* blobs, int n_steps,
+                                                int interval, int use_vis, int mode, int write_obs, double* metrics, const uint32_t* seedbuf) {
+  const DevParams& P = ctx->P;
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  Sim<TL> sim(*L.S, *L.X, P, ctx->tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
   if (seeds) {
     sim.reset(seeds[env], seedbuf ? seedbuf + (size_t)env * 4 * 624 : nullptr);
   } else {
     copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
     lds_sync();
-    sim.sync_clock();
   }
   for (int t = 0; t < n_steps; t++) {
     if (L.S->terminated || L.S->truncated) break;  // uniform: read from LDS after a barrier
-    sim.allocate(interval, use_vis, mode);
-    sim.step(true);
-    if (write_obs) obs_for_env(sim, P, O, env);
-    lds_sync();
-#ifdef MUAVTA_PROF
-    if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sim.prof_acc[20] += t_ - sim.prof_last; sim.prof_last = t_; }
-#endif
+    rollout_step<TL>(ctx, interval, use_vis, mode, write_obs);
   }
-#ifdef MUAVTA_PROF
-  sim.prof_flush();
-#endif
-  if (!write_obs) obs_for_env(sim, P, O, env);
+  sim.sync_clock();
+  if (!write_obs) obs_for_env(sim, P, ctx->O, env);
   sim.metrics(metrics + (size_t)env * MUAVTA_N_METRICS);
   lds_sync();
   copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_metrics(DevParams P, EnvState<TL>* blobs, double* metrics) {
+__global__ __launch_bounds__(WG) void k_metrics(const DevCtx* __restrict__ ctx, EnvState<TL>* blobs, double* metrics) {
+  const DevParams& P = ctx->P;
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
@@ -274,7 +296,8 @@ __global__ __launch_bounds__(WG) void k_metrics(DevParams P, EnvState<TL>* blobs
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_observe(DevParams P, EnvState<TL>* blobs, ObsPtrs O) {
+__global__ __launch_bounds__(WG) void k_observe(const DevCtx* __restrict__ ctx, EnvState<TL>* blobs) {
+  const DevParams& P = ctx->P; const ObsPtrs& O = ctx->O;
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
@@ -284,7 +307,8 @@ __global__ __launch_bounds__(WG) void k_observe(DevParams P, EnvState<TL>* blobs
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_tokens(DevParams P, const EnvState<TL>* blobs, typename Sim<TL>::TokPtrs K) {
+__global__ __launch_bounds__(WG) void k_tokens(const DevCtx* __restrict__ ctx, const EnvState<TL>* blobs, typename Sim<TL>::TokPtrs K) {
+  const DevParams& P = ctx->P;
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
@@ -380,13 +404,15 @@ struct MuavtaEnv {
   size_t state_bytes = 0, lds_bytes = 0;
   void* blobs = nullptr;
   uint32_t* tapes = nullptr;
+  DevCtx* d_ctx = nullptr;  // device copy of {P, O, tapes}
   uint64_t* d_seeds = nullptr;
   int32_t *d_act_agent = nullptr, *d_act_index = nullptr;
   double* d_metrics = nullptr;
   ObsPtrs O{};
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr;  // evs .. ev0: the seeding kernel, ev0 .. ev1: k_rollout
   float last_ms = 0.f;
+  bool last_seeded = false;
   bool did_reset = false;
   std::vector<unsigned char> host_blobs;  // cache for muavta_get
   bool host_valid = false;
@@ -425,7 +451,7 @@ static void launch_tokens(MuavtaEnv* e, int kind, int max_tasks, int max_agents,
                           int32_t* replanned) {
   typename Sim<TL>::TokPtrs K{task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned,
                               kind, max_tasks, max_agents};
-  hipLaunchKernelGGL(k_tokens<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (const EnvState<TL>*)e->blobs, K);
+  hipLaunchKernelGGL(k_tokens<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (const EnvState<TL>*)e->blobs, K);
 }
 
 int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
@@ -761,6 +787,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CK(hipEventCreate(&e->ev0));
   CK(hipEventCreate(&e->ev1));
+  CK(hipEventCreate(&e->evs));
   const size_t N = (size_t)n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
   CK(hipMalloc(&e->blobs, N * e->state_bytes));
   CK(hipMemsetAsync(e->blobs, 0, N * e->state_bytes, e->stream));
@@ -776,6 +803,14 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   CK(hipMalloc(&e->O.flags, N * 5 * sizeof(float)));
   CK(hipMalloc(&e->O.reward, N * sizeof(double)));
   CK(hipMalloc(&e->O.done, N));
+  {
+    DevCtx h;
+    memset(&h, 0, sizeof(h));
+    h.P = e->P; h.O = e->O; h.tapes = e->tapes;
+    CK(hipMalloc((void**)&e->d_ctx, sizeof(DevCtx)));
+    CK(hipMemcpyAsync(e->d_ctx, &h, sizeof(DevCtx), hipMemcpyHostToDevice, e->stream));
+    CK(hipStreamSynchronize(e->stream));  // `h` is a stack object
+  }
 #undef CK
   int arc = MUAVTA_OK;
   DISPATCH(e, arc = launch_attr<TL>(e));
@@ -788,10 +823,11 @@ int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
+  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
+  if (e->evs) hipEventDestroy(e->evs);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
   return MUAVTA_OK;
@@ -835,8 +871,8 @@ int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
   HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   const uint32_t* sb = nullptr;
   { int rc = seed_streams(e, &sb); if (rc) return rc; }
-  DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, e->d_seeds,
-                                 (EnvState<TL>*)e->blobs, e->tapes, e->O, sb));
+  DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, e->d_seeds,
+                                 (EnvState<TL>*)e->blobs, sb));
   HIPCHK(e, hipGetLastError());
   e->did_reset = true;
   e->host_valid = false;
@@ -854,8 +890,8 @@ static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
     da = e->d_act_agent; di = e->d_act_index;
   }
   if (e->d_rel) HIPCHK(e, hipMemsetAsync(e->d_rel, 0, (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double), e->stream));
-  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs,
-                                 e->tapes, da, di, e->A, e->O, e->d_rel));
+  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (EnvState<TL>*)e->blobs,
+                                 da, di, e->A, e->d_rel));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   return MUAVTA_OK;
@@ -863,6 +899,17 @@ static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
 
 int muavta_step(MuavtaEnv* e, const int32_t* act_agent, const int32_t* act_index) {
   if (!e || !act_agent || !act_index) return MUAVTA_E_ARG;
+  // agent ids index the per-agent arrays of the env blob on the device: reject anything outside [0, n_agents) up front
+  // (the reference's actions dict is keyed by agent name: an unknown name is a KeyError there, DroneEnv.py:813-816)
+  for (int n = 0; n < e->n_envs; n++)
+    for (int k = 0; k < e->A; k++) {
+      const int a = act_agent[(size_t)n * e->A + k];
+      if (a < 0) break;
+      if (a >= e->P.n_agents) {
+        e->err = "muavta_step: env " + std::to_string(n) + " names agent id " + std::to_string(a) + ", valid ids are 0.." + std::to_string(e->P.n_agents - 1);
+        return MUAVTA_E_ARG;
+      }
+    }
   return step_impl(e, act_agent, act_index);
 }
 int muavta_step_staged(MuavtaEnv* e) {
@@ -874,8 +921,8 @@ int muavta_allocate(MuavtaEnv* e, int32_t interval, int32_t use_vis, int32_t* ac
   if (!e) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "allocate before reset"; return MUAVTA_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
-  DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs,
-                                 e->tapes, interval, use_vis, e->alloc_mode, e->d_act_agent, e->d_act_index, e->A));
+  DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (EnvState<TL>*)e->blobs,
+                                 interval, use_vis, e->alloc_mode, e->d_act_agent, e->d_act_index, e->A));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   if (act_agent && act_index) {
@@ -897,11 +944,13 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
     ds = e->d_seeds;
   }
   const uint32_t* sb = nullptr;
+  HIPCHK(e, hipEventRecord(e->evs, e->stream));
   if (ds) { int rc = seed_streams(e, &sb); if (rc) return rc; }
+  e->last_seeded = ds != nullptr;
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
-  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds, e->stream, e->P, ds, (EnvState<TL>*)e->blobs,
-                                 e->tapes, n_steps, interval, use_vis, e->alloc_mode, write_obs, e->O, e->d_metrics, sb));
+  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds, e->stream, (const DevCtx*)e->d_ctx, ds, (EnvState<TL>*)e->blobs,
+                                 n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
   e->did_reset = true;
@@ -936,6 +985,16 @@ int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
   HIPCHK(e, hipEventSynchronize(e->ev1));
   HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
   e->last_ms = *ms;
+  return MUAVTA_OK;
+}
+
+int muavta_last_seed_ms(MuavtaEnv* e, float* ms) {  // the RNG seeding kernel that preceded the last muavta_rollout (0 without seeds)
+  if (!e || !ms) return MUAVTA_E_ARG;
+  HIPCHK(e, hipSetDevice(e->device));
+  *ms = 0.f;
+  if (!e->last_seeded) return MUAVTA_OK;
+  HIPCHK(e, hipEventSynchronize(e->ev0));
+  HIPCHK(e, hipEventElapsedTime(ms, e->evs, e->ev0));
   return MUAVTA_OK;
 }
 
@@ -1019,7 +1078,7 @@ int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
 int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from the current state (after muavta_set)
   if (!e) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
-  DISPATCH(e, hipLaunchKernelGGL(k_observe<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs, e->O));
+  DISPATCH(e, hipLaunchKernelGGL(k_observe<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (EnvState<TL>*)e->blobs));
   HIPCHK(e, hipGetLastError());
   return MUAVTA_OK;
 }
@@ -1037,7 +1096,7 @@ int muavta_metrics(MuavtaEnv* e, double* out) {
   if (!e || !out) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "metrics before reset"; return MUAVTA_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
-  DISPATCH(e, hipLaunchKernelGGL(k_metrics<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, e->P, (EnvState<TL>*)e->blobs, e->d_metrics));
+  DISPATCH(e, hipLaunchKernelGGL(k_metrics<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (EnvState<TL>*)e->blobs, e->d_metrics));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
