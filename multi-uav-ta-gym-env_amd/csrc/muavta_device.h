@@ -38,6 +38,14 @@ __device__ __forceinline__ void lds_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Publish point for the HBM-resident part of an env (EnvCold): placed at the entry and exit of every wave-parallel phase
+// that reads or writes it, so that a lane's loads are issued only after every other lane's stores have been acknowledged
+// by the memory system (one wave, one CU: the L1 is write-through and shared, no cache maintenance is needed).
+__device__ __forceinline__ void cold_sync() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- scene constants (mUAV_TA/MultiDroneEnvData.py:8-85) ------------------------------------------
 constexpr double AREA_W = 1200.0, AREA_H = 700.0, CONTACT_LINE = 550.0, BASE_X = 400.0, BASE_Y = 680.0;
 constexpr double MAX_COORD = 1200.0;
@@ -158,34 +166,6 @@ DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
   mt[0] = 0x80000000u;
 }
 
-// The workgroup's LDS: [EnvState | Scratch].  Out-of-line (noinline) routines re-derive their view from here.
-extern __shared__ __align__(16) unsigned char muavta_smem[];
-template <class TL> DEV EnvState<TL>* lds_state() { return reinterpret_cast<EnvState<TL>*>(muavta_smem); }
-template <class TL> DEV Scratch<TL>* lds_scratch() {
-  return reinterpret_cast<Scratch<TL>*>(muavta_smem + ((sizeof(EnvState<TL>) + 15) & ~size_t(15)));
-}
-
-// Order-dependent routines that run on lane 0 can be compiled OUT OF LINE (one copy each) with
-// -DMUAVTA_OUTLINE=__noinline__: that shrinks k_rollout from 152 KB to 68 KB of code, but measured 12 %
-// SLOWER on MI355X (call ABI + 672 B/lane of scratch), so the default keeps them inlined.
-#ifndef MUAVTA_OUTLINE
-#define MUAVTA_OUTLINE __forceinline__
-#endif
-#ifndef MUAVTA_OUTLINE_COLD
-#define MUAVTA_OUTLINE_COLD MUAVTA_OUTLINE
-#endif
-template <class TL> __device__ MUAVTA_OUTLINE void ni_release_all_tasks(const DevParams* P, uint32_t* tape, int for_type);
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_handle_threat_engagement(const DevParams* P, uint32_t* tape, int h);
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_generate_threat(const DevParams* P, uint32_t* tape);
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape);
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_sync_escorts(const DevParams* P, uint32_t* tape);
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_reset_serial(const DevParams* P, uint32_t* tape);
-template <class TL> __device__ MUAVTA_OUTLINE double ni_step_serial_move(const DevParams* P, uint32_t* tape, int first, int last);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_update_threats_serial(const DevParams* P, uint32_t* tape, int first, unsigned long long livemask);
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_create_escort_for(const DevParams* P, uint32_t* tape, int recon, int rec_slot);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_retire_escort_for(const DevParams* P, uint32_t* tape, int recon, bool failed);
-template <class TL> __device__ MUAVTA_OUTLINE void ni_desallocate_all(const DevParams* P, uint32_t* tape, int a);
-
 #ifdef MUAVTA_PROF
 __device__ unsigned long long g_prof[48];
 #define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; } } while (0)
@@ -197,11 +177,13 @@ template <class TL>
 struct Sim {
   typedef EnvState<TL> State;
 #ifdef MUAVTA_PROF
-  unsigned long long prof_acc[48] = {0}, prof_last = 0;
+  unsigned long long prof_acc[48] = {0}, prof_last = clock64();
   __device__ void prof_flush() { if (threadIdx.x == 0) for (int i = 0; i < 48; i++) atomicAdd(&g_prof[i], prof_acc[i]); }
 #endif
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
-  State& S;
+  typedef EnvCold<TL> Cold;
+  State& S;    // LDS
+  Cold& C;     // HBM (L2-resident): requirement vectors, queue-entry times, init/done times, obstacles
   Scratch<TL>& X;
   double* rel_log = nullptr;  // optional per-env release log in HBM (muavta_set_release_log)
   int tnow;                   // env.time_steps in a (uniform) register: it changes once per step, and every LDS read of it is ~100 cycles of latency
@@ -213,8 +195,8 @@ struct Sim {
   const uint32_t* win_ptr;
   uint32_t win_len, win_stride;
 
-  __device__ Sim(State& s, Scratch<TL>& x, const DevParams& p, uint32_t* t)
-      : S(s), X(x), P(p), tape(t), lane(threadIdx.x), win_ptr(&s.rng_win[0][0]), win_len(8), win_stride(8), tnow(s.time_steps) {}
+  __device__ Sim(State& s, Cold& c, Scratch<TL>& x, const DevParams& p, uint32_t* t)
+      : S(s), C(c), X(x), P(p), tape(t), lane(threadIdx.x), win_ptr(&s.rng_win[0][0]), win_len(8), win_stride(8), tnow(s.time_steps) {}
   DEV void sync_clock() { tnow = S.time_steps; }  // after the blob was (re)loaded or reset behind this object's back
 
   DEV void fail(int code) { if (S.error == 0) S.error = code; }
@@ -332,7 +314,7 @@ struct Sim {
     for (int i = k; i + 1 < n; i++) {
       S.a_qid[a][i] = S.a_qid[a][i + 1];
       S.a_qslot[a][i] = S.a_qslot[a][i + 1];
-      S.a_qtime[a][i] = S.a_qtime[a][i + 1];
+      C.a_qtime[a][i] = C.a_qtime[a][i + 1];
     }
     S.a_qlen[a] = n - 1;
   }
@@ -342,23 +324,21 @@ struct Sim {
   // initTime / doneTime are NOT maintained incrementally: the reference's upkeep keeps the invariants
   // initTime == min(details times), doneTime == max(details times) + duration (or -1, -1 when empty), and
   // details == the agents' queue entries, so refresh_task_times() rebuilds them per step in one parallel pass.
-  DEV void remove_agent_cap(int s, int a, double det) {
-    (void)det;
+  DEV void remove_agent_cap(int s, int a) {
     if (S.t_status[s] == 2) return;
-    for (int c = 0; c < 6; c++) S.t_alloc[c][s] -= S.a_caps[c][a];
+    for (int c = 0; c < 6; c++) C.t_alloc[c][s] -= S.a_caps[c][a];
     S.t_ndet[s] -= 1;
     S.times_dirty = 1;
   }
   // UAV.desAllocate (DroneEnvComponents.py:97-113) for a task id that IS in the queue at position k.
   DEV void des_allocate_at(int a, int k) {
     int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
-    double det = S.a_qtime[a][k];
     queue_erase(a, k);
     S.a_nft[a] = (double)tnow;
     S.a_nfx[a] = S.a_px[a];
     S.a_nfy[a] = S.a_py[a];
     S.a_commit[a] = 0;
-    if (ref_valid(id, slot)) remove_agent_cap(slot, a, det);
+    if (ref_valid(id, slot)) remove_agent_cap(slot, a);
   }
   DEV bool des_allocate(int a, int id) {
     int k = queue_find(a, id);
@@ -376,8 +356,7 @@ struct Sim {
       i++;
     }
   }
-  DEV void desallocate_all(int a) { ni_desallocate_all<TL>(&P, tape, a); }
-  DEV void desallocate_all_impl(int a) { iterate_desallocate(a); S.a_commit[a] = 0; }
+  DEV void desallocate_all(int a) { iterate_desallocate(a); S.a_commit[a] = 0; }
   DEV void out_of_service(int a) { S.a_state[a] = -1; S.a_commit[a] = 0; iterate_desallocate(a); }
 
   // UAV.taskDone (DroneEnvComponents.py:143-179)
@@ -420,7 +399,7 @@ struct Sim {
     if (n >= Q) { fail(MUAVTA_ERR_QUEUE); return false; }
     S.a_qid[a][n] = id;
     S.a_qslot[a][n] = s;
-    S.a_qtime[a][n] = time_to_task;
+    C.a_qtime[a][n] = time_to_task;
     S.a_qlen[a] = n + 1;
     S.a_nft[a] = end_time;
     S.a_nfx[a] = S.t_px[s];
@@ -428,7 +407,7 @@ struct Sim {
     // Task.addAgentCap (DroneEnvComponents.py:306-326); status != 2 checked above
     S.t_ndet[s] += 1;
     S.times_dirty = 1;
-    for (int c = 0; c < 6; c++) S.t_alloc[c][s] += S.a_caps[c][a];
+    for (int c = 0; c < 6; c++) C.t_alloc[c][s] += S.a_caps[c][a];
     S.t_status[s] = 1;
     return true;
   }
@@ -477,8 +456,8 @@ struct Sim {
         r[4] = (S.t_flags[s] & TF_DEADLINE) ? S.t_deadline[s] : -1; r[5] = S.t_created[s]; r[6] = S.t_required[s];
         r[7] = (S.t_flags[s] & TF_ESCORT) ? 1 : 0; r[8] = S.t_ndet[s]; r[9] = S.t_prot_agent[s];
         r[10] = (S.t_flags[s] & TF_ELIGIBLE) ? (double)S.t_elig[s] : -1.0; r[11] = S.t_px[s]; r[12] = S.t_py[s];
-        r[13] = S.t_org[s]; r[14] = S.t_done[s]; r[15] = S.t_init[s]; r[16] = S.t_dtime[s];
-        for (int c = 0; c < 6; c++) { r[17 + c] = S.t_cur[c][s]; r[23 + c] = S.t_alloc[c][s]; }
+        r[13] = S.t_org[s]; r[14] = S.t_done[s]; r[15] = C.t_init[s]; r[16] = C.t_dtime[s];
+        for (int c = 0; c < 6; c++) { r[17 + c] = C.t_cur[c][s]; r[23 + c] = C.t_alloc[c][s]; }
       }
     }
   }
@@ -509,6 +488,7 @@ struct Sim {
   // Task.__init__ (DroneEnvComponents.py:224-263) into a free slot; returns the slot or -1
   DEV int new_task(double x, double y, int type, double req) {
     int id = S.next_task_id++;  // _alloc_task_id (:325-328)
+    if (id > 32000) { fail(MUAVTA_ERR_TASK_SLOTS); return -1; }  // ids are stored in 16 bits
     int s = -1;
     for (int w = 0; w < KW; w++) if (S.free_slots[w]) { s = (w << 5) + __ffs((int)S.free_slots[w]) - 1; break; }
     if (s >= T) s = -1;
@@ -517,10 +497,10 @@ struct Sim {
     S.free_slots[s >> 5] &= ~(1u << (s & 31));
     S.t_id[s] = id;
     S.t_px[s] = x; S.t_py[s] = y;
-    for (int c = 0; c < 6; c++) { S.t_cur[c][s] = 0; S.t_alloc[c][s] = 0; }
-    S.t_cur[type][s] = req;
+    for (int c = 0; c < 6; c++) { C.t_cur[c][s] = 0; C.t_alloc[c][s] = 0; }
+    C.t_cur[type][s] = req;
     S.t_org[s] = req; S.t_done[s] = 0;
-    S.t_init[s] = -1; S.t_dtime[s] = -1;
+    C.t_init[s] = -1; C.t_dtime[s] = -1;
     S.t_status[s] = 0; S.t_type[s] = type; S.t_created[s] = 0; S.t_deadline[s] = -1; S.t_required[s] = 0;
     S.t_flags[s] = 0; S.t_elig[s] = 0; S.t_threat[s] = -1;
     S.t_prot_agent[s] = -1; S.t_prot_id[s] = -1; S.t_prot_slot[s] = -1;
@@ -550,7 +530,7 @@ struct Sim {
     }
   }
   // _wps_mark_window_outcome (:1543-1555) on explicit (flags, deadline) storage
-  DEV void mark_outcome(int32_t& flags, int deadline, bool success) {
+  DEV void mark_outcome(u8& flags, int deadline, bool success) {
     if (!(flags & TF_DEADLINE)) return;
     if (flags & TF_COUNTED) return;
     flags |= TF_COUNTED;
@@ -575,7 +555,7 @@ struct Sim {
     if ((S.t_flags[s] & TF_ELIGIBLE) && !((S.t_elig[s] >> S.a_type[a]) & 1u)) return false;
     int ty = S.t_type[s];
     if (P.capability_mask && S.a_caps[ty][a] <= 0) return false;
-    if (P.saturate_mask && S.t_alloc[ty][s] >= S.t_org[s]) return false;
+    if (P.saturate_mask && C.t_alloc[ty][s] >= S.t_org[s]) return false;
     return true;
   }
 
@@ -584,8 +564,7 @@ struct Sim {
     for (int k = 0; k < S.n_escorts; k++) if (S.esc_agent[k] == recon) return k;
     return -1;
   }
-  DEV void create_escort_for(int recon, int rec_slot) { ni_create_escort_for<TL>(&P, tape, recon, rec_slot); }
-  DEV void create_escort_for_impl(int recon, int rec_slot) {  // _create_escort_for (:1888-1917)
+  DEV void create_escort_for(int recon, int rec_slot) {  // _create_escort_for (:1888-1917)
     if (!P.escort_enabled) return;
     if (escort_lookup(recon) >= 0) return;
     int s = new_task(S.a_px[recon], S.a_py[recon], MUAVTA_DEF, P.escort_requirement);
@@ -641,8 +620,7 @@ struct Sim {
     if (failed) S.escort_failed++; else S.escort_completed++;
     push_event(MUAVTA_EV_ESCORT_RETIRED, id);
   }
-  DEV void retire_escort_for(int recon, bool failed) { ni_retire_escort_for<TL>(&P, tape, recon, failed); }
-  DEV void retire_escort_for_impl(int recon, bool failed) {  // :1952-1957
+  DEV void retire_escort_for(int recon, bool failed) {  // :1952-1957
     int k = escort_lookup(recon);
     if (k >= 0) retire_escort_entry(k, failed);
   }
@@ -684,8 +662,7 @@ struct Sim {
   }
 
   // ---------------------------------------------------------------- releaseAllTasks (:1442-1480)
-  DEV void release_all_tasks(int for_type) { ni_release_all_tasks<TL>(&P, tape, for_type); }
-  DEV void release_all_tasks_impl(int for_type) {
+  DEV void release_all_tasks(int for_type) {
     int ft = for_type < 0 ? for_type + 6 : for_type;  // python negative index -> caps[-1] == Det
     uint32_t avail = 0;
     for (int a = 0; a < P.n_agents; a++) {
@@ -737,6 +714,7 @@ struct Sim {
       }
     }
     unsigned long long bm = __ballot(busy);
+    if (bm) cold_sync();  // the queue teardown below reads / rewrites EnvCold rows other lanes wrote in earlier phases
     uint32_t avail = 0;
     {  // available_agents: set of type indices of the matched agents
       const int ty = a < P.n_agents ? S.a_type[a] : 0;
@@ -759,9 +737,9 @@ struct Sim {
         for (int i = 0; i < HQ; i++) if (2 * i < n) { rid[i] = S.a_qid[a][2 * i]; rsl[i] = S.a_qslot[a][2 * i]; }
         int kid[HQ], ksl[HQ]; double ktm[HQ];
 #pragma unroll
-        for (int i = 0; i < HQ; i++) if (2 * i + 1 < n) { kid[i] = S.a_qid[a][2 * i + 1]; ksl[i] = S.a_qslot[a][2 * i + 1]; ktm[i] = S.a_qtime[a][2 * i + 1]; }
+        for (int i = 0; i < HQ; i++) if (2 * i + 1 < n) { kid[i] = S.a_qid[a][2 * i + 1]; ksl[i] = S.a_qslot[a][2 * i + 1]; ktm[i] = C.a_qtime[a][2 * i + 1]; }
 #pragma unroll
-        for (int i = 0; i < HQ; i++) if (2 * i + 1 < n) { S.a_qid[a][i] = kid[i]; S.a_qslot[a][i] = ksl[i]; S.a_qtime[a][i] = ktm[i]; }
+        for (int i = 0; i < HQ; i++) if (2 * i + 1 < n) { S.a_qid[a][i] = kid[i]; S.a_qslot[a][i] = ksl[i]; C.a_qtime[a][i] = ktm[i]; }
         S.a_qlen[a] = n >> 1;
         S.a_nft[a] = (double)tnow; S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
         S.a_commit[a] = 0;
@@ -784,7 +762,7 @@ struct Sim {
           if (hit) {
             if (!touched) {
 #pragma unroll
-              for (int c = 0; c < 6; c++) al[c] = S.t_alloc[c][sl];
+              for (int c = 0; c < 6; c++) al[c] = C.t_alloc[c][sl];
               touched = true;
             }
 #pragma unroll
@@ -794,7 +772,7 @@ struct Sim {
         }
         if (touched) {
 #pragma unroll
-          for (int c = 0; c < 6; c++) S.t_alloc[c][sl] = al[c];
+          for (int c = 0; c < 6; c++) C.t_alloc[c][sl] = al[c];
           S.t_ndet[sl] -= nd;
           S.times_dirty = 1;
         }
@@ -803,10 +781,10 @@ struct Sim {
       while (bm) {
         const int b = __ffsll((long long)bm) - 1;
         bm &= bm - 1ull;
-        desallocate_all_impl(b);
+        desallocate_all(b);
       }
     }
-    lds_sync();
+    cold_sync();
     if (for_type < 0) return __ballot(chg) != 0ull;  // no task has typeIdx -1
     double cum = 0;
     for (int ty = 0; ty < 7; ty++) if ((avail >> ty) & 1u) cum += CAP_TABLE[ty][for_type];
@@ -850,8 +828,8 @@ struct Sim {
     ax = 0.0; ay = 0.0;
     const double PI = 3.14159265358979323846;
     for (int o = 0; o < P.num_obstacles; o++) {
-      double dx = S.obst[o][0] - px, dy = S.obst[o][1] - py;
-      double d_zone = sqrt(dx * dx + dy * dy) - S.obst[o][2];
+      double dx = C.obst[o][0] - px, dy = C.obst[o][1] - py;
+      double d_zone = sqrt(dx * dx + dy * dy) - C.obst[o][2];
       if (d_zone < 40.0) {
         double nx = dx / d_zone, ny = dy / d_zone;
         double force = log(fmax(1.05, d_zone));
@@ -883,9 +861,9 @@ struct Sim {
       bool valid = true;
       if (check_obs) {
         for (int o = 0; o < P.num_obstacles && o < 8; o++) {
-          if (S.obst[o][2] < 0) break;  // not created yet
-          double d = norm2(x - S.obst[o][0], y - S.obst[o][1]) - own_range;
-          if (d < S.obst[o][2] + min_distance) { valid = false; break; }
+          if (C.obst[o][2] < 0) break;  // not created yet
+          double d = norm2(x - C.obst[o][0], y - C.obst[o][1]) - own_range;
+          if (d < C.obst[o][2] + min_distance) { valid = false; break; }
         }
       }
       if (valid) { ox = x; oy = y; return; }
@@ -910,68 +888,50 @@ struct Sim {
   // ====================================================================================================
   // reset (:522-762).  All lanes enter; RNG seeding is cooperative, the rest runs on lane 0.
   // ====================================================================================================
-  // reset-time RNG setup for one stream whose seeded MT state sits in `seeded` (LDS): block0 -> `b0`,
-  // block1 -> `seeded` (in place of the consumed seed state); both go to the HBM tape with coalesced stores
-  // and the head of block0 to the reset window.  Everything is ordered by lds_sync(): no global hand-off.
+  // reset-time RNG setup for one stream whose seeded MT state (k_seed: CPython's init_by_array, one LANE per stream there —
+  // the recurrence is serial) sits in HBM: block0 = twist(seeded) -> `b0`, block1 = twist(block0) -> `b1` (both LDS); both
+  // go to the HBM tape with coalesced stores and the head of block0 to the reset window.  Ordered by lds_sync().
   static constexpr int RESET_WIN = 192;  // words per stream staged for the reset (it draws ~100)
-  DEV void reset_stream(int st, uint32_t* seeded, uint32_t* b0, uint32_t* win) {
+  DEV void reset_stream(int st, const uint32_t* seeded, uint32_t* b0, uint32_t* b1, uint32_t* win) {
     mt_twist_lds(seeded, b0);
-    mt_twist_lds(b0, seeded);
+    mt_twist_lds(b0, b1);
     uint32_t* t = tape + st * MUAVTA_RNG_WORDS;
-    for (int k = lane; k < 624; k += WG) { t[k] = b0[k]; t[624 + k] = seeded[k]; }
+    for (int k = lane; k < 624; k += WG) { t[k] = b0[k]; t[624 + k] = b1[k]; }
     for (int k = lane; k < RESET_WIN; k += WG) win[st * RESET_WIN + k] = b0[k];
     lds_sync();
   }
-  // `seeded`: this env's four init_by_array states [4][624] from k_seed_master / k_seed_streams (one LANE per stream
-  // there, instead of one wave per env here: the recurrence is serial), or nullptr to seed in this kernel.
-  DEV void reset(uint64_t seed, const uint32_t* seeded = nullptr) {
-    // RNG first.  The (not yet initialised) state blob doubles as scratch for four 624-word MT buffers; the
-    // stream cursors live beyond them.
-    static_assert(offsetof(State, rng_idx) >= 4 * 624 * 4 && offsetof(State, area) >= 4 * 624 * 4, "MT buffers overlap live scalars");
+  // `seeded`: this env's four init_by_array states [4][624] from k_seed
+  DEV void reset(uint64_t seed, const uint32_t* seeded) {
+    (void)seed;
+    // RNG first.  The (not yet initialised) arrays of the state blob double as scratch for two 624-word MT buffers; the
+    // stream cursors and the other scalars live beyond them.
+    static_assert(offsetof(State, area) >= 2 * 624 * 4, "MT buffers overlap live scalars");
     static_assert(sizeof(Scratch<TL>) >= 4 * RESET_WIN * 4, "scratch tile too small for the reset RNG window");
     tnow = 0;
     uint32_t* T0 = reinterpret_cast<uint32_t*>(&S);
-    uint32_t *T1 = T0 + 624, *T2 = T1 + 624, *T3 = T2 + 624;
+    uint32_t* T1 = T0 + 624;
     uint32_t* win = reinterpret_cast<uint32_t*>(&X);
     if (lane < 4) { S.rng_idx[lane] = 0; S.rng_win_at[lane] = 0; }
     PROF(39);
     if (lane == 0) S.error = 0;
-    if (seeded) { for (int k = lane; k < 624; k += WG) T0[k] = seeded[ST_AGENT * 624 + k]; }
-    else if (lane == 0) mt_seed(T0, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1);
     lds_sync();
     PROF(42);
-    reset_stream(ST_AGENT, T0, T1, win);
+    reset_stream(ST_AGENT, seeded + ST_AGENT * 624, T0, T1, win);
     PROF(43);
     win_ptr = win; win_len = RESET_WIN; win_stride = RESET_WIN;
-    if (lane == 0) {  // :535-538
-      uint64_t* sd = reinterpret_cast<uint64_t*>(&S.area[0][0]);  // parked until the areas are built
-      sd[0] = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);   // rndObsGen
-      sd[1] = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);   // rndTgtGen
-      sd[2] = (uint64_t)randint(ST_AGENT, 0, INT64_MAX);   // rndMissionGen
+    if (lane == 0) {  // :535-538 — the three stream seeds (rndObsGen, rndTgtGen, rndMissionGen): k_seed drew the same values
+      (void)randint(ST_AGENT, 0, INT64_MAX);
+      (void)randint(ST_AGENT, 0, INT64_MAX);
+      (void)randint(ST_AGENT, 0, INT64_MAX);
     }
     lds_sync();
-    uint64_t s_obs, s_tgt, s_mis;
-    {
-      const uint64_t* sd = reinterpret_cast<const uint64_t*>(&S.area[0][0]);
-      s_obs = sd[0]; s_tgt = sd[1]; s_mis = sd[2];
-    }
     const uint32_t agent_cursor = S.rng_idx[ST_AGENT];
     const int err0 = S.error;
     lds_sync();
-    if (seeded) {
-      for (int k = lane; k < 624; k += WG) {
-        T0[k] = seeded[ST_TGT * 624 + k]; T1[k] = seeded[ST_MISSION * 624 + k];
-        if (P.num_obstacles > 0) T2[k] = seeded[ST_OBS * 624 + k];
-      }
-    } else if (lane < 3 && (lane != 2 || P.num_obstacles > 0)) {  // three lanes, one init_by_array each, side by side
-      const uint64_t sd_ = lane == 0 ? s_tgt : lane == 1 ? s_mis : s_obs;
-      mt_seed(lane == 0 ? T0 : lane == 1 ? T1 : T2, (uint32_t)sd_, (uint32_t)(sd_ >> 32), (sd_ >> 32) ? 2 : 1);
-    }
-    lds_sync();
     PROF(44);
-    reset_stream(ST_TGT, T0, T3, win);
-    reset_stream(ST_MISSION, T1, T3, win);
-    if (P.num_obstacles > 0) reset_stream(ST_OBS, T2, T3, win);
+    reset_stream(ST_TGT, seeded + ST_TGT * 624, T0, T1, win);
+    reset_stream(ST_MISSION, seeded + ST_MISSION * 624, T0, T1, win);
+    if (P.num_obstacles > 0) reset_stream(ST_OBS, seeded + ST_OBS * 624, T0, T1, win);
     PROF(45);
     // now the blob itself: zero it, restore the cursors, build the episode
     {
@@ -982,7 +942,7 @@ struct Sim {
     if (lane == 0) { S.rng_idx[ST_AGENT] = agent_cursor; S.error = err0; }
     lds_sync();
     PROF(46);
-    if (lane == 0) reset_serial_impl();  // not through the out-of-line wrapper: it must see this object's window
+    if (lane == 0) reset_serial();
     lds_sync();
     {  // static / initial tasks are known to everyone (:757-758): every agent lane ORs the slots' mask into its row
       const int no = S.n_order;
@@ -997,12 +957,11 @@ struct Sim {
     PROF(47);
     win_ptr = &S.rng_win[0][0]; win_len = 8; win_stride = 8;
     if (lane < 4) S.rng_win_at[lane] = 0x7fffffffu;  // the small window is (re)filled at the next step boundary
-    lds_sync();
+    cold_sync();  // obstacles and the initial requirement vectors are read by every lane from here on
     finish_step_parallel(false);
   }
 
-  DEV void reset_serial() { ni_reset_serial<TL>(&P, tape); }
-  DEV void reset_serial_impl() {
+  DEV void reset_serial() {
     const int nA = P.n_agents;
     S.conclusion_time = P.max_time_steps + 1;
     S.next_task_id = 1;
@@ -1012,15 +971,15 @@ struct Sim {
     for (int h = 0; h < H; h++) { S.h_status[h] = -9; S.h_target[h] = -1; S.h_mission[h] = -1; S.h_intercept[h] = -1; S.h_task_id[h] = -1; S.h_task_slot[h] = -1; }
     for (int a = 0; a < A; a++) { S.a_state[a] = -1; S.a_last_id[a] = -1; S.a_last_slot[a] = -1; S.a_fail[a] = -1; S.a_task_start[a] = -1; S.a_name[a] = -1; S.a_type[a] = 0; }
     // obstacles (:579-583)
-    for (int o = 0; o < 8; o++) S.obst[o][2] = -1.0;
+    for (int o = 0; o < 8; o++) C.obst[o][2] = -1.0;
     for (int o = 0; o < P.num_obstacles && o < 8; o++) {
       double size = (double)randint(ST_OBS, 30, 100);
       double x, y;
       random_position(ST_OBS, 20, size, true, -1, true, x, y);
-      S.obst[o][0] = x; S.obst[o][1] = y; S.obst[o][2] = size;
+      C.obst[o][0] = x; C.obst[o][1] = y; C.obst[o][2] = size;
     }
     // agents (:591-612): shuffle ids, create in config order
-    int32_t* ids = S.act_agent;  // scratch: A ints in the blob, idle during a reset (the Scratch tile holds the reset RNG windows)
+    int32_t* ids = S.act_index;  // scratch: A ints in the blob, idle during a reset (the Scratch tile holds the reset RNG windows)
     for (int i = 0; i < nA; i++) ids[i] = i;
     for (int i = nA - 1; i >= 1; i--) {
       int j = (int)randbelow(ST_AGENT, (uint64_t)i + 1);
@@ -1145,21 +1104,21 @@ struct Sim {
       lds_sync();
       PROF(33);
       if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
-      lds_sync();
+      cold_sync();
     }
     PROF(3);
     // movement (:965-1129): lanes commit every agent up to the first "event" agent, lane 0 plays that one
     // agent exactly as the reference does, and the wave resumes behind it
     for (int start = 0; start < P.n_agents;) {
       const int first = move_parallel(start);
-      lds_sync();
+      cold_sync();  // (lanes that dropped a retired head shifted their EnvCold queue-time row)
       PROF(26);
 #ifdef MUAVTA_PROF
       if (threadIdx.x == 0) { prof_acc[40] += 1000; if (first < P.n_agents) prof_acc[41] += 1000; }
 #endif
       if (first >= P.n_agents) break;
       if (lane == 0) step_serial_move(first, first + 1, r_quality);
-      lds_sync();
+      cold_sync();  // (a concluded task / retired escort rewrites other agents' queue rows: the next pass reads them)
       PROF(4);
       start = first + 1;
     }
@@ -1365,6 +1324,7 @@ struct Sim {
   DEV bool apply_actions_parallel(double& action_reward, double& distance_reward, double& S_quality_reward) {
     const int n_act = S.n_act;
     if (!P.multiple_tasks_per_agent || P.saturate_mask || n_act > WG) return false;
+    cold_sync();  // allocatedReqs / queue times: written by whichever lane ran the previous phases
     const int k = lane;
     const bool mine = k < n_act;
     const int a = mine ? S.act_agent[k] : -1, s = mine ? S.act_slot[k] : -1;
@@ -1418,7 +1378,7 @@ struct Sim {
               if (qlen >= 1) { const int ps = S.a_qslot[a][qlen - 1]; total = norm2(tx - S.t_px[ps], ty_ - S.t_py[ps]); }
               else total = norm2(tx - px, ty_ - py);
               d1 = -1.0 * total / MAX_COORD; nd1 = 1;
-              S.a_qid[a][qlen] = tid; S.a_qslot[a][qlen] = s; S.a_qtime[a][qlen] = time_to_task; S.a_qlen[a] = qlen + 1;
+              S.a_qid[a][qlen] = tid; S.a_qslot[a][qlen] = s; C.a_qtime[a][qlen] = time_to_task; S.a_qlen[a] = qlen + 1;
               S.a_nft[a] = end_time; S.a_nfx[a] = tx; S.a_nfy[a] = ty_;
               if (S.a_state[a] != 1 && S.a_state[a] != -1) S.a_state[a] = 1;
 #pragma unroll
@@ -1439,7 +1399,7 @@ struct Sim {
       double pre[6] = {0, 0, 0, 0, 0, 0};
       if (succ) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) pre[c] = S.t_alloc[c][s];
+        for (int c = 0; c < 6; c++) pre[c] = C.t_alloc[c][s];
       }
       unsigned long long same = 0ull;  // successful lanes on my slot
       for (unsigned long long m = sm; m; m &= m - 1ull) {
@@ -1463,14 +1423,14 @@ struct Sim {
         double agentCap = caps[0], after_ty = after[0];
 #pragma unroll
         for (int c = 1; c < 6; c++) if (ty == c) { agentCap = caps[c]; after_ty = after[c]; }
-        double missing = S.t_cur[ty][s] - (after_ty - agentCap);
+        double missing = C.t_cur[ty][s] - (after_ty - agentCap);
         missing = missing > 0 ? missing : 0;
         const double addedCap = missing - fmax(missing - agentCap, 0.0);
         if (addedCap <= 0) { q2 = -1.5; q3 = addedCap; nq23 = 2; } else { q2 = addedCap; nq23 = 1; }
         atomicOr(&S.t_bucket[s], 1ull << a);
         if ((same >> k) >> 1 == 0ull) {  // last successful lane on this slot
 #pragma unroll
-          for (int c = 0; c < 6; c++) S.t_alloc[c][s] = after[c];
+          for (int c = 0; c < 6; c++) C.t_alloc[c][s] = after[c];
           S.t_ndet[s] += __popcll(same);
           S.t_status[s] = 1;
         }
@@ -1499,7 +1459,7 @@ struct Sim {
       if (c23 >= 2) S_quality_reward += readlane_f64(q3, j);
       if (__builtin_amdgcn_readlane(nd1, j)) distance_reward += readlane_f64(d1, j);
     }
-    lds_sync();
+    cold_sync();
     return true;
   }
   // action application (:813-933), dict order, lane 0
@@ -1554,7 +1514,7 @@ struct Sim {
         S.t_bucket[s] |= 1ull << a;
         int ty = S.t_type[s];
         double agentCap = S.a_caps[ty][a];
-        double missing = S.t_cur[ty][s] - (S.t_alloc[ty][s] - agentCap);
+        double missing = C.t_cur[ty][s] - (C.t_alloc[ty][s] - agentCap);
         missing = missing > 0 ? missing : 0;
         double addedCap = missing - fmax(missing - agentCap, 0.0);
         if (addedCap <= 0) S_quality_reward -= 1.5;
@@ -1581,7 +1541,7 @@ struct Sim {
 
   // ---- movement state machine (:965-1129), agents_obj order, lane 0 ----
   // the reference's loop body for agents [first, last) on lane 0
-  DEV void step_serial_move(int first, int last, double& quality_reward) { quality_reward += ni_step_serial_move<TL>(&P, tape, first, last); }
+  DEV void step_serial_move(int first, int last, double& quality_reward) { quality_reward += step_serial_move_impl(first, last); }
   DEV double step_serial_move_impl(int first, int last) {
     double quality_reward = 0;
     for (int a = first; a < last; a++) {
@@ -1644,11 +1604,10 @@ struct Sim {
                        ty != MUAVTA_INT && ty != MUAVTA_DET) {
               // task concluded by this agent (:1079-1107)
               S.a_px[a] = px; S.a_py[a] = py;  // taskDone reads agent.position
-              double det = S.a_qlen[a] > 0 ? S.a_qtime[a][0] : 0.0;
               bool was_head = task_done(a, cid, ty);
               S.t_done[cs] += S.a_caps[ty][a];
-              for (int c = 0; c < 6; c++) S.t_cur[c][cs] -= S.a_caps[c][a];
-              if (was_head) remove_agent_cap(cs, a, det);
+              for (int c = 0; c < 6; c++) C.t_cur[c][cs] -= S.a_caps[c][a];
+              if (was_head) remove_agent_cap(cs, a);
               if (S.t_done[cs] >= S.t_org[cs]) {
                 const bool esc = S.t_flags[cs] & TF_ESCORT;
                 if (!esc && !(S.t_flags[cs] & TF_REACHED)) { S.t_flags[cs] |= TF_REACHED; S.n_reached++; }
@@ -1744,8 +1703,7 @@ struct Sim {
       }
     }
   }
-  DEV void generate_threat() { ni_generate_threat<TL>(&P, tape); }
-  DEV void generate_threat_impl() {  // :1601-1643
+  DEV void generate_threat() {  // :1601-1643
     for (int g = 0; g < P.n_threat_groups; g++) {
       int left = S.g_end[g] - S.g_next[g];
       if (left > 0 && threat_spawn_step()) {
@@ -1772,8 +1730,8 @@ struct Sim {
             double attack = threat_attack(ty), defence = threat_defence(ty);
             int s = new_task(S.h_px[h], S.h_py[h], MUAVTA_INT, 2.0);
             if (s >= 0) {
-              S.t_cur[MUAVTA_ATT][s] = defence * 2;
-              S.t_cur[MUAVTA_DEF][s] = attack * 2;
+              C.t_cur[MUAVTA_ATT][s] = defence * 2;
+              C.t_cur[MUAVTA_DEF][s] = attack * 2;
               S.t_threat[s] = h;
               S.t_created[s] = tnow;
               if (ty == MUAVTA_T1) { S.t_required[s] = 2; S.t_flags[s] |= TF_ELIGIBLE; S.t_elig[s] = P.escort_mask; }
@@ -1782,7 +1740,7 @@ struct Sim {
             }
             S.h_status[h] = 1;
             S.h_order[S.n_active_threats++] = h;
-            S.t_cur[5][S.h_det_slot[h]] -= 1.0;
+            C.t_cur[5][S.h_det_slot[h]] -= 1.0;
             if (s >= 0) {
               register_dynamic(s);
               push_event(MUAVTA_EV_NEW_THREAT, S.t_id[s]);
@@ -1803,8 +1761,7 @@ struct Sim {
     else mark_outcome(S.h_tflags[h], S.h_tdeadline[h], success);
   }
 
-  DEV void handle_threat_engagement(int h) { ni_handle_threat_engagement<TL>(&P, tape, h); }
-  DEV void handle_threat_engagement_impl(int h) {  // :1781-1858
+  DEV void handle_threat_engagement(int h) {  // :1781-1858
     int primary = S.h_target[h];
     int mission = S.h_mission[h] >= 0 ? S.h_mission[h] : primary;
     int n_def = 0;
@@ -1930,8 +1887,7 @@ struct Sim {
     }
     return first;
   }
-  DEV void update_threats_serial(int first, unsigned long long livemask) { ni_update_threats_serial<TL>(&P, tape, first, livemask); }
-  DEV void update_threats_serial_impl(int first, unsigned long long livemask) {  // the reference's loop body for ONE threat
+  DEV void update_threats_serial(int first, unsigned long long livemask) {  // the reference's loop body for ONE threat
     const int n = first + 1 < S.n_active_threats ? first + 1 : S.n_active_threats;
     for (int k = first; k < n; k++) {
       if (!((livemask >> k) & 1ull)) continue;
@@ -1964,8 +1920,7 @@ struct Sim {
     }
   }
 
-  DEV void inject_dynamic_arrivals() { ni_inject_dynamic_arrivals<TL>(&P, tape); }
-  DEV void inject_dynamic_arrivals_impl() {  // :1646-1689
+  DEV void inject_dynamic_arrivals() {  // :1646-1689
     if (P.arrival_rate <= 0 || tnow < 5) return;
     if (rnd(ST_TGT) >= P.arrival_rate) return;
     if (S.next_task_id - 1 >= P.max_tasks - 1) return;  // len(self.tasks) >= max_tasks - 1
@@ -1992,8 +1947,7 @@ struct Sim {
     S.pending_reset = 1;
   }
 
-  DEV void sync_escorts() { ni_sync_escorts<TL>(&P, tape); }
-  DEV void sync_escorts_impl() {  // :1964-2000
+  DEV void sync_escorts() {  // :1964-2000
     for (int a = 0; a < P.n_agents; a++) {
       if (S.a_state[a] == -1 || !is_recon(S.a_type[a])) continue;
       if (S.a_qlen[a] == 0) continue;
@@ -2043,7 +1997,7 @@ struct Sim {
           while (nm) {
             const int b = __ffsll((long long)nm) - 1;
             nm &= nm - 1ull;
-            create_escort_for_impl(b, S.a_qslot[b][0]);
+            create_escort_for(b, S.a_qslot[b][0]);
           }
         }
         lds_sync();
@@ -2251,6 +2205,7 @@ struct Sim {
       if (threadIdx.x == 0) { prof_acc[30] += 1000; if (any_ret) prof_acc[31] += 1000; }
 #endif
       if (any_ret) {
+        if (rel_log) cold_sync();
         // slots still queued by a live agent (one agent per lane marks its queue entries), then the retired and
         // unreferenced ones are released (one slot per lane), then every agent lane drops the released columns
         // from its known mask and counts them into a_gone
@@ -2323,7 +2278,7 @@ struct Sim {
   // order them numerically.  One queue entry per lane.
   DEV void refresh_task_times() {
     if (!S.times_dirty) return;  // uniform: LDS word
-    lds_sync();
+    cold_sync();
     if (lane == 0) S.times_dirty = 0;
     unsigned long long* tmin = reinterpret_cast<unsigned long long*>(X.cost);
     unsigned long long* tmax = tmin + T;
@@ -2335,7 +2290,7 @@ struct Sim {
       if (k < S.a_qlen[a]) {
         const int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
         if (ref_valid(id, slot) && S.t_status[slot] != 2) {
-          const unsigned long long bits = (unsigned long long)__double_as_longlong(S.a_qtime[a][k]);
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(C.a_qtime[a][k]);
           atomicMin(&tmin[slot], bits);
           atomicMax(&tmax[slot], bits);
         }
@@ -2344,18 +2299,19 @@ struct Sim {
     lds_sync();
     for (int s = lane; s < T; s += WG) {
       if (S.t_id[s] >= 0 && S.t_status[s] != 2) {
-        if (tmin[s] == ~0ull) { S.t_init[s] = -1; S.t_dtime[s] = -1; }
+        if (tmin[s] == ~0ull) { C.t_init[s] = -1; C.t_dtime[s] = -1; }
         else {
-          S.t_init[s] = __longlong_as_double((long long)tmin[s]);
-          S.t_dtime[s] = __longlong_as_double((long long)tmax[s]) + (double)task_duration(S.t_type[s]);
+          C.t_init[s] = __longlong_as_double((long long)tmin[s]);
+          C.t_dtime[s] = __longlong_as_double((long long)tmax[s]) + (double)task_duration(S.t_type[s]);
         }
       }
     }
-    lds_sync();
+    cold_sync();
   }
 
   DEV void write_obs(float* o_tasks, unsigned long long* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags) {
     refresh_task_times();
+    cold_sync();  // the rows below read the requirement vectors the serial phases of this step may have changed
     const int MT = P.max_tasks, nA = P.n_agents;
     const int n = S.n_open;
     const double mts = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1);
@@ -2378,19 +2334,19 @@ struct Sim {
         tid = S.t_id[s];
         ty = S.t_type[s];
         typemask = (S.t_flags[s] & TF_ELIGIBLE) ? S.t_elig[s] : 0xffffffffu;
-        if (P.saturate_mask && S.t_alloc[ty][s] >= S.t_org[s]) typemask = 0;
+        if (P.saturate_mask && C.t_alloc[ty][s] >= S.t_org[s]) typemask = 0;
         r[0] = (float)tid;
         r[1] = (float)(S.t_px[s] / MAX_COORD);
         r[2] = (float)(S.t_py[s] / MAX_COORD);
         r[3] = (float)S.t_status[s];
 #pragma unroll
-        for (int c = 0; c < 6; c++) { r[4 + c] = (float)S.t_cur[c][s]; r[10 + c] = (float)S.t_alloc[c][s]; }
+        for (int c = 0; c < 6; c++) { r[4 + c] = (float)C.t_cur[c][s]; r[10 + c] = (float)C.t_alloc[c][s]; }
         if (P.include_time_windows) {
-          r[16] = (float)((S.t_init[s] - (double)tnow) / mts);
-          r[17] = (float)((S.t_dtime[s] - (double)tnow) / mts);
+          r[16] = (float)((C.t_init[s] - (double)tnow) / mts);
+          r[17] = (float)((C.t_dtime[s] - (double)tnow) / mts);
           r[18] = (float)((double)ty / 6.0);
         }
-        const double unmet = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+        const double unmet = fmax(C.t_cur[ty][s] - C.t_alloc[ty][s], 0.0);
         r[19] = (float)(unmet / fmax(S.t_org[s], 1e-6));
         r[20] = (float)fmin(((double)tnow - (double)S.t_created[s]) / mts, 1.0);
       } else if (!(j == 0 && n == 0)) {
@@ -2478,7 +2434,7 @@ struct Sim {
       return fmax(required - (double)S.t_ndet[s], 0.0);
     }
     int ty = S.t_type[s];
-    return fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+    return fmax(C.t_cur[ty][s] - C.t_alloc[ty][s], 0.0);
   }
 
   // mode 0 (MUAVTA_ALLOC_HUNGARIAN): Local-/Global-/Coalition-Hungarian as driven by the WPS / escort harness.
@@ -2513,6 +2469,7 @@ struct Sim {
     const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
     int nr = 0, n_live = 1;
     if (go) {
+      cold_sync();  // residual demand reads currentReqs / allocatedReqs
       // live agents -> free list (get_live_agents order), residual demand per open task: one lane each
       // Urgency-Coalition holds committed agents out of the match (committed_names, AttentionCommit.py:24-30)
       nr = compact_to(X.freeA, P.n_agents,
@@ -2529,7 +2486,7 @@ struct Sim {
           s = S.open_slot[k];
           const int ty = S.t_type[s];
           // Urgency-Pair only plans over build_att_tokens' open_tasks: underfilled at the type index (AttentionRAH.py:69-73)
-          under = mode != 1 || S.t_alloc[ty][s] < S.t_cur[ty][s];
+          under = mode != 1 || C.t_alloc[ty][s] < C.t_cur[ty][s];
           const double r = under ? residual_demand(s) : 0.0;
           X.resid[s] = r;
           any_open |= r > 0;
@@ -2770,7 +2727,7 @@ struct Sim {
                              if (S.t_status[s] == 2) return false;
                              if (kind == 2) return residual_demand(s) > 0;
                              const int ty = S.t_type[s];
-                             return S.t_alloc[ty][s] < S.t_cur[ty][s];
+                             return C.t_alloc[ty][s] < C.t_cur[ty][s];
                            },
                            [&](int k) { return S.t_order[k]; });
     lds_sync();
@@ -2842,7 +2799,7 @@ struct Sim {
           f[c++] = (float)(S.t_px[s] / MAX_COORD); f[c++] = (float)(S.t_py[s] / MAX_COORD); f[c++] = (float)((double)ty / 8.0);
           f[c++] = ty == MUAVTA_ATT ? 1.f : 0.f; f[c++] = ty == MUAVTA_REC ? 1.f : 0.f; f[c++] = ty == MUAVTA_INT ? 1.f : 0.f;
           if (kind != 2) {
-            const double rem = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+            const double rem = fmax(C.t_cur[ty][s] - C.t_alloc[ty][s], 0.0);
             urgent = urg >= URGENT && dyn;
             if (kind == 1) {
               int left = S.t_deadline[s] - tnow;
@@ -2860,7 +2817,7 @@ struct Sim {
             if (is_escort_task(s)) {
               req_agents = S.t_required[s] ? (double)S.t_required[s] : 1.0;
               rem = fmax(req_agents - (double)S.t_ndet[s], 0.0);
-            } else rem = fmax(S.t_cur[ty][s] - S.t_alloc[ty][s], 0.0);
+            } else rem = fmax(C.t_cur[ty][s] - C.t_alloc[ty][s], 0.0);
             const double n_know = vis ? (double)n_know_i : 0.0;
             const double deficit = fmin(rem / 4.0, 1.0);
             double pr, dn, fp;
@@ -3195,18 +3152,5 @@ struct Sim {
   }
 };
 
-#define MUAVTA_NI_SIM Sim<TL> sim(*lds_state<TL>(), *lds_scratch<TL>(), *P, tape)
-template <class TL> __device__ MUAVTA_OUTLINE void ni_release_all_tasks(const DevParams* P, uint32_t* tape, int for_type) { MUAVTA_NI_SIM; sim.release_all_tasks_impl(for_type); }
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_handle_threat_engagement(const DevParams* P, uint32_t* tape, int h) { MUAVTA_NI_SIM; sim.handle_threat_engagement_impl(h); }
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_generate_threat(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.generate_threat_impl(); }
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_inject_dynamic_arrivals(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.inject_dynamic_arrivals_impl(); }
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_sync_escorts(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.sync_escorts_impl(); }
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_reset_serial(const DevParams* P, uint32_t* tape) { MUAVTA_NI_SIM; sim.reset_serial_impl(); }
-template <class TL> __device__ MUAVTA_OUTLINE double ni_step_serial_move(const DevParams* P, uint32_t* tape, int first, int last) { MUAVTA_NI_SIM; return sim.step_serial_move_impl(first, last); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_update_threats_serial(const DevParams* P, uint32_t* tape, int first, unsigned long long livemask) { MUAVTA_NI_SIM; sim.update_threats_serial_impl(first, livemask); }
-template <class TL> __device__ MUAVTA_OUTLINE_COLD void ni_create_escort_for(const DevParams* P, uint32_t* tape, int recon, int rec_slot) { MUAVTA_NI_SIM; sim.create_escort_for_impl(recon, rec_slot); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_retire_escort_for(const DevParams* P, uint32_t* tape, int recon, bool failed) { MUAVTA_NI_SIM; sim.retire_escort_for_impl(recon, failed); }
-template <class TL> __device__ MUAVTA_OUTLINE void ni_desallocate_all(const DevParams* P, uint32_t* tape, int a) { MUAVTA_NI_SIM; sim.desallocate_all_impl(a); }
-#undef MUAVTA_NI_SIM
 
 }  // namespace muavta

@@ -25,6 +25,14 @@ using namespace muavta;
 
 namespace {
 
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+#define AS4 __attribute__((address_space(4)))
+// A pointer loaded from memory (or received by an out-of-line function) is a generic pointer to the compiler, and accesses
+// through it become FLAT instructions, which tie up the LDS counter as well as the memory counter.  A round trip through
+// the global address space tells the address-space inference what it is.
+template <class T> __device__ __forceinline__ T* as_global(T* p) { return (T*)(AS1 T*)p; }
+
 struct ObsPtrs {
   float* tasks;    // [N, 21, max_tasks]  (feature-major)
   unsigned long long* legal;  // [N, A, ceil(max_tasks/64)] bit rows
@@ -35,13 +43,31 @@ struct ObsPtrs {
   uint8_t* done;   // [N]
 };
 
-// Launch-invariant context in device memory (one copy per handle): every kernel gets a pointer to it, so the ~600 B of
-// parameters are read on demand through the scalar cache and can be handed to the out-of-line step body by pointer.
+// Launch-invariant context in device memory (one copy per handle).  Kernels get a pointer to it and read it through the
+// scalar cache as constant memory (it is written once, by muavta_create); the out-of-line step body of k_rollout gets the
+// same pointer instead of ~700 B of by-value arguments.
 struct DevCtx {
   DevParams P;
   ObsPtrs O;
   uint32_t* tapes;  // [N][4][1248] MT19937 tapes
+  void* blobs;      // EnvState<TL>[N]: the LDS image of every env between launches
+  void* cold;       // EnvCold<TL>[N]: the HBM-only part of every env
 };
+// the context as uniform constant memory: scalar loads, hoistable across the phase barriers
+__device__ __forceinline__ const DevCtx& ctx_ref(const DevCtx* p) {
+  const uint64_t b = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)b), hi = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
+  return *(const DevCtx*)(const AS4 DevCtx*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ ObsPtrs obs_ptrs(const DevCtx& c) {
+  ObsPtrs o;
+  o.tasks = as_global(c.O.tasks); o.legal = as_global(c.O.legal); o.pad = as_global(c.O.pad); o.agents = as_global(c.O.agents);
+  o.flags = as_global(c.O.flags); o.reward = as_global(c.O.reward); o.done = as_global(c.O.done);
+  return o;
+}
+template <class TL> __device__ __forceinline__ EnvState<TL>* blob_of(const DevCtx& c, int env) { return as_global(reinterpret_cast<EnvState<TL>*>(c.blobs)) + env; }
+template <class TL> __device__ __forceinline__ EnvCold<TL>* cold_of(const DevCtx& c, int env) { return as_global(reinterpret_cast<EnvCold<TL>*>(c.cold)) + env; }
+__device__ __forceinline__ uint32_t* tape_of(const DevCtx& c, int env) { return as_global(c.tapes) + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS; }
 
 template <class TL>
 __device__ __forceinline__ void obs_for_env(Sim<TL>& sim, const DevParams& P, const ObsPtrs& O, int env) {
@@ -61,26 +87,29 @@ __device__ __forceinline__ void copy16(void* dst, const void* src, int bytes) {
   for (int i = threadIdx.x; i < bytes / 16; i += WG) d[i] = s[i];
 }
 
+extern __shared__ __align__(16) unsigned char muavta_smem[];
 template <class TL>
 struct Lds {
   EnvState<TL>* S;
   Scratch<TL>* X;
-  __device__ Lds(unsigned char* smem) {
-    S = reinterpret_cast<EnvState<TL>*>(smem);
-    X = reinterpret_cast<Scratch<TL>*>(smem + ((sizeof(EnvState<TL>) + 15) & ~size_t(15)));
+  __device__ Lds(unsigned char* base) {
+    S = reinterpret_cast<EnvState<TL>*>(base);
+    X = reinterpret_cast<Scratch<TL>*>(base + ((sizeof(EnvState<TL>) + 15) & ~size_t(15)));
   }
-  static size_t bytes() { return ((sizeof(EnvState<TL>) + 15) & ~size_t(15)) + sizeof(Scratch<TL>); }
+  static constexpr size_t bytes() { return ((sizeof(EnvState<TL>) + 15) & ~size_t(15)) + sizeof(Scratch<TL>); }
 };
 
 #define smem muavta_smem
-// 8 workgroups per CU need <= 160 KiB / 8 = 20480 B of LDS each on the 16x32 tile (BASELINE config 2)
-static_assert(((sizeof(EnvState<Tile16>) + 15) & ~size_t(15)) + sizeof(Scratch<Tile16>) <= 20480, "Tile16 no longer fits 8 workgroups per CU");
-static_assert(((sizeof(EnvState<Tile16L>) + 15) & ~size_t(15)) + sizeof(Scratch<Tile16L>) <= 20480, "Tile16L no longer fits 8 workgroups per CU");
-static_assert(((sizeof(EnvState<Tile24>) + 15) & ~size_t(15)) + sizeof(Scratch<Tile24>) <= 26624, "Tile24 no longer fits 6 workgroups per CU (27,200 B measured at 5: the LDS granule is 1 KB)");
+// Residency on a CU is bound by LDS bytes per env (160 KiB per CU, 1 KiB granule): 16 envs of the 16-agent tile
+// (BASELINE configs 2 and 3: 4096 envs = 16 per CU, one round) need <= 10 KiB each.
+static_assert(Lds<Tile16>::bytes() <= 10240, "Tile16 no longer fits 16 workgroups per CU");
+static_assert(sizeof(EnvState<Tile16>) % 16 == 0 && sizeof(EnvState<Tile24>) % 16 == 0 && sizeof(EnvState<Tile64>) % 16 == 0, "blob copies move 16 B per lane");
+static_assert(sizeof(EnvCold<Tile16>) % 16 == 0 && sizeof(EnvCold<Tile24>) % 16 == 0 && sizeof(EnvCold<Tile64>) % 16 == 0, "cold records are 16 B aligned");
 
-// Minimum waves per SIMD the register allocator must leave room for (2 => at most 256 VGPR+AGPR).
+// Minimum waves per SIMD the register allocator must leave room for in the fused rollout (4 => at most 128 VGPRs, which is
+// what 16 single-wave workgroups per CU need).
 #ifndef MUAVTA_MIN_WAVES
-#define MUAVTA_MIN_WAVES 2
+#define MUAVTA_MIN_WAVES 4
 #endif
 
 // ---- RNG seeding, one LANE per stream --------------------------------------------------------------------------
@@ -175,28 +204,29 @@ __global__ __launch_bounds__(WG) void k_seed(const uint64_t* seeds, int n, int w
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_reset(const DevCtx* __restrict__ ctx, const uint64_t* seeds, EnvState<TL>* blobs,
-                                              const uint32_t* seedbuf) {
-  const DevParams& P = ctx->P; const ObsPtrs& O = ctx->O; uint32_t* const tapes = ctx->tapes;
+__global__ __launch_bounds__(WG) void k_reset(const DevCtx* __restrict__ ctxp, const uint64_t* seeds, const uint32_t* seedbuf) {
+  const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L(smem);
-  Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
-  sim.reset(seeds[env], seedbuf ? seedbuf + (size_t)env * 4 * 624 : nullptr);
-  obs_for_env(sim, P, O, env);
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
+  sim.reset(seeds[env], seedbuf + (size_t)env * 4 * 624);
+  obs_for_env(sim, ctx.P, obs_ptrs(ctx), env);
   lds_sync();
-  copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
+  copy16(blob_of<TL>(ctx, env), L.S, sizeof(EnvState<TL>));
 }
 
 // act_agent == nullptr: use the actions staged in the blob by k_allocate
 template <class TL>
-__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(const DevCtx* __restrict__ ctx, EnvState<TL>* blobs, const int32_t* act_agent,
-                                             const int32_t* act_index, int act_cap, double* rel_log) {
-  const DevParams& P = ctx->P; const ObsPtrs& O = ctx->O; uint32_t* const tapes = ctx->tapes;
+__global__ __launch_bounds__(WG, 2) void k_step(const DevCtx* __restrict__ ctxp, const int32_t* act_agent, const int32_t* act_index, int act_cap,
+                                             double* rel_log) {
+  const DevCtx& ctx = ctx_ref(ctxp);
+  const DevParams& P = ctx.P;
   const int env = blockIdx.x;
   Lds<TL> L(smem);
-  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  EnvState<TL>* blob = blob_of<TL>(ctx, env);
+  copy16(L.S, blob, sizeof(EnvState<TL>));
   lds_sync();
-  Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, P, tape_of(ctx, env));
   if (rel_log) sim.rel_log = rel_log + (size_t)env * (1 + MUAVTA_REL_ROW * TL::T);
   if (act_agent && threadIdx.x == 0) {
     EnvState<TL>& S = *L.S;
@@ -204,10 +234,11 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(const DevCtx* __r
     for (int k = 0; k < act_cap && n < TL::A; k++) {
       int a = act_agent[(size_t)env * act_cap + k];
       if (a < 0) break;
+      if (a >= P.n_agents) continue;  // (muavta_step rejects these on the host; never index the agent arrays with one)
       int idx = act_index[(size_t)env * act_cap + k];
       if (idx < 0) idx += S.n_open;  // python negative indexing into last_tasks_info
-      S.act_agent[n] = a;
-      S.act_slot[n] = (idx >= 0 && idx < S.n_open) ? S.open_slot[idx] : -1;
+      S.act_agent[n] = (i8)a;
+      S.act_slot[n] = (idx >= 0 && idx < S.n_open) ? (i8)S.open_slot[idx] : (i8)-1;
       S.act_index[n] = idx;
       n++;
     }
@@ -215,20 +246,21 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(const DevCtx* __r
   }
   lds_sync();
   sim.step(true);
-  obs_for_env(sim, P, O, env);
+  obs_for_env(sim, P, obs_ptrs(ctx), env);
   lds_sync();
-  copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
+  copy16(blob, L.S, sizeof(EnvState<TL>));
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctx, EnvState<TL>* blobs, int interval, int use_vis, int mode,
+__global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp, int interval, int use_vis, int mode,
                                                  int32_t* out_agent, int32_t* out_index, int act_cap) {
-  const DevParams& P = ctx->P; uint32_t* const tapes = ctx->tapes;
+  const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L(smem);
-  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  EnvState<TL>* blob = blob_of<TL>(ctx, env);
+  copy16(L.S, blob, sizeof(EnvState<TL>));
   lds_sync();
-  Sim<TL> sim(*L.S, *L.X, P, tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
   sim.allocate(interval, use_vis, mode);
   lds_sync();
   if (out_agent) {
@@ -238,22 +270,27 @@ __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctx,
       out_index[(size_t)env * act_cap + k] = k < S.n_act ? S.act_index[k] : 0;
     }
   }
-  copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
+  copy16(blob, L.S, sizeof(EnvState<TL>));
 }
 
-// One env step of the fused rollout: allocate -> step -> observation write.  OUT OF LINE on purpose: inlined into the
-// 150-step loop of k_rollout the compiler hoists loop invariants across the whole body and the kernel needs 255 VGPRs
-// (+188 B/lane of scratch); as a function of its own the body fits the 128 VGPRs of four waves per SIMD, the call costs
-// one entry/exit sequence per ~3,500 instructions.
+// The body of the fused rollout, OUT OF LINE on purpose.  Inlined into the 150-step loop of k_rollout the compiler hoists
+// loop invariants across the whole body and the kernel needs 255 VGPRs (+188 B/lane of scratch: two waves per SIMD); as a
+// function of its own the body fits the 128 VGPRs of FOUR waves per SIMD — with 10 KiB of LDS per env that is 16 resident
+// envs per CU, the whole 4096-env batch in one round.  The function must not name the `extern __shared__` array (every
+// reference becomes a load from the dynamic-LDS offset table) nor take generic pointers (FLAT accesses): it gets the LDS
+// base as a number and rebuilds typed pointers.  An iteration is  step -> observation write -> NEXT step's allocate:
+// the function's return waits for all memory operations, and this way the observation stores have drained by then.
+enum { PH_ALLOC = 1, PH_STEP = 2, PH_OBS = 4 };
 template <class TL>
-__device__ __noinline__ void rollout_step(const DevCtx* __restrict__ ctx, int interval, int use_vis, int mode, int write_obs) {
+__device__ __noinline__ void rollout_phase(const DevCtx* ctxp, uint32_t lds_base, int phases, int interval, int use_vis, int mode) {
+  const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
-  Lds<TL> L(smem);
-  Sim<TL> sim(*L.S, *L.X, ctx->P, ctx->tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
-  sim.allocate(interval, use_vis, mode);
-  sim.step(true);
-  if (write_obs) obs_for_env(sim, ctx->P, ctx->O, env);
+  Lds<TL> L((unsigned char*)(AS3 unsigned char*)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base));
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
+  if (phases & PH_STEP) sim.step(true);
+  if (phases & PH_OBS) obs_for_env(sim, ctx.P, obs_ptrs(ctx), env);
   lds_sync();
+  if ((phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) sim.allocate(interval, use_vis, mode);
 #ifdef MUAVTA_PROF
   if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sim.prof_acc[20] += t_ - sim.prof_last; sim.prof_last = t_; }
   sim.prof_flush();
@@ -261,59 +298,63 @@ __device__ __noinline__ void rollout_step(const DevCtx* __restrict__ ctx, int in
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* __restrict__ ctx, const uint64_t* seeds, EnvState<TL>* blobs, int n_steps,
-                                                int interval, int use_vis, int mode, int write_obs, double* metrics, const uint32_t* seedbuf) {
-  const DevParams& P = ctx->P;
+__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* __restrict__ ctxp, const uint64_t* seeds, int n_steps, int interval, int use_vis,
+                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf) {
+  const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L(smem);
-  Sim<TL> sim(*L.S, *L.X, P, ctx->tapes + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS);
+  EnvState<TL>* blob = blob_of<TL>(ctx, env);
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
   if (seeds) {
-    sim.reset(seeds[env], seedbuf ? seedbuf + (size_t)env * 4 * 624 : nullptr);
+    sim.reset(seeds[env], seedbuf + (size_t)env * 4 * 624);
   } else {
-    copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+    copy16(L.S, blob, sizeof(EnvState<TL>));
     lds_sync();
   }
+  uint32_t lds_base = (uint32_t)(uintptr_t)(AS3 unsigned char*)smem;
+  asm volatile("" : "+v"(lds_base));  // opaque: keeps constant propagation from re-introducing the symbol into the callee
+  if (n_steps > 0) rollout_phase<TL>(ctxp, lds_base, PH_ALLOC, interval, use_vis, mode);
   for (int t = 0; t < n_steps; t++) {
     if (L.S->terminated || L.S->truncated) break;  // uniform: read from LDS after a barrier
-    rollout_step<TL>(ctx, interval, use_vis, mode, write_obs);
+    rollout_phase<TL>(ctxp, lds_base, PH_STEP | (write_obs ? PH_OBS : 0) | (t + 1 < n_steps ? PH_ALLOC : 0), interval, use_vis, mode);
   }
+  if (!write_obs) rollout_phase<TL>(ctxp, lds_base, PH_OBS, interval, use_vis, mode);
   sim.sync_clock();
-  if (!write_obs) obs_for_env(sim, P, ctx->O, env);
+  sim.metrics(as_global(metrics) + (size_t)env * MUAVTA_N_METRICS);
+  lds_sync();
+  copy16(blob, L.S, sizeof(EnvState<TL>));
+}
+
+template <class TL>
+__global__ __launch_bounds__(WG) void k_metrics(const DevCtx* __restrict__ ctxp, double* metrics) {
+  const DevCtx& ctx = ctx_ref(ctxp);
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  copy16(L.S, blob_of<TL>(ctx, env), sizeof(EnvState<TL>));
+  lds_sync();
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, nullptr);
   sim.metrics(metrics + (size_t)env * MUAVTA_N_METRICS);
-  lds_sync();
-  copy16(&blobs[env], L.S, sizeof(EnvState<TL>));
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_metrics(const DevCtx* __restrict__ ctx, EnvState<TL>* blobs, double* metrics) {
-  const DevParams& P = ctx->P;
+__global__ __launch_bounds__(WG) void k_observe(const DevCtx* __restrict__ ctxp) {
+  const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L(smem);
-  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  copy16(L.S, blob_of<TL>(ctx, env), sizeof(EnvState<TL>));
   lds_sync();
-  Sim<TL> sim(*L.S, *L.X, P, nullptr);
-  sim.metrics(metrics + (size_t)env * MUAVTA_N_METRICS);
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, nullptr);
+  obs_for_env(sim, ctx.P, obs_ptrs(ctx), env);
 }
 
 template <class TL>
-__global__ __launch_bounds__(WG) void k_observe(const DevCtx* __restrict__ ctx, EnvState<TL>* blobs) {
-  const DevParams& P = ctx->P; const ObsPtrs& O = ctx->O;
+__global__ __launch_bounds__(WG) void k_tokens(const DevCtx* __restrict__ ctxp, typename Sim<TL>::TokPtrs K) {
+  const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L(smem);
-  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
+  copy16(L.S, blob_of<TL>(ctx, env), sizeof(EnvState<TL>));
   lds_sync();
-  Sim<TL> sim(*L.S, *L.X, P, nullptr);
-  obs_for_env(sim, P, O, env);
-}
-
-template <class TL>
-__global__ __launch_bounds__(WG) void k_tokens(const DevCtx* __restrict__ ctx, const EnvState<TL>* blobs, typename Sim<TL>::TokPtrs K) {
-  const DevParams& P = ctx->P;
-  const int env = blockIdx.x;
-  Lds<TL> L(smem);
-  copy16(L.S, &blobs[env], sizeof(EnvState<TL>));
-  lds_sync();
-  Sim<TL> sim(*L.S, *L.X, P, nullptr);
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, nullptr);
   sim.tokens(K, env);
 }
 
@@ -322,10 +363,10 @@ __global__ __launch_bounds__(WG) void k_tokens(const DevCtx* __restrict__ ctx, c
 typedef Tile<32, 64, 16, 16, 16, 8> TileLsapReg;
 typedef Tile<64, 128, 16, 16, 16, 8> TileLsapLds;  // keeps the full cost tile in LDS (the env's 64x128 tile evaluates costs on the fly)
 template <class TL, bool REG>
-__global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc, int64_t* row, int64_t* col) {
+__global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc, int64_t* row, int64_t* col, int32_t* status) {
   Lds<TL> L(smem);
   DevParams dummy;
-  Sim<TL> sim(*L.S, *L.X, dummy, nullptr);
+  Sim<TL> sim(*L.S, *reinterpret_cast<EnvCold<TL>*>(L.S) /* never touched by the solver */, *L.X, dummy, nullptr);
   const int prob = blockIdx.x;
   const double* c = cost + (size_t)prob * nr * nc;
   const bool tr = nc < nr;
@@ -338,6 +379,7 @@ __global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc,
   lds_sync();
   if constexpr (REG) sim.lsap_reg(Rr, Cc); else sim.lsap(Rr, Cc);
   if (threadIdx.x == 0) {
+    status[prob] = L.S->error;  // MUAVTA_ERR_LSAP: no finite assignment (scipy: "cost matrix is infeasible")
     int64_t* r = row + (size_t)prob * Rr;
     int64_t* cc = col + (size_t)prob * Rr;
     int n = 0;
@@ -386,7 +428,7 @@ thread_local std::string g_create_error;
     }                                                                                             \
   } while (0)
 
-enum TileKind { TK16 = 0, TK24 = 1, TK64 = 2, TK16L = 3 };
+enum TileKind { TK16 = 0, TK24 = 1, TK64 = 2 };
 
 }  // namespace
 
@@ -401,8 +443,9 @@ struct MuavtaEnv {
   size_t tok_bytes = 0;
   int n_envs = 0, device = 0;
   int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
-  size_t state_bytes = 0, lds_bytes = 0;
+  size_t state_bytes = 0, cold_bytes = 0, lds_bytes = 0;  // per env: LDS image (EnvState), HBM-only part (EnvCold)
   void* blobs = nullptr;
+  void* cold = nullptr;
   uint32_t* tapes = nullptr;
   DevCtx* d_ctx = nullptr;  // device copy of {P, O, tapes}
   uint64_t* d_seeds = nullptr;
@@ -414,7 +457,7 @@ struct MuavtaEnv {
   float last_ms = 0.f;
   bool last_seeded = false;
   bool did_reset = false;
-  std::vector<unsigned char> host_blobs;  // cache for muavta_get
+  std::vector<unsigned char> host_blobs, host_cold;  // cache for muavta_get
   bool host_valid = false;
   std::string err;
 };
@@ -426,13 +469,10 @@ int launch_attr(MuavtaEnv* e) {
   size_t lds = Lds<TL>::bytes();
   e->lds_bytes = lds;
   if (lds > 48 * 1024) {
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_reset<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_allocate<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_rollout<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_metrics<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_observe<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_tokens<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void* ks[] = {reinterpret_cast<const void*>(&k_reset<TL>), reinterpret_cast<const void*>(&k_step<TL>), reinterpret_cast<const void*>(&k_allocate<TL>),
+                        reinterpret_cast<const void*>(&k_rollout<TL>), reinterpret_cast<const void*>(&k_metrics<TL>), reinterpret_cast<const void*>(&k_observe<TL>),
+                        reinterpret_cast<const void*>(&k_tokens<TL>)};
+    for (const void* k : ks) HIPCHK(e, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   return MUAVTA_OK;
 }
@@ -440,7 +480,6 @@ int launch_attr(MuavtaEnv* e) {
 #define DISPATCH(e, CALL)                    \
   switch ((e)->tile) {                       \
     case TK16: { typedef Tile16 TL; CALL; } break; \
-    case TK16L: { typedef Tile16L TL; CALL; } break; \
     case TK24: { typedef Tile24 TL; CALL; } break; \
     default:   { typedef Tile64 TL; CALL; } break; \
   }
@@ -451,7 +490,7 @@ static void launch_tokens(MuavtaEnv* e, int kind, int max_tasks, int max_agents,
                           int32_t* replanned) {
   typename Sim<TL>::TokPtrs K{task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned,
                               kind, max_tasks, max_agents};
-  hipLaunchKernelGGL(k_tokens<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (const EnvState<TL>*)e->blobs, K);
+  hipLaunchKernelGGL(k_tokens<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, K);
 }
 
 int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
@@ -480,6 +519,10 @@ int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
   if (nA < 1) { *err = "no agents"; return MUAVTA_E_ARG; }
   if (p->num_obstacles < 0 || p->num_obstacles > 8) { *err = "num_obstacles must be in 0..8"; return MUAVTA_E_ARG; }
   if (p->max_time_steps < 1) { *err = "max_time_steps must be >= 1"; return MUAVTA_E_ARG; }
+  // time steps, deadlines (t + window_length), reveal times (t + threat_delay), commit locks (t + commit_horizon) and task
+  // ids (a few per step) are stored in 16 bits on the device
+  if (p->max_time_steps > 20000 || p->window_length > 10000 || p->threat_delay > 10000 || p->commit_horizon > 10000 || p->window_length < -10000 ||
+      p->threat_delay < -10000 || p->commit_horizon < -10000) { *err = "max_time_steps <= 20000 and window_length / threat_delay / commit_horizon within +-10000"; return MUAVTA_E_ARG; }
   d->n_agents = nA; d->n_tasks = nT + 1; d->max_tasks = d->n_tasks + 28; d->n_threats = nH;
   d->max_time_steps = p->max_time_steps; d->multiple_tasks_per_agent = p->multiple_tasks_per_agent;
   d->early_terminate = p->early_terminate; d->capability_mask = p->capability_mask; d->saturate_mask = p->saturate_mask;
@@ -518,7 +561,9 @@ size_t blob_bytes() { return sizeof(EnvState<TL>); }
 int sync_host(MuavtaEnv* e) {
   if (e->host_valid) return MUAVTA_OK;
   e->host_blobs.resize((size_t)e->n_envs * e->state_bytes);
+  e->host_cold.resize((size_t)e->n_envs * e->cold_bytes);
   HIPCHK(e, hipMemcpyAsync(e->host_blobs.data(), e->blobs, e->host_blobs.size(), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->host_cold.data(), e->cold, e->host_cold.size(), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->host_valid = true;
   return MUAVTA_OK;
@@ -530,6 +575,7 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
   typedef EnvState<TL> St;
   const int N = e->n_envs, A = e->P.n_agents, T = TL::T, H = e->P.n_threats, Q = TL::Q, E = TL::E, KW = TL::KW;
   St* blobs = reinterpret_cast<St*>(e->host_blobs.data());
+  EnvCold<TL>* cold = reinterpret_cast<EnvCold<TL>*>(e->host_cold.data());
   size_t need = 0;
   auto chk = [&](size_t n) { need = n; return bytes == n; };
   double* D = (double*)dst;
@@ -609,11 +655,11 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
       break;
     case MUAVTA_F_TASK_CUR:
       if (!chk((size_t)N * T * 6 * 8)) BAD();
-      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) for (int c = 0; c < 6; c++) RW(D[((size_t)n * T + s) * 6 + c], blobs[n].t_cur[c][s]);
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) for (int c = 0; c < 6; c++) RW(D[((size_t)n * T + s) * 6 + c], cold[n].t_cur[c][s]);
       break;
     case MUAVTA_F_TASK_ALLOC:
       if (!chk((size_t)N * T * 6 * 8)) BAD();
-      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) for (int c = 0; c < 6; c++) RW(D[((size_t)n * T + s) * 6 + c], blobs[n].t_alloc[c][s]);
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) for (int c = 0; c < 6; c++) RW(D[((size_t)n * T + s) * 6 + c], cold[n].t_alloc[c][s]);
       break;
     case MUAVTA_F_TASK_ORG_DONE:
       if (!chk((size_t)N * T * 2 * 8)) BAD();
@@ -621,7 +667,7 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
       break;
     case MUAVTA_F_TASK_TIMES:
       if (!chk((size_t)N * T * 2 * 8)) BAD();
-      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) { RW(D[((size_t)n * T + s) * 2], blobs[n].t_init[s]); RW(D[((size_t)n * T + s) * 2 + 1], blobs[n].t_dtime[s]); }
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) { RW(D[((size_t)n * T + s) * 2], cold[n].t_init[s]); RW(D[((size_t)n * T + s) * 2 + 1], cold[n].t_dtime[s]); }
       break;
     case MUAVTA_F_TASK_META:
       if (!chk((size_t)N * T * 8 * 4)) BAD();
@@ -771,16 +817,15 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   e->n_envs = n_envs;
   e->device = device;
   int ta = params->tile_agents > e->P.n_agents ? params->tile_agents : e->P.n_agents;
-  int tt = params->tile_tasks > 0 ? params->tile_tasks : 32;
+  int tt = params->tile_tasks > 0 ? params->tile_tasks : 0;
   int th = params->tile_threats > e->P.n_threats ? params->tile_threats : e->P.n_threats;
   if (ta <= Tile16::A && tt <= Tile16::T && th <= Tile16::H) e->tile = TK16;
-  else if (ta <= Tile16L::A && tt <= Tile16L::T && th <= Tile16L::H) e->tile = TK16L;
   else if (ta <= Tile24::A && tt <= Tile24::T && th <= Tile24::H) e->tile = TK24;
   else if (ta <= Tile64::A && tt <= Tile64::T && th <= Tile64::H) e->tile = TK64;
   else { g_create_error = "muavta_create: requested tile exceeds 64 agents x 128 task slots x 48 threats"; delete e; return MUAVTA_E_ARG; }
   size_t scratch_bytes = 0;
   DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->Q = TL::Q; e->state_bytes = sizeof(EnvState<TL>);
-                scratch_bytes = sizeof(Scratch<TL>); });
+                e->cold_bytes = sizeof(EnvCold<TL>); scratch_bytes = sizeof(Scratch<TL>); });
   (void)scratch_bytes;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); muavta_destroy(e); return MUAVTA_E_HIP; } } while (0)
   CK(hipSetDevice(device));
@@ -791,6 +836,8 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   const size_t N = (size_t)n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
   CK(hipMalloc(&e->blobs, N * e->state_bytes));
   CK(hipMemsetAsync(e->blobs, 0, N * e->state_bytes, e->stream));
+  CK(hipMalloc(&e->cold, N * e->cold_bytes));
+  CK(hipMemsetAsync(e->cold, 0, N * e->cold_bytes, e->stream));
   CK(hipMalloc(&e->tapes, N * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * sizeof(uint32_t)));
   CK(hipMalloc(&e->d_seeds, N * sizeof(uint64_t)));
   CK(hipMalloc(&e->d_act_agent, N * e->A * sizeof(int32_t)));
@@ -806,7 +853,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   {
     DevCtx h;
     memset(&h, 0, sizeof(h));
-    h.P = e->P; h.O = e->O; h.tapes = e->tapes;
+    h.P = e->P; h.O = e->O; h.tapes = e->tapes; h.blobs = e->blobs; h.cold = e->cold;
     CK(hipMalloc((void**)&e->d_ctx, sizeof(DevCtx)));
     CK(hipMemcpyAsync(e->d_ctx, &h, sizeof(DevCtx), hipMemcpyHostToDevice, e->stream));
     CK(hipStreamSynchronize(e->stream));  // `h` is a stack object
@@ -823,7 +870,7 @@ int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
+  hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -837,27 +884,21 @@ int muavta_dims(const MuavtaEnv* e, MuavtaDims* d) {
   if (!e || !d) return MUAVTA_E_ARG;
   d->n_envs = e->n_envs; d->n_agents = e->P.n_agents; d->tile_agents = e->A; d->tile_tasks = e->T; d->tile_threats = e->H;
   d->max_tasks = e->P.max_tasks; d->obs_task_width = 21; d->obs_agent_width = 9; d->queue_cap = e->Q; d->event_cap = e->E;
-  d->action_cap = e->A; d->state_bytes = (int64_t)e->state_bytes;
+  d->action_cap = e->A; d->state_bytes = (int64_t)(e->state_bytes + e->cold_bytes);
   d->n_threats = e->P.n_threats; d->known_words = (e->T + 31) / 32; d->lds_bytes = (int32_t)e->lds_bytes; d->legal_words = (e->P.max_tasks + 63) / 64;
   return MUAVTA_OK;
 }
 
-// seeds are in e->d_seeds: run the two seeding kernels on the handle's stream (MUAVTA_SEED_IN_KERNEL=1: leave it to the
-// reset kernel, the pre-existing path kept for A/B runs)
+// seeds are in e->d_seeds: run the seeding kernel on the handle's stream
 static int seed_streams(MuavtaEnv* e, const uint32_t** out) {
-  static const bool in_kernel = getenv("MUAVTA_SEED_IN_KERNEL") && atoi(getenv("MUAVTA_SEED_IN_KERNEL")) != 0;
   *out = nullptr;
-  if (in_kernel) return MUAVTA_OK;
   const size_t N = (size_t)e->n_envs;
   if (!e->d_seedbuf) {
     HIPCHK(e, hipMalloc((void**)&e->d_seedbuf, N * 4 * 624 * sizeof(uint32_t)));
   }
-  static const size_t seed_lds = (size_t)624 * SEED_LD * 4 + 16 * 3 * 8;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seed_lds));
-    attr_set = true;
-  }
+  const size_t seed_lds = (size_t)624 * SEED_LD * 4 + 16 * 3 * 8;
+  // (per device, and cheap: set it on every call rather than track which devices have seen it)
+  HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seed_lds));
   hipLaunchKernelGGL(k_seed, dim3((unsigned)((N + 15) / 16)), dim3(WG), seed_lds, e->stream, (const uint64_t*)e->d_seeds, (int)N,
                      (int)(e->P.num_obstacles > 0), e->d_seedbuf);
   HIPCHK(e, hipGetLastError());
@@ -871,8 +912,7 @@ int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
   HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   const uint32_t* sb = nullptr;
   { int rc = seed_streams(e, &sb); if (rc) return rc; }
-  DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, e->d_seeds,
-                                 (EnvState<TL>*)e->blobs, sb));
+  DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (const uint64_t*)e->d_seeds, sb));
   HIPCHK(e, hipGetLastError());
   e->did_reset = true;
   e->host_valid = false;
@@ -890,8 +930,7 @@ static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
     da = e->d_act_agent; di = e->d_act_index;
   }
   if (e->d_rel) HIPCHK(e, hipMemsetAsync(e->d_rel, 0, (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double), e->stream));
-  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (EnvState<TL>*)e->blobs,
-                                 da, di, e->A, e->d_rel));
+  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, da, di, e->A, e->d_rel));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   return MUAVTA_OK;
@@ -921,8 +960,8 @@ int muavta_allocate(MuavtaEnv* e, int32_t interval, int32_t use_vis, int32_t* ac
   if (!e) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "allocate before reset"; return MUAVTA_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
-  DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (EnvState<TL>*)e->blobs,
-                                 interval, use_vis, e->alloc_mode, e->d_act_agent, e->d_act_index, e->A));
+  DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, interval, use_vis, e->alloc_mode,
+                                 e->d_act_agent, e->d_act_index, e->A));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   if (act_agent && act_index) {
@@ -949,8 +988,8 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
   e->last_seeded = ds != nullptr;
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
-  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds, e->stream, (const DevCtx*)e->d_ctx, ds, (EnvState<TL>*)e->blobs,
-                                 n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb));
+  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds, e->stream, (const DevCtx*)e->d_ctx, ds, n_steps, interval, use_vis,
+                                 e->alloc_mode, write_obs, e->d_metrics, sb));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
   e->did_reset = true;
@@ -1078,7 +1117,7 @@ int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
 int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from the current state (after muavta_set)
   if (!e) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
-  DISPATCH(e, hipLaunchKernelGGL(k_observe<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (EnvState<TL>*)e->blobs));
+  DISPATCH(e, hipLaunchKernelGGL(k_observe<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx));
   HIPCHK(e, hipGetLastError());
   return MUAVTA_OK;
 }
@@ -1096,7 +1135,7 @@ int muavta_metrics(MuavtaEnv* e, double* out) {
   if (!e || !out) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "metrics before reset"; return MUAVTA_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
-  DISPATCH(e, hipLaunchKernelGGL(k_metrics<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (EnvState<TL>*)e->blobs, e->d_metrics));
+  DISPATCH(e, hipLaunchKernelGGL(k_metrics<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, e->d_metrics));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1131,21 +1170,24 @@ int muavta_set(MuavtaEnv* e, MuavtaField field, const void* src, size_t bytes) {
   DISPATCH(e, rc = gather<TL>(e, field, const_cast<void*>(src), bytes, true));
   if (rc) return rc;
   HIPCHK(e, hipMemcpyAsync(e->blobs, e->host_blobs.data(), e->host_blobs.size(), hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->cold, e->host_cold.data(), e->host_cold.size(), hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
 }
 
-int muavta_get_state(MuavtaEnv* e, void* dst, size_t bytes) {
-  if (!e || !dst || bytes != (size_t)e->n_envs * e->state_bytes) return MUAVTA_E_ARG;
+int muavta_get_state(MuavtaEnv* e, void* dst, size_t bytes) {  // [N x EnvState | N x EnvCold]
+  if (!e || !dst || bytes != (size_t)e->n_envs * (e->state_bytes + e->cold_bytes)) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
-  HIPCHK(e, hipMemcpyAsync(dst, e->blobs, bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync(dst, e->blobs, (size_t)e->n_envs * e->state_bytes, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipMemcpyAsync((char*)dst + (size_t)e->n_envs * e->state_bytes, e->cold, (size_t)e->n_envs * e->cold_bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
 }
 int muavta_set_state(MuavtaEnv* e, const void* src, size_t bytes) {
-  if (!e || !src || bytes != (size_t)e->n_envs * e->state_bytes) return MUAVTA_E_ARG;
+  if (!e || !src || bytes != (size_t)e->n_envs * (e->state_bytes + e->cold_bytes)) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
-  HIPCHK(e, hipMemcpyAsync(e->blobs, src, bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->blobs, src, (size_t)e->n_envs * e->state_bytes, hipMemcpyHostToDevice, e->stream));
+  HIPCHK(e, hipMemcpyAsync(e->cold, (const char*)src + (size_t)e->n_envs * e->state_bytes, (size_t)e->n_envs * e->cold_bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->host_valid = false;
   e->did_reset = true;
@@ -1196,31 +1238,41 @@ int muavta_lsap_impl(int32_t device, const double* cost, int32_t n, int32_t nr, 
   if (!cost || !row || !col || n < 1 || nr < 1 || nc < 1) { g_create_error = "muavta_lsap: bad arguments"; return MUAVTA_E_ARG; }
   int mn = nr < nc ? nr : nc, mx = nr < nc ? nc : nr;
   if (mn > Tile64::A || mx > Tile64::T) { g_create_error = "muavta_lsap: at most 64 x 128"; return MUAVTA_E_ARG; }
+  // scipy.optimize.linear_sum_assignment raises ValueError("matrix contains invalid numeric entries") for NaN / -inf
+  for (size_t i = 0, m = (size_t)n * nr * nc; i < m; i++)
+    if (std::isnan(cost[i]) || cost[i] == -INFINITY) { g_create_error = "muavta_lsap: matrix contains invalid numeric entries (NaN or -inf)"; return MUAVTA_E_ARG; }
   const bool fits_reg = mn <= TileLsapReg::A && mx <= TileLsapReg::T;
   if (impl < MUAVTA_LSAP_AUTO || impl > MUAVTA_LSAP_REGISTERS || (impl == MUAVTA_LSAP_REGISTERS && !fits_reg)) {
     g_create_error = "muavta_lsap_impl: unknown solver, or problem beyond 32 x 64 for the register solver"; return MUAVTA_E_ARG;
   }
   const bool use_reg = impl == MUAVTA_LSAP_REGISTERS || (impl == MUAVTA_LSAP_AUTO && fits_reg);
-#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); hipFree(dc); hipFree(dr); hipFree(dcl); return MUAVTA_E_HIP; } } while (0)
-  double* dc = nullptr; int64_t *dr = nullptr, *dcl = nullptr;
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); hipFree(dc); hipFree(dr); hipFree(dcl); hipFree(dst); return MUAVTA_E_HIP; } } while (0)
+  double* dc = nullptr; int64_t *dr = nullptr, *dcl = nullptr; int32_t* dst = nullptr;
   CK(hipSetDevice(device));
   size_t cb = (size_t)n * nr * nc * sizeof(double), rb = (size_t)n * mn * sizeof(int64_t);
-  CK(hipMalloc(&dc, cb)); CK(hipMalloc(&dr, rb)); CK(hipMalloc(&dcl, rb));
+  CK(hipMalloc(&dc, cb)); CK(hipMalloc(&dr, rb)); CK(hipMalloc(&dcl, rb)); CK(hipMalloc(&dst, (size_t)n * sizeof(int32_t)));
   CK(hipMemcpy(dc, cost, cb, hipMemcpyHostToDevice));
   if (use_reg) {
     size_t lds = Lds<TileLsapReg>::bytes();
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap<TileLsapReg, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_lsap<TileLsapReg, true>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
+    hipLaunchKernelGGL((k_lsap<TileLsapReg, true>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl, dst);
   } else {
     size_t lds = Lds<TileLsapLds>::bytes();
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_lsap<TileLsapLds, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_lsap<TileLsapLds, false>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl);
+    hipLaunchKernelGGL((k_lsap<TileLsapLds, false>), dim3(n), dim3(WG), lds, 0, dc, nr, nc, dr, dcl, dst);
   }
   CK(hipGetLastError());
+  std::vector<int32_t> status((size_t)n);
+  CK(hipMemcpy(status.data(), dst, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
   CK(hipMemcpy(row, dr, rb, hipMemcpyDeviceToHost));
   CK(hipMemcpy(col, dcl, rb, hipMemcpyDeviceToHost));
 #undef CK
-  hipFree(dc); hipFree(dr); hipFree(dcl);
+  hipFree(dc); hipFree(dr); hipFree(dcl); hipFree(dst);
+  for (int i = 0; i < n; i++)
+    if (status[(size_t)i]) {  // scipy: ValueError("cost matrix is infeasible")
+      g_create_error = "muavta_lsap: cost matrix " + std::to_string(i) + " is infeasible";
+      return MUAVTA_E_ARG;
+    }
   return MUAVTA_OK;
 }
 

@@ -62,70 +62,96 @@ struct Tile {
   static constexpr int H = H_;  // threats
   static constexpr int R = R_;  // pending reveals
   static constexpr int E = E_;  // events per list
-  static constexpr int Q = Q_;  // agent queue depth (reference max measured: 6 / 10 / 5 on the three tiles)
+  static constexpr int Q = Q_;  // agent queue depth (reference max measured: 7 / 10 / 5 on the three tiles)
   static constexpr int KW = (T_ + 31) / 32;  // known-mask words per agent
+  static_assert(A_ <= 64 && T_ <= 128 && H_ <= 64, "ids of agents / slots / threats are stored in int8");
 };
 
 template <int A> struct KnowMask { typedef uint64_t type; };  // one bit per agent
 template <> struct KnowMask<16> { typedef uint16_t type; };
 template <> struct KnowMask<24> { typedef uint32_t type; };
+template <int A> struct BucketMask { typedef unsigned long long type; };  // one bit per agent, set by LDS atomics (>= 32 bits)
+template <> struct BucketMask<16> { typedef uint32_t type; };
+template <> struct BucketMask<24> { typedef uint32_t type; };
+
+// Narrow storage types: every index below is bounded by the tile (agents < 64, slots < 128, threats < 64), task ids and
+// time steps by muavta_create's argument checks (max_time_steps <= 20000; ids grow by a few per step).  The device code
+// reads them as int: LDS sub-dword loads cost the same as dword loads and the blob shrinks by ~3.5 KB on the 16-agent
+// tile — residency on the CU is bound by LDS bytes per env.
+typedef int8_t i8;
+typedef int16_t i16;
+typedef uint8_t u8;
+
+// Part of an env that lives in HBM only (one record per env, L2-resident while the rollout runs): the six-component
+// requirement vectors of the tasks, the per-queue-entry travel times and the derived init/done times — touched when an
+// allocation changes, when a task is created or concluded, and by the observation / token writers (all lanes, coalesced
+// within a row), never by the per-step movement / sensing / threat phases.  Keeping them out of LDS is what lets 16 envs
+// of the 16-agent tile share one CU's 160 KiB.
+template <class TL>
+struct alignas(16) EnvCold {
+  enum { A = TL::A, T = TL::T, Q = TL::Q };
+  double t_cur[6][T], t_alloc[6][T];  // currentReqs, allocatedReqs
+  double t_init[T], t_dtime[T];       // initTime, doneTime
+  double a_qtime[A][Q];               // allocationDetails[agent][1] (time_to_task) of each queued task
+  double obst[8][3];                  // obstacles (x, y, size): only with num_obstacles > 0
+};
 
 template <class TL>
 struct alignas(16) EnvState {
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
-  // ---- agents (index = UAV.id = position in agents_obj) ------------------------------------
+  // ---- 8-byte arrays --------------------------------------------------------------------------
   double a_px[A], a_py[A];          // position
   double a_nfx[A], a_nfy[A];        // next_free_position
   double a_nft[A];                  // next_free_time
   double a_dist[A];                 // env.agent_distances
   double a_caps[6][A];              // currentCap2Task
-  double a_qtime[A][Q];             // allocationDetails[agent][1] (time_to_task) of each queued task
-  int32_t a_qid[A][Q];              // queued task ids (head first); qlen == 0 <=> [task_idle]
-  int32_t a_qslot[A][Q];            // slot hint for a_qid (valid iff t_id[slot] == id)
-  int32_t a_qlen[A];
-  int32_t a_state[A], a_task_start[A], a_fail[A], a_acap[A], a_type[A], a_name[A];
-  int32_t a_reeval[A], a_last_id[A], a_last_slot[A], a_commit[A];
-  int32_t a_gone[A];                // ids in agent_known_tasks[a] whose slot was released: len(known) = popcount(known[a]) + a_gone[a]
-  // ---- task slots -----------------------------------------------------------------------------
   double t_px[T], t_py[T];
-  double t_cur[6][T], t_alloc[6][T];  // currentReqs, allocatedReqs
-  double t_org[T], t_done[T];         // orgReqs[typeIdx], doneReqs[typeIdx]
-  double t_init[T], t_dtime[T];       // initTime, doneTime
-  int32_t t_id[T];                    // -1 = free slot
-  int32_t t_status[T], t_type[T], t_created[T], t_deadline[T], t_required[T], t_flags[T];
-  uint32_t t_elig[T];
-  int32_t t_threat[T];                // relative_threat (threat id) or -1
-  int32_t t_prot_agent[T], t_prot_id[T], t_prot_slot[T];  // escort: protected agent / Rec task
-  int32_t t_ndet[T];                  // len(allocationDetails)
-  uint64_t t_bucket[T];               // allocation_table[id] as agent bitmask
-  int32_t t_order[T];                 // live slots in ascending id (== creation) order
-  int32_t open_slot[T];               // env.last_tasks_info (slots), status != 2 at last observation
-  uint8_t t_row[T];                   // inverse of open_slot: row of a slot in last_tasks_info
-  uint32_t known[A][KW];              // agent_known_tasks as slot bitmask (bits of free slots are kept clear)
-  uint32_t free_slots[KW];            // bit s set <=> slot s is free
-  // ---- threats (index = Threat.id) ------------------------------------------------------------
+  double t_org[T], t_done[T];       // orgReqs[typeIdx], doneReqs[typeIdx]
   double h_px[H], h_py[H];
-  int32_t h_status[H];                // -9 = still waiting in its group
-  int32_t h_target[H], h_mission[H], h_intercept[H];
-  int32_t h_task_id[H], h_task_slot[H], h_det_slot[H], h_acap[H], h_type[H], h_group[H];
-  int32_t h_tflags[H];                // copy of the Int task's TF_DEADLINE|TF_COUNTED once its slot is freed
-  int32_t h_tdeadline[H];
-  int32_t h_order[H];                 // env.threats (spawn order)
-  int32_t g_next[MUAVTA_MAX_GROUPS], g_end[MUAVTA_MAX_GROUPS];  // threats_groups as [next, end) id ranges
-  // ---- lists ------------------------------------------------------------------------------------
-  int32_t ev_tag[E], ev_arg[E];       // env.event_list (generated this step)
-  int32_t dev_tag[E], dev_arg[E];     // infos['events'] (drained at the start of the last step)
-  int32_t pend_time[R], pend_id[R];
+  // ---- 4-byte arrays --------------------------------------------------------------------------
+  typename BucketMask<A>::type t_bucket[T];  // allocation_table[id] as agent bitmask
+  uint32_t known[A][KW];            // agent_known_tasks as slot bitmask (bits of free slots are kept clear)
+  uint32_t free_slots[KW];          // bit s set <=> slot s is free
+  int32_t act_index[A];             // staged actions: index into last_tasks_info as given (may be out of range)
+  // ---- 2-byte arrays --------------------------------------------------------------------------
+  i16 a_qid[A][Q];                  // queued task ids (head first); qlen == 0 <=> [task_idle]
+  i16 a_task_start[A], a_fail[A], a_last_id[A], a_commit[A];
+  i16 a_gone[A];                    // ids in agent_known_tasks[a] whose slot was released: len(known) = popcount(known[a]) + a_gone[a]
+  i16 t_id[T];                      // -1 = free slot
+  i16 t_created[T], t_deadline[T], t_prot_id[T];
+  i16 h_task_id[H], h_tdeadline[H];
+  i16 ev_arg[E], dev_arg[E];
+  i16 pend_time[R], pend_id[R];
+  i16 esc_id[A], esc_pid[A];
   typename KnowMask<A>::type pend_know[R];  // who knew the task when its slot was released before the reveal came due
-  uint8_t pend_slot[R];
-  int32_t esc_agent[A], esc_id[A], esc_slot[A];  // _escort_by_recon in insertion order (entries of escorts that
-  int32_t esc_pid[A], esc_pslot[A];              // expired by window are never popped, as in the reference); protected Rec task
-  int32_t act_agent[A], act_slot[A], act_index[A];  // actions staged by the allocator
-  double area[3][3];                  // mission areas: top-left x, y, width (height == width)
-  double obst[8][3];
-  // ---- scalars --------------------------------------------------------------------------------
+  // ---- 1-byte arrays --------------------------------------------------------------------------
+  i8 a_qslot[A][Q];                 // slot hint for a_qid (valid iff t_id[slot] == id)
+  i8 a_qlen[A];
+  i8 a_state[A], a_acap[A], a_type[A], a_name[A], a_reeval[A], a_last_slot[A];
+  i8 t_status[T], t_type[T], t_required[T];
+  u8 t_flags[T], t_elig[T];
+  i8 t_threat[T];                   // relative_threat (threat id) or -1
+  i8 t_prot_agent[T], t_prot_slot[T];  // escort: protected agent / Rec task
+  i8 t_ndet[T];                     // len(allocationDetails)
+  u8 t_order[T];                    // live slots in ascending id (== creation) order
+  u8 open_slot[T];                  // env.last_tasks_info (slots), status != 2 at last observation
+  u8 t_row[T];                      // inverse of open_slot: row of a slot in last_tasks_info
+  i8 h_status[H];                   // -9 = still waiting in its group
+  i8 h_target[H], h_mission[H], h_intercept[H];
+  i8 h_task_slot[H], h_det_slot[H], h_acap[H], h_type[H], h_group[H];
+  u8 h_tflags[H];                   // copy of the Int task's TF_DEADLINE|TF_COUNTED once its slot is freed
+  u8 h_order[H];                    // env.threats (spawn order)
+  i8 g_next[MUAVTA_MAX_GROUPS], g_end[MUAVTA_MAX_GROUPS];  // threats_groups as [next, end) id ranges
+  u8 ev_tag[E];                     // env.event_list (generated this step)
+  u8 dev_tag[E];                    // infos['events'] (drained at the start of the last step)
+  u8 pend_slot[R];
+  i8 esc_agent[A], esc_slot[A], esc_pslot[A];  // _escort_by_recon in insertion order (entries of escorts that expired by
+                                               // window are never popped, as in the reference); esc_pid/pslot: protected Rec task
+  i8 act_agent[A], act_slot[A];     // actions staged by the allocator
+  // ---- scalars (everything above may double as scratch while a reset sets up the RNG) -----------
+  double area[3][3];                // mission areas: top-left x, y, width (height == width)
   double F_Reward, total_distance, last_reward, step_reward;
-  double r_time_penalty, r_alloc;     // reward terms evaluated mid-step (DroneEnv.py:1140-1145), before the world dynamics
+  double r_time_penalty, r_alloc;   // reward terms evaluated mid-step (DroneEnv.py:1140-1145), before the world dynamics
   int32_t time_steps, conclusion_time, n_order, n_open, n_active_threats, n_events, n_dev, n_pending, n_escorts, n_act;
   int32_t next_task_id, n_reached, n_retired_empty_buckets;
   int32_t n_reallocations, n_task_switches, n_arrivals, n_missed_windows, n_on_time, n_windowed_tasks,
@@ -141,12 +167,11 @@ struct alignas(16) EnvState {
   int32_t times_dirty;                // some allocationDetails changed since initTime/doneTime were rebuilt
 };
 
-// Standard tiles (BASELINE.json configs): 16x32, 24x48, 64x128.
-typedef Tile<16, 32, 16, 48, 40, 8> Tile16;  // events <= 16, pending reveals <= 22 measured over 4096 seeds
-// Same fleet as Tile16 with head-room: 40 task slots (the reference stops creating arrivals at max_tasks - 1 = 40 tasks for
-// the 16-UAV configs) and queues of 10; the cost tile gives way to register-built cost columns so that it still fits
-// 8 workgroups per CU.  Chosen with tile_tasks in (32, 40]: ~1 in 16,000 seeds of WPS_hard_x2 needs more than 32 slots.
-typedef Tile<16, 40, 16, 48, 40, 10, true> Tile16L;
+// Standard tiles (BASELINE.json configs).  The 16-agent tile has 40 task slots — the bound at which the reference stops
+// creating arrivals for a 16-UAV config (DroneEnv.py:145-147,1646-1689: len(tasks) >= max_tasks - 1) — and queues of 10:
+// with 32 slots / queue 8 about 1 in 10,000 seeds of WPS_hard_x2 overflowed (34 slots); events <= 16, pending reveals <= 22
+// measured over 4096 seeds.
+typedef Tile<16, 40, 16, 48, 40, 10, true> Tile16;
 typedef Tile<24, 48, 24, 88, 40, 12, true> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
 typedef Tile<64, 128, 48, 128, 96, 8, false, true> Tile64;
 

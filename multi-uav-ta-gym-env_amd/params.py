@@ -198,7 +198,7 @@ def params_from_config(config: Any, flags: Optional[Dict[str, Any]] = None, *, t
     p.escort_agent_type_mask = mask
     n_threats = sum(p.threat_count[: p.n_threat_groups])
     p.tile_agents = int(tile_agents) or max(16, _round_up(p.n_agents, 8))
-    p.tile_tasks = int(tile_tasks) or max(32, _round_up(p.n_tasks + p.n_threat_groups + n_threats + 8, 16))
+    p.tile_tasks = int(tile_tasks) or max(40, _round_up(p.n_tasks + p.n_threat_groups + n_threats + 8, 16))
     p.tile_threats = int(tile_threats) or max(16, _round_up(n_threats, 8))
     if p.n_agents > p.tile_agents or n_threats > p.tile_threats:
         raise ValueError("tile too small for this fleet / threat list")

@@ -167,13 +167,13 @@ WPS_ENV_FLAGS: Dict[str, Any] = {
 
 # (agent tile, task-slot tile, threat capacity) used for each benchmark configuration.
 TILES = {
-    "WPS_easy": (16, 32, 16),
-    "WPS_hard": (16, 32, 16),
-    "WPS_burst": (16, 32, 16),
+    "WPS_easy": (16, 40, 16),
+    "WPS_hard": (16, 40, 16),
+    "WPS_burst": (16, 40, 16),
     "WPS_attn": (16, 48, 16),
     "WPS_attn_AWACS": (16, 48, 16),
-    "D2_popup_threats": (16, 32, 16),
-    "WPS_hard_x2": (16, 32, 16),
+    "D2_popup_threats": (16, 40, 16),
+    "WPS_hard_x2": (16, 40, 16),
     "WPS_escort": (24, 48, 24),
     "WPS_escort24": (24, 48, 24),
     "WPS_burst64": (64, 128, 48),

@@ -180,3 +180,36 @@ def lsap(cost):
     n = lib().orc_lsap(_p(cost), nr, nc, _p(row), _p(col))
     assert n == m
     return row, col
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Oracle episodes in parallel worker processes (spawned, so they never inherit a GPU context): the checker for the
+# full-size GPU tests.  Returns the [len(seeds), 30] metrics array of `rollout_mode(seed, 150, interval, use_vis, mode)`.
+def _metrics_worker(args):
+    case, seeds, n_steps, interval, use_vis, mode = args
+    import numpy as _np
+    from muavta_amd.params import params_for_case
+    e = OracleEnv(params_for_case(case))
+    out = _np.zeros((len(seeds), 30))
+    for i, s in enumerate(seeds):
+        e.rollout_mode(int(s), n_steps, interval, use_vis, mode)
+        out[i] = e.metrics()
+    return out
+
+
+def parallel_metrics(case, seeds, interval, use_vis=1, mode=0, n_steps=150, procs=None):
+    import multiprocessing as mp
+    lib()  # build the oracle once, before the workers race for it
+    seeds = [int(s) for s in seeds]
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    procs = max(1, min(procs or 32, cores, (len(seeds) + 63) // 64))
+    if procs == 1:
+        return _metrics_worker((case, seeds, n_steps, interval, use_vis, mode))
+    chunk = (len(seeds) + procs * 4 - 1) // (procs * 4)
+    jobs = [(case, seeds[i:i + chunk], n_steps, interval, use_vis, mode) for i in range(0, len(seeds), chunk)]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        parts = pool.map(_metrics_worker, jobs)
+    return np.concatenate(parts, axis=0)

@@ -161,19 +161,70 @@ def test_fused_rollout_matches_reference_metrics(path):
     assert np.array_equal(env.metrics(), want)
 
 
-@pytest.mark.parametrize("case,interval,n", [("WPS_hard_x2", 20, 4096), ("WPS_escort24", 12, 1024), ("WPS_burst64", 20, 256), ("WPS_escort", 12, 1024),
+@pytest.mark.parametrize("case,interval,n", [("WPS_hard_x2", 20, 4096), ("WPS_escort24", 12, 4096), ("WPS_burst64", 20, 1024), ("WPS_escort", 12, 1024),
                                               ("WPS_hard", 20, 2048), ("WPS_attn", 20, 512)],
                          ids=["cfg2b", "cfg4b", "cfg5", "escort", "hard", "attn"])
 def test_fused_rollout_vs_oracle_many_seeds(case, interval, n):
+    """BASELINE configs 2, 4 and 5 at their full per-GPU sizes (4096 / 4096 / 1024 envs): every env's 30 metrics."""
     env = _env(case, n)
     seeds = np.arange(1000, 1000 + n, dtype=np.uint64)
     env.rollout(seeds, 150, interval, True, False)
     got = env.rollout_metrics()
     assert np.all(env.get("ERROR") == 0)
-    o = orc.OracleEnv(params_for_case(case))
-    for i, s in enumerate(seeds):
-        o.rollout(int(s), 150, interval, 1)
-        assert np.array_equal(got[i], o.metrics()), f"{case} seed {s}: {dict(zip(METRIC_KEYS, got[i] - o.metrics()))}"
+    want = orc.parallel_metrics(case, seeds, interval)
+    bad = np.nonzero(~np.all(got == want, axis=1))[0]
+    assert len(bad) == 0, f"{case}: seeds {seeds[bad[:8]]} differ, e.g. {dict(zip(METRIC_KEYS, got[bad[0]] - want[bad[0]]))}"
+
+
+def test_config3_seed_range_0_32767_no_overflow_bit_equal():
+    """BASELINE config 3: global env indices 0..32767 of WPS_hard_x2 in 4096-env shards (what each of the 8 GPUs runs).
+    Every env must produce a result (ERROR == 0: no tile overflow) and all 30 metrics must equal the oracle's."""
+    case, shard = "WPS_hard_x2", 4096
+    env = _env(case, shard)
+    want = orc.parallel_metrics(case, np.arange(32768), 20)
+    for r in range(8):
+        seeds = np.arange(r * shard, (r + 1) * shard, dtype=np.uint64)
+        env.rollout(seeds, 150, 20, True, True)
+        got = env.rollout_metrics()
+        err = env.get("ERROR")
+        assert not err.any(), f"shard {r}: envs {seeds[np.nonzero(err)[0][:8]]} overflowed the tile (codes {np.unique(err[err != 0])})"
+        bad = np.nonzero(~np.all(got == want[r * shard:(r + 1) * shard], axis=1))[0]
+        assert len(bad) == 0, f"shard {r}: seeds {seeds[bad[:8]]} differ"
+
+
+SOAK = [("WPS_easy", "hungarian", 0, 20, 1024), ("WPS_burst", "hungarian", 0, 20, 1024), ("WPS_attn_AWACS", "hungarian", 0, 20, 512),
+        ("D2_popup_threats", "hungarian", 0, 20, 512), ("WPS_hard", "urgency_pair", 1, 20, 1024), ("WPS_hard_x2", "urgency_pair", 1, 20, 2048),
+        ("WPS_escort", "urgency_coalition", 2, 12, 1024), ("WPS_escort24", "urgency_coalition", 2, 12, 512), ("WPS_hard", "hungarian_gated", 3, 20, 1024)]
+
+
+@pytest.mark.parametrize("case,name,mode,interval,n", SOAK, ids=[f"{c[0]}-{c[1]}" for c in SOAK])
+def test_soak_slice(case, name, mode, interval, n):
+    """A bounded slice of tests/soak.py: other cases / allocator modes on a seed range no other test uses."""
+    env = _env(case, n)
+    env.set_allocator(name)
+    seeds = np.arange(200000, 200000 + n, dtype=np.uint64)
+    env.rollout(seeds, 150, interval, True, False)
+    got, err = env.rollout_metrics(), env.get("ERROR")
+    assert not err.any(), f"{case} {name}: envs {seeds[np.nonzero(err)[0][:8]]} overflowed the tile"
+    want = orc.parallel_metrics(case, seeds, interval, 1, mode)
+    bad = np.nonzero(~np.all(got == want, axis=1))[0]
+    assert len(bad) == 0, f"{case} {name}: seeds {seeds[bad[:8]]} differ"
+
+
+@pytest.mark.parametrize("case,interval", [("WPS_hard_x2", 20), ("WPS_escort24", 12), ("WPS_burst64", 20)])
+def test_observation_after_fused_rollout(case, interval):
+    """The observation tensors a fused rollout leaves behind (written by its last step) equal the oracle's, per-step
+    observation write on and off; so do the step result and the whole device state."""
+    n = 6
+    seeds = np.arange(40, 40 + n, dtype=np.uint64)
+    for write_obs, steps in ((True, 150), (False, 150), (True, 67)):
+        env = _env(case, n)
+        env.rollout(seeds, steps, interval, True, write_obs)
+        snap = Snapshot(env)
+        for i in range(n):
+            o = orc.OracleEnv(params_for_case(case))
+            o.rollout(int(seeds[i]), steps, interval, 1)
+            compare(snap, i, o, f"{case} seed {seeds[i]} after a fused rollout of {steps} steps (obs write {write_obs})")
 
 
 def test_global_hungarian_and_split_rollout():
@@ -192,7 +243,7 @@ def test_global_hungarian_and_split_rollout():
 
 
 def test_full_size_properties_cfg2():
-    """BASELINE config 2 (4096 envs, 16x32 tile): determinism, checkpoint/resume, and counter invariants."""
+    """BASELINE config 2 (4096 envs, 16-agent tile): determinism, checkpoint/resume, and counter invariants."""
     case, n = "WPS_hard_x2", 4096
     env = _env(case, n)
     seeds = np.arange(n, dtype=np.uint64)
@@ -336,6 +387,44 @@ def test_invalid_and_out_of_range_actions():
         for i, o in enumerate(oracles):
             o.step([a for a, _ in acts[i]], [j for _, j in acts[i]])
             compare(snap, i, o, f"random actions seed {i} t={t + 1}")
+
+
+def test_agent_ids_outside_the_fleet_are_rejected():
+    """An agent id >= n_agents would index the per-agent arrays of the env blob: muavta_step refuses it (MUAVTA_E_ARG)
+    and leaves the state untouched (the reference's actions dict is keyed by name: an unknown name is a KeyError)."""
+    from muavta_amd.native import MuavtaError
+    case, n = "WPS_hard", 3
+    env = _env(case, n)
+    env.reset(np.arange(n, dtype=np.uint64))
+    before = env.get_state()
+    for bad_id in (env.n_agents, env.A_tile, 1 << 20):
+        aa, ai = env.pack_actions([[(0, 1)], [(1, 0), (bad_id, 2)], []])
+        with pytest.raises(MuavtaError, match="agent id"):
+            env.step(aa, ai)
+    assert np.array_equal(before, env.get_state())
+    aa, ai = env.pack_actions([[(0, 1)], [(1, 0)], [(env.n_agents - 1, 0)]])
+    aa[2, 1] = -1; aa[2, 2] = 1 << 20  # behind the terminator: ignored
+    env.step(aa, ai)
+    assert np.all(env.get("ERROR") == 0) and np.all(env.get("SCALARS")[:, 0] == 1)
+
+
+def test_lsap_rejects_what_scipy_rejects():
+    """scipy.optimize.linear_sum_assignment raises ValueError for NaN / -inf entries and for an infeasible matrix."""
+    from muavta_amd.batched import lsap
+    from muavta_amd.native import MuavtaError
+    c = np.arange(12, dtype=np.float64).reshape(3, 4)
+    for bad in (np.nan, -np.inf):
+        d = c.copy(); d[1, 2] = bad
+        with pytest.raises(MuavtaError, match="invalid numeric"):
+            lsap(d)
+    d = c.copy(); d[1, :] = np.inf
+    for impl in ("registers", "lds"):
+        with pytest.raises(MuavtaError, match="infeasible"):
+            lsap(d, impl=impl)
+    d = c.copy(); d[1, :3] = np.inf  # still feasible through column 3
+    r, cc = lsap(d)
+    orow, ocol = orc.lsap(d)
+    assert np.array_equal(r, orow) and np.array_equal(cc, ocol)
 
 
 @pytest.mark.parametrize("case,seed", [("WPS_hard", 2), ("WPS_escort", 1)])
@@ -737,7 +826,7 @@ def test_large_bursts_on_the_64_agent_tile():
                                                             ("WPS_burst64", "urgency_coalition", 2, 12, 1, 128)])
 def test_fused_rollout_allocator_modes_vs_oracle_many_seeds(case, name, mode, interval, vis, n):
     # Urgency-Pair keeps more tasks open on the 16-UAV workload: 5 of 8192 seeds need more than 32 slots / 8 queue entries
-    env = _env(case, n, **({"tile_tasks": 40} if (case, name) == ("WPS_hard_x2", "urgency_pair") else {}))
+    env = _env(case, n)
     env.set_allocator(name)
     seeds = np.arange(5000, 5000 + n, dtype=np.uint64)
     env.rollout(seeds, 150, interval, bool(vis), False)
@@ -749,11 +838,11 @@ def test_fused_rollout_allocator_modes_vs_oracle_many_seeds(case, name, mode, in
         assert np.array_equal(got[i], o.metrics()), f"{case} {name} seed {s}"
 
 
-def test_roomier_16_agent_tile_runs_the_seeds_that_overflow_32_slots():
-    """tile_tasks=40 selects the 16x40 tile (register-built cost columns, queue 10): stepwise parity, and the seeds that
-    need more than 32 task slots / 8 queue entries (flagged MUAVTA_E_CAPACITY on the 16x32 tile) match the oracle."""
+def test_16_agent_tile_holds_the_seeds_that_need_more_than_32_slots():
+    """The 16-agent tile has 40 task slots and queues of 10 (the reference stops creating arrivals at max_tasks - 1 = 40
+    tasks for a 16-UAV config): stepwise parity on the seeds that need more than 32 live slots / 8 queue entries."""
     case = "WPS_hard_x2"
-    env = _env(case, 4, tile_tasks=40)
+    env = _env(case, 4)
     assert env.T == 40 and env.Q == 10
     seeds = np.array([9649, 6231, 0, 1], dtype=np.uint64)  # 9649: 34 slots under Local-Hungarian
     oracles = [orc.OracleEnv(params_for_case(case)) for _ in seeds]
@@ -770,11 +859,8 @@ def test_roomier_16_agent_tile_runs_the_seeds_that_overflow_32_slots():
         snap = Snapshot(env)
         for i, o in enumerate(oracles):
             compare(snap, i, o, f"16x40 tile seed {seeds[i]} t={t + 1}")
-    small = _env(case, 1)
-    small.rollout(np.array([9649], dtype=np.uint64), 150, 20, True, False)
-    assert small.get("ERROR")[0] == 1  # the 16x32 tile says so instead of returning a wrong episode
     for name, mode, sd in (("urgency_pair", 1, [6231, 8273, 9649, 11430, 11656]),):
-        big = _env(case, len(sd), tile_tasks=40)
+        big = _env(case, len(sd))
         big.set_allocator(name)
         big.rollout(np.array(sd, dtype=np.uint64), 150, 20, True, False)
         assert not big.get("ERROR").any()
