@@ -168,7 +168,10 @@ DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
 
 #ifdef MUAVTA_PROF
 __device__ unsigned long long g_prof[48];
-#define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_acc[i] += t_ - prof_last; prof_last = t_; } } while (0)
+// per-phase cycle accumulators of a diagnostic build: 48 + 1 (last stamp) u64 words in LDS right behind the Scratch tile
+#define MUAVTA_PROF_LDS_BYTES 400
+#define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_lds()[i] += t_ - prof_lds()[48]; prof_lds()[48] = t_; } } while (0)
+#define PROF_COUNT(i, n) do { if (threadIdx.x == 0) prof_lds()[i] += (n); } while (0)
 #else
 #define PROF(i) do { } while (0)
 #endif
@@ -177,8 +180,9 @@ template <class TL>
 struct Sim {
   typedef EnvState<TL> State;
 #ifdef MUAVTA_PROF
-  unsigned long long prof_acc[48] = {0}, prof_last = clock64();
-  __device__ void prof_flush() { if (threadIdx.x == 0) for (int i = 0; i < 48; i++) atomicAdd(&g_prof[i], prof_acc[i]); }
+  DEV unsigned long long* prof_lds() { return reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(&X) + sizeof(Scratch<TL>)); }
+  DEV void prof_begin() { if (threadIdx.x < 48) prof_lds()[threadIdx.x] = 0; if (threadIdx.x == 0) prof_lds()[48] = clock64(); lds_sync(); }
+  DEV void prof_flush() { lds_sync(); if (threadIdx.x < 48) atomicAdd(&g_prof[threadIdx.x], prof_lds()[threadIdx.x]); }
 #endif
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   typedef EnvCold<TL> Cold;
@@ -1114,7 +1118,7 @@ struct Sim {
       cold_sync();  // (lanes that dropped a retired head shifted their EnvCold queue-time row)
       PROF(26);
 #ifdef MUAVTA_PROF
-      if (threadIdx.x == 0) { prof_acc[40] += 1000; if (first < P.n_agents) prof_acc[41] += 1000; }
+      PROF_COUNT(40, 1000); if (first < P.n_agents) PROF_COUNT(41, 1000);
 #endif
       if (first >= P.n_agents) break;
       if (lane == 0) step_serial_move(first, first + 1, r_quality);
@@ -2202,7 +2206,7 @@ struct Sim {
         return;
       }
 #ifdef MUAVTA_PROF
-      if (threadIdx.x == 0) { prof_acc[30] += 1000; if (any_ret) prof_acc[31] += 1000; }
+      PROF_COUNT(30, 1000); if (any_ret) PROF_COUNT(31, 1000);
 #endif
       if (any_ret) {
         if (rel_log) cold_sync();

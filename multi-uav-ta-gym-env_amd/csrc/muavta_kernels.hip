@@ -280,9 +280,19 @@ __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp
 // reference becomes a load from the dynamic-LDS offset table) nor take generic pointers (FLAT accesses): it gets the LDS
 // base as a number and rebuilds typed pointers.  An iteration is  step -> observation write -> NEXT step's allocate:
 // the function's return waits for all memory operations, and this way the observation stores have drained by then.
+#ifdef MUAVTA_PROF
+#define PROF_AT(sim, i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); (sim).prof_lds()[i] += t_ - (sim).prof_lds()[48]; (sim).prof_lds()[48] = t_; } } while (0)
+#define PROF_EXTRA_LDS MUAVTA_PROF_LDS_BYTES
+#else
+#define PROF_AT(sim, i) do { } while (0)
+#define PROF_EXTRA_LDS 0
+#endif
+#ifndef MUAVTA_PHASE_ATTR
+#define MUAVTA_PHASE_ATTR __forceinline__
+#endif
 enum { PH_ALLOC = 1, PH_STEP = 2, PH_OBS = 4 };
 template <class TL>
-__device__ __noinline__ void rollout_phase(const DevCtx* ctxp, uint32_t lds_base, int phases, int interval, int use_vis, int mode) {
+__device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds_base, int phases, int interval, int use_vis, int mode) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L((unsigned char*)(AS3 unsigned char*)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base));
@@ -291,10 +301,7 @@ __device__ __noinline__ void rollout_phase(const DevCtx* ctxp, uint32_t lds_base
   if (phases & PH_OBS) obs_for_env(sim, ctx.P, obs_ptrs(ctx), env);
   lds_sync();
   if ((phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) sim.allocate(interval, use_vis, mode);
-#ifdef MUAVTA_PROF
-  if (threadIdx.x == 0) { unsigned long long t_ = clock64(); sim.prof_acc[20] += t_ - sim.prof_last; sim.prof_last = t_; }
-  sim.prof_flush();
-#endif
+  PROF_AT(sim, 20);
 }
 
 template <class TL>
@@ -305,6 +312,9 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* 
   Lds<TL> L(smem);
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
+#ifdef MUAVTA_PROF
+  sim.prof_begin();
+#endif
   if (seeds) {
     sim.reset(seeds[env], seedbuf + (size_t)env * 4 * 624);
   } else {
@@ -313,16 +323,24 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* 
   }
   uint32_t lds_base = (uint32_t)(uintptr_t)(AS3 unsigned char*)smem;
   asm volatile("" : "+v"(lds_base));  // opaque: keeps constant propagation from re-introducing the symbol into the callee
-  if (n_steps > 0) rollout_phase<TL>(ctxp, lds_base, PH_ALLOC, interval, use_vis, mode);
-  for (int t = 0; t < n_steps; t++) {
-    if (L.S->terminated || L.S->truncated) break;  // uniform: read from LDS after a barrier
-    rollout_phase<TL>(ctxp, lds_base, PH_STEP | (write_obs ? PH_OBS : 0) | (t + 1 < n_steps ? PH_ALLOC : 0), interval, use_vis, mode);
+  // schedule: [allocate] , n_steps x [step, observation, next allocate] , [observation if it was not written per step] —
+  // driven through ONE call site so that an inlined build carries one copy of the body
+  for (int k = n_steps > 0 ? 0 : n_steps + 1; k <= n_steps + 1; k++) {
+    int ph;
+    if (k == 0) ph = PH_ALLOC;
+    else if (k <= n_steps) {
+      if (L.S->terminated || L.S->truncated) { k = n_steps; continue; }  // uniform: read from LDS after a barrier
+      ph = PH_STEP | (write_obs ? PH_OBS : 0) | (k < n_steps ? PH_ALLOC : 0);
+    } else ph = write_obs ? 0 : PH_OBS;
+    if (ph) rollout_phase<TL>(ctxp, lds_base, ph, interval, use_vis, mode);
   }
-  if (!write_obs) rollout_phase<TL>(ctxp, lds_base, PH_OBS, interval, use_vis, mode);
   sim.sync_clock();
   sim.metrics(as_global(metrics) + (size_t)env * MUAVTA_N_METRICS);
   lds_sync();
   copy16(blob, L.S, sizeof(EnvState<TL>));
+#ifdef MUAVTA_PROF
+  sim.prof_flush();
+#endif
 }
 
 template <class TL>
@@ -988,7 +1006,7 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
   e->last_seeded = ds != nullptr;
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
-  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds, e->stream, (const DevCtx*)e->d_ctx, ds, n_steps, interval, use_vis,
+  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds + PROF_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, ds, n_steps, interval, use_vis,
                                  e->alloc_mode, write_obs, e->d_metrics, sb));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));

@@ -9,7 +9,7 @@ timeout -k 10 420 python -m pytest tests -m gpu -x -q > "$OUT/pytest.log" 2>&1; 
 tail -5 "$OUT/pytest.log"
 timeout -k 10 300 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "bench rc=$?"
 cat "$OUT/bench.json"
-for v in w2; do
+for v in none; do
   if [ -f tools/_build/libmuavta_$v.so ]; then
     MUAVTA_SO=tools/_build/libmuavta_$v.so timeout -k 10 300 python bench.py --no-cpu-baseline > "$OUT/bench_$v.json" 2> "$OUT/bench_$v.err"; echo "bench $v rc=$?"
     cat "$OUT/bench_$v.json"

@@ -10,7 +10,7 @@ from muavta_amd import native
 so = os.path.join(ROOT, "tools", "_build", "libmuavta_prof.so")
 os.makedirs(os.path.dirname(so), exist_ok=True)
 if "--build" in sys.argv:
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + [f for f in native.HIPCC_FLAGS if not f.startswith("-O")] + ["-O3", "-DMUAVTA_PROF", "-o", so, os.path.join(native.CSRC, "muavta_kernels.hip")])
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + native.HIPCC_FLAGS + ["-DMUAVTA_PROF"] + [a for a in sys.argv if a.startswith("-D")] + ["-o", so, os.path.join(native.CSRC, "muavta_kernels.hip")])
     sys.exit(0)
 native.SO_PATH = so
 from muavta_amd.batched import BatchedMultiUAVEnv

@@ -5,7 +5,7 @@ from muavta_amd.params import params_from_config
 from muavta_amd.scenarios import CASE_SPECS, WPS_ENV_FLAGS
 base = dict(CASE_SPECS["WPS_hard_x2"])
 def run(name, spec, obs=True, interval=20):
-    p = params_from_config(spec, dict(WPS_ENV_FLAGS), tile_agents=16, tile_tasks=32, tile_threats=16)
+    p = params_from_config(spec, dict(WPS_ENV_FLAGS), tile_agents=16, tile_tasks=40, tile_threats=16)
     env = BatchedMultiUAVEnv(p, 4096)
     seeds = np.arange(4096, dtype=np.uint64)
     for _ in range(2): env.rollout(seeds, 150, interval, True, obs); env.sync()
