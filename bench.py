@@ -67,6 +67,9 @@ def measured_traffic(case: str, envs: int):
 
 
 def host_cpu():
+    """(CPU model, cores this process may actually use, logical CPUs visible).  The usable count is the smaller of the
+    affinity mask and the cgroup CPU quota: a GPU box leases a share of its host (16 CPUs per GPU on this pool) while
+    still showing every logical CPU, and oversubscribing the share only slows the baseline down."""
     model = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -76,17 +79,33 @@ def host_cpu():
     except OSError:
         pass
     try:
-        cores = len(os.sched_getaffinity(0))
+        visible = len(os.sched_getaffinity(0))
     except AttributeError:
-        cores = os.cpu_count() or 1
-    return model, max(1, cores)
+        visible = os.cpu_count() or 1
+    quota = None
+    try:  # cgroup v2
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = int(q) / int(period)
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    cores = visible if quota is None else max(1, min(visible, int(quota + 0.5)))
+    return model, max(1, cores), visible
 
 
 def cpu_baseline(case: str, interval: int, seconds: float):
     """Oracle (CPU restatement, test infrastructure) on every host core this process may use: bounded sample."""
     import multiprocessing as mp
 
-    model, cores = host_cpu()
+    model, cores, visible = host_cpu()
+    if os.environ.get("MUAVTA_CPU_BASELINE_PROCS"):
+        cores = int(os.environ["MUAVTA_CPU_BASELINE_PROCS"])
     with mp.get_context("spawn").Pool(cores) as pool:
         t0 = time.perf_counter()
         res = pool.starmap(_cpu_worker, [(case, interval, seconds, 10_000_000 + 4096 * r) for r in range(cores)])
@@ -94,9 +113,9 @@ def cpu_baseline(case: str, interval: int, seconds: float):
     steps = sum(r[0] for r in res)
     busy = max(r[1] for r in res)
     return {
-        "value": steps / busy, "unit": "env-steps/s", "cores": cores, "cpu_model": model, "kind": "port",
+        "value": steps / busy, "unit": "env-steps/s", "cores": cores, "cpu_model": model, "logical_cpus_visible": visible, "kind": "port",
         "sample": f"{steps // HORIZON} episodes of {case} (150 steps each, Local-Hungarian interval {interval}) "
-                  f"split over {cores} processes (one per usable host core), {busy:.1f} s of work each ({wall:.1f} s wall incl. spawn)",
+                  f"split over {cores} processes (one per host core this box may use: min of affinity mask and cgroup CPU quota), {busy:.1f} s of work each ({wall:.1f} s wall incl. spawn)",
     }
 
 

@@ -154,6 +154,7 @@ typedef enum MuavtaField {
                                                        eligible mask(-1), x, y, orgReqs[type], doneReqs[type], initTime, doneTime,
                                                        currentReqs[6], allocatedReqs[6]                              (read-only) */
   MUAVTA_F_KNOWN_COUNT,        /* i32 [N, A]         len(agent_known_tasks[a]) incl. ids of released tasks (read-only)  */
+  MUAVTA_F_ESCORTS,            /* i32 [N, tile_agents, 2]  env._escort_by_recon in insertion order: (recon UAV.id, escort Task.id), -1 padded (read-only) */
   MUAVTA_F_COUNT_
 } MuavtaField;
 
@@ -234,6 +235,28 @@ int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
  * with task column j on a valid edge); replanned i32 [N] = that allocate's replan gate fired at the current time step (the trainer builds a sample then).
  * muavta_tokens copies into host buffers (NULL = skip that output) and synchronises; muavta_tokens_device writes to
  * device buffers of the caller (e.g. torch tensors on the same GPU) on the handle's stream without synchronising. */
+/* The reference's mutators that callers invoke on the env objects directly, outside step() — experiments/test_escort.py
+ * :61-75,95-96,107,236 and the allocators' scaffolding — for ONE env of the batch (env_index).  iargs[8], darg and the
+ * meaning of out[MUAVTA_CALL_OUT] depend on `op`; ids are UAV.id / Task.id as everywhere in this ABI:
+ *   MUAVTA_OP_UAV_ALLOCATE        UAV.allocate(task, time_step) (DroneEnvComponents.py:55-95): iargs = {agent, task id, time_step};
+ *                                 out[0] = its return value (1 = queued now, 0 = already queued / task concluded)
+ *   MUAVTA_OP_CREATE_ESCORT       MultiUAVEnv._create_escort_for(recon, rec_task) (DroneEnv.py:1888-1917): iargs = {recon agent, Rec
+ *                                 task id}; out[0] = id of the (new or existing) escort task, -1 = None (escorts disabled)
+ *   MUAVTA_OP_SYNC_ESCORTS        MultiUAVEnv._sync_escorts() (:1964-2000)
+ *   MUAVTA_OP_RETIRE_ESCORT       MultiUAVEnv._retire_escort(escort_task, failed) (:1938-1950): iargs = {escort task id, failed}
+ *   MUAVTA_OP_ESCORT_FIGHTERS_NEAR  MultiUAVEnv._escort_fighters_near(agent, radius) (:1746-1764): iargs = {agent}, darg = radius
+ *                                 (< 0: escort_radius); out[0] = n, out[1..n] = UAV.id nearest first
+ *   MUAVTA_OP_ACTION_VALID        MultiUAVEnv._is_task_action_valid(agent, task) (:341-363): iargs = {agent, task id}; out[0] = 0/1
+ *   MUAVTA_OP_SET_QUEUE           `agent.tasks = [t0, t1, ...]` (plain list assignment, e.g. test_escort.py:95: no Task bookkeeping):
+ *                                 iargs = {agent, n <= 6, id0 .. id5}; [task_idle] (id 0) is the empty queue
+ * Runs on the handle's stream and synchronises.  Returns MUAVTA_E_ARG for ids outside the env. */
+typedef enum MuavtaOp {
+  MUAVTA_OP_UAV_ALLOCATE = 0, MUAVTA_OP_CREATE_ESCORT, MUAVTA_OP_SYNC_ESCORTS, MUAVTA_OP_RETIRE_ESCORT,
+  MUAVTA_OP_ESCORT_FIGHTERS_NEAR, MUAVTA_OP_ACTION_VALID, MUAVTA_OP_SET_QUEUE, MUAVTA_OP_COUNT_
+} MuavtaOp;
+#define MUAVTA_CALL_OUT 72
+int muavta_call(MuavtaEnv* env, int32_t env_index, int32_t op, const int32_t* iargs, double darg, int32_t* out);
+
 /* Per-step log of released task slots (off by default; the Python facade turns it on to keep agent_visibility_map()
  * exact for retired ids, DroneEnv.py:1595-1599).  Costs one global atomic per released slot in muavta_step only. */
 int muavta_set_release_log(MuavtaEnv* env, int32_t enable);

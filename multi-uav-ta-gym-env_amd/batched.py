@@ -20,7 +20,7 @@ F = {name: i for i, name in enumerate([
     "AGENT_POS", "AGENT_STATE", "AGENT_HEAD", "AGENT_QUEUE", "AGENT_NFT", "AGENT_NFP", "AGENT_CAPS", "AGENT_ATTACK_CAP",
     "AGENT_TYPE", "AGENT_NAME_IDX", "AGENT_DIST", "AGENT_MISC", "TASK_ID", "TASK_STATUS", "TASK_POS", "TASK_CUR",
     "TASK_ALLOC", "TASK_ORG_DONE", "TASK_META", "TASK_TIMES", "KNOWN", "THREAT_POS", "THREAT_META", "SCALARS",
-    "OPEN_IDS", "EVENTS", "EVENT_LIST", "STAGED_ACTIONS", "ERROR", "RELEASE_LOG", "KNOWN_COUNT"])}
+    "OPEN_IDS", "EVENTS", "EVENT_LIST", "STAGED_ACTIONS", "ERROR", "RELEASE_LOG", "KNOWN_COUNT", "ESCORTS"])}
 
 
 def _vp(a: Optional[np.ndarray]):
@@ -131,6 +131,17 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_tokens(self.h, k, mt, ma, *[_vp(a) for a in arrs.values()]))
         return arrs
 
+    OPS = {"uav_allocate": 0, "create_escort": 1, "sync_escorts": 2, "retire_escort": 3, "escort_fighters_near": 4,
+           "action_valid": 5, "set_queue": 6}
+
+    def call(self, op: str, iargs=(), darg: float = -1.0, env_index: int = 0) -> np.ndarray:
+        """The reference's out-of-step mutators on one env (include/muavta.h: muavta_call): returns out[72]."""
+        ia = np.zeros(8, dtype=np.int32)
+        ia[: len(iargs)] = np.asarray(list(iargs), dtype=np.int32)
+        out = np.zeros(72, dtype=np.int32)
+        self._ck(self.L.muavta_call(self.h, int(env_index), self.OPS[op], _vp(ia), float(darg), _vp(out)))
+        return out
+
     def set_release_log(self, enable: bool = True):
         """Per-step log of released task slots (`get("RELEASE_LOG")`): id + knower mask; used by the facade."""
         self._ck(self.L.muavta_set_release_log(self.h, int(bool(enable))))
@@ -210,7 +221,7 @@ class BatchedMultiUAVEnv:
             "THREAT_POS": ((N, H, 2), f64), "THREAT_META": ((N, H, 8), i32), "SCALARS": ((N, N_SCALARS), f64),
             "OPEN_IDS": ((N, T), i32), "EVENTS": ((N, E, 2), i32), "EVENT_LIST": ((N, E, 2), i32),
             "STAGED_ACTIONS": ((N, self.A_tile, 3), i32), "ERROR": ((N,), i32),
-            "RELEASE_LOG": ((N, 1 + 29 * T), f64), "KNOWN_COUNT": ((N, A), i32),
+            "RELEASE_LOG": ((N, 1 + 29 * T), f64), "KNOWN_COUNT": ((N, A), i32), "ESCORTS": ((N, self.A_tile, 2), i32),
         }[name]
 
     def get(self, name: str) -> np.ndarray:

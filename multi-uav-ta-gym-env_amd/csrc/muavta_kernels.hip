@@ -376,6 +376,83 @@ __global__ __launch_bounds__(WG) void k_tokens(const DevCtx* __restrict__ ctxp, 
   sim.tokens(K, env);
 }
 
+// muavta_call: one of the reference's out-of-step mutators on ONE env, with the device routines step() itself uses.
+struct CallArgs { int32_t op, env, i[8]; double d; };
+template <class TL>
+__global__ __launch_bounds__(WG) void k_call(const DevCtx* __restrict__ ctxp, CallArgs a, int32_t* out) {
+  const DevCtx& ctx = ctx_ref(ctxp);
+  const int env = a.env, lane = threadIdx.x;
+  Lds<TL> L(smem);
+  EnvState<TL>& S = *L.S;
+  EnvState<TL>* blob = blob_of<TL>(ctx, env);
+  copy16(L.S, blob, sizeof(EnvState<TL>));
+  lds_sync();
+  Sim<TL> sim(S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
+  auto slot_of = [&](int id) -> int {  // uniform: the live slot holding task `id`, or -1
+    int found = -1;
+    for (int base = 0; base < TL::T; base += WG) {
+      const int s = base + lane;
+      const unsigned long long m = __ballot(id > 0 && s < TL::T && S.t_id[s] == id);
+      if (m) found = base + __ffsll((long long)m) - 1;
+    }
+    return found;
+  };
+  for (int k = lane; k < MUAVTA_CALL_OUT; k += WG) out[k] = 0;
+  __syncthreads();
+  const int ag = a.i[0];
+  switch (a.op) {
+    case MUAVTA_OP_UAV_ALLOCATE: {
+      const int s = slot_of(a.i[1]);
+      sim.tnow = a.i[2];
+      if (lane == 0) out[0] = (s >= 0 && sim.uav_allocate(ag, s)) ? 1 : 0;
+    } break;
+    case MUAVTA_OP_CREATE_ESCORT: {
+      const int s = slot_of(a.i[1]);
+      if (lane == 0) {
+        if (ctx.P.escort_enabled && s >= 0) sim.create_escort_for(ag, s);
+        const int k = sim.escort_lookup(ag);
+        out[0] = (ctx.P.escort_enabled && k >= 0) ? (int)S.esc_id[k] : -1;
+      }
+    } break;
+    case MUAVTA_OP_SYNC_ESCORTS:
+      if (ctx.P.escort_enabled) sim.sync_escorts_coop();
+      break;
+    case MUAVTA_OP_RETIRE_ESCORT:
+      if (lane == 0)
+        for (int k = 0; k < S.n_escorts; k++)
+          if (S.esc_id[k] == a.i[0]) { sim.retire_escort_entry(k, a.i[1] != 0); break; }
+      break;
+    case MUAVTA_OP_ESCORT_FIGHTERS_NEAR:
+      if (lane == 0) {
+        int* who = L.X->remaining;
+        const int n = sim.escort_fighters_near(ag, a.d < 0 ? ctx.P.escort_radius : a.d, who, L.X->v);
+        out[0] = n;
+        for (int k = 0; k < n && k + 1 < MUAVTA_CALL_OUT; k++) out[1 + k] = who[k];
+      }
+      break;
+    case MUAVTA_OP_ACTION_VALID: {
+      const int s = slot_of(a.i[1]);
+      if (lane == 0) out[0] = (s >= 0 && sim.action_valid(ag, s)) ? 1 : 0;
+    } break;
+    case MUAVTA_OP_SET_QUEUE: {
+      int slots[6];
+      for (int k = 0; k < 6; k++) slots[k] = (k < a.i[1]) ? slot_of(a.i[2 + k]) : -1;
+      if (lane == 0) {
+        int n = 0;
+        for (int k = 0; k < a.i[1] && k < 6 && n < TL::Q; k++) {
+          if (a.i[2 + k] == 0 || slots[k] < 0) continue;  // task_idle, or a task that is no longer resident
+          S.a_qid[ag][n] = (i16)a.i[2 + k]; S.a_qslot[ag][n] = (i8)slots[k]; sim.C.a_qtime[ag][n] = 0.0;
+          n++;
+        }
+        S.a_qlen[ag] = (i8)n;
+      }
+    } break;
+    default: break;
+  }
+  cold_sync();
+  copy16(blob, L.S, sizeof(EnvState<TL>));
+}
+
 // Stand-alone LSAP: one problem per workgroup, cost tile staged in LDS (transposed when nc < nr).
 // REG: the register-resident solver of the allocator path (rows <= 32, columns <= 64); else the LDS solver (64 x 128).
 typedef Tile<32, 64, 16, 16, 16, 8> TileLsapReg;
@@ -467,7 +544,7 @@ struct MuavtaEnv {
   uint32_t* tapes = nullptr;
   DevCtx* d_ctx = nullptr;  // device copy of {P, O, tapes}
   uint64_t* d_seeds = nullptr;
-  int32_t *d_act_agent = nullptr, *d_act_index = nullptr;
+  int32_t *d_act_agent = nullptr, *d_act_index = nullptr, *d_call_out = nullptr;
   double* d_metrics = nullptr;
   ObsPtrs O{};
   hipStream_t stream = nullptr;
@@ -489,7 +566,7 @@ int launch_attr(MuavtaEnv* e) {
   if (lds > 48 * 1024) {
     const void* ks[] = {reinterpret_cast<const void*>(&k_reset<TL>), reinterpret_cast<const void*>(&k_step<TL>), reinterpret_cast<const void*>(&k_allocate<TL>),
                         reinterpret_cast<const void*>(&k_rollout<TL>), reinterpret_cast<const void*>(&k_metrics<TL>), reinterpret_cast<const void*>(&k_observe<TL>),
-                        reinterpret_cast<const void*>(&k_tokens<TL>)};
+                        reinterpret_cast<const void*>(&k_tokens<TL>), reinterpret_cast<const void*>(&k_call<TL>)};
     for (const void* k : ks) HIPCHK(e, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
   return MUAVTA_OK;
@@ -768,6 +845,15 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
       if (scatter) { e->err = "ERROR is read-only"; return MUAVTA_E_ARG; }
       for (int n = 0; n < N; n++) I[n] = blobs[n].error;
       break;
+    case MUAVTA_F_ESCORTS:
+      if (!chk((size_t)N * TL::A * 2 * 4)) BAD();
+      if (scatter) { e->err = "ESCORTS is read-only"; return MUAVTA_E_ARG; }
+      for (int n = 0; n < N; n++) for (int k = 0; k < TL::A; k++) {
+        const bool v = k < blobs[n].n_escorts;
+        I[((size_t)n * TL::A + k) * 2] = v ? blobs[n].esc_agent[k] : -1;
+        I[((size_t)n * TL::A + k) * 2 + 1] = v ? blobs[n].esc_id[k] : -1;
+      }
+      break;
     case MUAVTA_F_KNOWN_COUNT:
       if (!chk((size_t)N * A * 4)) BAD();
       if (scatter) { e->err = "KNOWN_COUNT is read-only"; return MUAVTA_E_ARG; }
@@ -888,7 +974,7 @@ int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
+  hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -1114,6 +1200,26 @@ int muavta_tokens(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t max_age
   for (int i = 0; i < 10; i++)
     if (host[i]) HIPCHK(e, hipMemcpyAsync(host[i], b + off[i], sz[i], hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_call(MuavtaEnv* e, int32_t env_index, int32_t op, const int32_t* iargs, double darg, int32_t* out) {
+  if (!e || !out || op < 0 || op >= MUAVTA_OP_COUNT_ || env_index < 0 || env_index >= e->n_envs) { if (e) e->err = "muavta_call: bad argument"; return MUAVTA_E_ARG; }
+  if (!e->did_reset) { e->err = "muavta_call before reset"; return MUAVTA_E_STATE; }
+  CallArgs a;
+  memset(&a, 0, sizeof(a));
+  a.op = op; a.env = env_index; a.d = darg;
+  if (iargs) memcpy(a.i, iargs, sizeof(a.i));
+  const bool has_agent = op != MUAVTA_OP_SYNC_ESCORTS && op != MUAVTA_OP_RETIRE_ESCORT;
+  if (has_agent && (a.i[0] < 0 || a.i[0] >= e->P.n_agents)) { e->err = "muavta_call: agent id out of range"; return MUAVTA_E_ARG; }
+  if (op == MUAVTA_OP_SET_QUEUE && (a.i[1] < 0 || a.i[1] > 6)) { e->err = "muavta_call(SET_QUEUE): at most 6 tasks"; return MUAVTA_E_ARG; }
+  HIPCHK(e, hipSetDevice(e->device));
+  if (!e->d_call_out) HIPCHK(e, hipMalloc((void**)&e->d_call_out, MUAVTA_CALL_OUT * sizeof(int32_t)));
+  DISPATCH(e, hipLaunchKernelGGL(k_call<TL>, dim3(1), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, a, e->d_call_out));
+  HIPCHK(e, hipGetLastError());
+  HIPCHK(e, hipMemcpyAsync(out, e->d_call_out, MUAVTA_CALL_OUT * sizeof(int32_t), hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->host_valid = false;
   return MUAVTA_OK;
 }
 

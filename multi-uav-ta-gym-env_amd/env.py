@@ -12,9 +12,10 @@ object views below: UAV / Task / Threat proxies are cached per id, so identity t
 ``agent_visibility_map()`` is exact for every task that is still open; ids of tasks that were revealed only
 after they had retired (the reference keeps adding those to its sets) may be absent — no caller looks them up.
 
-Not mirrored (raise ``NotImplementedError``): the reference's private mutators that tests poke
-directly (``_create_escort_for``, ``UAV.allocate`` ...) — on this path state changes only through
-``reset`` / ``step``.
+The reference's out-of-step mutators that tests and allocator scaffolding call on the objects directly —
+``UAV.allocate``, ``UAV.tasks = [...]``, ``_create_escort_for``, ``_sync_escorts``, ``_retire_escort``,
+``_escort_fighters_near``, ``_is_task_action_valid``, ``_escort_by_recon`` (experiments/test_escort.py:61-75,95-96,236) —
+go through ``muavta_call`` (include/muavta.h) and run the same device routines ``step`` uses.
 """
 from __future__ import annotations
 
@@ -254,6 +255,15 @@ class UAVView:
         q = self._env._snap["AGENT_QUEUE"][self.id]
         return [self._env._task(int(t)) for t in q if t >= 0]
 
+    @tasks.setter
+    def tasks(self, value):
+        """Plain list assignment (e.g. `a.tasks = [env.task_idle]`, experiments/test_escort.py:95): no Task bookkeeping."""
+        ids = [int(t.id) for t in value]
+        if len(ids) > 6:
+            raise ValueError("at most 6 queued tasks can be assigned at once")
+        self._env._b.call("set_queue", [self.id, len(ids)] + ids)
+        self._env._after_call()
+
     @property
     def next_free_position(self):
         return np.array(self._env._snap["AGENT_NFP"][self.id])
@@ -298,7 +308,16 @@ class UAVView:
         return _ENGAGE[self.type]
 
     def allocate(self, task, time_step):
-        raise NotImplementedError("state changes only through MultiUAVEnv.step on the batched path")
+        """UAV.allocate (DroneEnvComponents.py:55-95) on the device state; returns what the reference returns."""
+        if task.id == 0:  # the idle task: `self.tasks = [task]`, next_free_* reset, returns False (:85-92)
+            if any(t.id == 0 for t in self.tasks):
+                return False
+            self._env._b.call("set_queue", [self.id, 0])
+            self._env._after_call()
+            return False
+        out = self._env._b.call("uav_allocate", [self.id, int(task.id), int(time_step)])
+        self._env._after_call()
+        return bool(out[0])
 
     def __repr__(self):
         return f"<UAV {self.name} id={self.id} state={self.state}>"
@@ -401,7 +420,7 @@ class MultiUAVEnv:
     def _scalar(self, col: int) -> float:
         return float(self._snap["SCALARS"][col])
 
-    def _refresh(self):
+    def _refresh(self, new_step: bool = True):
         self._snap.clear()
         ids = self._snap["TASK_ID"]
         for tid in ids[ids >= 0]:
@@ -612,13 +631,91 @@ class MultiUAVEnv:
     def get_initial_state(self):
         return {"state": self._b.get_state().copy(), "rng": self._b.get_rng().copy()}
 
+    # ------------------------------------------------------------------ spaces (DroneEnv.py:298-308, 310-323)
     def observation_space(self, agent):
-        raise NotImplementedError("the reference's declared space does not match what it returns (SURVEY A.2)")
+        """The reference's declared per-agent space (which its observations do not follow): a gymnasium
+        `Dict` of `Box`es when gymnasium is importable, else objects with the same `shape` / `low` / `high` / `dtype`."""
+        Dict_, Box_, _ = _spaces()
+        f32 = np.float32
+        return Dict_({
+            "agent_position": Box_(low=0, high=1, shape=(2,), dtype=f32),
+            "agent_state": Box_(low=0, high=1, shape=(5,), dtype=f32),
+            "agent_type": Box_(low=0, high=1, shape=(6,), dtype=f32),
+            "next_free_time": Box_(low=0, high=1, shape=(1,), dtype=f32),
+            "position_after_last_task": Box_(low=0, high=1, shape=(2,), dtype=f32),
+            "tasks_info": Box_(low=0, high=1, shape=(self.max_tasks * 12,), dtype=f32),
+        })
 
     def action_space(self, agent):
-        raise NotImplementedError("see observation_space")
+        """`Discrete(max_tasks)` for action_mode 'TaskAssign' (DroneEnv.py:283-285)."""
+        return _spaces()[2](self.max_tasks)
 
-    def _create_escort_for(self, *a, **k):
-        raise NotImplementedError("private mutators are not part of the batched path; escorts appear through step()")
+    # ------------------------------------------------------------------ out-of-step mutators (muavta_call)
+    def _after_call(self):
+        """A mutator changed the device state behind the cached views: re-read it (new tasks get their proxies)."""
+        self._refresh(new_step=False)
 
-    _sync_escorts = _retire_escort = _escort_fighters_near = _create_escort_for
+    @property
+    def _escort_by_recon(self) -> Dict[str, TaskView]:
+        """{recon UAV name: escort Task} in insertion order (DroneEnv.py:232)."""
+        out = {}
+        for a, tid in self._snap["ESCORTS"]:
+            if a >= 0:
+                out[self.agents_obj[int(a)].name] = self._task(int(tid))
+        return out
+
+    def _is_task_action_valid(self, agent, task) -> bool:  # :341-363
+        if task is None or task.id == 0:
+            return task is not None and task.status != 2
+        return bool(self._b.call("action_valid", [agent.id, int(task.id)])[0])
+
+    def _create_escort_for(self, recon_agent, rec_task):  # :1888-1917
+        if not self.escort_enabled or recon_agent is None:
+            return None
+        out = self._b.call("create_escort", [recon_agent.id, int(rec_task.id) if rec_task is not None else 0])
+        self._after_call()
+        return None if out[0] < 0 else self._task(int(out[0]))
+
+    def _sync_escorts(self):  # :1964-2000
+        self._b.call("sync_escorts")
+        self._after_call()
+
+    def _retire_escort(self, escort_task, failed: bool = False):  # :1938-1950
+        if escort_task is None or escort_task.status == 2:
+            return
+        self._b.call("retire_escort", [int(escort_task.id), int(bool(failed))])
+        self._after_call()
+
+    def _retire_escort_for(self, recon_agent, failed: bool = False):  # :1952-1957
+        if recon_agent is not None:
+            self._retire_escort(self._escort_by_recon.get(recon_agent.name), failed=failed)
+
+    def _escort_fighters_near(self, protected_agent, radius=None):  # :1746-1764
+        if protected_agent is None:
+            return []
+        out = self._b.call("escort_fighters_near", [protected_agent.id], -1.0 if radius is None else float(radius))
+        return [self.agents_obj[int(i)] for i in out[1:1 + int(out[0])]]
+
+
+class _Box:
+    def __init__(self, low, high, shape, dtype):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+
+class _Dict(dict):
+    @property
+    def spaces(self):
+        return self
+
+
+class _Discrete:
+    def __init__(self, n):
+        self.n, self.shape, self.dtype = int(n), (), np.int64
+
+
+def _spaces():
+    try:
+        from gymnasium.spaces import Box, Dict as GDict, Discrete
+        return GDict, Box, Discrete
+    except Exception:
+        return _Dict, _Box, _Discrete

@@ -26,7 +26,7 @@ EXPORTS = [
     "muavta_avoid_obstacles", "muavta_device_ptrs", "muavta_last_kernel_ms", "muavta_sync",
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
-    "muavta_last_seed_ms",
+    "muavta_last_seed_ms", "muavta_call",
 ]
 
 
@@ -104,6 +104,7 @@ def lib() -> C.CDLL:
     L.muavta_device_ptrs.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.muavta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.muavta_last_seed_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.muavta_call.argtypes = [vp, i32, i32, vp, C.c_double, vp]
     L.muavta_sync.argtypes = [vp]
     L.muavta_refresh_observation.argtypes = [vp]
     L.muavta_set_allocator.argtypes = [vp, i32]

@@ -1870,6 +1870,55 @@ void orc_get_scalars(void* h, double* s) {  // MUAVTA_S_* order
   s[17] = e->protection_breaches; s[18] = e->threats_intercepted; s[19] = e->recon_losses; s[20] = e->escort_losses;
   s[21] = e->mutual_support_engagements; s[22] = e->protected_rec_completed; s[23] = e->n_replans;
 }
+// ---- the reference's out-of-step mutators (include/muavta.h: muavta_call; same ops, same iargs / out conventions) and the
+// attribute writes its tests make on the objects (UAV.position / state / tasks, Task.position / required_agents)
+int orc_call(void* h, int op, const int32_t* i, double d, int32_t* out) {
+  Env* e = (Env*)h;
+  for (int k = 0; k < MUAVTA_CALL_OUT; k++) out[k] = 0;
+  const int nt = (int)e->tasks.size();
+  auto task_ok = [&](int id) { return id > 0 && id < nt; };
+  const bool has_agent = op != MUAVTA_OP_SYNC_ESCORTS && op != MUAVTA_OP_RETIRE_ESCORT;
+  if (has_agent && (i[0] < 0 || i[0] >= e->n_agents)) return -1;
+  switch (op) {
+    case MUAVTA_OP_UAV_ALLOCATE: {  // DroneEnvComponents.py:55-95
+      if (!task_ok(i[1])) return 0;
+      UAV& a = e->agents[i[0]];
+      const bool fresh = !Env::in_queue(a, i[1]) && e->tasks[i[1]].status != 2;
+      e->uav_allocate(a, i[1], i[2]);
+      out[0] = fresh ? 1 : 0;
+    } break;
+    case MUAVTA_OP_CREATE_ESCORT:
+      out[0] = task_ok(i[1]) ? e->create_escort_for(i[0], i[1]) : (e->P.escort_enabled ? e->escort_lookup(i[0]) : -1);
+      break;
+    case MUAVTA_OP_SYNC_ESCORTS: if (e->P.escort_enabled) e->sync_escorts(); break;
+    case MUAVTA_OP_RETIRE_ESCORT: if (task_ok(i[0])) e->retire_escort(i[0], i[1] != 0); break;
+    case MUAVTA_OP_ESCORT_FIGHTERS_NEAR: {
+      std::vector<int> v = e->escort_fighters_near(i[0], d < 0 ? e->P.escort_radius : d);
+      out[0] = (int)v.size();
+      for (size_t k = 0; k < v.size() && k + 1 < MUAVTA_CALL_OUT; k++) out[1 + k] = v[k];
+    } break;
+    case MUAVTA_OP_ACTION_VALID: out[0] = task_ok(i[1]) && e->is_task_action_valid(e->agents[i[0]], e->tasks[i[1]]) ? 1 : 0; break;
+    case MUAVTA_OP_SET_QUEUE: {
+      UAV& a = e->agents[i[0]];
+      a.tasks.clear();
+      for (int k = 0; k < i[1] && k < 6; k++) if (task_ok(i[2 + k])) a.tasks.push_back(i[2 + k]);
+      if (a.tasks.empty()) a.tasks.push_back(0);
+    } break;
+    default: return -1;
+  }
+  return 0;
+}
+void orc_set_agent_pos(void* h, int a, double x, double y) { Env* e = (Env*)h; e->agents[a].pos = {x, y}; }
+void orc_set_agent_state(void* h, int a, int st) { ((Env*)h)->agents[a].state = st; }
+void orc_set_agent_commit(void* h, int a, int v) { ((Env*)h)->agents[a].commit_until = v; }
+void orc_set_task_pos(void* h, int t, double x, double y) { Env* e = (Env*)h; e->tasks[t].pos = {x, y}; }
+void orc_set_task_required(void* h, int t, int n) { ((Env*)h)->tasks[t].required_agents = n; }
+int orc_get_escorts(void* h, int32_t* out, int cap) {  // _escort_by_recon in insertion order: (recon agent id, escort task id)
+  Env* e = (Env*)h;
+  int n = 0;
+  for (auto& p : e->escort_by_recon) { if (n >= cap) break; out[2 * n] = p.first; out[2 * n + 1] = p.second; n++; }
+  return n;
+}
 void orc_get_open(void* h, int32_t* ids) { Env* e = (Env*)h; for (size_t i = 0; i < e->last_tasks_info.size(); i++) ids[i] = e->last_tasks_info[i]; }
 void orc_get_events(void* h, int32_t* ev) { Env* e = (Env*)h; for (size_t i = 0; i < e->done_events.size(); i++) { ev[2 * i] = e->done_events[i].tag; ev[2 * i + 1] = e->done_events[i].arg; } }
 void orc_get_actions(void* h, int32_t* out) { Env* e = (Env*)h; for (size_t i = 0; i < e->last_actions.size(); i++) { out[2 * i] = e->last_actions[i].first; out[2 * i + 1] = e->last_actions[i].second; } }

@@ -57,12 +57,49 @@ class OracleBackend:
 
     get_rng = get_state
 
+    OPS = {"uav_allocate": 0, "create_escort": 1, "sync_escorts": 2, "retire_escort": 3, "escort_fighters_near": 4,
+           "action_valid": 5, "set_queue": 6}
+
+    def call(self, op, iargs=(), darg=-1.0, env_index=0):
+        ia = np.zeros(8, dtype=np.int32)
+        ia[: len(iargs)] = np.asarray(list(iargs), dtype=np.int32)
+        out = np.zeros(72, dtype=np.int32)
+        rc = self.o.L.orc_call(self.o.h, self.OPS[op], orc._p(ia), orc.C.c_double(float(darg)), orc._p(out))
+        if rc != 0:
+            raise ValueError(f"orc_call({op}) rejected its arguments")
+        return out
+
+    def set(self, name, value):
+        """The attribute writes the facade's proxies make (slot == task id here)."""
+        L, h, v = self.o.L, self.o.h, np.asarray(value)
+        if name == "AGENT_POS":
+            for a in range(self.n_agents):
+                L.orc_set_agent_pos(h, a, orc.C.c_double(float(v[0, a, 0])), orc.C.c_double(float(v[0, a, 1])))
+        elif name == "AGENT_STATE":
+            for a in range(self.n_agents):
+                L.orc_set_agent_state(h, a, int(v[0, a]))
+        elif name == "AGENT_MISC":
+            for a in range(self.n_agents):
+                L.orc_set_agent_commit(h, a, int(v[0, a, 4]))
+        elif name == "TASK_POS":
+            for t in range(1, v.shape[1]):
+                L.orc_set_task_pos(h, t, orc.C.c_double(float(v[0, t, 0])), orc.C.c_double(float(v[0, t, 1])))
+        elif name == "TASK_META":
+            for t in range(1, v.shape[1]):
+                L.orc_set_task_required(h, t, int(v[0, t, 3]))
+        else:
+            raise KeyError(name)
+
     def set_release_log(self, enable=True):  # the oracle keeps every task id resident: nothing is ever released
         pass
 
     def get(self, name):
         if name == "RELEASE_LOG":
             return np.zeros((1, 30), dtype=np.float64)
+        if name == "ESCORTS":
+            out = np.full((self.A_tile, 2), -1, dtype=np.int32)
+            self.o.L.orc_get_escorts(self.o.h, orc._p(out), self.A_tile)
+            return out[None]
         rows, caps, q = self.o.agents()
         trow, reqs = self.o.tasks()
         nt = trow.shape[0]

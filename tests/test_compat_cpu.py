@@ -1,0 +1,71 @@
+"""Drop-in proof, this container only: the reference's OWN harness files — experiments/wps_eval.py::
+run_wps_episode, experiments/escort_eval.py::run_escort_episode and experiments/test_escort.py — run unchanged over
+`muavta_amd.compat` (the facade + the oracle backend; no GPU here) and reproduce the metrics the reference env produced
+itself (tests/golden/*metrics*).  A scratch copy of the checkout is used because test_escort.py writes a checkpoint next
+to itself and /root/reference is read-only; nothing of it is kept."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from muavta_amd.params import METRIC_KEYS
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "mUAV_TA")), reason="reference checkout not present (GPU box)")
+
+
+@pytest.fixture(scope="module")
+def ref_copy(tmp_path_factory):
+    dst = tmp_path_factory.mktemp("ref")
+    for d in ("experiments", "TaskAllocation"):
+        shutil.copytree(os.path.join(REF, d), os.path.join(dst, d), ignore=shutil.ignore_patterns("results", "__pycache__", "*.pth", "*.csv"))
+    yield str(dst)
+    shutil.rmtree(dst, ignore_errors=True)
+
+
+def _drive(mode, ref_copy):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "compat_driver.py"), mode, ref_copy], capture_output=True, text=True, timeout=1500, env=env, cwd=ref_copy)
+    assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
+    return json.loads(p.stdout.strip().splitlines()[-1]), p.stdout
+
+
+def test_reference_episode_runners_run_unchanged_and_reproduce_the_reference_metrics(ref_copy):
+    out, _ = _drive("episodes", ref_copy)
+    K = {k: i for i, k in enumerate(METRIC_KEYS)}
+    files = {("Local-Hungarian", "WPS_hard"): "metrics_WPS_hard.npz", ("Local-Hungarian", "WPS_easy"): "metrics_WPS_easy.npz",
+             ("Urgency-Pair", "WPS_hard"): "urgpair_metrics_WPS_hard.npz", ("Coalition-Hungarian", "WPS_escort"): "metrics_WPS_escort.npz",
+             ("Urgency-Coalition", "WPS_escort"): "urgcoal_metrics_WPS_escort.npz"}
+    assert len(out["wps"]) == 6 and len(out["escort"]) == 3
+    for r in out["wps"]:
+        g = np.load(os.path.join(GOLDEN, files[(r["algorithm"], r["case"])]))
+        want = g["metrics"][int(r["seed"])]
+        for key in ("F_Reward", "S_WPS", "on_time_rate", "n_missed_windows", "n_on_time", "n_windowed_tasks", "reserve_idle_fraction",
+                    "makespan", "total_distance", "n_task_switches"):
+            assert r[key] == want[K[key]], (r["algorithm"], r["case"], r["seed"], key, r[key], want[K[key]])
+        assert r["max_coord"] == 1200.0
+        if r["algorithm"] == "Local-Hungarian":  # (the Urgency-* runners count their own plan() calls)
+            assert r["algo_replans"] == float(g["n_replans"][int(r["seed"])])
+    for r in out["escort"]:
+        g = np.load(os.path.join(GOLDEN, files[(r["algorithm"], r["case"])]))
+        want = g["metrics"][int(r["seed"])]
+        for key in ("S_ESC", "S_WPS", "escort_coverage_rate", "protected_rec_completed", "recon_losses", "escort_losses",
+                    "threats_intercepted", "mutual_support_engagements", "n_missed_windows", "on_time_rate", "n_task_switches"):
+            assert r[key] == want[K[key]], (r["algorithm"], r["seed"], key, r[key], want[K[key]])
+        if r["algorithm"] == "Coalition-Hungarian":
+            assert r["n_replans"] == float(g["n_replans"][int(r["seed"])])
+
+
+def test_reference_test_escort_passes_7_of_7(ref_copy):
+    out, stdout = _drive("test_escort", ref_copy)
+    assert out == {"ok": True}
+    for name in ("unique_task_ids", "escort_lifecycle", "coalition_hungarian", "threat_diversion_inputs", "cbba_pi_coalition",
+                 "pi_schedule_impact", "att_coalition_v2"):
+        assert f"OK {name}" in stdout, stdout[-2000:]
+    assert "ALL PASSED" in stdout

@@ -470,6 +470,94 @@ def test_facade_on_gpu_matches_reference_observations(case, seed):
     assert len(env.tasks) == int(g["metrics"][13])
 
 
+def test_out_of_step_mutators_hip_vs_oracle():
+    """muavta_call (UAV.allocate, UAV.tasks = [...], _create_escort_for, _sync_escorts, _retire_escort, _escort_fighters_near,
+    _is_task_action_valid) and the attribute writes of experiments/test_escort.py, through the facade, on the HIP backend and
+    on the oracle backend side by side: every device field equal after each call, then 30 more env steps."""
+    from oracle_backend import OracleBackend
+    from muavta_amd.env import MultiUAVEnv
+    from muavta_amd.scenarios import CASE_SPECS, TILES, WPS_ENV_FLAGS
+    case = "WPS_escort"
+    ta, tt, th = TILES[case]
+    p = params_for_case(case)
+    hip = MultiUAVEnv(CASE_SPECS[case], flags=dict(WPS_ENV_FLAGS), tile_agents=ta, tile_tasks=tt, tile_threats=th)
+    ref = MultiUAVEnv(CASE_SPECS[case], backend=OracleBackend(p), flags=dict(WPS_ENV_FLAGS))
+    envs = (hip, ref)
+
+    def both(f):
+        r = [f(e) for e in envs]
+        hip._b.refresh_observation()
+        compare(Snapshot(hip._b), 0, ref._b.o, f"after {f.__doc__}")
+        return r
+
+    for e in envs:
+        e.reset(seed=3)
+    pick = lambda e: (next(a for a in e.agents_obj if a.type.startswith("R")), next(t for t in e.tasks if t.type == "Rec"))
+
+    def alloc(e):
+        "recon.allocate(rec)"
+        recon, rec = pick(e)
+        assert e._is_task_action_valid(recon, rec)
+        return recon.allocate(rec, e.time_steps), recon.allocate(rec, e.time_steps)
+    assert both(alloc) == [(True, False), (True, False)]
+
+    def mk(e):
+        "_create_escort_for"
+        recon, rec = pick(e)
+        esc = e._create_escort_for(recon, rec)
+        assert esc is e._create_escort_for(recon, rec) and e._escort_by_recon[recon.name] is esc
+        assert esc.kind == "Escort" and esc.eligible_agent_types == {"F1", "F2"} and not e._is_task_action_valid(recon, esc)
+        assert e._is_task_action_valid(next(a for a in e.agents_obj if a.type == "F1"), esc)
+        return esc.id, esc.required_agents
+    r = both(mk)
+    assert r[0] == r[1]
+
+    def follow(e):
+        "position writes + _sync_escorts + fighters on the escort"
+        recon, _ = pick(e)
+        esc = e._escort_by_recon[recon.name]
+        recon.position = np.array([500.0, 400.0])
+        f1 = next(a for a in e.agents_obj if a.type == "F1"); f2 = next(a for a in e.agents_obj if a.type == "F2")
+        f1.position = recon.position + np.array([10.0, 0.0]); f2.position = recon.position + np.array([0.0, 10.0])
+        assert f1.allocate(esc, e.time_steps) and f2.allocate(esc, e.time_steps)
+        e._sync_escorts()
+        assert np.array_equal(esc.position, recon.position)
+        return [a.id for a in e._escort_fighters_near(recon)], [a.id for a in e._escort_fighters_near(recon, 5.0)]
+    r = both(follow)
+    assert r[0] == r[1] and len(r[0][0]) == 2 and r[0][1] == []
+
+    def scaffold(e):
+        "UAV.tasks = [...], UAV.state, Task.required_agents writes"
+        held = {a.id for a in e._escort_fighters_near(pick(e)[0], 1e9)}
+        fs = [a for a in e.get_live_agents() if a.type in ("F1", "F2") and a.id not in held][:3]
+        for a in fs:
+            a.tasks = [e.task_idle]   # (the reference's tests only ever assign [task_idle]: no Task bookkeeping to mirror)
+            a.state = 0
+        att = next(t for t in e.tasks if t.type == "Att")
+        att.required_agents = 3
+        return [[t.id for t in a.tasks] for a in fs], att.required_agents
+    r = both(scaffold)
+    assert r[0] == r[1]
+
+    def retire(e):
+        "_retire_escort"
+        recon, _ = pick(e)
+        esc = e._escort_by_recon[recon.name]
+        e._retire_escort(esc, failed=False)
+        assert esc.status == 2 and recon.name not in e._escort_by_recon
+        return e.escort_completed
+    assert both(retire) == [1, 1]
+    for t in range(30):  # the episode goes on from the scaffolded state, allocator on each backend
+        acts = []
+        for e in envs:
+            aa, ai = e._b.allocate(12, True)
+            acts.append({e.agents_obj[int(a)].name: int(i) for a, i in zip(aa[0], ai[0]) if a >= 0})
+        assert acts[0] == acts[1], f"t={t}"
+        for e, ac in zip(envs, acts):
+            e.step(ac)
+        compare(Snapshot(hip._b), 0, ref._b.o, f"step {t} after the mutators")
+
+
 # ---- next row: Urgency-Pair allocator (edge scores fused into the cost tile) ----------------------------------
 @pytest.mark.parametrize("case,n", [("WPS_hard", 8), ("WPS_attn", 4), ("WPS_hard_x2", 6), ("WPS_attn_AWACS", 3)])
 def test_urgency_pair_stepwise_vs_oracle(case, n):
