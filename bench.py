@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API / other-tile / IL figures (profiling runs)")
+    ap.add_argument("--abi-collective", action="store_true", help="reduce the metrics through muavta_allreduce_metrics (RCCL behind the C ABI) instead of torch.distributed")
     ap.add_argument("--seed-base", type=int, default=0, help="first global env index (default 0: seeds = global env index)")
     args = ap.parse_args()
     if args.interval is None:
@@ -199,13 +200,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
 
     from muavta_amd.batched import BatchedMultiUAVEnv
-    from muavta_amd.dist import reduce_metrics, shard_seeds
+    from muavta_amd.dist import init_abi_comm, reduce_metrics, shard_seeds
     from muavta_amd.params import params_for_case
 
     env = BatchedMultiUAVEnv(params_for_case(args.case), args.envs, device=local_rank)
     tile = f"{env.dims.tile_agents}x{env.dims.tile_tasks}"
     seeds = shard_seeds(rank, args.envs, args.seed_base)  # seed = global env index
     write_obs = not args.no_obs
+    if args.abi_collective:
+        init_abi_comm(env, rank, world)
 
     def barrier():
         if dist is not None:
@@ -228,7 +231,7 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         raise SystemExit(f"{n_flagged} env(s) overflowed the {tile} tile (muavta_get ERROR): results would be incomplete")
-    summary = reduce_metrics(m, device="cuda" if dist is not None else None)
+    summary = reduce_metrics(m, device="cuda" if dist is not None else None, comm=env if args.abi_collective else None)
 
     # secondary figures (rank 0 at N=1 only, outside the timed region)
     extras = {}
@@ -247,7 +250,8 @@ def main():
                                    f"obs write {'on' if write_obs else 'off'}",
                        "envs_per_gpu": args.envs, "total_envs": total_envs, "tile": tile, "n_agents": env.n_agents,
                        "lds_bytes_per_env": int(env.dims.lds_bytes),
-                       "horizon": HORIZON, "parallelism": f"env-sharded x{world}, RCCL all-reduce of the metric vector only"},
+                       "horizon": HORIZON, "parallelism": f"env-sharded x{world}, RCCL all-reduce of the metric vector only"
+                                      + (" (muavta_allreduce_metrics)" if args.abi_collective else " (torch.distributed nccl backend)" if dist is not None else "")},
             "roofline": roofline(args.case, args.envs, env.dims.tile_agents, mean_kernel_ms),
             "seed_kernel_ms": mean_seed_ms,
             "quality": {"mean_S_WPS": summary["mean_S_WPS"], "std_S_WPS": summary["std_S_WPS"], "on_time_rate": summary["on_time_rate"],

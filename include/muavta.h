@@ -257,6 +257,21 @@ typedef enum MuavtaOp {
 #define MUAVTA_CALL_OUT 72
 int muavta_call(MuavtaEnv* env, int32_t env_index, int32_t op, const int32_t* iargs, double darg, int32_t* out);
 
+/* Multi-GPU: env instances are independent, so each rank owns a contiguous range of global env indices
+ * (seed = global index) and the ONLY exchange is the end-of-batch reduction of a small per-rank metric vector.  These entry
+ * points run it over RCCL (xGMI between the GPUs of a node) for binders that do not bring torch.distributed:
+ *   muavta_comm_uid    rank 0 creates the 128-byte RCCL unique id; the caller ships it to the other ranks out of band
+ *   muavta_comm_init   every rank joins (collective: returns when all n_ranks have called it); one communicator per handle
+ *   muavta_allreduce_metrics  float partial sums are all-gathered and added in RANK ORDER (the result does not depend on
+ *                      the ring order: bit-stable), int64 counters are all-reduced (exact).  nf, nc <= 64.
+ * librccl is loaded on first use (the copy already in the process, e.g. PyTorch's, if there is one). */
+#define MUAVTA_COMM_UID_BYTES 128
+int muavta_comm_uid(uint8_t* uid /* [128] out */);
+int muavta_comm_init(MuavtaEnv* env, int32_t rank, int32_t n_ranks, const uint8_t* uid /* [128] */);
+int muavta_allreduce_metrics(MuavtaEnv* env, const double* f_partials, int32_t nf, const int64_t* counters, int32_t nc,
+                             double* f_total /* [nf] */, int64_t* c_total /* [nc] */);
+int muavta_comm_destroy(MuavtaEnv* env);
+
 /* Per-step log of released task slots (off by default; the Python facade turns it on to keep agent_visibility_map()
  * exact for retired ids, DroneEnv.py:1595-1599).  Costs one global atomic per released slot in muavta_step only. */
 int muavta_set_release_log(MuavtaEnv* env, int32_t enable);

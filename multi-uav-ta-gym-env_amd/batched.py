@@ -142,6 +142,31 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_call(self.h, int(env_index), self.OPS[op], _vp(ia), float(darg), _vp(out)))
         return out
 
+    # ------------------------------------------------------------------ multi-GPU metric reduction over RCCL (C ABI)
+    @staticmethod
+    def comm_uid() -> bytes:
+        """128-byte RCCL unique id (rank 0 creates it and ships it to the other ranks)."""
+        buf = (C.c_uint8 * 128)()
+        L = native.lib()
+        rc = L.muavta_comm_uid(buf)
+        if rc != 0:
+            raise MuavtaError(f"muavta_comm_uid failed ({rc}): {L.muavta_last_error(None).decode()}")
+        return bytes(buf)
+
+    def comm_init(self, rank: int, n_ranks: int, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._ck(self.L.muavta_comm_init(self.h, int(rank), int(n_ranks), buf))
+
+    def allreduce_metrics(self, f_partials: np.ndarray, counters: np.ndarray):
+        f = np.ascontiguousarray(f_partials, dtype=np.float64)
+        c = np.ascontiguousarray(counters, dtype=np.int64)
+        fo, co = np.empty_like(f), np.empty_like(c)
+        self._ck(self.L.muavta_allreduce_metrics(self.h, _vp(f), f.size, _vp(c), c.size, _vp(fo), _vp(co)))
+        return fo, co
+
+    def comm_destroy(self):
+        self._ck(self.L.muavta_comm_destroy(self.h))
+
     def set_release_log(self, enable: bool = True):
         """Per-step log of released task slots (`get("RELEASE_LOG")`): id + knower mask; used by the facade."""
         self._ck(self.L.muavta_set_release_log(self.h, int(bool(enable))))

@@ -10,6 +10,8 @@
 //   k_lsap / k_avoid   stand-alone solver / obstacle-avoidance entry points
 // There is no CPU fallback: without a HIP device every entry point fails with MUAVTA_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: the library is dlopen()ed by muavta_comm_*
 
 #include <cmath>
 #include <cstdio>
@@ -450,6 +452,8 @@ __global__ __launch_bounds__(WG) void k_call(const DevCtx* __restrict__ ctxp, Ca
     default: break;
   }
   cold_sync();
+  sim.refresh_task_times();  // initTime / doneTime follow the allocationDetails the call may have changed
+  lds_sync();
   copy16(blob, L.S, sizeof(EnvState<TL>));
 }
 
@@ -545,6 +549,9 @@ struct MuavtaEnv {
   DevCtx* d_ctx = nullptr;  // device copy of {P, O, tapes}
   uint64_t* d_seeds = nullptr;
   int32_t *d_act_agent = nullptr, *d_act_index = nullptr, *d_call_out = nullptr;
+  ncclComm_t comm = nullptr;  // muavta_comm_init
+  int comm_rank = 0, comm_ranks = 0;
+  void* d_comm = nullptr;     // [64 f64 send | 64 x n_ranks f64 recv | 64 i64 send | 64 i64 recv]
   double* d_metrics = nullptr;
   ObsPtrs O{};
   hipStream_t stream = nullptr;
@@ -972,6 +979,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
 
 int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
+  muavta_comm_destroy(e);
   hipSetDevice(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
@@ -1223,6 +1231,105 @@ int muavta_call(MuavtaEnv* e, int32_t env_index, int32_t op, const int32_t* iarg
   return MUAVTA_OK;
 }
 
+// ---- RCCL, loaded on first use --------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string err;
+};
+Rccl* rccl() {
+  static Rccl R;
+  if (R.lib || !R.err.empty()) return &R;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names) if ((R.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;   // a copy already in the process (PyTorch's)
+  if (!R.lib) for (const char* n : names) if ((R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+  if (!R.lib) { R.err = std::string("librccl not found: ") + dlerror(); return &R; }
+  *(void**)&R.GetUniqueId = dlsym(R.lib, "ncclGetUniqueId");
+  *(void**)&R.CommInitRank = dlsym(R.lib, "ncclCommInitRank");
+  *(void**)&R.CommDestroy = dlsym(R.lib, "ncclCommDestroy");
+  *(void**)&R.AllReduce = dlsym(R.lib, "ncclAllReduce");
+  *(void**)&R.AllGather = dlsym(R.lib, "ncclAllGather");
+  *(void**)&R.GetErrorString = dlsym(R.lib, "ncclGetErrorString");
+  if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllReduce || !R.AllGather || !R.GetErrorString) { R.err = "librccl lacks an expected symbol"; R.lib = nullptr; }
+  return &R;
+}
+}  // namespace
+#define NCCLCHK(env, expr)                                                                        \
+  do {                                                                                            \
+    ncclResult_t r_ = (expr);                                                                     \
+    if (r_ != ncclSuccess) { (env)->err = std::string(#expr) + ": " + rccl()->GetErrorString(r_); return MUAVTA_E_HIP; } \
+  } while (0)
+
+int muavta_comm_uid(uint8_t* uid) {
+  if (!uid) return MUAVTA_E_ARG;
+  Rccl* R = rccl();
+  if (!R->lib) { g_create_error = R->err; return MUAVTA_E_NO_DEVICE; }
+  static_assert(sizeof(ncclUniqueId) == MUAVTA_COMM_UID_BYTES, "RCCL unique id size");
+  ncclUniqueId id;
+  ncclResult_t r = R->GetUniqueId(&id);
+  if (r != ncclSuccess) { g_create_error = std::string("ncclGetUniqueId: ") + R->GetErrorString(r); return MUAVTA_E_HIP; }
+  memcpy(uid, &id, sizeof(id));
+  return MUAVTA_OK;
+}
+int muavta_comm_init(MuavtaEnv* e, int32_t rank, int32_t n_ranks, const uint8_t* uid) {
+  if (!e || !uid || n_ranks < 1 || rank < 0 || rank >= n_ranks) { if (e) e->err = "muavta_comm_init: bad arguments"; return MUAVTA_E_ARG; }
+  if (e->comm) { e->err = "muavta_comm_init: this handle already has a communicator"; return MUAVTA_E_STATE; }
+  Rccl* R = rccl();
+  if (!R->lib) { e->err = R->err; return MUAVTA_E_NO_DEVICE; }
+  HIPCHK(e, hipSetDevice(e->device));
+  ncclUniqueId id;
+  memcpy(&id, uid, sizeof(id));
+  NCCLCHK(e, R->CommInitRank(&e->comm, n_ranks, id, rank));
+  e->comm_rank = rank; e->comm_ranks = n_ranks;
+  HIPCHK(e, hipMalloc(&e->d_comm, (size_t)(64 + 64 * n_ranks + 128) * 8));
+  return MUAVTA_OK;
+}
+int muavta_allreduce_metrics(MuavtaEnv* e, const double* f_partials, int32_t nf, const int64_t* counters, int32_t nc, double* f_total, int64_t* c_total) {
+  if (!e || nf < 0 || nc < 0 || nf > 64 || nc > 64 || (nf && (!f_partials || !f_total)) || (nc && (!counters || !c_total))) { if (e) e->err = "muavta_allreduce_metrics: bad arguments"; return MUAVTA_E_ARG; }
+  if (!e->comm) { e->err = "muavta_allreduce_metrics before muavta_comm_init"; return MUAVTA_E_STATE; }
+  Rccl* R = rccl();
+  HIPCHK(e, hipSetDevice(e->device));
+  const int n = e->comm_ranks;
+  double* fs = (double*)e->d_comm; double* fr = fs + 64;
+  int64_t* cs = (int64_t*)(fr + (size_t)64 * n); int64_t* cr = cs + 64;
+  if (nf) {
+    HIPCHK(e, hipMemcpyAsync(fs, f_partials, (size_t)nf * 8, hipMemcpyHostToDevice, e->stream));
+    NCCLCHK(e, R->AllGather(fs, fr, (size_t)nf, ncclDouble, e->comm, e->stream));
+  }
+  if (nc) {
+    HIPCHK(e, hipMemcpyAsync(cs, counters, (size_t)nc * 8, hipMemcpyHostToDevice, e->stream));
+    NCCLCHK(e, R->AllReduce(cs, cr, (size_t)nc, ncclInt64, ncclSum, e->comm, e->stream));
+  }
+  std::vector<double> gathered((size_t)nf * n);
+  if (nf) HIPCHK(e, hipMemcpyAsync(gathered.data(), fr, gathered.size() * 8, hipMemcpyDeviceToHost, e->stream));
+  if (nc) HIPCHK(e, hipMemcpyAsync(c_total, cr, (size_t)nc * 8, hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int k = 0; k < nf; k++) {  // rank order: the same bits on every rank, whatever the ring order
+    double s = 0.0;
+    for (int r = 0; r < n; r++) s += gathered[(size_t)r * nf + k];
+    f_total[k] = s;
+  }
+  return MUAVTA_OK;
+}
+int muavta_comm_destroy(MuavtaEnv* e) {
+  if (!e) return MUAVTA_E_ARG;
+  if (e->comm) {
+    hipSetDevice(e->device);
+    hipStreamSynchronize(e->stream);
+    rccl()->CommDestroy(e->comm);
+    e->comm = nullptr;
+    hipFree(e->d_comm);
+    e->d_comm = nullptr;
+  }
+  return MUAVTA_OK;
+}
+
 int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
   if (!e) return MUAVTA_E_ARG;
   HIPCHK(e, hipSetDevice(e->device));
@@ -1243,6 +1350,7 @@ int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from 
   HIPCHK(e, hipSetDevice(e->device));
   DISPATCH(e, hipLaunchKernelGGL(k_observe<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx));
   HIPCHK(e, hipGetLastError());
+  e->host_valid = false;  // (the kernel refreshes the derived initTime / doneTime rows of the HBM record)
   return MUAVTA_OK;
 }
 

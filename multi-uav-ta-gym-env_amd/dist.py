@@ -29,12 +29,28 @@ def partial_sums(metrics: np.ndarray):
     return np.array(f, dtype=np.float64), np.array(c, dtype=np.int64)
 
 
-def reduce_metrics(metrics: np.ndarray, device=None) -> Dict[str, float]:
-    """All ranks call this with their shard's metrics; every rank gets the whole-job summary."""
+def init_abi_comm(env, rank: int, world: int):
+    """Join the RCCL communicator of the C ABI (muavta_comm_init): rank 0 creates the unique id, torch.distributed (already
+    initialised by the launcher) only carries its 128 bytes to the other ranks."""
+    import torch.distributed as dist
+
+    box = [env.comm_uid() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    env.comm_init(rank, world, box[0])
+
+
+def reduce_metrics(metrics: np.ndarray, device=None, comm=None) -> Dict[str, float]:
+    """All ranks call this with their shard's metrics; every rank gets the whole-job summary.  `comm`: a
+    BatchedMultiUAVEnv whose muavta_comm_init has run -> the reduction goes through muavta_allreduce_metrics (RCCL behind
+    the C ABI) instead of torch.distributed."""
+    f, c = partial_sums(metrics)
+    if comm is not None:
+        f, c = comm.allreduce_metrics(f, c)
+        return _summary(f, c)
     import torch
     import torch.distributed as dist
 
-    f, c = partial_sums(metrics)
     tf = torch.from_numpy(f)
     tc = torch.from_numpy(c)
     if device is not None:
@@ -44,7 +60,10 @@ def reduce_metrics(metrics: np.ndarray, device=None) -> Dict[str, float]:
         dist.all_gather(parts, tf)                 # float partials: fixed (rank) summation order
         tf = torch.stack(parts).sum(dim=0)
         dist.all_reduce(tc, op=dist.ReduceOp.SUM)  # exact integer totals
-    f, c = tf.cpu().numpy(), tc.cpu().numpy()
+    return _summary(tf.cpu().numpy(), tc.cpu().numpy())
+
+
+def _summary(f: np.ndarray, c: np.ndarray) -> Dict[str, float]:
     n = int(c[-1])
     out = {f"sum_{k}": float(v) for k, v in zip(SUM_KEYS, f)}
     out.update({k: int(v) for k, v in zip(COUNT_KEYS, c)})

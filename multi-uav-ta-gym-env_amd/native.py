@@ -16,7 +16,7 @@ from .params import MuavtaDims, MuavtaParams
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 SO_PATH = os.environ.get("MUAVTA_SO") or os.path.join(PKG_DIR, "libmuavta.so")  # MUAVTA_SO: diagnostic builds only
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-Os",  # -Os: the rollout kernel is ~150 KB of code; smaller code measured +3.5 % over -O3
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-Os", "-ldl",  # -Os: the rollout kernel is ~150 KB of code; smaller code measured +3.5 % over -O3
                 "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
 EXPORTS = [
@@ -26,7 +26,7 @@ EXPORTS = [
     "muavta_avoid_obstacles", "muavta_device_ptrs", "muavta_last_kernel_ms", "muavta_sync",
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
-    "muavta_last_seed_ms", "muavta_call",
+    "muavta_last_seed_ms", "muavta_call", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
 ]
 
 
@@ -104,6 +104,10 @@ def lib() -> C.CDLL:
     L.muavta_device_ptrs.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.muavta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.muavta_last_seed_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.muavta_comm_uid.argtypes = [vp]
+    L.muavta_comm_init.argtypes = [vp, i32, i32, vp]
+    L.muavta_allreduce_metrics.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.muavta_comm_destroy.argtypes = [vp]
     L.muavta_call.argtypes = [vp, i32, i32, vp, C.c_double, vp]
     L.muavta_sync.argtypes = [vp]
     L.muavta_refresh_observation.argtypes = [vp]

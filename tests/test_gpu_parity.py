@@ -956,3 +956,51 @@ def test_16_agent_tile_holds_the_seeds_that_need_more_than_32_slots():
         for i, s_ in enumerate(sd):
             o.rollout_mode(int(s_), 150, 20, 1, mode)
             assert np.array_equal(big.rollout_metrics()[i], o.metrics()), f"{name} seed {s_}"
+
+
+# ---- multi-GPU readiness on one GPU -------------------------------------------------------------------
+def test_comm_abi_single_rank():
+    """muavta_comm_uid / muavta_comm_init / muavta_allreduce_metrics / muavta_comm_destroy over RCCL with one rank."""
+    from muavta_amd.dist import partial_sums, reduce_metrics
+    from muavta_amd.native import MuavtaError
+    env = _env("WPS_hard", 64)
+    env.rollout(np.arange(64, dtype=np.uint64), 150, 20, True, False)
+    m = env.rollout_metrics()
+    with pytest.raises(MuavtaError, match="before muavta_comm_init"):
+        env.allreduce_metrics(np.zeros(2), np.zeros(2, dtype=np.int64))
+    uid = env.comm_uid()
+    assert len(uid) == 128 and uid != env.comm_uid()
+    env.comm_init(0, 1, uid)
+    with pytest.raises(MuavtaError, match="already has a communicator"):
+        env.comm_init(0, 1, uid)
+    f, c = partial_sums(m)
+    fo, co = env.allreduce_metrics(f, c)
+    assert np.array_equal(fo, f) and np.array_equal(co, c)
+    assert reduce_metrics(m, comm=env) == reduce_metrics(m)
+    env.comm_destroy()
+    env.comm_init(0, 1, env.comm_uid())  # a handle can join again after destroy
+    env.close()
+
+
+@pytest.mark.parametrize("extra", [[], ["--abi-collective"]], ids=["torch-nccl", "abi-rccl"])
+def test_bench_under_torchrun_world_size_1(extra):
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, nccl backend = RCCL), at world size 1:
+    sharding, barrier-bracketed timing, metric reduction and the single JSON line."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--envs", "512",
+           "--no-cpu-baseline", "--no-extras"] + extra
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=root)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["total_envs"] == 512 and out["quality"]["n_envs"] == 512
+    want = orc.parallel_metrics("WPS_hard_x2", np.arange(512), 20)
+    assert out["quality"]["mean_S_WPS"] == float(want[:, 4].sum()) / 512
