@@ -34,8 +34,8 @@ class Snapshot:
         self.reward, self.term, self.trunc = env.step_result()
 
 
-def compare(snap, i, o, tag):
-    """env i of the device snapshot vs oracle env o."""
+def compare(snap, i, o, tag, check_obs=True):
+    """env i of the device snapshot vs oracle env o (check_obs=False: between steps the reference holds no fresh observation)."""
     assert snap.ERROR[i] == 0, f"{tag}: device tile overflow code {snap.ERROR[i]}"
     rows, caps, q = o.agents()
     A = rows.shape[0]
@@ -98,6 +98,8 @@ def compare(snap, i, o, tag):
     dev = snap.EVENTS[i]
     n_ev = int((dev[:, 0] >= 0).sum())
     assert n_ev == len(ev) and np.array_equal(dev[:n_ev], ev), f"{tag}: drained events"
+    if not check_obs:
+        return
     ti, legal, pad, ag, fl = o.observe()
     assert np.array_equal(snap.obs["tasks"][i], ti), f"{tag}: obs tasks_info"
     assert np.array_equal(snap.obs["legal_mask"][i], legal), f"{tag}: legal_mask"
@@ -486,8 +488,7 @@ def test_out_of_step_mutators_hip_vs_oracle():
 
     def both(f):
         r = [f(e) for e in envs]
-        hip._b.refresh_observation()
-        compare(Snapshot(hip._b), 0, ref._b.o, f"after {f.__doc__}")
+        compare(Snapshot(hip._b), 0, ref._b.o, f"after {f.__doc__}", check_obs=False)
         return r
 
     for e in envs:
