@@ -291,6 +291,29 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     out["fused_step_api_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
     env.rollout(seeds, HORIZON, args.interval, True, write_obs)  # restore the headline batch's final state
     env.sync()
+    # the trainers' data loop: samples = (env, step) pairs with token tensors + expert labels + step reward
+    try:
+        from muavta_amd.il import il_record, il_stream
+
+        n_il = min(args.envs, 1024)
+        e3 = BatchedMultiUAVEnv(params_for_case(args.case), n_il, device=0)
+        s3 = np.arange(n_il, dtype=np.uint64)
+        rings = il_record(e3, s3, HORIZON, args.interval)  # warm-up (allocates the rings)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            il_record(e3, s3, HORIZON, args.interval, rings=rings)
+        out["il_samples_per_s"] = 3 * n_il * HORIZON / (time.perf_counter() - t1)
+        out["il_samples_per_s_is"] = (f"muavta_rollout_record: {n_il} envs x {HORIZON} steps per launch, pair tokens 32x16 + expert mask + S_WPS "
+                                      "series written to device rings (no host hop)")
+        t1 = time.perf_counter()
+        for _t, _b in il_stream(e3, s3, 30, args.interval, with_reward=True):
+            pass
+        out["il_stream_per_step_api_samples_per_s"] = n_il * 30 / (time.perf_counter() - t1)
+        del rings
+        e3.close()
+    except Exception as exc:  # torch without CUDA tensors etc.: the figure is optional
+        out["il_samples_per_s"] = None
+        out["il_error"] = repr(exc)
     if args.case == "WPS_hard_x2":
         tiles = {}
         for case, n, interval in OTHER_TILES:

@@ -338,6 +338,24 @@ int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double
 int muavta_device_ptrs(MuavtaEnv* env, void** state, void** obs_tasks, void** obs_legal, void** obs_agents,
                        void** metrics, void** stream);
 
+/* The trainers' data loop fused into the rollout (experiments/train_pair_cost.py:96-156: run_il_episode / run_rl_episode):
+ * like muavta_rollout, and for every step t = 0 .. n_steps-1, right after the allocator staged its plan and before the env
+ * step, slot t of the caller's DEVICE rings receives what muavta_tokens_device would return at that point (token tensors,
+ * edge_valid, expert_mask = _expert_mask(tok, plan), replanned = the gate fired at t) and s_wps[t] = compute_s_wps() before the
+ * step; s_wps[n_steps] is the value after the last step, so the RL step reward of step t is (s_wps[t+1] - s_wps[t]) / 20.
+ * Ring layouts: every muavta_tokens_device output with a leading [n_steps] axis (slot-major: [n_steps][N][...]); s_wps f64
+ * [n_steps + 1][N].  n_urgent / expert_mask / replanned may be NULL.  Use muavta_set_allocator(MUAVTA_ALLOC_HUNGARIAN_GATED)
+ * and use_vis = 0 for the reference's expert.  Asynchronous on the handle's stream (muavta_sync / an event before reading). */
+typedef struct MuavtaRecord {
+  int32_t kind, max_tasks, max_agents, reserved;  /* MUAVTA_TOK_*, token pads */
+  float* task_feats; uint8_t* task_mask; int32_t* task_ids;
+  float* agent_feats; uint8_t* agent_mask; int32_t* agent_ids;
+  float* edge_valid; int32_t* n_urgent; float* expert_mask; int32_t* replanned;
+  double* s_wps;
+} MuavtaRecord;
+int muavta_rollout_record(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps, int32_t replan_interval, int32_t use_visibility,
+                          int32_t write_obs, const MuavtaRecord* rec);
+
 /* Duration of the last muavta_rollout launch, measured with HIP events recorded on the handle's own
  * stream around the kernel (ms).  Blocks until that launch has finished. */
 int muavta_last_kernel_ms(MuavtaEnv* env, float* ms);

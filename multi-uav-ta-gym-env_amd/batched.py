@@ -40,6 +40,7 @@ class BatchedMultiUAVEnv:
         d = MuavtaDims()
         self._ck(self.L.muavta_dims(self.h, C.byref(d)))
         self.dims = d
+        self.device_index = int(device)
         self.n_envs, self.n_agents = d.n_envs, d.n_agents
         self.T, self.H, self.Q, self.E, self.A_tile = d.tile_tasks, d.n_threats, d.queue_cap, d.event_cap, d.tile_agents
         self.max_tasks = d.max_tasks
@@ -182,6 +183,37 @@ class BatchedMultiUAVEnv:
             if s.shape != (self.n_envs,):
                 raise ValueError(f"seeds must have shape ({self.n_envs},)")
         self._ck(self.L.muavta_rollout(self.h, _vp(s), int(n_steps), int(replan_interval), int(use_visibility), int(write_obs)))
+
+    def record_shapes(self, kind: str, n_steps: int, max_tasks: int, max_agents: int):
+        """name -> (shape, numpy dtype) of the rings `rollout_record` fills."""
+        _, dt, da = self.TOKEN_KINDS[kind]
+        K, N, mt, ma = int(n_steps), self.n_envs, int(max_tasks), int(max_agents)
+        return {"task_feats": ((K, N, mt, dt), np.float32), "task_mask": ((K, N, mt), np.uint8), "task_ids": ((K, N, mt), np.int32),
+                "agent_feats": ((K, N, ma, da), np.float32), "agent_mask": ((K, N, ma), np.uint8), "agent_ids": ((K, N, ma), np.int32),
+                "edge_valid": ((K, N, ma, mt), np.float32), "n_urgent": ((K, N), np.int32), "expert_mask": ((K, N, ma, mt), np.float32),
+                "replanned": ((K, N), np.int32), "s_wps": ((K + 1, N), np.float64)}
+
+    def rollout_record(self, seeds: Optional[Sequence[int]], n_steps: int, replan_interval: int, use_visibility: bool, rings: dict,
+                       kind: str = "pair", max_tasks: int = 32, max_agents: int = 16, write_obs: bool = False):
+        """muavta_rollout_record: the fused rollout that also fills `rings` (dict of contiguous CUDA torch tensors with the
+        shapes of `record_shapes`) with the per-step training data — no host hop, one launch for the whole episode batch.
+        Asynchronous on the handle's stream: call `sync()` before reading the rings from another stream."""
+        from .params import MuavtaRecord
+
+        k, _, _ = self.TOKEN_KINDS[kind]
+        rec = MuavtaRecord()
+        rec.kind, rec.max_tasks, rec.max_agents = k, int(max_tasks), int(max_agents)
+        for name, (shape, dtype) in self.record_shapes(kind, n_steps, max_tasks, max_agents).items():
+            t = rings[name]
+            if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != np.dtype(dtype).itemsize:
+                raise ValueError(f"rollout_record: {name} must be a contiguous CUDA tensor of shape {shape}, {np.dtype(dtype).name}")
+            setattr(rec, name, t.data_ptr())
+        s = None
+        if seeds is not None:
+            s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
+            if s.shape != (self.n_envs,):
+                raise ValueError(f"seeds must have shape ({self.n_envs},)")
+        self._ck(self.L.muavta_rollout_record(self.h, _vp(s), int(n_steps), int(replan_interval), int(use_visibility), int(write_obs), C.byref(rec)))
 
     def sync(self):
         self._ck(self.L.muavta_sync(self.h))

@@ -3126,6 +3126,12 @@ struct Sim {
     lds_sync();
   }
 
+  // compute_s_wps (:1321-1337), same operation order as metrics() below
+  DEV double s_wps() const {
+    const double dist_term = 0.01 * S.total_distance / fmax(MAX_COORD, 1.0);
+    const double rematch = P.reassign_penalty * (double)S.n_task_switches;
+    return 12.0 * (double)S.n_on_time - 30.0 * (double)S.n_missed_windows - dist_term - rematch;
+  }
   // calculate_metrics (:1231-1319) -> out[30]
   DEV void metrics(double* m) {
     if (lane != 0) return;

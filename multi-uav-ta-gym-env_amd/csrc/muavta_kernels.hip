@@ -293,8 +293,17 @@ __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp
 #define MUAVTA_PHASE_ATTR __forceinline__
 #endif
 enum { PH_ALLOC = 1, PH_STEP = 2, PH_OBS = 4 };
+// muavta_rollout_record: per-step training data of the fused rollout in caller-owned rings [n_slots][N][...] — the token
+// tensors / expert labels of the plan staged for step t and S_WPS before step t (experiments/train_pair_cost.py:96-156).
 template <class TL>
-__device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds_base, int phases, int interval, int use_vis, int mode) {
+struct RecordPtrs {
+  typename Sim<TL>::TokPtrs K;
+  double* s_wps;   // [n_steps + 1][N]
+  int n_envs;
+};
+template <class TL, bool REC>
+__device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds_base, int phases, int interval, int use_vis, int mode,
+                                                const RecordPtrs<TL>& rec, int slot) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L((unsigned char*)(AS3 unsigned char*)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base));
@@ -302,13 +311,26 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds
   if (phases & PH_STEP) sim.step(true);
   if (phases & PH_OBS) obs_for_env(sim, ctx.P, obs_ptrs(ctx), env);
   lds_sync();
-  if ((phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) sim.allocate(interval, use_vis, mode);
+  if ((phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) {
+    sim.allocate(interval, use_vis, mode);
+    if constexpr (REC) {  // the sample of step `slot`: tokens + labels of the plan just staged, S_WPS before the step
+      typename Sim<TL>::TokPtrs K = rec.K;
+      K.task_feats = as_global(K.task_feats); K.task_mask = as_global(K.task_mask); K.task_ids = as_global(K.task_ids);
+      K.agent_feats = as_global(K.agent_feats); K.agent_mask = as_global(K.agent_mask); K.agent_ids = as_global(K.agent_ids);
+      K.edge_valid = as_global(K.edge_valid); K.n_urgent = as_global(K.n_urgent); K.expert_mask = as_global(K.expert_mask);
+      K.replanned = as_global(K.replanned);
+      cold_sync();
+      sim.tokens(K, slot * rec.n_envs + env);
+      if (threadIdx.x == 0) as_global(rec.s_wps)[(size_t)slot * rec.n_envs + env] = sim.s_wps();
+      lds_sync();
+    }
+  }
   PROF_AT(sim, 20);
 }
 
-template <class TL>
+template <class TL, bool REC>
 __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* __restrict__ ctxp, const uint64_t* seeds, int n_steps, int interval, int use_vis,
-                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf) {
+                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf, RecordPtrs<TL> rec) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L(smem);
@@ -334,7 +356,10 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* 
       if (L.S->terminated || L.S->truncated) { k = n_steps; continue; }  // uniform: read from LDS after a barrier
       ph = PH_STEP | (write_obs ? PH_OBS : 0) | (k < n_steps ? PH_ALLOC : 0);
     } else ph = write_obs ? 0 : PH_OBS;
-    if (ph) rollout_phase<TL>(ctxp, lds_base, ph, interval, use_vis, mode);
+    if (ph) rollout_phase<TL, REC>(ctxp, lds_base, ph, interval, use_vis, mode, rec, k < n_steps ? k : n_steps);
+  }
+  if constexpr (REC) {  // S_WPS after the last step closes the reward series
+    if (threadIdx.x == 0) as_global(rec.s_wps)[(size_t)n_steps * rec.n_envs + env] = sim.s_wps();
   }
   sim.sync_clock();
   sim.metrics(as_global(metrics) + (size_t)env * MUAVTA_N_METRICS);
@@ -572,7 +597,7 @@ int launch_attr(MuavtaEnv* e) {
   e->lds_bytes = lds;
   if (lds > 48 * 1024) {
     const void* ks[] = {reinterpret_cast<const void*>(&k_reset<TL>), reinterpret_cast<const void*>(&k_step<TL>), reinterpret_cast<const void*>(&k_allocate<TL>),
-                        reinterpret_cast<const void*>(&k_rollout<TL>), reinterpret_cast<const void*>(&k_metrics<TL>), reinterpret_cast<const void*>(&k_observe<TL>),
+                        reinterpret_cast<const void*>(&k_rollout<TL, false>), reinterpret_cast<const void*>(&k_rollout<TL, true>), reinterpret_cast<const void*>(&k_metrics<TL>), reinterpret_cast<const void*>(&k_observe<TL>),
                         reinterpret_cast<const void*>(&k_tokens<TL>), reinterpret_cast<const void*>(&k_call<TL>)};
     for (const void* k : ks) HIPCHK(e, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
@@ -1085,7 +1110,26 @@ int muavta_allocate(MuavtaEnv* e, int32_t interval, int32_t use_vis, int32_t* ac
   return MUAVTA_OK;
 }
 
-int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t interval, int32_t use_vis, int32_t write_obs) {
+static int token_dims(int kind, int* dt, int* da);
+}  // extern "C" (the launcher below is a template)
+template <class TL>
+static void launch_rollout(MuavtaEnv* e, const uint64_t* ds, int n_steps, int interval, int use_vis, int write_obs, const uint32_t* sb, size_t extra_lds,
+                           const MuavtaRecord* rec) {
+  RecordPtrs<TL> R;
+  memset(&R, 0, sizeof(R));
+  if (rec) {
+    typename Sim<TL>::TokPtrs K{rec->task_feats, rec->task_mask, rec->task_ids, rec->agent_feats, rec->agent_mask, rec->agent_ids, rec->edge_valid,
+                                rec->n_urgent, rec->expert_mask, rec->replanned, rec->kind, rec->max_tasks, rec->max_agents};
+    R.K = K; R.s_wps = rec->s_wps; R.n_envs = e->n_envs;
+    hipLaunchKernelGGL((k_rollout<TL, true>), dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds + PROF_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, ds,
+                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R);
+  } else {
+    hipLaunchKernelGGL((k_rollout<TL, false>), dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds + PROF_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, ds,
+                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R);
+  }
+}
+extern "C" {
+static int rollout_impl(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t interval, int32_t use_vis, int32_t write_obs, const MuavtaRecord* rec) {
   if (!e || n_steps < 0) return MUAVTA_E_ARG;
   if (!seeds && !e->did_reset) { e->err = "rollout without seeds before reset"; return MUAVTA_E_STATE; }
   HIPCHK(e, hipSetDevice(e->device));
@@ -1100,13 +1144,24 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
   e->last_seeded = ds != nullptr;
   HIPCHK(e, hipEventRecord(e->ev0, e->stream));
   static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
-  DISPATCH(e, hipLaunchKernelGGL(k_rollout<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds + PROF_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, ds, n_steps, interval, use_vis,
-                                 e->alloc_mode, write_obs, e->d_metrics, sb));
+  DISPATCH(e, launch_rollout<TL>(e, ds, n_steps, interval, use_vis, write_obs, sb, extra_lds, rec));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1, e->stream));
   e->did_reset = true;
   e->host_valid = false;
   return MUAVTA_OK;
+}
+int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t interval, int32_t use_vis, int32_t write_obs) {
+  return rollout_impl(e, seeds, n_steps, interval, use_vis, write_obs, nullptr);
+}
+int muavta_rollout_record(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t interval, int32_t use_vis, int32_t write_obs, const MuavtaRecord* rec) {
+  int dt, da;
+  if (!e || !rec || token_dims(rec->kind, &dt, &da) || rec->max_tasks < 1 || rec->max_agents < 1 || rec->max_tasks > 4096 || rec->max_agents > 4096 ||
+      !rec->task_feats || !rec->task_mask || !rec->task_ids || !rec->agent_feats || !rec->agent_mask || !rec->agent_ids || !rec->edge_valid || !rec->s_wps) {
+    if (e) e->err = "muavta_rollout_record: bad argument";
+    return MUAVTA_E_ARG;
+  }
+  return rollout_impl(e, seeds, n_steps, interval, use_vis, write_obs, rec);
 }
 
 #ifdef MUAVTA_PROF

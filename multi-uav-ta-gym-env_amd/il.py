@@ -40,8 +40,32 @@ def il_stream(env: BatchedMultiUAVEnv, seeds, n_steps: int = 150, interval: int 
             batch = dict(batch)
             batch["step_reward"] = (now - prev) / 20.0
             prev = now
+        if out is not None:
+            env.sync()  # k_tokens ran on the handle's own (non-blocking) stream: the caller's stream must not race it
         yield t, batch
         env.step_staged()                                   # the rollout follows the expert (:126-127)
+
+
+def il_record(env: BatchedMultiUAVEnv, seeds, n_steps: int = 150, interval: int = 20, kind: str = "pair", max_tasks: int = 32,
+              max_agents: int = 16, rings: Optional[dict] = None, device=None) -> dict:
+    """The same data as `il_stream(..., with_reward=True)` for the WHOLE episode batch in ONE launch (muavta_rollout_record):
+    returns CUDA torch tensors `[n_steps, N, ...]` (token tensors, `expert_mask`, `replanned`), `s_wps [n_steps + 1, N]` and
+    `step_reward [n_steps, N]` = `(s_wps[t+1] - s_wps[t]) / 20`, the reward of the step taken after sample t
+    (train_pair_cost.py:146-148).  Nothing crosses PCIe except the 8-byte seeds; a learner slices the rings on the device.
+    `rings`: reuse tensors of a previous call."""
+    import torch
+
+    dev = torch.device("cuda", env.device_index if device is None else device)
+    shapes = env.record_shapes(kind, n_steps, max_tasks, max_agents)
+    if rings is None:
+        tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32, np.float64: torch.float64}
+        rings = {name: torch.empty(shape, dtype=tdt[dtype], device=dev) for name, (shape, dtype) in shapes.items()}
+    env.set_allocator("hungarian_gated")
+    env.rollout_record(np.asarray(seeds, dtype=np.uint64), n_steps, interval, False, rings, kind, max_tasks, max_agents)
+    env.sync()
+    out = dict(rings)
+    out["step_reward"] = (rings["s_wps"][1:] - rings["s_wps"][:-1]) / 20.0
+    return out
 
 
 def step_rewards(s_wps_prev: np.ndarray, s_wps_now: np.ndarray) -> np.ndarray:

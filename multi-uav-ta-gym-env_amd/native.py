@@ -26,7 +26,7 @@ EXPORTS = [
     "muavta_avoid_obstacles", "muavta_device_ptrs", "muavta_last_kernel_ms", "muavta_sync",
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
-    "muavta_last_seed_ms", "muavta_call", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
+    "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
 ]
 
 
@@ -108,6 +108,7 @@ def lib() -> C.CDLL:
     L.muavta_comm_init.argtypes = [vp, i32, i32, vp]
     L.muavta_allreduce_metrics.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.muavta_comm_destroy.argtypes = [vp]
+    L.muavta_rollout_record.argtypes = [vp, u64p, i32, i32, i32, i32, vp]
     L.muavta_call.argtypes = [vp, i32, i32, vp, C.c_double, vp]
     L.muavta_sync.argtypes = [vp]
     L.muavta_refresh_observation.argtypes = [vp]

@@ -115,6 +115,14 @@ class MuavtaDims(C.Structure):
     ]
 
 
+class MuavtaRecord(C.Structure):
+    """include/muavta.h: MuavtaRecord (device pointers of the per-step rings of muavta_rollout_record)."""
+    _fields_ = [("kind", C.c_int32), ("max_tasks", C.c_int32), ("max_agents", C.c_int32), ("reserved", C.c_int32),
+                ("task_feats", C.c_void_p), ("task_mask", C.c_void_p), ("task_ids", C.c_void_p), ("agent_feats", C.c_void_p),
+                ("agent_mask", C.c_void_p), ("agent_ids", C.c_void_p), ("edge_valid", C.c_void_p), ("n_urgent", C.c_void_p),
+                ("expert_mask", C.c_void_p), ("replanned", C.c_void_p), ("s_wps", C.c_void_p)]
+
+
 class _Cfg:
     """Uniform getattr-with-default view over an options object or a (spec, flags) dict pair."""
 

@@ -136,6 +136,14 @@ CASE_SPECS: Dict[str, Dict[str, Any]] = {
         tasks={"Att": 4, "Rec": 10, "Hold": 0},
         threats_list=[("T1", 7), ("T2", 10)],
     ),
+    # registry cases of experiments/paper_scenarios.py:146-240: oversized fleets, scale clones and the commit/hold stress
+    "WPS_attn_OS18": _derive(_WPS_ATTN, agents={"F1": 6, "F2": 3, "R1": 6, "R2": 3}),
+    "WPS_attn_OS24": _derive(_WPS_ATTN, agents={"F1": 8, "F2": 4, "R1": 8, "R2": 4}),
+    "WPS_attn_L": _derive(_WPS_ATTN, agents={"F1": 10, "F2": 5, "R1": 10, "R2": 5}, tasks={"Att": 10, "Rec": 20, "Hold": 0},
+                          threats_list=[("T1", 20), ("T2", 15)]),
+    "WPS_attn_XL": _derive(_WPS_ATTN, agents={"F1": 14, "F2": 6, "R1": 14, "R2": 6}, tasks={"Att": 13, "Rec": 26, "Hold": 0},
+                           threats_list=[("T1", 26), ("T2", 20)]),
+    "WPS_commit": _derive(_WPS_ATTN, commit_horizon=25, reassign_penalty=2.0),
     "WPS_burst64": _derive(
         _WPS_BURST,
         agents={"F1": 16, "F2": 16, "R1": 16, "R2": 16},
@@ -177,4 +185,9 @@ TILES = {
     "WPS_escort": (24, 48, 24),
     "WPS_escort24": (24, 48, 24),
     "WPS_burst64": (64, 128, 48),
+    "WPS_attn_OS18": (24, 48, 24),
+    "WPS_attn_OS24": (24, 48, 24),
+    "WPS_attn_L": (64, 128, 48),
+    "WPS_attn_XL": (64, 128, 48),
+    "WPS_commit": (16, 48, 16),
 }

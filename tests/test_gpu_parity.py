@@ -111,7 +111,8 @@ def compare(snap, i, o, tag, check_obs=True):
 
 
 CASES = [("WPS_easy", 20, 6), ("WPS_hard", 20, 8), ("WPS_burst", 20, 4), ("WPS_attn", 20, 4), ("WPS_attn_AWACS", 20, 3),
-         ("D2_popup_threats", 20, 2), ("WPS_hard_x2", 20, 8), ("WPS_escort", 12, 6), ("WPS_escort24", 12, 4), ("WPS_burst64", 20, 2)]
+         ("D2_popup_threats", 20, 2), ("WPS_hard_x2", 20, 8), ("WPS_escort", 12, 6), ("WPS_escort24", 12, 4), ("WPS_burst64", 20, 2),
+         ("WPS_commit", 20, 3), ("WPS_attn_OS24", 20, 2), ("WPS_attn_L", 20, 2), ("WPS_attn_XL", 20, 2)]
 
 
 @pytest.mark.parametrize("case,interval,n", CASES, ids=[c[0] for c in CASES])
@@ -775,6 +776,31 @@ def test_il_stream_vs_reference_and_oracle(path):
     assert np.array_equal(env.metrics()[0], g["metrics"])
     for i, o in enumerate(oracles):
         assert np.array_equal(env.metrics()[i], o.metrics())
+
+
+@pytest.mark.parametrize("case,kind,mt,ma", [("WPS_hard", "pair", 32, 16), ("WPS_hard_x2", "pair_raw", 32, 16), ("WPS_escort", "escort", 48, 16)])
+def test_il_record_rings_equal_the_per_step_stream(case, kind, mt, ma):
+    """muavta_rollout_record (one launch, per-step rings on the device) against il_stream (three launches per step, already
+    pinned to the reference's samples above): every ring slot bit-equal, S_WPS series and final metrics included."""
+    import torch
+    from muavta_amd.il import il_record, il_stream
+    n, steps = 5, 150
+    seeds = np.arange(11, 11 + n)
+    interval = 12 if "escort" in case else 20
+    env = _env(case, n)
+    rec = il_record(env, seeds, steps, interval, kind, mt, ma)
+    m_rec = env.rollout_metrics()
+    assert not env.get("ERROR").any()
+    got = {k: v.cpu().numpy() for k, v in rec.items()}
+    env2 = _env(case, n)
+    prev = None
+    for t, b in il_stream(env2, seeds, steps, interval, kind, mt, ma, with_reward=True):
+        for key in ("task_feats", "task_mask", "task_ids", "agent_feats", "agent_mask", "agent_ids", "edge_valid", "n_urgent", "expert_mask", "replanned"):
+            assert np.array_equal(got[key][t], b[key]), f"{case} t={t}: {key}"
+        if t:
+            assert np.array_equal(got["step_reward"][t - 1], b["step_reward"]), f"{case} t={t}: step reward"
+    assert np.array_equal(got["s_wps"][steps], env2.metrics()[:, 4]) and np.array_equal(m_rec, env2.metrics())
+    assert isinstance(rec["task_feats"], torch.Tensor) and rec["task_feats"].is_cuda and rec["step_reward"].shape == (steps, n)
 
 
 # ---- fuzzed configurations (knob combinations no registry case has); reference traces in tests/golden/trace_FUZZ* ----

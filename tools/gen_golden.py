@@ -339,6 +339,11 @@ TRACE_PLAN = [
     ("WPS_escort", 12, (0, 1), 24),
     ("WPS_escort24", 12, (0,), 16),
     ("WPS_burst64", 20, (0,), 8),
+    ("WPS_commit", 20, (0,), 16),
+    ("WPS_attn_OS18", 20, (0,), 8),
+    ("WPS_attn_OS24", 20, (0,), 8),
+    ("WPS_attn_L", 20, (0,), 8),
+    ("WPS_attn_XL", 20, (0,), 8),
 ]
 
 
