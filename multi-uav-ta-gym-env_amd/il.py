@@ -64,7 +64,8 @@ def il_record(env: BatchedMultiUAVEnv, seeds, n_steps: int = 150, interval: int 
     env.rollout_record(np.asarray(seeds, dtype=np.uint64), n_steps, interval, False, rings, kind, max_tasks, max_agents)
     env.sync()
     out = dict(rings)
-    out["step_reward"] = (rings["s_wps"][1:] - rings["s_wps"][:-1]) / 20.0
+    diff = rings["s_wps"][1:] - rings["s_wps"][:-1]
+    out["step_reward"] = torch.div(diff, torch.full_like(diff, 20.0))  # tensor / tensor: IEEE division (a scalar divisor becomes a multiplication by its reciprocal)
     return out
 
 
