@@ -24,6 +24,11 @@
 #define DEV __device__ __forceinline__
 #define DEVN __device__ __noinline__
 
+// 1: the observation rows' HBM operands are requested before the task-time rebuild (latency overlap, +28 live VGPRs there)
+#ifndef MUAVTA_OBS_PREFETCH
+#define MUAVTA_OBS_PREFETCH 0
+#endif
+
 namespace muavta {
 
 constexpr int WG = 64;  // one wave64 per env
@@ -200,7 +205,15 @@ struct Sim {
   uint32_t win_len, win_stride;
 
   __device__ Sim(State& s, Cold& c, Scratch<TL>& x, const DevParams& p, uint32_t* t)
-      : S(s), C(c), X(x), P(p), tape(t), lane(threadIdx.x), win_ptr(&s.rng_win[0][0]), win_len(8), win_stride(8), tnow(s.time_steps) {}
+      : S(s), C(c), X(x), P(p), tape(t), lane(opaque_lane()), win_ptr(&s.rng_win[0][0]), win_len(8), win_stride(8), tnow(s.time_steps) {}
+  // The lane id, opaque to the optimiser.  A Sim built inside the 150-step loop of k_rollout would otherwise have every
+  // lane-derived value (ballot prefix masks, lane & 7, lane < n ...) hoisted out of the loop, where they overflow the 128
+  // VGPRs and come back as scratch (HBM) reloads at ~150 sites of the step; recomputing them is one or two VALU ops.
+  static __device__ __forceinline__ int opaque_lane() {
+    int l = threadIdx.x;
+    asm volatile("" : "+v"(l));
+    return l;
+  }
   DEV void sync_clock() { tnow = S.time_steps; }  // after the blob was (re)loaded or reset behind this object's back
 
   DEV void fail(int code) { if (S.error == 0) S.error = code; }
@@ -252,6 +265,10 @@ struct Sim {
 
   // All lanes: regenerate consumed blocks (called at step boundaries, uniform control flow).
   DEV void rng_refill() {
+    {  // fast path (almost every step): no stream has consumed its current block — one 16-byte LDS read decides
+      const uint4 c = *reinterpret_cast<const uint4*>(&S.rng_idx[0]);
+      if ((c.x & 0xffffu) < 624u && (c.y & 0xffffu) < 624u && (c.z & 0xffffu) < 624u && (c.w & 0xffffu) < 624u) return;
+    }
     for (int st = 0; st < 4; st++) {
       uint32_t p = S.rng_idx[st];
       uint32_t blk = (p >> 16) & 1u, off = p & 0xffffu;
@@ -2280,9 +2297,13 @@ struct Sim {
   // Task.initTime / doneTime of every live, non-retired slot from the agents' queue entries (== the task's
   // allocationDetails): times are non-negative doubles, so u64 min/max on their bit patterns (LDS atomics)
   // order them numerically.  One queue entry per lane.
-  DEV void refresh_task_times() {
-    if (!S.times_dirty) return;  // uniform: LDS word
-    cold_sync();
+  // The caller has passed a cold_sync() (the queue-time rows other lanes wrote are visible).  Besides updating the HBM
+  // rows it leaves (initTime, doneTime) of every slot in the scratch tile (obs_times()), where the observation rows of
+  // this step pick them up without another trip to memory.  Returns whether it ran.
+  DEV double* obs_times() { return X.cost; }  // [2][T] after refresh_task_times() returned true
+  DEV bool refresh_task_times() {
+    if (!S.times_dirty) return false;  // uniform: LDS word
+    lds_sync();
     if (lane == 0) S.times_dirty = 0;
     unsigned long long* tmin = reinterpret_cast<unsigned long long*>(X.cost);
     unsigned long long* tmax = tmin + T;
@@ -2301,23 +2322,38 @@ struct Sim {
       }
     }
     lds_sync();
+    double* tt = obs_times();
     for (int s = lane; s < T; s += WG) {
+      double ti, td;
       if (S.t_id[s] >= 0 && S.t_status[s] != 2) {
-        if (tmin[s] == ~0ull) { C.t_init[s] = -1; C.t_dtime[s] = -1; }
+        if (tmin[s] == ~0ull) { ti = -1; td = -1; }
         else {
-          C.t_init[s] = __longlong_as_double((long long)tmin[s]);
-          C.t_dtime[s] = __longlong_as_double((long long)tmax[s]) + (double)task_duration(S.t_type[s]);
+          ti = __longlong_as_double((long long)tmin[s]);
+          td = __longlong_as_double((long long)tmax[s]) + (double)task_duration(S.t_type[s]);
         }
-      }
+        C.t_init[s] = ti; C.t_dtime[s] = td;
+      } else { ti = -1; td = -1; }  // retired / free slots: no observation row reads them
+      tt[s] = ti; tt[T + s] = td;
     }
-    cold_sync();
+    lds_sync();
+    return true;
   }
 
   DEV void write_obs(float* o_tasks, unsigned long long* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags) {
-    refresh_task_times();
     cold_sync();  // the rows below read the requirement vectors the serial phases of this step may have changed
     const int MT = P.max_tasks, nA = P.n_agents;
     const int n = S.n_open;
+    // The HBM rows of the first 64 observation rows are requested NOW, so that their latency runs under the rebuild of the
+    // task times below (LDS work); (initTime, doneTime) then come from the scratch tile when they were rebuilt.
+    double pc[6], pa[6], pti = 0, ptd = 0;
+    const bool dirty = S.times_dirty != 0;
+    if (MUAVTA_OBS_PREFETCH) {
+      const int s0 = lane < n ? (int)S.open_slot[lane] : 0;
+#pragma unroll
+      for (int c = 0; c < 6; c++) { pc[c] = lane < n ? C.t_cur[c][s0] : 0.0; pa[c] = lane < n ? C.t_alloc[c][s0] : 0.0; }
+      if (!dirty && lane < n) { pti = C.t_init[s0]; ptd = C.t_dtime[s0]; }
+    }
+    refresh_task_times();
     const double mts = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1);
     unsigned long long leg0 = 0ull, leg1 = 0ull;  // lane a: legal bits of agent a (rows 0..63, 64..127)
     PROF(15);
@@ -2338,19 +2374,32 @@ struct Sim {
         tid = S.t_id[s];
         ty = S.t_type[s];
         typemask = (S.t_flags[s] & TF_ELIGIBLE) ? S.t_elig[s] : 0xffffffffu;
-        if (P.saturate_mask && C.t_alloc[ty][s] >= S.t_org[s]) typemask = 0;
         r[0] = (float)tid;
         r[1] = (float)(S.t_px[s] / MAX_COORD);
         r[2] = (float)(S.t_py[s] / MAX_COORD);
         r[3] = (float)S.t_status[s];
+        double cur[6], alc[6], ti, td;
+        if (MUAVTA_OBS_PREFETCH && base == 0) {
 #pragma unroll
-        for (int c = 0; c < 6; c++) { r[4 + c] = (float)C.t_cur[c][s]; r[10 + c] = (float)C.t_alloc[c][s]; }
+          for (int c = 0; c < 6; c++) { cur[c] = pc[c]; alc[c] = pa[c]; }
+          if (dirty) { ti = obs_times()[s]; td = obs_times()[T + s]; } else { ti = pti; td = ptd; }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 6; c++) { cur[c] = C.t_cur[c][s]; alc[c] = C.t_alloc[c][s]; }
+          if (dirty) { ti = obs_times()[s]; td = obs_times()[T + s]; } else { ti = C.t_init[s]; td = C.t_dtime[s]; }
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) { r[4 + c] = (float)cur[c]; r[10 + c] = (float)alc[c]; }
         if (P.include_time_windows) {
-          r[16] = (float)((C.t_init[s] - (double)tnow) / mts);
-          r[17] = (float)((C.t_dtime[s] - (double)tnow) / mts);
+          r[16] = (float)((ti - (double)tnow) / mts);
+          r[17] = (float)((td - (double)tnow) / mts);
           r[18] = (float)((double)ty / 6.0);
         }
-        const double unmet = fmax(C.t_cur[ty][s] - C.t_alloc[ty][s], 0.0);
+        double cur_ty = cur[0], alc_ty = alc[0];  // (selects, not cur[ty]: a dynamically indexed local array would live in scratch memory)
+#pragma unroll
+        for (int c = 1; c < 6; c++) if (ty == c) { cur_ty = cur[c]; alc_ty = alc[c]; }
+        if (P.saturate_mask && alc_ty >= S.t_org[s]) typemask = 0;
+        const double unmet = fmax(cur_ty - alc_ty, 0.0);
         r[19] = (float)(unmet / fmax(S.t_org[s], 1e-6));
         r[20] = (float)fmin(((double)tnow - (double)S.t_created[s]) / mts, 1.0);
       } else if (!(j == 0 && n == 0)) {
@@ -2588,18 +2637,90 @@ struct Sim {
       cost_vec c0, c1;
       if constexpr (TL::REGC) {
         // lane = LSAP column (a task, or an agent when scipy transposes): its whole cost column goes straight into
-        // uniformly indexed registers, one row per iteration — no A x T tile in LDS
-        const bool incol = lane < Cc;
-        const int my_a = (tr && incol) ? X.freeA[lane] : -1;
-        const int my_s = (!tr && incol) ? S.open_slot[X.roundT[lane]] : -1;
-        for (int i = 0; i < Rr; i++) {
-          double c = 0.0;
-          if (incol) {
-            if (tr) c = pair_cost(my_a, S.open_slot[X.roundT[i]], i);
-            else c = pair_cost(X.freeA[i], my_s, lane);
-            feasible |= c < 1e5 / 2;
+        // uniformly indexed registers, one row per iteration — no A x T tile in LDS.  pair_cost() split in two: the column's
+        // side (task or agent fields) is read from LDS ONCE per lane, the row's side is the same for every lane (broadcast
+        // reads, issued together), so an iteration costs one LDS round trip instead of a chain of six.  Same arithmetic.
+        static_assert(!TL::REGC || KW <= 2, "the register-built cost columns keep an agent's known mask in two words");
+        struct TS { double px, py, urgency, missing, press; int type, info; bool elig_on, esc_task, esc_flag; uint32_t elig; };
+        struct AS { double px, py; int type, rank; uint32_t k0, k1; };
+        auto load_ts = [&](int sl, int jr) {
+          TS t;
+          const int fl = S.t_flags[sl];
+          t.px = S.t_px[sl]; t.py = S.t_py[sl]; t.type = S.t_type[sl]; t.elig = S.t_elig[sl];
+          t.elig_on = (fl & TF_ELIGIBLE) != 0; t.esc_flag = (fl & TF_ESCORT) != 0;
+          t.esc_task = t.esc_flag || S.t_required[sl] > 0;
+          t.urgency = 0.0;
+          if (fl & TF_DEADLINE) {
+            int remaining = S.t_deadline[sl] - tnow;
+            remaining = remaining > 0 ? remaining : 0;
+            t.urgency = 1.0 - fmin((double)remaining / 40.0, 1.0);
           }
-          if constexpr (A > 16) { if (i < 16) c0[i] = c; else c1[i - 16] = c; } else c0[i] = c;
+          t.missing = fmax(X.resid[sl], 1e-6);
+          t.info = mode == 1 ? pair_info()[sl] : 0;
+          t.press = mode == 2 ? X.spc[jr] : 0.0;
+          return t;
+        };
+        auto load_as = [&](int a) {
+          AS g;
+          g.px = S.a_px[a]; g.py = S.a_py[a]; g.type = S.a_type[a];
+          g.k0 = S.known[a][0]; g.k1 = KW > 1 ? S.known[a][KW > 1 ? 1 : 0] : 0u;
+          g.rank = mode == 1 ? (int)X.live_rank[a] : 0;
+          return g;
+        };
+        auto pair_eval = [&](int a, const AS& g, int sl, const TS& t) -> double {  // == pair_cost(a, sl, jr)
+          double c = 1e6;
+          bool ok = !(vis && !((((sl >> 5) ? g.k1 : g.k0) >> (sl & 31)) & 1u));
+          if (ok && t.elig_on && !((t.elig >> g.type) & 1u)) ok = false;
+          if (ok) {
+            const double capv = S.a_caps[t.type][a];
+            const double delivered = t.esc_task ? 1.0 : capv;
+            if (delivered > 0) {
+              const double dist = norm2(g.px - t.px, g.py - t.py);
+              const double base = dist / fmax(MAX_COORD, 1.0) - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
+              double score = 0.0;
+              if (mode == 1) {
+                if ((t.info & 255) < 32 && g.rank < 16 && capv > 0) {
+                  double scar = 0.0;
+                  if (vis) scar = 1.0 - fmin((double)(t.info >> 8) / (double)n_live, 1.0);
+                  double v = 0.5 * t.urgency + 0.3 * scar - 0.4 * (dist / fmax(MAX_COORD, 1.0));
+                  v = fmin(fmax(v, -0.35), 0.35);
+                  score = (double)(float)v;
+                }
+              }
+              if (mode == 2) {
+                const double cap = capv > 0 ? capv : 0.0;
+                double v = 0.45 * t.urgency + 0.35 * t.press * (0.5 + 0.5 * (t.esc_flag ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
+                const bool fighter = is_fighter(g.type);
+                if (fighter && (t.esc_flag || t.type == MUAVTA_INT)) v += 0.2;
+                if (!fighter && t.type == MUAVTA_REC) v += 0.2;
+                score = fmin(fmax(v, 0.0), 1.0);
+              }
+              if (base < 1e5 / 2) c = base - score;
+            }
+          }
+          return c;
+        };
+        const bool incol = lane < Cc;
+        if (!tr) {
+          const int my_s = incol ? (int)S.open_slot[X.roundT[lane]] : (int)S.open_slot[X.roundT[0]];
+          const TS ts = load_ts(my_s, incol ? lane : 0);
+          for (int i = 0; i < Rr; i++) {
+            const int a = X.freeA[i];
+            const AS g = load_as(a);
+            double c = 0.0;
+            if (incol) { c = pair_eval(a, g, my_s, ts); feasible |= c < 1e5 / 2; }
+            if constexpr (A > 16) { if (i < 16) c0[i] = c; else c1[i - 16] = c; } else c0[i] = c;
+          }
+        } else {
+          const int my_a = incol ? X.freeA[lane] : X.freeA[0];
+          const AS g = load_as(my_a);
+          for (int i = 0; i < Rr; i++) {
+            const int sl = S.open_slot[X.roundT[i]];
+            const TS ts = load_ts(sl, i);
+            double c = 0.0;
+            if (incol) { c = pair_eval(my_a, g, sl, ts); feasible |= c < 1e5 / 2; }
+            if constexpr (A > 16) { if (i < 16) c0[i] = c; else c1[i - 16] = c; } else c0[i] = c;
+          }
         }
       } else {
         for (int p = lane; p < nr * nc; p += WG) {  // one (agent, task) pair per lane

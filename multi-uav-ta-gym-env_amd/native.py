@@ -16,7 +16,7 @@ from .params import MuavtaDims, MuavtaParams
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 SO_PATH = os.environ.get("MUAVTA_SO") or os.path.join(PKG_DIR, "libmuavta.so")  # MUAVTA_SO: diagnostic builds only
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-Os", "-ldl",  # -Os: the rollout kernel is ~150 KB of code; smaller code measured +3.5 % over -O3
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ldl",  # (-Os / -O2 / -O3 within 1.5 % of each other on the 128-VGPR kernel, -Oz -12 %: profiles/ r02 notes)
                 "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
 
 EXPORTS = [
