@@ -1224,21 +1224,31 @@ struct Sim {
   // Returns the index of the first event agent >= start (n_agents if none).
   DEV int move_parallel(int start) {
     const int a = lane;
-    const bool live = a >= start && a < P.n_agents && S.a_state[a] != -1;
+    const bool in_fleet = a >= start && a < P.n_agents;
+    const int ai = in_fleet ? a : 0;  // (lanes outside the fleet read agent 0's fields and discard them)
+    // Every operand of the lane's agent is read up front — two LDS round trips (agent fields, then the fields of the task
+    // they point to) instead of one per branch of the state machine; the values of untaken branches are simply unused.
+    const int st0 = S.a_state[ai], fail_at = S.a_fail[ai], ts0 = S.a_task_start[ai], qlen = S.a_qlen[ai], reeval = S.a_reeval[ai];
+    const int atype = S.a_type[ai];
+    const int last_id = S.a_last_id[ai], last_slot = S.a_last_slot[ai], head_id_ = S.a_qid[ai][0], head_slot = S.a_qslot[ai][0];
+    double px = S.a_px[ai], py = S.a_py[ai];
+    const bool live = in_fleet && st0 != -1;
+    int cid = 0, cs = -1;
+    if (reeval) { cid = last_id; cs = last_slot; }
+    else if (qlen > 0) { cid = head_id_; cs = head_slot; }
+    const int csi = cs >= 0 ? cs : 0;
+    const int tid_at = S.t_id[csi], tstat = S.t_status[csi], ty = S.t_type[csi];
+    const double tpx = S.t_px[csi], tpy = S.t_py[csi];
     bool evt = false, pop_head = false;
-    int new_st = 0, new_ts = 0, cid = 0, cs = -1;
-    double px = 0, py = 0, ddx = 0.0, ddy = 0.0;
+    int new_st = 0, new_ts = 0;
+    double ddx = 0.0, ddy = 0.0;
     if (live) {
-      if (S.a_fail[a] == tnow) {
+      if (fail_at == tnow) {
         evt = true;
       } else {
-        px = S.a_px[a]; py = S.a_py[a];
-        const double speed = speed_of(S.a_type[a]);
-        new_st = S.a_state[a]; new_ts = S.a_task_start[a];
-        const int qlen = S.a_qlen[a], reeval = S.a_reeval[a];
-        if (reeval) { cid = S.a_last_id[a]; cs = S.a_last_slot[a]; }
-        else if (qlen > 0) { cid = S.a_qid[a][0]; cs = S.a_qslot[a][0]; }
-        const bool retired = cid != 0 && ref_retired(cid, cs);
+        const double speed = speed_of(atype);
+        new_st = st0; new_ts = ts0;
+        const bool retired = cid != 0 && (!(cs >= 0 && tid_at == cid) || tstat == 2);  // ref_retired(cid, cs)
         const bool to_task = cid != 0 && !retired;
         const bool idle_check = new_st == 0 && !reeval && qlen == 0;    // :987-993
         const bool to_base = !to_task && (idle_check || new_st == 3);
@@ -1247,7 +1257,7 @@ struct Sim {
           // vector to the target, its norm, unit vector, displacement — identical arithmetic on both paths:
           // task: dir/dist with the EPS guard (:1014-1020); base: norm_vector(base - pos) (:1119) whose norm
           // equals norm(pos - base) used by the distance tests (:992,:1116)
-          const double tx = to_task ? S.t_px[cs] : BASE_X, ty_ = to_task ? S.t_py[cs] : BASE_Y;
+          const double tx = to_task ? tpx : BASE_X, ty_ = to_task ? tpy : BASE_Y;
           const double dx = tx - px, dy = ty_ - py;
           const double dist = norm2(dx, dy);
           double ux = 0, uy = 0;
@@ -1256,21 +1266,20 @@ struct Sim {
           double ndx, ndy;
           displacement(px, py, ux, uy, speed, ndx, ndy);
           if (to_task) {
-            const int ty = S.t_type[cs];
-            const double engage = engage_range(S.a_type[a]);
+            const double engage = engage_range(atype);
             if (new_st == 1) {
               if (ty == MUAVTA_INT) {
                 if (dist < engage) evt = true;
                 else { ddx = ndx; ddy = ndy; }
               } else if (dist < speed) {
                 new_st = 2; new_ts = tnow;
-                px = S.t_px[cs]; py = S.t_py[cs];
+                px = tpx; py = tpy;
               } else { ddx = ndx; ddy = ndy; }
             } else if (new_st == 2) {
               if (ty == MUAVTA_INT && dist >= engage) new_st = 1;
               if (new_ts == -1) {
                 new_ts = tnow;
-                px = S.t_px[cs]; py = S.t_py[cs];
+                px = tpx; py = tpy;
               } else if ((tnow - new_ts) >= task_duration(ty) && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
                          ty != MUAVTA_INT && ty != MUAVTA_DET) {
                 evt = true;
@@ -1859,26 +1868,29 @@ struct Sim {
     static_assert(H <= 64, "one threat per lane");
     const int n = S.n_active_threats;
     const int k = lane;
-    int h = 0;
-    bool active = false;
-    if (k < n) { h = S.h_order[k]; active = S.h_status[h] != 2; }
+    // operands in three LDS round trips (spawn-order slot -> the threat's record -> its target's position and its Int
+    // task's slot), whatever branch the lane takes afterwards
+    const int h = k < n ? (int)S.h_order[k] : 0;
+    const int hst = S.h_status[h], hty = S.h_type[h], slot = S.h_task_slot[h], task_id = S.h_task_id[h], htf = S.h_tflags[h];
+    int tgt = S.h_target[h], icpt = S.h_intercept[h];
+    const int hmis = S.h_mission[h];
+    const double px = S.h_px[h], py = S.h_py[h];
+    bool active = k < n && hst != 2;
     if (start == 0) livemask = __ballot(active);  // python snapshots [t for t in self.threats if t.status != 2] before the loop
     active = k >= start && k < n && ((livemask >> k) & 1ull);
+    const int sli = slot >= 0 ? slot : 0;
+    const int t_id_at = S.t_id[sli], t_stat = S.t_status[sli], t_fl = S.t_flags[sli];
     bool evt = false;
     double npx = 0, npy = 0;
-    int tgt = -1, icpt = -1, slot = -1;
     bool live_task = false;
     if (active) {
-      const int hty = S.h_type[h];
       const double speed = speed_of(hty);
-      const double px = S.h_px[h], py = S.h_py[h];
-      tgt = S.h_target[h]; icpt = S.h_intercept[h];
-      if (S.h_status[h] == 0 || tgt < 0) {
+      if (hst == 0 || tgt < 0) {
         npx = px + speed * 0.0;
         npy = py + speed * -1.0;
       } else {
         if (P.escort_enabled) {  // _retarget_threat_via_escort (:1766-1779): reads agents only
-          int mission = S.h_mission[h] >= 0 ? S.h_mission[h] : tgt;
+          int mission = hmis >= 0 ? hmis : tgt;
           if (mission >= 0 && S.a_state[mission] != -1 && is_recon(S.a_type[mission])) {
             int cnt;
             int e0 = closest_escort(mission, P.escort_intercept_radius, &cnt);
@@ -1886,17 +1898,17 @@ struct Sim {
             else { tgt = e0; icpt = e0; }
           }
         }
-        double dx = S.a_px[tgt] - px, dy = S.a_py[tgt] - py;
+        const double ax = S.a_px[tgt], ay = S.a_py[tgt];
+        double dx = ax - px, dy = ay - py;
         norm_vector(dx, dy);
         npx = px + speed * dx;
         npy = py + speed * dy;
-        if (norm2(S.a_px[tgt] - npx, S.a_py[tgt] - npy) < engage_range(hty)) evt = true;
+        if (norm2(ax - npx, ay - npy) < engage_range(hty)) evt = true;
       }
-      slot = S.h_task_slot[h];
-      live_task = ref_valid(S.h_task_id[h], slot);
+      live_task = slot >= 0 && t_id_at == task_id;  // ref_valid(S.h_task_id[h], slot)
       if (npy <= 0) {  // leaving the area: an event only if the retirement would still change something
-        if (live_task) evt |= (S.t_status[slot] != 2) || ((S.t_flags[slot] & TF_DEADLINE) && !(S.t_flags[slot] & TF_COUNTED));
-        else evt |= (S.h_tflags[h] & TF_DEADLINE) && !(S.h_tflags[h] & TF_COUNTED);
+        if (live_task) evt |= (t_stat != 2) || ((t_fl & TF_DEADLINE) && !(t_fl & TF_COUNTED));
+        else evt |= (htf & TF_DEADLINE) && !(htf & TF_COUNTED);
       }
     }
     const unsigned long long em = __ballot(evt);

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(WG) void k_reset(const DevCtx* __restrict__ ctxp, c
 
 // act_agent == nullptr: use the actions staged in the blob by k_allocate
 template <class TL>
-__global__ __launch_bounds__(WG, 2) void k_step(const DevCtx* __restrict__ ctxp, const int32_t* act_agent, const int32_t* act_index, int act_cap,
+__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(const DevCtx* __restrict__ ctxp, const int32_t* act_agent, const int32_t* act_index, int act_cap,
                                              double* rel_log) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const DevParams& P = ctx.P;
