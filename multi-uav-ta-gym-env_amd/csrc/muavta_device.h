@@ -1182,21 +1182,30 @@ struct Sim {
     lds_sync();
     PROF(7);
     {
-      // wave-wide pre-checks so that lane 0 only walks the lists when something is due this step
+      // wave-wide pre-checks so that lane 0 only walks the lists when something is due this step.  ONE pass over the live
+      // slots gives both "a window expired" and "a task still blocks mission completion"; the agents' idle / responding
+      // flags are read alongside.  Only a window expiry (status changes, agents freed) invalidates them: evaluated again then.
       bool due = false, expiring = false, idle = false, resp = false, blocking = false;
       for (int k = lane; k < S.n_pending; k += WG) due |= tnow >= S.pend_time[k];
-      for (int k = lane; k < S.n_order; k += WG) {
-        const int s = S.t_order[k];
-        expiring |= (S.t_flags[s] & TF_DEADLINE) && S.t_status[s] != 2 && tnow > S.t_deadline[s];
-      }
+      auto scan_slots = [&]() {
+        expiring = false; blocking = false;
+        for (int k = lane; k < S.n_order; k += WG) {
+          const int s = S.t_order[k];
+          const int fl = S.t_flags[s], st = S.t_status[s], dl = S.t_deadline[s], ty = S.t_type[s];
+          expiring |= (fl & TF_DEADLINE) && st != 2 && tnow > dl;
+          blocking |= !((fl & TF_ESCORT) || ty == MUAVTA_DET || ty == MUAVTA_HOLD || st == 2);  // !counts_for_mission_done(s)
+        }
+        idle = false; resp = false;
+        if (lane < P.n_agents && S.a_state[lane] != -1) { idle = S.a_qlen[lane] == 0; resp = !idle; }
+      };
+      scan_slots();
       const bool any_due = __ballot(due) != 0ull;
       const bool any_exp = P.hard_windows && __ballot(expiring) != 0ull;
       PROF(28);
       if (any_due || any_exp) process_lists_coop(any_due, any_exp);
       lds_sync();
       PROF(29);
-      if (lane < P.n_agents && S.a_state[lane] != -1) { idle = S.a_qlen[lane] == 0; resp = !idle; }
-      for (int k = lane; k < S.n_order; k += WG) blocking |= !counts_for_mission_done(S.t_order[k]);
+      if (any_exp) scan_slots();
       const int n_idle = __popcll(__ballot(idle));
       const bool responding = __ballot(resp) != 0ull;
       const bool all_done_tasks = __ballot(blocking) == 0ull;
@@ -2646,7 +2655,8 @@ struct Sim {
         return c;
       };
       bool feasible = false;
-      cost_vec c0, c1;
+      cost_vec c0;
+      cost_vec_hi c1;
       if constexpr (TL::REGC) {
         // lane = LSAP column (a task, or an agent when scipy transposes): its whole cost column goes straight into
         // uniformly indexed registers, one row per iteration — no A x T tile in LDS.  pair_cost() split in two: the column's
@@ -3167,17 +3177,20 @@ struct Sim {
   // only as each column's POSITION in it (filled in reverse, swap-removed), which is all its tie rule looks at:
   // among the minima take the unassigned column at the LAST position if there is one, else the FIRST position.
   typedef double cost_vec __attribute__((ext_vector_type(16)));
+  // rows 16 .. A-1 of a column: 8 registers pairs are enough up to 24 agents (16 fewer VGPRs held through the solve)
+  typedef double cost_vec_hi __attribute__((ext_vector_type((A > 24) ? 16 : 8)));
   DEV void lsap_reg(int nr, int nc) {  // cost tile staged in X.cost (R x C row-major)
-    cost_vec c0, c1;
+    cost_vec c0;
+    cost_vec_hi c1;
 #pragma unroll
     for (int i = 0; i < 16; i++) { c0[i] = (i < nr && lane < nc) ? X.cost[i * nc + lane] : 0.0; }
     if (A > 16) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) { c1[i] = (16 + i < nr && lane < nc) ? X.cost[(16 + i) * nc + lane] : 0.0; }
+      for (int i = 0; i < ((A > 24) ? 16 : 8); i++) { c1[i] = (16 + i < nr && lane < nc) ? X.cost[(16 + i) * nc + lane] : 0.0; }
     }
     lsap_reg_core(nr, nc, c0, c1);
   }
-  DEV void lsap_reg_core(int nr, int nc, const cost_vec& c0, const cost_vec& c1) {
+  DEV void lsap_reg_core(int nr, int nc, const cost_vec& c0, const cost_vec_hi& c1) {
     const double INF = __builtin_huge_val();
     double u_r = 0, vj = 0;  // lane r < nr: u[r];  lane j < nc: v[j]
     int c4r = -1, r4c = -1;  // lane r: col4row[r];  lane j: row4col[j]
