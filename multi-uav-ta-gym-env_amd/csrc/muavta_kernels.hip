@@ -554,6 +554,17 @@ thread_local std::string g_create_error;
 
 enum TileKind { TK16 = 0, TK24 = 1, TK64 = 2 };
 
+// An ABI call runs on its handle's device and leaves the calling thread's current device as it found it (a caller that
+// mixes this library with torch on another device must not have its current device changed under it).
+struct DeviceScope {
+  int prev = -1, want;
+  explicit DeviceScope(int d) : want(d) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != want) (void)hipSetDevice(want);
+  }
+  ~DeviceScope() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+
 }  // namespace
 
 struct MuavtaEnv {
@@ -964,7 +975,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
                 e->cold_bytes = sizeof(EnvCold<TL>); scratch_bytes = sizeof(Scratch<TL>); });
   (void)scratch_bytes;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); muavta_destroy(e); return MUAVTA_E_HIP; } } while (0)
-  CK(hipSetDevice(device));
+  DeviceScope scope_(device);
   CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
   CK(hipEventCreate(&e->ev0));
   CK(hipEventCreate(&e->ev1));
@@ -1005,7 +1016,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
 int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   muavta_comm_destroy(e);
-  hipSetDevice(e->device);
+  DeviceScope scope_(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
   hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
@@ -1045,7 +1056,7 @@ static int seed_streams(MuavtaEnv* e, const uint32_t** out) {
 
 int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
   if (!e || !seeds) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
   const uint32_t* sb = nullptr;
   { int rc = seed_streams(e, &sb); if (rc) return rc; }
@@ -1058,7 +1069,7 @@ int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
 
 static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
   if (!e->did_reset) { e->err = "step before reset"; return MUAVTA_E_STATE; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   const int32_t *da = nullptr, *di = nullptr;
   if (aa) {
     size_t bytes = (size_t)e->n_envs * e->A * sizeof(int32_t);
@@ -1096,7 +1107,7 @@ int muavta_step_staged(MuavtaEnv* e) {
 int muavta_allocate(MuavtaEnv* e, int32_t interval, int32_t use_vis, int32_t* act_agent, int32_t* act_index) {
   if (!e) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "allocate before reset"; return MUAVTA_E_STATE; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, interval, use_vis, e->alloc_mode,
                                  e->d_act_agent, e->d_act_index, e->A));
   HIPCHK(e, hipGetLastError());
@@ -1132,7 +1143,7 @@ extern "C" {
 static int rollout_impl(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t interval, int32_t use_vis, int32_t write_obs, const MuavtaRecord* rec) {
   if (!e || n_steps < 0) return MUAVTA_E_ARG;
   if (!seeds && !e->did_reset) { e->err = "rollout without seeds before reset"; return MUAVTA_E_STATE; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   const uint64_t* ds = nullptr;
   if (seeds) {
     HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
@@ -1180,14 +1191,14 @@ int muavta_set_allocator(MuavtaEnv* e, int32_t mode) {
 
 int muavta_sync(MuavtaEnv* e) {
   if (!e) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
 }
 
 int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
   if (!e || !ms) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipEventSynchronize(e->ev1));
   HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
   e->last_ms = *ms;
@@ -1196,7 +1207,7 @@ int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
 
 int muavta_last_seed_ms(MuavtaEnv* e, float* ms) {  // the RNG seeding kernel that preceded the last muavta_rollout (0 without seeds)
   if (!e || !ms) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   *ms = 0.f;
   if (!e->last_seeded) return MUAVTA_OK;
   HIPCHK(e, hipEventSynchronize(e->ev0));
@@ -1207,7 +1218,7 @@ int muavta_last_seed_ms(MuavtaEnv* e, float* ms) {  // the RNG seeding kernel th
 int muavta_observe(MuavtaEnv* e, float* tasks, uint64_t* legal, uint8_t* pad, float* agents, float* flags) {
   if (!e) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "observe before reset"; return MUAVTA_E_STATE; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   const size_t N = (size_t)e->n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
   if (tasks) HIPCHK(e, hipMemcpyAsync(tasks, e->O.tasks, N * mt * 21 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   if (legal) HIPCHK(e, hipMemcpyAsync(legal, e->O.legal, N * nA * ((mt + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
@@ -1233,7 +1244,7 @@ int muavta_tokens_device(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t 
   if (!e || token_dims(kind, &dt, &da) || max_tasks < 1 || max_agents < 1 || max_tasks > 4096 || max_agents > 4096 || !task_feats || !task_mask ||
       !task_ids || !agent_feats || !agent_mask || !agent_ids || !edge_valid) { if (e) e->err = "muavta_tokens: bad argument"; return MUAVTA_E_ARG; }
   if (!e->did_reset) { e->err = "tokens before reset"; return MUAVTA_E_STATE; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   DISPATCH(e, launch_tokens<TL>(e, kind, max_tasks, max_agents, task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned));
   HIPCHK(e, hipGetLastError());
   return MUAVTA_OK;
@@ -1243,7 +1254,7 @@ int muavta_tokens(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t max_age
                   float* expert_mask, int32_t* replanned) {
   int dt, da;
   if (!e || token_dims(kind, &dt, &da) || max_tasks < 1 || max_agents < 1) { if (e) e->err = "muavta_tokens: bad argument"; return MUAVTA_E_ARG; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   const size_t N = (size_t)e->n_envs, MT = (size_t)max_tasks, MA = (size_t)max_agents;
   const size_t sz[10] = {N * MT * dt * 4, N * MT, N * MT * 4, N * MA * da * 4, N * MA, N * MA * 4, N * MA * MT * 4, N * 4, N * MA * MT * 4, N * 4};
   size_t off[11] = {0};
@@ -1276,7 +1287,7 @@ int muavta_call(MuavtaEnv* e, int32_t env_index, int32_t op, const int32_t* iarg
   const bool has_agent = op != MUAVTA_OP_SYNC_ESCORTS && op != MUAVTA_OP_RETIRE_ESCORT;
   if (has_agent && (a.i[0] < 0 || a.i[0] >= e->P.n_agents)) { e->err = "muavta_call: agent id out of range"; return MUAVTA_E_ARG; }
   if (op == MUAVTA_OP_SET_QUEUE && (a.i[1] < 0 || a.i[1] > 6)) { e->err = "muavta_call(SET_QUEUE): at most 6 tasks"; return MUAVTA_E_ARG; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   if (!e->d_call_out) HIPCHK(e, hipMalloc((void**)&e->d_call_out, MUAVTA_CALL_OUT * sizeof(int32_t)));
   DISPATCH(e, hipLaunchKernelGGL(k_call<TL>, dim3(1), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, a, e->d_call_out));
   HIPCHK(e, hipGetLastError());
@@ -1337,7 +1348,7 @@ int muavta_comm_init(MuavtaEnv* e, int32_t rank, int32_t n_ranks, const uint8_t*
   if (e->comm) { e->err = "muavta_comm_init: this handle already has a communicator"; return MUAVTA_E_STATE; }
   Rccl* R = rccl();
   if (!R->lib) { e->err = R->err; return MUAVTA_E_NO_DEVICE; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   ncclUniqueId id;
   memcpy(&id, uid, sizeof(id));
   NCCLCHK(e, R->CommInitRank(&e->comm, n_ranks, id, rank));
@@ -1349,7 +1360,7 @@ int muavta_allreduce_metrics(MuavtaEnv* e, const double* f_partials, int32_t nf,
   if (!e || nf < 0 || nc < 0 || nf > 64 || nc > 64 || (nf && (!f_partials || !f_total)) || (nc && (!counters || !c_total))) { if (e) e->err = "muavta_allreduce_metrics: bad arguments"; return MUAVTA_E_ARG; }
   if (!e->comm) { e->err = "muavta_allreduce_metrics before muavta_comm_init"; return MUAVTA_E_STATE; }
   Rccl* R = rccl();
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   const int n = e->comm_ranks;
   double* fs = (double*)e->d_comm; double* fr = fs + 64;
   int64_t* cs = (int64_t*)(fr + (size_t)64 * n); int64_t* cr = cs + 64;
@@ -1375,7 +1386,7 @@ int muavta_allreduce_metrics(MuavtaEnv* e, const double* f_partials, int32_t nf,
 int muavta_comm_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_E_ARG;
   if (e->comm) {
-    hipSetDevice(e->device);
+    DeviceScope scope_(e->device);
     hipStreamSynchronize(e->stream);
     rccl()->CommDestroy(e->comm);
     e->comm = nullptr;
@@ -1387,7 +1398,7 @@ int muavta_comm_destroy(MuavtaEnv* e) {
 
 int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
   if (!e) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   if (enable && !e->d_rel) {
     const size_t bytes = (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double);
@@ -1402,7 +1413,7 @@ int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
 
 int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from the current state (after muavta_set)
   if (!e) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   DISPATCH(e, hipLaunchKernelGGL(k_observe<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;  // (the kernel refreshes the derived initTime / doneTime rows of the HBM record)
@@ -1411,7 +1422,7 @@ int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from 
 
 int muavta_step_result(MuavtaEnv* e, double* reward, uint8_t* done) {
   if (!e) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   if (reward) HIPCHK(e, hipMemcpyAsync(reward, e->O.reward, (size_t)e->n_envs * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   if (done) HIPCHK(e, hipMemcpyAsync(done, e->O.done, (size_t)e->n_envs, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1421,7 +1432,7 @@ int muavta_step_result(MuavtaEnv* e, double* reward, uint8_t* done) {
 int muavta_metrics(MuavtaEnv* e, double* out) {
   if (!e || !out) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "metrics before reset"; return MUAVTA_E_STATE; }
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   DISPATCH(e, hipLaunchKernelGGL(k_metrics<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, e->d_metrics));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1434,7 +1445,7 @@ int muavta_metrics(MuavtaEnv* e, double* out) {
 
 int muavta_get(MuavtaEnv* e, MuavtaField field, void* dst, size_t bytes) {
   if (!e || !dst) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   if (field == MUAVTA_F_RELEASE_LOG) {
     const size_t want = (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double);
     if (!e->d_rel) { e->err = "release log is off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
@@ -1451,7 +1462,7 @@ int muavta_get(MuavtaEnv* e, MuavtaField field, void* dst, size_t bytes) {
 
 int muavta_set(MuavtaEnv* e, MuavtaField field, const void* src, size_t bytes) {
   if (!e || !src) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   int rc = sync_host(e);
   if (rc) return rc;
   DISPATCH(e, rc = gather<TL>(e, field, const_cast<void*>(src), bytes, true));
@@ -1464,7 +1475,7 @@ int muavta_set(MuavtaEnv* e, MuavtaField field, const void* src, size_t bytes) {
 
 int muavta_get_state(MuavtaEnv* e, void* dst, size_t bytes) {  // [N x EnvState | N x EnvCold]
   if (!e || !dst || bytes != (size_t)e->n_envs * (e->state_bytes + e->cold_bytes)) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipMemcpyAsync(dst, e->blobs, (size_t)e->n_envs * e->state_bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipMemcpyAsync((char*)dst + (size_t)e->n_envs * e->state_bytes, e->cold, (size_t)e->n_envs * e->cold_bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1472,7 +1483,7 @@ int muavta_get_state(MuavtaEnv* e, void* dst, size_t bytes) {  // [N x EnvState 
 }
 int muavta_set_state(MuavtaEnv* e, const void* src, size_t bytes) {
   if (!e || !src || bytes != (size_t)e->n_envs * (e->state_bytes + e->cold_bytes)) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipMemcpyAsync(e->blobs, src, (size_t)e->n_envs * e->state_bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync(e->cold, (const char*)src + (size_t)e->n_envs * e->state_bytes, (size_t)e->n_envs * e->cold_bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1483,7 +1494,7 @@ int muavta_set_state(MuavtaEnv* e, const void* src, size_t bytes) {
 int muavta_get_rng(MuavtaEnv* e, void* dst, size_t bytes) {  // raw MT tapes, for checkpoint/resume next to get_state
   size_t need = e ? (size_t)e->n_envs * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * 4 : 0;
   if (!e || !dst || bytes != need) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipMemcpyAsync(dst, e->tapes, bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
@@ -1491,7 +1502,7 @@ int muavta_get_rng(MuavtaEnv* e, void* dst, size_t bytes) {  // raw MT tapes, fo
 int muavta_set_rng(MuavtaEnv* e, const void* src, size_t bytes) {
   size_t need = e ? (size_t)e->n_envs * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * 4 : 0;
   if (!e || !src || bytes != need) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipMemcpyAsync(e->tapes, src, bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
@@ -1510,7 +1521,7 @@ int muavta_device_ptrs(MuavtaEnv* e, void** state, void** obs_tasks, void** obs_
 
 int muavta_rollout_metrics(MuavtaEnv* e, double* out) {  // metrics written by the last muavta_rollout (no extra kernel)
   if (!e || !out) return MUAVTA_E_ARG;
-  HIPCHK(e, hipSetDevice(e->device));
+  DeviceScope scope_(e->device);
   HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
@@ -1535,7 +1546,7 @@ int muavta_lsap_impl(int32_t device, const double* cost, int32_t n, int32_t nr, 
   const bool use_reg = impl == MUAVTA_LSAP_REGISTERS || (impl == MUAVTA_LSAP_AUTO && fits_reg);
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); hipFree(dc); hipFree(dr); hipFree(dcl); hipFree(dst); return MUAVTA_E_HIP; } } while (0)
   double* dc = nullptr; int64_t *dr = nullptr, *dcl = nullptr; int32_t* dst = nullptr;
-  CK(hipSetDevice(device));
+  DeviceScope scope_(device);
   size_t cb = (size_t)n * nr * nc * sizeof(double), rb = (size_t)n * mn * sizeof(int64_t);
   CK(hipMalloc(&dc, cb)); CK(hipMalloc(&dr, rb)); CK(hipMalloc(&dcl, rb)); CK(hipMalloc(&dst, (size_t)n * sizeof(int32_t)));
   CK(hipMemcpy(dc, cost, cb, hipMemcpyHostToDevice));
@@ -1570,7 +1581,7 @@ int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double
   if (!agent_pos || !movement || !out || n < 1 || n_obstacles < 0 || (n_obstacles > 0 && !obstacles)) return MUAVTA_E_ARG;
   double *dp = nullptr, *dm = nullptr, *dob = nullptr, *dout = nullptr;
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); hipFree(dp); hipFree(dm); hipFree(dob); hipFree(dout); return MUAVTA_E_HIP; } } while (0)
-  CK(hipSetDevice(device));
+  DeviceScope scope_(device);
   CK(hipMalloc(&dp, (size_t)n * 16)); CK(hipMalloc(&dm, (size_t)n * 16)); CK(hipMalloc(&dout, (size_t)n * 16));
   CK(hipMalloc(&dob, (size_t)(n_obstacles > 0 ? n_obstacles : 1) * 24));
   CK(hipMemcpy(dp, agent_pos, (size_t)n * 16, hipMemcpyHostToDevice));
