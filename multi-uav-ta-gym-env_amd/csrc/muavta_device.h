@@ -243,8 +243,26 @@ struct Sim {
     y ^= (y >> 18);
     return y;
   }
+  DEV static uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+  }
   DEV double rnd(int st) {  // random.random()
-    uint32_t a = next32(st) >> 5, b = next32(st) >> 6;
+    // fast path (the per-step arrival / spawn / engagement draws): both words sit in the prefetched LDS window — cursor and
+    // window base in one round trip, the two words in a second one, instead of a dependent chain per word
+    const uint32_t p = S.rng_idx[st], at = S.rng_win_at[st];
+    const uint32_t w = p - at, off = p & 0xffffu;
+    uint32_t a, b;
+    if (w < win_len - 1u && off + 2u <= 1248u) {
+      const uint32_t y0 = win_ptr[st * win_stride + w], y1 = win_ptr[st * win_stride + w + 1u];
+      S.rng_idx[st] = p + 2u;  // (block marker in the high half is untouched: off + 2 <= 1248)
+      a = mt_temper(y0) >> 5; b = mt_temper(y1) >> 6;
+    } else {
+      a = next32(st) >> 5; b = next32(st) >> 6;
+    }
     return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
   }
   DEV uint64_t getrandbits(int st, int k) {
@@ -1743,6 +1761,7 @@ struct Sim {
     }
   }
   DEV void generate_threat() {  // :1601-1643
+    if (!threat_spawn_step()) return;  // (the per-group test below needs it anyway: nine steps in ten end here)
     for (int g = 0; g < P.n_threat_groups; g++) {
       int left = S.g_end[g] - S.g_next[g];
       if (left > 0 && threat_spawn_step()) {
