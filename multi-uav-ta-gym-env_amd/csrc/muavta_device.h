@@ -82,10 +82,12 @@ struct alignas(16) Scratch {
   double cost[COSTN];  // LSAP cost tile, R x C row-major with R = min(nr, nc) (unless TL::REGC)
   double u[A], v[T], spc[T], resid[T];  // (the register-resident LSAP leaves u/v/spc to their other users)
   double press[TL::OTFC ? T : 1];       // Urgency-Coalition threat pressure per round task where the LDS solver (which owns spc) evaluates costs on the fly
-  int32_t path[T], col4row[A], row4col[T], remaining[T], freeA[A], roundT[T];
+  // index lists of the allocator / LSAP and scratch lists of the serial phases: agent ids, slot ids, row numbers (< 128), -1
+  // markers, and Urgency-Pair's (rank | n_know << 8) — 16 bits each
+  int16_t path[T], col4row[A], row4col[T], remaining[T], freeA[A], roundT[T];
   uint8_t SR[A], SC[T];
   uint8_t live_rank[A];                  // Urgency-Pair: rank of an agent among the live ones (255 = beyond the token pad)
-  int32_t pair_info_big[T > 64 ? T : 1]; // Urgency-Pair per-slot (rank, n_know) when `remaining` is busy (LDS LSAP, T > 64)
+  int16_t pair_info_big[T > 64 ? T : 1]; // Urgency-Pair per-slot (rank, n_know) when `remaining` is busy (LDS LSAP, T > 64)
 };
 
 // ====================================================================================================
@@ -214,7 +216,11 @@ struct Sim {
     asm volatile("" : "+v"(l));
     return l;
   }
-  DEV void sync_clock() { tnow = S.time_steps; }  // after the blob was (re)loaded or reset behind this object's back
+  DEV void sync_clock() { tnow = S.time_steps; }
+  // next_free_* / orgReqs / doneReqs / mission areas: LDS or the HBM record, by tile (QueueSide in muavta_state.h)
+  DEV QueueSide<A, T, true>& qs() const {
+    if constexpr (TL::SLIM) return static_cast<QueueSide<A, T, true>&>(C); else return static_cast<QueueSide<A, T, true>&>(S);
+  }  // after the blob was (re)loaded or reset behind this object's back
 
   DEV void fail(int code) { if (S.error == 0) S.error = code; }
   DEV double speed_of(int t) const {  // P.speed[t] without a memory access for a per-lane t
@@ -373,9 +379,9 @@ struct Sim {
   DEV void des_allocate_at(int a, int k) {
     int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
     queue_erase(a, k);
-    S.a_nft[a] = (double)tnow;
-    S.a_nfx[a] = S.a_px[a];
-    S.a_nfy[a] = S.a_py[a];
+    qs().a_nft[a] = (double)tnow;
+    qs().a_nfx[a] = S.a_px[a];
+    qs().a_nfy[a] = S.a_py[a];
     S.a_commit[a] = 0;
     if (ref_valid(id, slot)) remove_agent_cap(slot, a);
   }
@@ -410,9 +416,9 @@ struct Sim {
     while (S.a_qlen[a] > 0 && ref_retired(S.a_qid[a][0], S.a_qslot[a][0])) queue_erase(a, 0);
     if (S.a_qlen[a] == 0) {
       if (S.a_reeval[a]) { S.a_last_id[a] = -1; S.a_last_slot[a] = -1; S.a_reeval[a] = 0; }
-      S.a_nft[a] = 0;
-      S.a_nfx[a] = S.a_px[a];
-      S.a_nfy[a] = S.a_py[a];
+      qs().a_nft[a] = 0;
+      qs().a_nfx[a] = S.a_px[a];
+      qs().a_nfy[a] = S.a_py[a];
       S.a_state[a] = 0;
     } else {
       S.a_state[a] = 1;
@@ -426,8 +432,8 @@ struct Sim {
     S.a_reeval[a] = 0;
     S.a_last_id[a] = -1;
     S.a_last_slot[a] = -1;
-    double time_to_task = pre_time >= 0 ? pre_time : norm2(S.a_nfx[a] - S.t_px[s], S.a_nfy[a] - S.t_py[s]) / speed_of(S.a_type[a]);
-    double start_time = (S.a_nft[a] - (double)tnow) > 0 ? S.a_nft[a] : (double)tnow;
+    double time_to_task = pre_time >= 0 ? pre_time : norm2(qs().a_nfx[a] - S.t_px[s], qs().a_nfy[a] - S.t_py[s]) / speed_of(S.a_type[a]);
+    double start_time = (qs().a_nft[a] - (double)tnow) > 0 ? qs().a_nft[a] : (double)tnow;
     double dur = (double)task_duration(S.t_type[s]);
     double end_time = start_time + time_to_task + dur;
     int n = S.a_qlen[a];
@@ -440,9 +446,9 @@ struct Sim {
     S.a_qslot[a][n] = s;
     C.a_qtime[a][n] = time_to_task;
     S.a_qlen[a] = n + 1;
-    S.a_nft[a] = end_time;
-    S.a_nfx[a] = S.t_px[s];
-    S.a_nfy[a] = S.t_py[s];
+    qs().a_nft[a] = end_time;
+    qs().a_nfx[a] = S.t_px[s];
+    qs().a_nfy[a] = S.t_py[s];
     // Task.addAgentCap (DroneEnvComponents.py:306-326); status != 2 checked above
     S.t_ndet[s] += 1;
     S.times_dirty = 1;
@@ -495,7 +501,7 @@ struct Sim {
         r[4] = (S.t_flags[s] & TF_DEADLINE) ? S.t_deadline[s] : -1; r[5] = S.t_created[s]; r[6] = S.t_required[s];
         r[7] = (S.t_flags[s] & TF_ESCORT) ? 1 : 0; r[8] = S.t_ndet[s]; r[9] = S.t_prot_agent[s];
         r[10] = (S.t_flags[s] & TF_ELIGIBLE) ? (double)S.t_elig[s] : -1.0; r[11] = S.t_px[s]; r[12] = S.t_py[s];
-        r[13] = S.t_org[s]; r[14] = S.t_done[s]; r[15] = C.t_init[s]; r[16] = C.t_dtime[s];
+        r[13] = qs().t_org[s]; r[14] = qs().t_done[s]; r[15] = C.t_init[s]; r[16] = C.t_dtime[s];
         for (int c = 0; c < 6; c++) { r[17 + c] = C.t_cur[c][s]; r[23 + c] = C.t_alloc[c][s]; }
       }
     }
@@ -538,7 +544,7 @@ struct Sim {
     S.t_px[s] = x; S.t_py[s] = y;
     for (int c = 0; c < 6; c++) { C.t_cur[c][s] = 0; C.t_alloc[c][s] = 0; }
     C.t_cur[type][s] = req;
-    S.t_org[s] = req; S.t_done[s] = 0;
+    qs().t_org[s] = req; qs().t_done[s] = 0;
     C.t_init[s] = -1; C.t_dtime[s] = -1;
     S.t_status[s] = 0; S.t_type[s] = type; S.t_created[s] = 0; S.t_deadline[s] = -1; S.t_required[s] = 0;
     S.t_flags[s] = 0; S.t_elig[s] = 0; S.t_threat[s] = -1;
@@ -594,7 +600,7 @@ struct Sim {
     if ((S.t_flags[s] & TF_ELIGIBLE) && !((S.t_elig[s] >> S.a_type[a]) & 1u)) return false;
     int ty = S.t_type[s];
     if (P.capability_mask && S.a_caps[ty][a] <= 0) return false;
-    if (P.saturate_mask && C.t_alloc[ty][s] >= S.t_org[s]) return false;
+    if (P.saturate_mask && C.t_alloc[ty][s] >= qs().t_org[s]) return false;
     return true;
   }
 
@@ -640,9 +646,9 @@ struct Sim {
         if (S.a_qlen[a] == 0) {
           S.a_state[a] = 0;
           S.a_commit[a] = 0;
-          S.a_nft[a] = (double)tnow;
-          S.a_nfx[a] = S.a_px[a];
-          S.a_nfy[a] = S.a_py[a];
+          qs().a_nft[a] = (double)tnow;
+          qs().a_nfx[a] = S.a_px[a];
+          qs().a_nfy[a] = S.a_py[a];
         }
       }
     }
@@ -665,7 +671,8 @@ struct Sim {
   }
   // _escort_fighters_near (:1746-1764): nearest-first list into out[], returns count.
   // Stable insertion sort == python's sort(key=dist) on (dist, agent) pairs built in id order.
-  DEV int escort_fighters_near(int prot, double radius, int* out, double* outd) {
+  template <class Out>
+  DEV int escort_fighters_near(int prot, double radius, Out* out, double* outd) {
     int k = escort_lookup(prot);
     if (k < 0 || ref_retired(S.esc_id[k], S.esc_slot[k])) return 0;
     int eid = S.esc_id[k];
@@ -677,7 +684,7 @@ struct Sim {
       if (d <= radius) {
         int i = n;
         while (i > 0 && outd[i - 1] > d) { outd[i] = outd[i - 1]; out[i] = out[i - 1]; i--; }
-        outd[i] = d; out[i] = a;
+        outd[i] = d; out[i] = (Out)a;
         n++;
       }
     }
@@ -780,7 +787,7 @@ struct Sim {
 #pragma unroll
         for (int i = 0; i < HQ; i++) if (2 * i + 1 < n) { S.a_qid[a][i] = kid[i]; S.a_qslot[a][i] = ksl[i]; C.a_qtime[a][i] = ktm[i]; }
         S.a_qlen[a] = n >> 1;
-        S.a_nft[a] = (double)tnow; S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
+        qs().a_nft[a] = (double)tnow; qs().a_nfx[a] = S.a_px[a]; qs().a_nfy[a] = S.a_py[a];
         S.a_commit[a] = 0;
       }
       for (int base = 0; base < T; base += WG) {
@@ -889,7 +896,7 @@ struct Sim {
     for (int tries = 0; tries < 100; tries++) {
       double x, y;
       if (area >= 0) {
-        double tlx = S.area[area][0], tly = S.area[area][1], w = S.area[area][2];
+        double tlx = qs().area[area][0], tly = qs().area[area][1], w = qs().area[area][2];
         x = uniform(st, tlx, tlx + w);
         y = uniform(st, tly, tly + w);
       } else {
@@ -930,7 +937,7 @@ struct Sim {
   // reset-time RNG setup for one stream whose seeded MT state (k_seed: CPython's init_by_array, one LANE per stream there —
   // the recurrence is serial) sits in HBM: block0 = twist(seeded) -> `b0`, block1 = twist(block0) -> `b1` (both LDS); both
   // go to the HBM tape with coalesced stores and the head of block0 to the reset window.  Ordered by lds_sync().
-  static constexpr int RESET_WIN = 192;  // words per stream staged for the reset (it draws ~100)
+  static constexpr int RESET_WIN = 160;  // words per stream staged for the reset (it draws ~100; a draw beyond the window reads the HBM tape)
   DEV void reset_stream(int st, const uint32_t* seeded, uint32_t* b0, uint32_t* b1, uint32_t* win) {
     mt_twist_lds(seeded, b0);
     mt_twist_lds(b0, b1);
@@ -944,7 +951,8 @@ struct Sim {
     (void)seed;
     // RNG first.  The (not yet initialised) arrays of the state blob double as scratch for two 624-word MT buffers; the
     // stream cursors and the other scalars live beyond them.
-    static_assert(offsetof(State, area) >= 2 * 624 * 4, "MT buffers overlap live scalars");
+    static_assert(offsetof(State, pending_reset) >= 2 * 624 * 4 && offsetof(State, rng_idx) >= 2 * 624 * 4,
+                  "MT buffers overlap the scalars that are live while the RNG is set up (error word, stream cursors)");
     static_assert(sizeof(Scratch<TL>) >= 4 * RESET_WIN * 4, "scratch tile too small for the reset RNG window");
     tnow = 0;
     uint32_t* T0 = reinterpret_cast<uint32_t*>(&S);
@@ -1018,7 +1026,7 @@ struct Sim {
       C.obst[o][0] = x; C.obst[o][1] = y; C.obst[o][2] = size;
     }
     // agents (:591-612): shuffle ids, create in config order
-    int32_t* ids = S.act_index;  // scratch: A ints in the blob, idle during a reset (the Scratch tile holds the reset RNG windows)
+    i16* ids = S.act_index;  // scratch: A ints in the blob, idle during a reset (the Scratch tile holds the reset RNG windows)
     for (int i = 0; i < nA; i++) ids[i] = i;
     for (int i = nA - 1; i >= 1; i--) {
       int j = (int)randbelow(ST_AGENT, (uint64_t)i + 1);
@@ -1037,7 +1045,8 @@ struct Sim {
         for (int c = 0; c < 6; c++) S.a_caps[c][a] = CAP_TABLE[ty][c];
         S.a_acap[a] = is_fighter(ty) ? 10 : 0;
         S.a_state[a] = 0;
-        S.a_nfx[a] = S.a_px[a]; S.a_nfy[a] = S.a_py[a];
+        qs().a_nfx[a] = S.a_px[a]; qs().a_nfy[a] = S.a_py[a];
+        qs().a_nft[a] = 0.0;  // (the HBM record is not zeroed by a reset)
       }
     for (int i = 0; i < nA; i++) ids[i] = 0;
     // fail events (:616-618)
@@ -1050,7 +1059,7 @@ struct Sim {
       double ah = (double)(700 * randint(ST_MISSION, 10, 20)) / 100;
       double cx, cy;
       random_position(ST_MISSION, fmax(aw, ah), 3, false, -1, false, cx, cy);
-      S.area[i][0] = cx - aw / 2; S.area[i][1] = cy - aw / 2; S.area[i][2] = aw;
+      qs().area[i][0] = cx - aw / 2; qs().area[i][1] = cy - aw / 2; qs().area[i][2] = aw;
     }
     // static tasks (:641-667)
     int hold_num = 0;
@@ -1347,6 +1356,7 @@ struct Sim {
   // expected-distance term (:1216-1229).  Agent / task positions do not change while actions are applied.
   DEV double* act_f(int k) { return X.cost + k * A; }   // 4 arrays of A doubles in the idle cost tile
   DEV void precompute_actions() {
+    cold_sync();  // next_free_position rows: written by whichever lane ran the previous phases
     const int k = lane;
     if (k >= S.n_act) return;
     const int a = S.act_agent[k], s = S.act_slot[k];
@@ -1357,7 +1367,7 @@ struct Sim {
     if (S.a_qlen[a] > 0) { const int hs = S.a_qslot[a][0]; d_old = norm2(px - S.t_px[hs], py - S.t_py[hs]); }
     act_f(0)[k] = d_old;
     act_f(1)[k] = norm2(px - tx, py - ty);
-    act_f(2)[k] = norm2(S.a_nfx[a] - tx, S.a_nfy[a] - ty) / speed_of(S.a_type[a]);
+    act_f(2)[k] = norm2(qs().a_nfx[a] - tx, qs().a_nfy[a] - ty) / speed_of(S.a_type[a]);
     const int n = S.a_qlen[a];  // after the append the queue holds n + 1 entries; tasks[-2] is the current last one
     double total;
     if (n >= 1) { const int ps = S.a_qslot[a][n - 1]; total = norm2(tx - S.t_px[ps], ty - S.t_py[ps]); }
@@ -1423,8 +1433,8 @@ struct Sim {
           if (!action_valid(a, s)) n_pen = 1;
           else if (!(queue_find(a, tid) >= 0 || S.t_status[s] == 2)) {  // UAV.allocate (DroneEnvComponents.py:55-96)
             S.a_reeval[a] = 0; S.a_last_id[a] = -1; S.a_last_slot[a] = -1;
-            const double time_to_task = norm2(S.a_nfx[a] - tx, S.a_nfy[a] - ty_) / speed_of(S.a_type[a]);
-            const double start_time = (S.a_nft[a] - (double)tnow) > 0 ? S.a_nft[a] : (double)tnow;
+            const double time_to_task = norm2(qs().a_nfx[a] - tx, qs().a_nfy[a] - ty_) / speed_of(S.a_type[a]);
+            const double start_time = (qs().a_nft[a] - (double)tnow) > 0 ? qs().a_nft[a] : (double)tnow;
             ty = S.t_type[s];
             const double end_time = start_time + time_to_task + (double)task_duration(ty);
             if (qlen == 0) { S.a_task_start[a] = -1; S.a_state[a] = 1; }
@@ -1436,7 +1446,7 @@ struct Sim {
               else total = norm2(tx - px, ty_ - py);
               d1 = -1.0 * total / MAX_COORD; nd1 = 1;
               S.a_qid[a][qlen] = tid; S.a_qslot[a][qlen] = s; C.a_qtime[a][qlen] = time_to_task; S.a_qlen[a] = qlen + 1;
-              S.a_nft[a] = end_time; S.a_nfx[a] = tx; S.a_nfy[a] = ty_;
+              qs().a_nft[a] = end_time; qs().a_nfx[a] = tx; qs().a_nfy[a] = ty_;
               if (S.a_state[a] != 1 && S.a_state[a] != -1) S.a_state[a] = 1;
 #pragma unroll
               for (int c = 0; c < 6; c++) caps[c] = S.a_caps[c][a];
@@ -1562,9 +1572,9 @@ struct Sim {
           des_allocate_at(a, 0);
           if (ref_valid(qi, qs)) S.t_bucket[qs] &= ~(1ull << a);
         }
-        S.a_nft[a] = (double)tnow;
-        S.a_nfx[a] = S.a_px[a];
-        S.a_nfy[a] = S.a_py[a];
+        qs().a_nft[a] = (double)tnow;
+        qs().a_nfx[a] = S.a_px[a];
+        qs().a_nfy[a] = S.a_py[a];
       }
       if (!action_valid(a, s)) { action_reward += -1; continue; }
       if (uav_allocate(a, s, pre ? act_f(2)[k] : -1.0)) {
@@ -1584,9 +1594,9 @@ struct Sim {
           double total;
           if (n >= 2) {
             int ps = S.a_qslot[a][n - 2];  // live agents' queue entries are never freed by the GC
-            total = norm2(S.a_nfx[a] - S.t_px[ps], S.a_nfy[a] - S.t_py[ps]);
+            total = norm2(qs().a_nfx[a] - S.t_px[ps], qs().a_nfy[a] - S.t_py[ps]);
           } else {
-            total = norm2(S.a_nfx[a] - S.a_px[a], S.a_nfy[a] - S.a_py[a]);
+            total = norm2(qs().a_nfx[a] - S.a_px[a], qs().a_nfy[a] - S.a_py[a]);
           }
           distance_reward += -1.0 * total / MAX_COORD;
         }
@@ -1662,14 +1672,14 @@ struct Sim {
               // task concluded by this agent (:1079-1107)
               S.a_px[a] = px; S.a_py[a] = py;  // taskDone reads agent.position
               bool was_head = task_done(a, cid, ty);
-              S.t_done[cs] += S.a_caps[ty][a];
+              qs().t_done[cs] += S.a_caps[ty][a];
               for (int c = 0; c < 6; c++) C.t_cur[c][cs] -= S.a_caps[c][a];
               if (was_head) remove_agent_cap(cs, a);
-              if (S.t_done[cs] >= S.t_org[cs]) {
+              if (qs().t_done[cs] >= qs().t_org[cs]) {
                 const bool esc = S.t_flags[cs] & TF_ESCORT;
                 if (!esc && !(S.t_flags[cs] & TF_REACHED)) { S.t_flags[cs] |= TF_REACHED; S.n_reached++; }
-                quality_reward += S.t_org[cs] * 2;
-                S.F_Reward += S.t_org[cs] * 1 / P.reward_norm_factor;
+                quality_reward += qs().t_org[cs] * 2;
+                S.F_Reward += qs().t_org[cs] * 1 / P.reward_norm_factor;
                 if (!esc) mark_outcome_slot(cs, true);
                 S.t_status[cs] = 2;
                 if (ty == MUAVTA_REC && is_recon(S.a_type[a])) {  // _on_protected_rec_done (:1959-1962)
@@ -1823,7 +1833,7 @@ struct Sim {
     int primary = S.h_target[h];
     int mission = S.h_mission[h] >= 0 ? S.h_mission[h] : primary;
     int n_def = 0;
-    int* defs = X.remaining;       // scratch lists (T >= A)
+    int16_t* defs = X.remaining;   // scratch lists (T >= A)
     double* defd = X.v;
     if (P.escort_enabled && mission >= 0 && is_recon(S.a_type[mission])) {
       n_def = escort_fighters_near(mission, P.mutual_support_radius, defs, defd);
@@ -2018,7 +2028,7 @@ struct Sim {
     }
     // iterate a snapshot of the map (retiring pops entries)
     int n = S.n_escorts;
-    int32_t* snap = X.row4col;  // T >= A
+    int16_t* snap = X.row4col;  // T >= A
     for (int k = 0; k < n; k++) snap[k] = S.esc_agent[k];
     for (int k = 0; k < n; k++) {
       int recon = snap[k];
@@ -2127,7 +2137,7 @@ struct Sim {
   DEV void sense_parallel() {
     if (P.sense_radius <= 0) return;
     const int nA = P.n_agents, nO = S.n_order;
-    int32_t* cand = X.roundT;  // T entries
+    int16_t* cand = X.roundT;  // T entries
     int nc = 0;
     for (int base = 0; base < nO; base += WG) {
       const int k = base + lane;
@@ -2438,9 +2448,10 @@ struct Sim {
         double cur_ty = cur[0], alc_ty = alc[0];  // (selects, not cur[ty]: a dynamically indexed local array would live in scratch memory)
 #pragma unroll
         for (int c = 1; c < 6; c++) if (ty == c) { cur_ty = cur[c]; alc_ty = alc[c]; }
-        if (P.saturate_mask && alc_ty >= S.t_org[s]) typemask = 0;
+        const double org = qs().t_org[s];
+        if (P.saturate_mask && alc_ty >= org) typemask = 0;
         const double unmet = fmax(cur_ty - alc_ty, 0.0);
-        r[19] = (float)(unmet / fmax(S.t_org[s], 1e-6));
+        r[19] = (float)(unmet / fmax(org, 1e-6));
         r[20] = (float)fmin(((double)tnow - (double)S.t_created[s]) / mts, 1.0);
       } else if (!(j == 0 && n == 0)) {
         r[3] = -1.f;  // pad rows are {"status": -1}; with no open task row 0 is task_idle (all zeros)
@@ -2534,7 +2545,7 @@ struct Sim {
   // mode 1 (MUAVTA_ALLOC_URGENCY_PAIR): TaskAllocation/Hybrid/PairCostHybrid.py:31-86,520-550 — engineered
   //   float32 edge scores 0.5*urgency + 0.3*scarcity - 0.4*dist, clipped to +-0.35, for the first 16 live agents x
   //   first 32 underfilled tasks, subtracted from the Hungarian cost; replan gate = experiments/wps_eval.py:64-74.
-  DEV int32_t* pair_info() { return T > 64 ? X.pair_info_big : X.remaining; }
+  DEV int16_t* pair_info() { return T > 64 ? X.pair_info_big : X.remaining; }
   DEV void allocate(int interval, int use_visibility, int mode = 0) {
     PROF(10);
     interval = interval < 1 ? 1 : interval;
@@ -2903,7 +2914,7 @@ struct Sim {
       X.SC[k] = (slot_urgency(s) >= URGENT && (S.t_flags[s] & TF_DEADLINE)) ? 1 : 0;
     }
     lds_sync();
-    int32_t* list = X.roundT;  // the token rows' task list
+    int16_t* list = X.roundT;  // the token rows' task list
     int n_list = n_all;
     if (kind == 2) {
       if (vis) {  // local task set: known by at least one live agent; all of open_all if that leaves nothing
@@ -3073,14 +3084,14 @@ struct Sim {
     }
   }
   // out[0..n) = f(k) for the k in [0, count) with pred(k), order preserved (ballot + popcount); returns n
-  template <class Pred, class Val>
-  DEV int compact_to(int32_t* out, int count, Pred pred, Val val) {
+  template <class Out, class Pred, class Val>
+  DEV int compact_to(Out* out, int count, Pred pred, Val val) {
     int n = 0;
     for (int base = 0; base < count; base += WG) {
       const int k = base + lane;
       const bool p = k < count && pred(k);
       const unsigned long long m = __ballot(p);
-      if (p) out[n + __popcll(m & ((1ull << lane) - 1ull))] = val(k);
+      if (p) out[n + __popcll(m & ((1ull << lane) - 1ull))] = (Out)val(k);
       n += __popcll(m);
     }
     return n;

@@ -105,6 +105,7 @@ struct Lds {
 // Residency on a CU is bound by LDS bytes per env (160 KiB per CU, 1 KiB granule): 16 envs of the 16-agent tile
 // (BASELINE configs 2 and 3: 4096 envs = 16 per CU, one round) need <= 10 KiB each.
 static_assert(Lds<Tile16>::bytes() <= 10240, "Tile16 no longer fits 16 workgroups per CU");
+static_assert(Lds<Tile24>::bytes() <= 10240, "Tile24 no longer fits 16 workgroups per CU");
 static_assert(sizeof(EnvState<Tile16>) % 16 == 0 && sizeof(EnvState<Tile24>) % 16 == 0 && sizeof(EnvState<Tile64>) % 16 == 0, "blob copies move 16 B per lane");
 static_assert(sizeof(EnvCold<Tile16>) % 16 == 0 && sizeof(EnvCold<Tile24>) % 16 == 0 && sizeof(EnvCold<Tile64>) % 16 == 0, "cold records are 16 B aligned");
 
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(const DevCtx* __r
       if (idx < 0) idx += S.n_open;  // python negative indexing into last_tasks_info
       S.act_agent[n] = (i8)a;
       S.act_slot[n] = (idx >= 0 && idx < S.n_open) ? (i8)S.open_slot[idx] : (i8)-1;
-      S.act_index[n] = idx;
+      S.act_index[n] = (i16)(idx < -32768 ? -32768 : idx > 32767 ? 32767 : idx);
       n++;
     }
     S.n_act = n;
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(WG) void k_call(const DevCtx* __restrict__ ctxp, Ca
       break;
     case MUAVTA_OP_ESCORT_FIGHTERS_NEAR:
       if (lane == 0) {
-        int* who = L.X->remaining;
+        int16_t* who = L.X->remaining;
         const int n = sim.escort_fighters_near(ag, a.d < 0 ? ctx.P.escort_radius : a.d, who, L.X->v);
         out[0] = n;
         for (int k = 0; k < n && k + 1 < MUAVTA_CALL_OUT; k++) out[1 + k] = who[k];
@@ -719,6 +720,9 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
   double* D = (double*)dst;
   int32_t* I = (int32_t*)dst;
   uint32_t* U = (uint32_t*)dst;
+  auto QS = [&](int n) -> QueueSide<TL::A, TL::T, true>& {  // where this tile keeps next_free_* / orgReqs / doneReqs
+    if constexpr (TL::SLIM) return static_cast<QueueSide<TL::A, TL::T, true>&>(cold[n]); else return static_cast<QueueSide<TL::A, TL::T, true>&>(blobs[n]);
+  };
 #define BAD() do { e->err = "muavta_get/set: buffer size mismatch, need " + std::to_string(need) + " bytes"; return MUAVTA_E_ARG; } while (0)
 #define RW(dstv, srcv) do { if (scatter) (srcv) = (dstv); else (dstv) = (srcv); } while (0)
   switch (f) {
@@ -728,11 +732,11 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
       break;
     case MUAVTA_F_AGENT_NFP:
       if (!chk((size_t)N * A * 2 * 8)) BAD();
-      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) { RW(D[((size_t)n * A + a) * 2], blobs[n].a_nfx[a]); RW(D[((size_t)n * A + a) * 2 + 1], blobs[n].a_nfy[a]); }
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) { RW(D[((size_t)n * A + a) * 2], QS(n).a_nfx[a]); RW(D[((size_t)n * A + a) * 2 + 1], QS(n).a_nfy[a]); }
       break;
     case MUAVTA_F_AGENT_NFT:
       if (!chk((size_t)N * A * 8)) BAD();
-      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) RW(D[(size_t)n * A + a], blobs[n].a_nft[a]);
+      for (int n = 0; n < N; n++) for (int a = 0; a < A; a++) RW(D[(size_t)n * A + a], QS(n).a_nft[a]);
       break;
     case MUAVTA_F_AGENT_DIST:
       if (!chk((size_t)N * A * 8)) BAD();
@@ -801,7 +805,7 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
       break;
     case MUAVTA_F_TASK_ORG_DONE:
       if (!chk((size_t)N * T * 2 * 8)) BAD();
-      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) { RW(D[((size_t)n * T + s) * 2], blobs[n].t_org[s]); RW(D[((size_t)n * T + s) * 2 + 1], blobs[n].t_done[s]); }
+      for (int n = 0; n < N; n++) for (int s = 0; s < T; s++) { RW(D[((size_t)n * T + s) * 2], QS(n).t_org[s]); RW(D[((size_t)n * T + s) * 2 + 1], QS(n).t_done[s]); }
       break;
     case MUAVTA_F_TASK_TIMES:
       if (!chk((size_t)N * T * 2 * 8)) BAD();

@@ -52,8 +52,9 @@ struct DevParams {
   double rw[8];
 };
 
-template <int A_, int T_, int H_, int R_, int E_, int Q_, bool REGC_ = false, bool OTFC_ = false>
+template <int A_, int T_, int H_, int R_, int E_, int Q_, bool REGC_ = false, bool OTFC_ = false, bool SLIM_ = false>
 struct Tile {
+  static constexpr bool SLIM = SLIM_;  // next_free_* / orgReqs / doneReqs / mission areas live in the HBM record instead of LDS (the 24-agent tile: 16 envs per CU need <= 10 KiB)
   static constexpr bool REGC = REGC_;  // the allocator builds the LSAP cost columns in registers: no A x T cost tile in LDS
   static constexpr bool OTFC = OTFC_;  // the (LDS) solver evaluates cost elements on the fly: no A x T cost tile either
   static constexpr bool NO_COST_TILE = REGC_ || OTFC_;
@@ -82,13 +83,22 @@ typedef int8_t i8;
 typedef int16_t i16;
 typedef uint8_t u8;
 
+// Fields that change with the queues / on task completion only: in LDS on the tiles that have room (their readers sit on
+// the serial paths of a re-plan step), in the HBM record on the SLIM tile.
+template <int A, int T, bool HERE> struct QueueSide {
+  double a_nfx[A], a_nfy[A], a_nft[A];  // next_free_position, next_free_time
+  double t_org[T], t_done[T];           // orgReqs[typeIdx], doneReqs[typeIdx]
+  double area[3][3];                    // mission areas: top-left x, y, width (height == width)
+};
+template <int A, int T> struct QueueSide<A, T, false> {};
+
 // Part of an env that lives in HBM only (one record per env, L2-resident while the rollout runs): the six-component
 // requirement vectors of the tasks, the per-queue-entry travel times and the derived init/done times — touched when an
 // allocation changes, when a task is created or concluded, and by the observation / token writers (all lanes, coalesced
 // within a row), never by the per-step movement / sensing / threat phases.  Keeping them out of LDS is what lets 16 envs
 // of the 16-agent tile share one CU's 160 KiB.
 template <class TL>
-struct alignas(16) EnvCold {
+struct alignas(16) EnvCold : QueueSide<TL::A, TL::T, TL::SLIM> {
   enum { A = TL::A, T = TL::T, Q = TL::Q };
   double t_cur[6][T], t_alloc[6][T];  // currentReqs, allocatedReqs
   double t_init[T], t_dtime[T];       // initTime, doneTime
@@ -97,23 +107,20 @@ struct alignas(16) EnvCold {
 };
 
 template <class TL>
-struct alignas(16) EnvState {
+struct alignas(16) EnvState : QueueSide<TL::A, TL::T, !TL::SLIM> {
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   // ---- 8-byte arrays --------------------------------------------------------------------------
   double a_px[A], a_py[A];          // position
-  double a_nfx[A], a_nfy[A];        // next_free_position
-  double a_nft[A];                  // next_free_time
   double a_dist[A];                 // env.agent_distances
   double a_caps[6][A];              // currentCap2Task
   double t_px[T], t_py[T];
-  double t_org[T], t_done[T];       // orgReqs[typeIdx], doneReqs[typeIdx]
   double h_px[H], h_py[H];
   // ---- 4-byte arrays --------------------------------------------------------------------------
   typename BucketMask<A>::type t_bucket[T];  // allocation_table[id] as agent bitmask
   uint32_t known[A][KW];            // agent_known_tasks as slot bitmask (bits of free slots are kept clear)
   uint32_t free_slots[KW];          // bit s set <=> slot s is free
-  int32_t act_index[A];             // staged actions: index into last_tasks_info as given (may be out of range)
   // ---- 2-byte arrays --------------------------------------------------------------------------
+  i16 act_index[A];                 // staged actions: index into last_tasks_info as given (clamped to 16 bits when out of range)
   i16 a_qid[A][Q];                  // queued task ids (head first); qlen == 0 <=> [task_idle]
   i16 a_task_start[A], a_fail[A], a_last_id[A], a_commit[A];
   i16 a_gone[A];                    // ids in agent_known_tasks[a] whose slot was released: len(known) = popcount(known[a]) + a_gone[a]
@@ -149,7 +156,6 @@ struct alignas(16) EnvState {
                                                // window are never popped, as in the reference); esc_pid/pslot: protected Rec task
   i8 act_agent[A], act_slot[A];     // actions staged by the allocator
   // ---- scalars (everything above may double as scratch while a reset sets up the RNG) -----------
-  double area[3][3];                // mission areas: top-left x, y, width (height == width)
   double F_Reward, total_distance, last_reward, step_reward;
   double r_time_penalty, r_alloc;   // reward terms evaluated mid-step (DroneEnv.py:1140-1145), before the world dynamics
   int32_t time_steps, conclusion_time, n_order, n_open, n_active_threats, n_events, n_dev, n_pending, n_escorts, n_act;
@@ -172,7 +178,7 @@ struct alignas(16) EnvState {
 // with 32 slots / queue 8 about 1 in 10,000 seeds of WPS_hard_x2 overflowed (34 slots); events <= 16, pending reveals <= 22
 // measured over 4096 seeds.
 typedef Tile<16, 40, 16, 48, 40, 10, true> Tile16;
-typedef Tile<24, 48, 24, 88, 40, 12, true> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
+typedef Tile<24, 48, 24, 88, 32, 12, true, false, true> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
 typedef Tile<64, 128, 48, 128, 96, 8, false, true> Tile64;
 
 #define MUAVTA_REL_ROW 29  // doubles per release-log row (include/muavta.h: MUAVTA_F_RELEASE_LOG)

@@ -17,7 +17,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 SO_PATH = os.environ.get("MUAVTA_SO") or os.path.join(PKG_DIR, "libmuavta.so")  # MUAVTA_SO: diagnostic builds only
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ldl",  # (-Os / -O2 / -O3 within 1.5 % of each other on the 128-VGPR kernel, -Oz -12 %: profiles/ r02 notes)
-                "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value"]
+                "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-invalid-offsetof"]
 
 EXPORTS = [
     "muavta_create", "muavta_destroy", "muavta_last_error", "muavta_dims", "muavta_reset", "muavta_step",
