@@ -2684,6 +2684,72 @@ struct Sim {
         }
         return c;
       };
+      static_assert(KW <= 4, "an agent's known mask is cached in four words");
+      // pair_cost() split in two for the solvers that keep one column per lane: the column's side (task or agent fields) is
+      // read from LDS ONCE per lane, the row's side is the same for every lane (broadcast reads, issued together).  Same arithmetic.
+      struct TS { double px, py, urgency, missing, press; int type, info; bool elig_on, esc_task, esc_flag; uint32_t elig; };
+      struct AS { double px, py; int type, rank; uint32_t k0, k1, k2, k3; };
+      auto load_ts = [&](int sl, int jr) {
+        TS t;
+        const int fl = S.t_flags[sl];
+        t.px = S.t_px[sl]; t.py = S.t_py[sl]; t.type = S.t_type[sl]; t.elig = S.t_elig[sl];
+        t.elig_on = (fl & TF_ELIGIBLE) != 0; t.esc_flag = (fl & TF_ESCORT) != 0;
+        t.esc_task = t.esc_flag || S.t_required[sl] > 0;
+        t.urgency = 0.0;
+        if (fl & TF_DEADLINE) {
+          int remaining = S.t_deadline[sl] - tnow;
+          remaining = remaining > 0 ? remaining : 0;
+          t.urgency = 1.0 - fmin((double)remaining / 40.0, 1.0);
+        }
+        t.missing = fmax(X.resid[sl], 1e-6);
+        t.info = mode == 1 ? pair_info()[sl] : 0;
+        t.press = mode == 2 ? (TL::OTFC ? X.press : X.spc)[jr] : 0.0;
+        return t;
+      };
+      auto load_as = [&](int a) {
+        AS g;
+        g.px = S.a_px[a]; g.py = S.a_py[a]; g.type = S.a_type[a];
+        g.k0 = S.known[a][0]; g.k1 = KW > 1 ? S.known[a][KW > 1 ? 1 : 0] : 0u;
+        g.k2 = KW > 2 ? S.known[a][KW > 2 ? 2 : 0] : 0u; g.k3 = KW > 3 ? S.known[a][KW > 3 ? 3 : 0] : 0u;
+        g.rank = mode == 1 ? (int)X.live_rank[a] : 0;
+        return g;
+      };
+      auto pair_eval = [&](int a, const AS& g, int sl, const TS& t) -> double {  // == pair_cost(a, sl, jr)
+        double c = 1e6;
+        uint32_t kword;
+        if constexpr (KW <= 2) kword = (sl >> 5) ? g.k1 : g.k0;
+        else { const int kw = sl >> 5; kword = kw == 0 ? g.k0 : kw == 1 ? g.k1 : kw == 2 ? g.k2 : g.k3; }
+        bool ok = !(vis && !((kword >> (sl & 31)) & 1u));
+        if (ok && t.elig_on && !((t.elig >> g.type) & 1u)) ok = false;
+        if (ok) {
+          const double capv = S.a_caps[t.type][a];
+          const double delivered = t.esc_task ? 1.0 : capv;
+          if (delivered > 0) {
+            const double dist = norm2(g.px - t.px, g.py - t.py);
+            const double base = dist / fmax(MAX_COORD, 1.0) - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
+            double score = 0.0;
+            if (mode == 1) {
+              if ((t.info & 255) < 32 && g.rank < 16 && capv > 0) {
+                double scar = 0.0;
+                if (vis) scar = 1.0 - fmin((double)(t.info >> 8) / (double)n_live, 1.0);
+                double v = 0.5 * t.urgency + 0.3 * scar - 0.4 * (dist / fmax(MAX_COORD, 1.0));
+                v = fmin(fmax(v, -0.35), 0.35);
+                score = (double)(float)v;
+              }
+            }
+            if (mode == 2) {
+              const double cap = capv > 0 ? capv : 0.0;
+              double v = 0.45 * t.urgency + 0.35 * t.press * (0.5 + 0.5 * (t.esc_flag ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
+              const bool fighter = is_fighter(g.type);
+              if (fighter && (t.esc_flag || t.type == MUAVTA_INT)) v += 0.2;
+              if (!fighter && t.type == MUAVTA_REC) v += 0.2;
+              score = fmin(fmax(v, 0.0), 1.0);
+            }
+            if (base < 1e5 / 2) c = base - score;
+          }
+        }
+        return c;
+      };
       bool feasible = false;
       cost_vec c0;
       cost_vec_hi c1;
@@ -2692,66 +2758,6 @@ struct Sim {
         // uniformly indexed registers, one row per iteration — no A x T tile in LDS.  pair_cost() split in two: the column's
         // side (task or agent fields) is read from LDS ONCE per lane, the row's side is the same for every lane (broadcast
         // reads, issued together), so an iteration costs one LDS round trip instead of a chain of six.  Same arithmetic.
-        static_assert(!TL::REGC || KW <= 2, "the register-built cost columns keep an agent's known mask in two words");
-        struct TS { double px, py, urgency, missing, press; int type, info; bool elig_on, esc_task, esc_flag; uint32_t elig; };
-        struct AS { double px, py; int type, rank; uint32_t k0, k1; };
-        auto load_ts = [&](int sl, int jr) {
-          TS t;
-          const int fl = S.t_flags[sl];
-          t.px = S.t_px[sl]; t.py = S.t_py[sl]; t.type = S.t_type[sl]; t.elig = S.t_elig[sl];
-          t.elig_on = (fl & TF_ELIGIBLE) != 0; t.esc_flag = (fl & TF_ESCORT) != 0;
-          t.esc_task = t.esc_flag || S.t_required[sl] > 0;
-          t.urgency = 0.0;
-          if (fl & TF_DEADLINE) {
-            int remaining = S.t_deadline[sl] - tnow;
-            remaining = remaining > 0 ? remaining : 0;
-            t.urgency = 1.0 - fmin((double)remaining / 40.0, 1.0);
-          }
-          t.missing = fmax(X.resid[sl], 1e-6);
-          t.info = mode == 1 ? pair_info()[sl] : 0;
-          t.press = mode == 2 ? X.spc[jr] : 0.0;
-          return t;
-        };
-        auto load_as = [&](int a) {
-          AS g;
-          g.px = S.a_px[a]; g.py = S.a_py[a]; g.type = S.a_type[a];
-          g.k0 = S.known[a][0]; g.k1 = KW > 1 ? S.known[a][KW > 1 ? 1 : 0] : 0u;
-          g.rank = mode == 1 ? (int)X.live_rank[a] : 0;
-          return g;
-        };
-        auto pair_eval = [&](int a, const AS& g, int sl, const TS& t) -> double {  // == pair_cost(a, sl, jr)
-          double c = 1e6;
-          bool ok = !(vis && !((((sl >> 5) ? g.k1 : g.k0) >> (sl & 31)) & 1u));
-          if (ok && t.elig_on && !((t.elig >> g.type) & 1u)) ok = false;
-          if (ok) {
-            const double capv = S.a_caps[t.type][a];
-            const double delivered = t.esc_task ? 1.0 : capv;
-            if (delivered > 0) {
-              const double dist = norm2(g.px - t.px, g.py - t.py);
-              const double base = dist / fmax(MAX_COORD, 1.0) - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
-              double score = 0.0;
-              if (mode == 1) {
-                if ((t.info & 255) < 32 && g.rank < 16 && capv > 0) {
-                  double scar = 0.0;
-                  if (vis) scar = 1.0 - fmin((double)(t.info >> 8) / (double)n_live, 1.0);
-                  double v = 0.5 * t.urgency + 0.3 * scar - 0.4 * (dist / fmax(MAX_COORD, 1.0));
-                  v = fmin(fmax(v, -0.35), 0.35);
-                  score = (double)(float)v;
-                }
-              }
-              if (mode == 2) {
-                const double cap = capv > 0 ? capv : 0.0;
-                double v = 0.45 * t.urgency + 0.35 * t.press * (0.5 + 0.5 * (t.esc_flag ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
-                const bool fighter = is_fighter(g.type);
-                if (fighter && (t.esc_flag || t.type == MUAVTA_INT)) v += 0.2;
-                if (!fighter && t.type == MUAVTA_REC) v += 0.2;
-                score = fmin(fmax(v, 0.0), 1.0);
-              }
-              if (base < 1e5 / 2) c = base - score;
-            }
-          }
-          return c;
-        };
         const bool incol = lane < Cc;
         if (!tr) {
           const int my_s = incol ? (int)S.open_slot[X.roundT[lane]] : (int)S.open_slot[X.roundT[0]];
@@ -2787,8 +2793,24 @@ struct Sim {
       lds_sync();
       PROF(12);
       if constexpr (TL::REGC) lsap_reg_core(Rr, Cc, c0, c1);
-      else if constexpr (TL::OTFC)  // element (row i, column j) of scipy's (possibly transposed) matrix, evaluated when scanned
-        lsap(Rr, Cc, [&](int i, int j) { return tr ? pair_cost(X.freeA[j], S.open_slot[X.roundT[i]], i) : pair_cost(X.freeA[i], S.open_slot[X.roundT[j]], j); });
+      else if constexpr (TL::OTFC) {
+        if (Cc <= WG) {
+          // up to 64 columns: the register-resident solver with one column per lane, its cost in row i evaluated on the fly from
+          // the column's cached operands and row i's broadcast operands — no cost tile, no LDS traffic for v / spc / path / remaining
+          const bool incol = lane < Cc;
+          if (!tr) {
+            const int my_s = (int)S.open_slot[X.roundT[incol ? lane : 0]];
+            const TS ts = load_ts(my_s, incol ? lane : 0);
+            lsap_reg_solve(Rr, Cc, [&](int i) -> double { const int a = X.freeA[i]; const AS g = load_as(a); return pair_eval(a, g, my_s, ts); });
+          } else {
+            const int my_a = X.freeA[incol ? lane : 0];
+            const AS g = load_as(my_a);
+            lsap_reg_solve(Rr, Cc, [&](int i) -> double { const int sl = S.open_slot[X.roundT[i]]; const TS ts = load_ts(sl, i); return pair_eval(my_a, g, sl, ts); });
+          }
+        } else {  // element (row i, column j) of scipy's (possibly transposed) matrix, evaluated when scanned
+          lsap(Rr, Cc, [&](int i, int j) { return tr ? pair_cost(X.freeA[j], S.open_slot[X.roundT[i]], i) : pair_cost(X.freeA[i], S.open_slot[X.roundT[j]], j); });
+        }
+      }
       else if constexpr (T <= WG && A <= 32) lsap_reg(Rr, Cc);
       else lsap(Rr, Cc);
       PROF(13);
@@ -3237,6 +3259,90 @@ struct Sim {
         SRmask |= 1ull << i;
         const double ui = readlane_f64(u_r, i);
         const double ci = (A > 16 && i >= 16) ? c1[i - 16] : c0[i];
+        double val = INF;
+        bool un = false;
+        if (active) {
+          const double r = minVal + ci - ui - vj;
+          if (r < sp) { sp = r; pth = i; }
+          val = sp;
+          un = r4c == -1;
+        }
+        const double m = wave_min(val);  // (a variant that skips the DPP rows without columns measured 3.5 % SLOWER: r02p)
+        if (m == INF) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }
+        const unsigned long long eq = __ballot(active && val == m);
+        const unsigned long long equ = __ballot(active && val == m && un);
+        int sel;
+        if (equ) {
+          sel = 63 - __clzll((long long)equ);
+          if (equ & (equ - 1ull)) {  // several unassigned minima: the one at the last position
+            int best = -1;
+            for (unsigned long long t = equ; t; t &= t - 1ull) {
+              const int b = __ffsll((long long)t) - 1;
+              const int pb = __builtin_amdgcn_readlane(pos, b);
+              if (pb > best) { best = pb; sel = b; }
+            }
+          }
+        } else {
+          sel = __ffsll((long long)eq) - 1;
+          if (eq & (eq - 1ull)) {    // several (assigned) minima: the one at the first position
+            int best = 1 << 30;
+            for (unsigned long long t = eq; t; t &= t - 1ull) {
+              const int b = __ffsll((long long)t) - 1;
+              const int pb = __builtin_amdgcn_readlane(pos, b);
+              if (pb < best) { best = pb; sel = b; }
+            }
+          }
+        }
+        minVal = m;
+        const int rj = __builtin_amdgcn_readlane(r4c, sel), psel = __builtin_amdgcn_readlane(pos, sel);
+        SCmask |= 1ull << sel;
+        if (pos == nrem - 1) pos = psel;  // remaining[index] = remaining[--num_remaining]
+        if (lane == sel) active = false;
+        nrem--;
+        if (rj == -1) sink = sel; else i = rj;
+      }
+      // dual updates (u over the scanned rows, v over the scanned columns)
+      const double spc_of_my_col = __shfl(sp, c4r < 0 ? 0 : c4r);  // rows in SR other than cur are assigned
+      if (lane < nr) {
+        if (lane == cur) u_r += minVal;
+        else if ((SRmask >> lane) & 1ull) u_r += minVal - spc_of_my_col;
+      }
+      if (incol && ((SCmask >> lane) & 1ull)) vj -= minVal - sp;
+      // augmentation along `path` (uniform walk)
+      int jj = sink;
+      while (true) {
+        const int r = __builtin_amdgcn_readlane(pth, jj);
+        if (lane == jj) r4c = r;
+        const int t = __builtin_amdgcn_readlane(c4r, r);
+        if (lane == r) c4r = jj;
+        jj = t;
+        if (r == cur) break;
+      }
+    }
+    if (lane < nr) X.col4row[lane] = c4r;
+    if (incol) X.row4col[lane] = r4c;
+    lds_sync();
+  }
+  // cost_row(i): this lane's (= this column's) cost in row i, for a uniform i — a register of the column built beforehand, or
+  // evaluated on the fly from the column's cached operands and the row's broadcast operands (64-agent tile)
+  template <class CostRow>
+  DEV void lsap_reg_solve(int nr, int nc, CostRow cost_row) {
+    const double INF = __builtin_huge_val();
+    double u_r = 0, vj = 0;  // lane r < nr: u[r];  lane j < nc: v[j]
+    int c4r = -1, r4c = -1;  // lane r: col4row[r];  lane j: row4col[j]
+    const bool incol = lane < nc;
+    for (int cur = 0; cur < nr; cur++) {
+      int pos = nc - 1 - lane;  // scipy fills `remaining` in reverse: column j sits at position nc-1-j
+      double sp = INF;
+      int pth = -1;
+      bool active = incol;
+      unsigned long long SRmask = 0ull, SCmask = 0ull;
+      double minVal = 0;
+      int i = cur, nrem = nc, sink = -1;
+      while (sink == -1) {
+        SRmask |= 1ull << i;
+        const double ui = readlane_f64(u_r, i);
+        const double ci = cost_row(i);
         double val = INF;
         bool un = false;
         if (active) {
