@@ -351,8 +351,14 @@ struct Sim {
   DEV bool ref_retired(int id, int slot) const { return !ref_valid(id, slot) || S.t_status[slot] == 2; }
   DEV int head_id(int a) const { return S.a_qlen[a] > 0 ? S.a_qid[a][0] : 0; }
   DEV int queue_find(int a, int id) const {
-    for (int k = 0; k < S.a_qlen[a]; k++) if (S.a_qid[a][k] == id) return k;
-    return -1;
+    // every entry of the row is read at once (entries beyond the queue's length are stale but in bounds) and the first
+    // match picked from a bit mask: one LDS round trip instead of one per entry
+    const int n = S.a_qlen[a];
+    unsigned m = 0;
+#pragma unroll
+    for (int k = 0; k < Q; k++) m |= (unsigned)(S.a_qid[a][k] == id) << k;
+    m &= (1u << n) - 1u;
+    return m ? __ffs((int)m) - 1 : -1;
   }
   DEV void queue_erase(int a, int k) {
     int n = S.a_qlen[a];
@@ -605,13 +611,14 @@ struct Sim {
   }
 
   // ---------------------------------------------------------------- escorts (lane 0)
+  DEV bool has_escort(int recon) const { return (S.esc_mask >> recon) & 1ull; }  // recon in _escort_by_recon, in one LDS read
   DEV int escort_lookup(int recon) const {
     for (int k = 0; k < S.n_escorts; k++) if (S.esc_agent[k] == recon) return k;
     return -1;
   }
   DEV void create_escort_for(int recon, int rec_slot) {  // _create_escort_for (:1888-1917)
     if (!P.escort_enabled) return;
-    if (escort_lookup(recon) >= 0) return;
+    if (has_escort(recon)) return;
     int s = new_task(S.a_px[recon], S.a_py[recon], MUAVTA_DEF, P.escort_requirement);
     if (s < 0) return;
     S.t_flags[s] |= TF_ESCORT | TF_ELIGIBLE;
@@ -624,6 +631,7 @@ struct Sim {
     register_dynamic(s);
     int n = S.n_escorts;
     if (n >= A) { fail(MUAVTA_ERR_ESCORTS); return; }
+    S.esc_mask |= 1ull << recon;
     S.esc_agent[n] = recon; S.esc_id[n] = S.t_id[s]; S.esc_slot[n] = s;
     S.esc_pid[n] = S.t_prot_id[s]; S.esc_pslot[n] = rec_slot;
     S.n_escorts = n + 1;
@@ -656,6 +664,7 @@ struct Sim {
     int recon = S.t_prot_agent[s];
     int kk = escort_lookup(recon);
     if (kk >= 0) {
+      S.esc_mask &= ~(1ull << recon);
       for (int i = kk; i + 1 < S.n_escorts; i++) {
         S.esc_agent[i] = S.esc_agent[i + 1]; S.esc_id[i] = S.esc_id[i + 1]; S.esc_slot[i] = S.esc_slot[i + 1];
         S.esc_pid[i] = S.esc_pid[i + 1]; S.esc_pslot[i] = S.esc_pslot[i + 1];
@@ -1457,7 +1466,7 @@ struct Sim {
       }
     }
     // actions that will create an escort (and with it set pending_reset) further down, in action order
-    const bool creates = P.escort_enabled && succ && ty == MUAVTA_REC && is_recon(S.a_type[a]) && escort_lookup(a) < 0;
+    const bool creates = P.escort_enabled && succ && ty == MUAVTA_REC && is_recon(S.a_type[a]) && !has_escort(a);
     const unsigned long long cm = __ballot(creates);
     if (idle_br && P.dynamic_idle_penalty != 0 && (pending0 || (cm & ((1ull << k) - 1ull)) != 0ull)) { q1 = -P.dynamic_idle_penalty; nq01 = 2; }
     // ---- task side: Task.addAgentCap in action order over the lanes that share a slot ----
@@ -1601,7 +1610,7 @@ struct Sim {
           distance_reward += -1.0 * total / MAX_COORD;
         }
         if (S.a_state[a] != 1 && S.a_state[a] != -1) S.a_state[a] = 1;
-        if (P.escort_enabled && ty == MUAVTA_REC && is_recon(S.a_type[a]) && escort_lookup(a) < 0) create_escort_for(a, s);
+        if (P.escort_enabled && ty == MUAVTA_REC && is_recon(S.a_type[a]) && !has_escort(a)) create_escort_for(a, s);
       }
     }
   }
@@ -2024,7 +2033,7 @@ struct Sim {
       if (S.a_qlen[a] == 0) continue;
       int cid = S.a_qid[a][0], cs = S.a_qslot[a][0];
       if (ref_retired(cid, cs)) continue;
-      if (S.t_type[cs] == MUAVTA_REC && escort_lookup(a) < 0) create_escort_for(a, cs);
+      if (S.t_type[cs] == MUAVTA_REC && !has_escort(a)) create_escort_for(a, cs);
     }
     // iterate a snapshot of the map (retiring pops entries)
     int n = S.n_escorts;
@@ -2060,7 +2069,7 @@ struct Sim {
       if (a < P.n_agents && S.a_state[a] != -1 && is_recon(S.a_type[a]) && S.a_qlen[a] > 0) {
         const int cid = S.a_qid[a][0];
         cs = S.a_qslot[a][0];
-        need = !ref_retired(cid, cs) && S.t_type[cs] == MUAVTA_REC && escort_lookup(a) < 0;
+        need = !ref_retired(cid, cs) && S.t_type[cs] == MUAVTA_REC && !has_escort(a);
       }
       unsigned long long nm = __ballot(need);
       if (nm) {

@@ -156,6 +156,7 @@ struct alignas(16) EnvState : QueueSide<TL::A, TL::T, !TL::SLIM> {
                                                // window are never popped, as in the reference); esc_pid/pslot: protected Rec task
   i8 act_agent[A], act_slot[A];     // actions staged by the allocator
   // ---- scalars (everything above may double as scratch while a reset sets up the RNG) -----------
+  unsigned long long esc_mask;      // bit a set <=> recon UAV a has an entry in _escort_by_recon (the esc_* lists above)
   double F_Reward, total_distance, last_reward, step_reward;
   double r_time_penalty, r_alloc;   // reward terms evaluated mid-step (DroneEnv.py:1140-1145), before the world dynamics
   int32_t time_steps, conclusion_time, n_order, n_open, n_active_threats, n_events, n_dev, n_pending, n_escorts, n_act;
