@@ -94,7 +94,7 @@ typedef struct MuavtaParams {
   double mutual_support_radius;
   /* Tile (capacity) of one env instance in device memory; 0 = derive a default. */
   int32_t tile_agents;   /* >= n_agents; 16 / 24 / 64 in BASELINE configs */
-  int32_t tile_tasks;    /* live task slots (open + retired-but-referenced); 32 / 48 / 128 */
+  int32_t tile_tasks;    /* live task slots (open + retired-but-referenced); 40 / 48 / 128 */
   int32_t tile_threats;  /* >= sum(threat_count) */
   int32_t random_init_pos; /* config.random_init_pos (DroneEnv.py:607) */
 } MuavtaParams;
@@ -106,7 +106,7 @@ typedef struct MuavtaDims {
   int32_t obs_task_width; /* 21 features per task (leading dim of the feature-major tasks tensor) */
   int32_t obs_agent_width;/* 9 floats per agent row */
   int32_t queue_cap, event_cap, action_cap;
-  int64_t state_bytes;    /* bytes of one env's device state blob */
+  int64_t state_bytes;    /* bytes of one env's device state: its LDS-image record + its HBM-only record */
   int32_t n_threats;      /* sum(threat_count): leading dim of the THREAT_* fields */
   int32_t known_words;    /* ceil(tile_tasks / 32) */
   int32_t lds_bytes;      /* LDS one workgroup (= one env) occupies */
@@ -314,7 +314,8 @@ int muavta_metrics(MuavtaEnv* env, double* out);
 int muavta_get(MuavtaEnv* env, MuavtaField field, void* dst, size_t bytes);
 int muavta_set(MuavtaEnv* env, MuavtaField field, const void* src, size_t bytes);
 
-/* Whole-state snapshot (checkpoint/resume): bytes = n_envs * dims.state_bytes. */
+/* Whole-state snapshot (checkpoint/resume): bytes = n_envs * dims.state_bytes, laid out as the n_envs LDS-image records
+ * followed by the n_envs HBM-only records (opaque to the caller; same build, same tile). */
 int muavta_get_state(MuavtaEnv* env, void* dst, size_t bytes);
 int muavta_set_state(MuavtaEnv* env, const void* src, size_t bytes);
 
