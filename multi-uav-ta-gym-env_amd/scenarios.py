@@ -144,6 +144,27 @@ CASE_SPECS: Dict[str, Dict[str, Any]] = {
     "WPS_attn_XL": _derive(_WPS_ATTN, agents={"F1": 14, "F2": 6, "R1": 14, "R2": 6}, tasks={"Att": 13, "Rec": 26, "Hold": 0},
                            threats_list=[("T1", 26), ("T2", 20)]),
     "WPS_commit": _derive(_WPS_ATTN, commit_horizon=25, reassign_penalty=2.0),
+    # COP sweeps of WPS_attn (experiments/paper_scenarios.py:268-342): sensing radius, reveal delay, cue-only variants
+    **{f"WPS_attn_COP_R{r}": _derive(_WPS_ATTN, sense_radius=float(r)) for r in (60, 90, 150, 250)},
+    **{f"WPS_attn_COP_d{d}": _derive(_WPS_ATTN, threat_delay=d) for d in (0, 6, 12, 18)},
+    **{f"WPS_attn_COP_cue_d{d}": _derive(_WPS_ATTN, sense_radius=0.0, threat_delay=d, share_knowledge=True) for d in (0, 6, 12, 18)},
+    # the static / attrition cases of the paper's first experiment block (experiments/paper_scenarios.py:7-58)
+    "static_strike": {"agents": {"F1": 0, "F2": 2, "R1": 0, "R2": 0}, "tasks": {"Att": 15, "Rec": 0, "Hold": 0}, "fail_rate": 0.0,
+                      "threats_list": [], "arrival_rate": 0.0},
+    "scal_None": {"agents": {"F1": 0, "F2": 2, "R1": 0, "R2": 0}, "tasks": {"Att": 15, "Rec": 0, "Hold": 0}, "fail_rate": 0.0,
+                  "threats_list": [], "arrival_rate": 0.0},
+    "recon_strike_mix": {"agents": {"F1": 2, "F2": 0, "R1": 4, "R2": 0}, "tasks": {"Att": 6, "Rec": 12, "Hold": 0}, "fail_rate": 0.0,
+                         "threats_list": [], "arrival_rate": 0.0},
+    "train_mixed": {"agents": {"F1": 2, "F2": 0, "R1": 4, "R2": 0}, "tasks": {"Att": 6, "Rec": 12, "Hold": 0}, "fail_rate": 0.0,
+                    "threats_list": [], "arrival_rate": 0.0},
+    "agent_scaling_mid": {"agents": {"F1": 3, "F2": 0, "R1": 6, "R2": 0}, "tasks": {"Att": 6, "Rec": 24, "Hold": 0}, "fail_rate": 0.0,
+                          "threats_list": [], "arrival_rate": 0.0},
+    "scal_Agents_mid": {"agents": {"F1": 3, "F2": 0, "R1": 6, "R2": 0}, "tasks": {"Att": 6, "Rec": 24, "Hold": 0}, "fail_rate": 0.0,
+                        "threats_list": [], "arrival_rate": 0.0},
+    "D1_attrition": {"agents": {"F1": 2, "F2": 0, "R1": 4, "R2": 0}, "tasks": {"Att": 6, "Rec": 12, "Hold": 0}, "fail_rate": 0.1,
+                     "threats_list": [], "arrival_rate": 0.0},
+    "D3_combined": {"agents": {"F1": 2, "F2": 2, "R1": 2, "R2": 2}, "tasks": {"Att": 4, "Rec": 8, "Hold": 0}, "fail_rate": 0.1,
+                    "threats_list": [("T1", 3), ("T2", 2)], "arrival_rate": 0.02},
     "WPS_burst64": _derive(
         _WPS_BURST,
         agents={"F1": 16, "F2": 16, "R1": 16, "R2": 16},
@@ -190,4 +211,7 @@ TILES = {
     "WPS_attn_L": (64, 128, 48),
     "WPS_attn_XL": (64, 128, 48),
     "WPS_commit": (16, 48, 16),
+    **{f"WPS_attn_COP_R{r}": (16, 48, 16) for r in (60, 90, 150, 250)},
+    **{f"WPS_attn_COP_d{d}": (16, 48, 16) for d in (0, 6, 12, 18)},
+    **{f"WPS_attn_COP_cue_d{d}": (16, 48, 16) for d in (0, 6, 12, 18)},
 }

@@ -344,6 +344,12 @@ TRACE_PLAN = [
     ("WPS_attn_OS24", 20, (0,), 8),
     ("WPS_attn_L", 20, (0,), 8),
     ("WPS_attn_XL", 20, (0,), 8),
+    # the rest of the reference registry: final metrics only
+    *[(f"WPS_attn_COP_R{r}", 20, (), 4) for r in (60, 90, 150, 250)],
+    *[(f"WPS_attn_COP_d{d}", 20, (), 4) for d in (0, 6, 12, 18)],
+    *[(f"WPS_attn_COP_cue_d{d}", 20, (), 4) for d in (0, 6, 12, 18)],
+    ("static_strike", 20, (0,), 6), ("scal_None", 20, (), 2), ("recon_strike_mix", 20, (), 6), ("train_mixed", 20, (), 2),
+    ("agent_scaling_mid", 20, (0,), 6), ("scal_Agents_mid", 20, (), 2), ("D1_attrition", 20, (), 6), ("D3_combined", 20, (0,), 6),
 ]
 
 
