@@ -289,6 +289,34 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
         env.rollout(None, 1, args.interval, True, write_obs)
     env.sync()
     out["fused_step_api_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
+    # obs_ring: the fused rollout in launches of K steps whose per-step observations (+ reward, done) land in slot t of device
+    # rings [K][N][...] (muavta_rollout_record) instead of overwriting one buffer — every step's observation stays readable by
+    # a consumer on the device, at K steps per launch instead of one
+    try:
+        import torch
+
+        shapes = env.obs_ring_shapes(1)
+        slot_bytes = sum(int(np.prod(sh)) * np.dtype(dt).itemsize for sh, dt in shapes.values())
+        dev = torch.device("cuda", env.device_index)
+        for key, k_max in (("obs_ring", HORIZON), ("obs_ring_k10", 10)):
+            K = max(1, min(k_max, int(32e9 // slot_bytes)))
+            while HORIZON % K:
+                K -= 1
+            rings = {k: torch.empty(sh, dtype=getattr(torch, np.dtype(dt).name), device=dev) for k, (sh, dt) in env.obs_ring_shapes(K).items()}
+            env.rollout_record(seeds, K, args.interval, True, obs_rings=rings)  # warm-up
+            env.sync()
+            t1 = time.perf_counter()
+            for c in range(HORIZON // K):
+                env.rollout_record(seeds if c == 0 else None, K, args.interval, True, obs_rings=rings)
+            env.sync()
+            out[key + "_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
+            out[key + "_is"] = (f"muavta_rollout_record, {HORIZON // K} launch(es) of {K} steps per episode batch, every step's observation dict + reward "
+                                f"+ done kept in device rings [{K}][{args.envs}][...] ({slot_bytes * K / 1e9:.2f} GB)")
+            del rings
+        torch.cuda.empty_cache()
+    except Exception as exc:
+        out["obs_ring_env_steps_per_s"] = None
+        out["obs_ring_error"] = repr(exc)
     env.rollout(seeds, HORIZON, args.interval, True, write_obs)  # restore the headline batch's final state
     env.sync()
     # the trainers' data loop: samples = (env, step) pairs with token tensors + expert labels + step reward

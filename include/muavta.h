@@ -345,14 +345,25 @@ int muavta_device_ptrs(MuavtaEnv* env, void** state, void** obs_tasks, void** ob
  * edge_valid, expert_mask = _expert_mask(tok, plan), replanned = the gate fired at t) and s_wps[t] = compute_s_wps() before the
  * step; s_wps[n_steps] is the value after the last step, so the RL step reward of step t is (s_wps[t+1] - s_wps[t]) / 20.
  * Ring layouts: every muavta_tokens_device output with a leading [n_steps] axis (slot-major: [n_steps][N][...]); s_wps f64
- * [n_steps + 1][N].  n_urgent / expert_mask / replanned may be NULL.  Use muavta_set_allocator(MUAVTA_ALLOC_HUNGARIAN_GATED)
- * and use_vis = 0 for the reference's expert.  Asynchronous on the handle's stream (muavta_sync / an event before reading). */
+ * [n_steps + 1][N].  n_urgent / expert_mask / replanned may be NULL; kind < 0 leaves the whole token part out (its pointers
+ * and s_wps are then ignored).  Use muavta_set_allocator(MUAVTA_ALLOC_HUNGARIAN_GATED) and use_vis = 0 for the
+ * reference's expert.
+ * Observation rings (optional, all seven or none — obs_tasks == NULL means none; they need write_obs != 0): the observation
+ * the env would return from step t (DroneEnv.step -> _get_observations, DroneEnv.py:1226-1243, in muavta_observe's device
+ * layouts) goes to slot t of obs_tasks f32 [n_steps][N][21][max_tasks], obs_legal u64 [n_steps][N][A][ceil(max_tasks/64)],
+ * obs_pad u8 [n_steps][N][max_tasks], obs_agents f32 [n_steps][N][A][9], obs_flags f32 [n_steps][N][5], obs_reward f64
+ * [n_steps][N], obs_done u8 [n_steps][N] (bit 0 terminated, bit 1 truncated) instead of overwriting the handle's single
+ * observation buffer each step; the handle's buffer receives the final observation once, at the end.  An env whose episode
+ * ended at step t < n_steps - 1 leaves its later slots unwritten: obs_done is pre-filled with MUAVTA_OBS_UNWRITTEN for that.
+ * Asynchronous on the handle's stream (muavta_sync / an event before reading). */
+#define MUAVTA_OBS_UNWRITTEN 0x80
 typedef struct MuavtaRecord {
-  int32_t kind, max_tasks, max_agents, reserved;  /* MUAVTA_TOK_*, token pads */
+  int32_t kind, max_tasks, max_agents, reserved;  /* MUAVTA_TOK_* or -1, token pads */
   float* task_feats; uint8_t* task_mask; int32_t* task_ids;
   float* agent_feats; uint8_t* agent_mask; int32_t* agent_ids;
   float* edge_valid; int32_t* n_urgent; float* expert_mask; int32_t* replanned;
   double* s_wps;
+  float* obs_tasks; uint64_t* obs_legal; uint8_t* obs_pad; float* obs_agents; float* obs_flags; double* obs_reward; uint8_t* obs_done;
 } MuavtaRecord;
 int muavta_rollout_record(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps, int32_t replan_interval, int32_t use_visibility,
                           int32_t write_obs, const MuavtaRecord* rec);

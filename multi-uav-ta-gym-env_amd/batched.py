@@ -193,20 +193,42 @@ class BatchedMultiUAVEnv:
                 "edge_valid": ((K, N, ma, mt), np.float32), "n_urgent": ((K, N), np.int32), "expert_mask": ((K, N, ma, mt), np.float32),
                 "replanned": ((K, N), np.int32), "s_wps": ((K + 1, N), np.float64)}
 
-    def rollout_record(self, seeds: Optional[Sequence[int]], n_steps: int, replan_interval: int, use_visibility: bool, rings: dict,
-                       kind: str = "pair", max_tasks: int = 32, max_agents: int = 16, write_obs: bool = False):
+    def obs_ring_shapes(self, n_steps: int):
+        """name -> (shape, numpy dtype) of the per-step observation rings `rollout_record(obs_rings=...)` fills
+        (muavta_observe's device layouts with a leading [n_steps] axis)."""
+        K, N, A, MT = int(n_steps), self.n_envs, self.n_agents, self.max_tasks
+        return {"obs_tasks": ((K, N, 21, MT), np.float32), "obs_legal": ((K, N, A, self.dims.legal_words), np.uint64), "obs_pad": ((K, N, MT), np.uint8),
+                "obs_agents": ((K, N, A, 9), np.float32), "obs_flags": ((K, N, 5), np.float32), "obs_reward": ((K, N), np.float64),
+                "obs_done": ((K, N), np.uint8)}
+
+    OBS_UNWRITTEN = 0x80  # include/muavta.h: MUAVTA_OBS_UNWRITTEN
+
+    def rollout_record(self, seeds: Optional[Sequence[int]], n_steps: int, replan_interval: int, use_visibility: bool, rings: Optional[dict] = None,
+                       kind: str = "pair", max_tasks: int = 32, max_agents: int = 16, write_obs: bool = False, obs_rings: Optional[dict] = None):
         """muavta_rollout_record: the fused rollout that also fills `rings` (dict of contiguous CUDA torch tensors with the
-        shapes of `record_shapes`) with the per-step training data — no host hop, one launch for the whole episode batch.
+        shapes of `record_shapes`) with the per-step training data and/or `obs_rings` (shapes of `obs_ring_shapes`; implies
+        write_obs) with every step's observation — no host hop, one launch for the whole episode batch.
         Asynchronous on the handle's stream: call `sync()` before reading the rings from another stream."""
         from .params import MuavtaRecord
 
-        k, _, _ = self.TOKEN_KINDS[kind]
+        if rings is None and obs_rings is None:
+            raise ValueError("rollout_record: pass rings and/or obs_rings")
         rec = MuavtaRecord()
-        rec.kind, rec.max_tasks, rec.max_agents = k, int(max_tasks), int(max_agents)
-        for name, (shape, dtype) in self.record_shapes(kind, n_steps, max_tasks, max_agents).items():
-            t = rings[name]
+        rec.kind = -1
+        want = {}
+        if rings is not None:
+            k, _, _ = self.TOKEN_KINDS[kind]
+            rec.kind, rec.max_tasks, rec.max_agents = k, int(max_tasks), int(max_agents)
+            want.update({n: (rings, v) for n, v in self.record_shapes(kind, n_steps, max_tasks, max_agents).items()})
+        if obs_rings is not None:
+            write_obs = True
+            want.update({n: (obs_rings, v) for n, v in self.obs_ring_shapes(n_steps).items()})
+        for name, (src, (shape, dtype)) in want.items():
+            t = src[name]
             if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != np.dtype(dtype).itemsize:
                 raise ValueError(f"rollout_record: {name} must be a contiguous CUDA tensor of shape {shape}, {np.dtype(dtype).name}")
+            if t.device.index != self.device_index:
+                raise ValueError(f"rollout_record: {name} lives on {t.device}, the env batch on cuda:{self.device_index}")
             setattr(rec, name, t.data_ptr())
         s = None
         if seeds is not None:

@@ -25,6 +25,12 @@
 #define DEVN __device__ __noinline__
 
 // 1: the observation rows' HBM operands are requested before the task-time rebuild (latency overlap, +28 live VGPRs there)
+// k_rollout's issue-priority pacing of the envs that share a SIMD: 0 off, 1..3 = that priority for the env furthest behind,
+// 4 = ranked (3 for the last, one less per neighbour further behind).  Measured on the headline tile (profiles/r02_pacing.txt):
+// off 164 M env-steps/s, 1 -> 177 M, 4 -> 182 M; raising priority only while an env replans: 172 M.
+#ifndef MUAVTA_PACE_PRIO
+#define MUAVTA_PACE_PRIO 4
+#endif
 #ifndef MUAVTA_OBS_PREFETCH
 #define MUAVTA_OBS_PREFETCH 0
 #endif

@@ -54,7 +54,9 @@ struct DevCtx {
   uint32_t* tapes;  // [N][4][1248] MT19937 tapes
   void* blobs;      // EnvState<TL>[N]: the LDS image of every env between launches
   void* cold;       // EnvCold<TL>[N]: the HBM-only part of every env
+  uint32_t* pace;   // [PACE_KEYS][16] step counters of the waves resident on each SIMD (k_rollout's issue-priority pacing)
 };
+enum { PACE_KEYS = 1 << 16 };  // (XCC_ID[3:0], HW_ID[15:4] = se, sh, cu, pipe, simd)
 // the context as uniform constant memory: scalar loads, hoistable across the phase barriers
 __device__ __forceinline__ const DevCtx& ctx_ref(const DevCtx* p) {
   const uint64_t b = (uint64_t)p;
@@ -298,23 +300,35 @@ enum { PH_ALLOC = 1, PH_STEP = 2, PH_OBS = 4 };
 // tensors / expert labels of the plan staged for step t and S_WPS before step t (experiments/train_pair_cost.py:96-156).
 template <class TL>
 struct RecordPtrs {
-  typename Sim<TL>::TokPtrs K;
+  typename Sim<TL>::TokPtrs K;  // K.task_feats == nullptr: no token rings
   double* s_wps;   // [n_steps + 1][N]
+  ObsPtrs O;       // O.tasks == nullptr: no observation rings
   int n_envs;
 };
 template <class TL, bool REC>
 __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds_base, int phases, int interval, int use_vis, int mode,
-                                                const RecordPtrs<TL>& rec, int slot) {
+                                                const RecordPtrs<TL>& rec, int slot, int oslot) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L((unsigned char*)(AS3 unsigned char*)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base));
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
   if (phases & PH_STEP) sim.step(true);
-  if (phases & PH_OBS) obs_for_env(sim, ctx.P, obs_ptrs(ctx), env);
+  if (phases & PH_OBS) {
+    ObsPtrs O = obs_ptrs(ctx);
+    int at = env;
+    if constexpr (REC) {
+      if (oslot >= 0) {  // slot `oslot` of the caller's observation rings instead of the handle's single buffer
+        O.tasks = as_global(rec.O.tasks); O.legal = as_global(rec.O.legal); O.pad = as_global(rec.O.pad); O.agents = as_global(rec.O.agents);
+        O.flags = as_global(rec.O.flags); O.reward = as_global(rec.O.reward); O.done = as_global(rec.O.done);
+        at = oslot * rec.n_envs + env;
+      }
+    }
+    obs_for_env(sim, ctx.P, O, at);
+  }
   lds_sync();
   if ((phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) {
     sim.allocate(interval, use_vis, mode);
-    if constexpr (REC) {  // the sample of step `slot`: tokens + labels of the plan just staged, S_WPS before the step
+    if (REC && rec.K.task_feats) {  // the sample of step `slot`: tokens + labels of the plan just staged, S_WPS before the step
       typename Sim<TL>::TokPtrs K = rec.K;
       K.task_feats = as_global(K.task_feats); K.task_mask = as_global(K.task_mask); K.task_ids = as_global(K.task_ids);
       K.agent_feats = as_global(K.agent_feats); K.agent_mask = as_global(K.agent_mask); K.agent_ids = as_global(K.agent_ids);
@@ -331,12 +345,22 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds
 
 template <class TL, bool REC>
 __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* __restrict__ ctxp, const uint64_t* seeds, int n_steps, int interval, int use_vis,
-                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf, RecordPtrs<TL> rec) {
+                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf, RecordPtrs<TL> rec, int epoch) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
   Lds<TL> L(smem);
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
+#if MUAVTA_PACE_PRIO
+  constexpr bool PACED = TL::A <= 32;  // the 64-agent tile has one or two waves per SIMD: nothing to pace
+  // Pacing: the envs whose waves share a SIMD advance at different speeds (replans, episode length), and the launch ends on
+  // the SIMD whose last env runs alone, at a quarter of the SIMD's multi-wave throughput.  Each wave publishes its step
+  // counter in a row of the SIMD it runs on (hardware ids), reads its neighbours' and asks for issue priority while nobody
+  // on the SIMD is further behind, so that the co-resident envs finish together.  Timing only: results do not depend on it.
+  const uint32_t hw_id = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc_id = __builtin_amdgcn_s_getreg(20 | (3 << 11));
+  uint32_t* pace_row = as_global(ctx.pace) + ((((xcc_id & 15u) << 12) | ((hw_id >> 4) & 0xFFFu)) << 4);
+  const uint32_t pace_tag = (uint32_t)epoch << 16;
+#endif
 #ifdef MUAVTA_PROF
   sim.prof_begin();
 #endif
@@ -356,10 +380,34 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* 
     else if (k <= n_steps) {
       if (L.S->terminated || L.S->truncated) { k = n_steps; continue; }  // uniform: read from LDS after a barrier
       ph = PH_STEP | (write_obs ? PH_OBS : 0) | (k < n_steps ? PH_ALLOC : 0);
-    } else ph = write_obs ? 0 : PH_OBS;
-    if (ph) rollout_phase<TL, REC>(ctxp, lds_base, ph, interval, use_vis, mode, rec, k < n_steps ? k : n_steps);
+    } else ph = (write_obs && !(REC && rec.O.tasks)) ? 0 : PH_OBS;  // with observation rings the handle's buffer gets the final one
+#if MUAVTA_PACE_PRIO
+    uint32_t seen = 0;
+    if (PACED && k >= 1 && k <= n_steps) {
+      if (threadIdx.x == 0) __hip_atomic_store(pace_row + (hw_id & 15u), pace_tag | (uint32_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x < 16) seen = __hip_atomic_load(pace_row + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+    if (ph) rollout_phase<TL, REC>(ctxp, lds_base, ph, interval, use_vis, mode, rec, k < n_steps ? k : n_steps,
+                                   (REC && rec.O.tasks && k >= 1 && k <= n_steps) ? k - 1 : -1);
+#if MUAVTA_PACE_PRIO
+    if (PACED && k >= 1 && k <= n_steps) {  // consumed a step later: the load's latency stays off the env's dependent chain
+      const bool behind_me = threadIdx.x < 16 && (seen >> 16) == (uint32_t)epoch && (seen & 0xFFFFu) < (uint32_t)k;
+#if MUAVTA_PACE_PRIO == 4  // ranked: 3 for the last env of the SIMD, one less per neighbour that is further behind
+      const int n_behind = __popcll(__ballot(behind_me));
+      if (n_behind == 0) __builtin_amdgcn_s_setprio(3); else if (n_behind == 1) __builtin_amdgcn_s_setprio(2);
+      else if (n_behind == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#else
+      if (__ballot(behind_me) != 0ull) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(MUAVTA_PACE_PRIO);
+#endif
+    }
+#endif
   }
-  if constexpr (REC) {  // S_WPS after the last step closes the reward series
+#if MUAVTA_PACE_PRIO
+  if (PACED && threadIdx.x == 0) __hip_atomic_store(pace_row + (hw_id & 15u), pace_tag | 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_setprio(0);
+#endif
+  if (REC && rec.K.task_feats) {  // S_WPS after the last step closes the reward series
     if (threadIdx.x == 0) as_global(rec.s_wps)[(size_t)n_steps * rec.n_envs + env] = sim.s_wps();
   }
   sim.sync_clock();
@@ -584,6 +632,8 @@ struct MuavtaEnv {
   void* cold = nullptr;
   uint32_t* tapes = nullptr;
   DevCtx* d_ctx = nullptr;  // device copy of {P, O, tapes}
+  uint32_t* d_pace = nullptr;
+  uint32_t pace_epoch = 0;
   uint64_t* d_seeds = nullptr;
   int32_t *d_act_agent = nullptr, *d_act_index = nullptr, *d_call_out = nullptr;
   ncclComm_t comm = nullptr;  // muavta_comm_init
@@ -1004,7 +1054,9 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   {
     DevCtx h;
     memset(&h, 0, sizeof(h));
-    h.P = e->P; h.O = e->O; h.tapes = e->tapes; h.blobs = e->blobs; h.cold = e->cold;
+    CK(hipMalloc((void**)&e->d_pace, (size_t)PACE_KEYS * 16 * sizeof(uint32_t)));
+    CK(hipMemsetAsync(e->d_pace, 0, (size_t)PACE_KEYS * 16 * sizeof(uint32_t), e->stream));  // epoch 0 is never issued
+    h.P = e->P; h.O = e->O; h.tapes = e->tapes; h.blobs = e->blobs; h.cold = e->cold; h.pace = e->d_pace;
     CK(hipMalloc((void**)&e->d_ctx, sizeof(DevCtx)));
     CK(hipMemcpyAsync(e->d_ctx, &h, sizeof(DevCtx), hipMemcpyHostToDevice, e->stream));
     CK(hipStreamSynchronize(e->stream));  // `h` is a stack object
@@ -1022,7 +1074,7 @@ int muavta_destroy(MuavtaEnv* e) {
   muavta_comm_destroy(e);
   DeviceScope scope_(e->device);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
+  hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   if (e->ev0) hipEventDestroy(e->ev0);
   if (e->ev1) hipEventDestroy(e->ev1);
@@ -1132,15 +1184,23 @@ static void launch_rollout(MuavtaEnv* e, const uint64_t* ds, int n_steps, int in
                            const MuavtaRecord* rec) {
   RecordPtrs<TL> R;
   memset(&R, 0, sizeof(R));
+  const int epoch = (int)(e->pace_epoch++ % 65535u) + 1;  // 1..65535: the zero-filled table matches no launch
   if (rec) {
-    typename Sim<TL>::TokPtrs K{rec->task_feats, rec->task_mask, rec->task_ids, rec->agent_feats, rec->agent_mask, rec->agent_ids, rec->edge_valid,
-                                rec->n_urgent, rec->expert_mask, rec->replanned, rec->kind, rec->max_tasks, rec->max_agents};
-    R.K = K; R.s_wps = rec->s_wps; R.n_envs = e->n_envs;
+    if (rec->kind >= 0) {
+      typename Sim<TL>::TokPtrs K{rec->task_feats, rec->task_mask, rec->task_ids, rec->agent_feats, rec->agent_mask, rec->agent_ids, rec->edge_valid,
+                                  rec->n_urgent, rec->expert_mask, rec->replanned, rec->kind, rec->max_tasks, rec->max_agents};
+      R.K = K; R.s_wps = rec->s_wps;
+    }
+    if (rec->obs_tasks) {
+      R.O.tasks = rec->obs_tasks; R.O.legal = (unsigned long long*)rec->obs_legal; R.O.pad = rec->obs_pad; R.O.agents = rec->obs_agents;
+      R.O.flags = rec->obs_flags; R.O.reward = rec->obs_reward; R.O.done = rec->obs_done;
+    }
+    R.n_envs = e->n_envs;
     hipLaunchKernelGGL((k_rollout<TL, true>), dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds + PROF_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, ds,
-                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R);
+                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch);
   } else {
     hipLaunchKernelGGL((k_rollout<TL, false>), dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds + PROF_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, ds,
-                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R);
+                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch);
   }
 }
 extern "C" {
@@ -1171,10 +1231,21 @@ int muavta_rollout(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t
 }
 int muavta_rollout_record(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, int32_t interval, int32_t use_vis, int32_t write_obs, const MuavtaRecord* rec) {
   int dt, da;
-  if (!e || !rec || token_dims(rec->kind, &dt, &da) || rec->max_tasks < 1 || rec->max_agents < 1 || rec->max_tasks > 4096 || rec->max_agents > 4096 ||
-      !rec->task_feats || !rec->task_mask || !rec->task_ids || !rec->agent_feats || !rec->agent_mask || !rec->agent_ids || !rec->edge_valid || !rec->s_wps) {
+  bool bad = !e || !rec;
+  if (!bad && rec->kind >= 0)
+    bad = token_dims(rec->kind, &dt, &da) || rec->max_tasks < 1 || rec->max_agents < 1 || rec->max_tasks > 4096 || rec->max_agents > 4096 || !rec->task_feats ||
+          !rec->task_mask || !rec->task_ids || !rec->agent_feats || !rec->agent_mask || !rec->agent_ids || !rec->edge_valid || !rec->s_wps;
+  const bool any_obs = !bad && (rec->obs_tasks || rec->obs_legal || rec->obs_pad || rec->obs_agents || rec->obs_flags || rec->obs_reward || rec->obs_done);
+  if (any_obs)  // all seven or none, and only with per-step observations switched on
+    bad = !(rec->obs_tasks && rec->obs_legal && rec->obs_pad && rec->obs_agents && rec->obs_flags && rec->obs_reward && rec->obs_done) || !write_obs;
+  if (!bad && rec->kind < 0 && !any_obs) bad = true;  // nothing to record
+  if (bad) {
     if (e) e->err = "muavta_rollout_record: bad argument";
     return MUAVTA_E_ARG;
+  }
+  if (any_obs && n_steps > 0) {
+    DeviceScope scope_(e->device);
+    HIPCHK(e, hipMemsetAsync(rec->obs_done, MUAVTA_OBS_UNWRITTEN, (size_t)n_steps * (size_t)e->n_envs, e->stream));
   }
   return rollout_impl(e, seeds, n_steps, interval, use_vis, write_obs, rec);
 }

@@ -120,7 +120,9 @@ class MuavtaRecord(C.Structure):
     _fields_ = [("kind", C.c_int32), ("max_tasks", C.c_int32), ("max_agents", C.c_int32), ("reserved", C.c_int32),
                 ("task_feats", C.c_void_p), ("task_mask", C.c_void_p), ("task_ids", C.c_void_p), ("agent_feats", C.c_void_p),
                 ("agent_mask", C.c_void_p), ("agent_ids", C.c_void_p), ("edge_valid", C.c_void_p), ("n_urgent", C.c_void_p),
-                ("expert_mask", C.c_void_p), ("replanned", C.c_void_p), ("s_wps", C.c_void_p)]
+                ("expert_mask", C.c_void_p), ("replanned", C.c_void_p), ("s_wps", C.c_void_p),
+                ("obs_tasks", C.c_void_p), ("obs_legal", C.c_void_p), ("obs_pad", C.c_void_p), ("obs_agents", C.c_void_p),
+                ("obs_flags", C.c_void_p), ("obs_reward", C.c_void_p), ("obs_done", C.c_void_p)]
 
 
 class _Cfg:

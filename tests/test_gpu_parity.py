@@ -803,6 +803,54 @@ def test_il_record_rings_equal_the_per_step_stream(case, kind, mt, ma):
     assert isinstance(rec["task_feats"], torch.Tensor) and rec["task_feats"].is_cuda and rec["step_reward"].shape == (steps, n)
 
 
+@pytest.mark.parametrize("case,interval", [("WPS_hard", 20), ("WPS_escort24", 12), ("WPS_burst64", 20)])
+def test_observation_rings_of_the_fused_rollout_vs_oracle(case, interval):
+    """muavta_rollout_record with observation rings: slot t holds exactly what DroneEnv.step would have returned from step t
+    (observation dict, reward, done flags) — checked against the oracle stepping the same seeds — instead of every step
+    overwriting one buffer; slots after an env's last step stay MUAVTA_OBS_UNWRITTEN; the handle's own buffer gets the final
+    observation; metrics equal the ring-less rollout's."""
+    import torch
+    n, steps = 4, 150
+    seeds = np.arange(70, 70 + n, dtype=np.uint64)
+    env = _env(case, n)
+    dev = torch.device("cuda", env.device_index)
+    rings = {k: torch.zeros(shape, dtype=getattr(torch, np.dtype(dt).name), device=dev) for k, (shape, dt) in env.obs_ring_shapes(steps).items()}
+    env.rollout_record(seeds, steps, interval, True, obs_rings=rings)
+    env.sync()
+    m = env.rollout_metrics()
+    snap = Snapshot(env)
+    R = {k: v.cpu().numpy() for k, v in rings.items()}
+    MT = env.max_tasks
+    for i in range(n):
+        o = orc.OracleEnv(params_for_case(case))
+        o.reset(int(seeds[i]))
+        t_end = steps
+        for t in range(steps):
+            a, ix = o.allocate_mode(interval, 1, 0)
+            o.step(a, ix)
+            ti, legal, pad, ag, fl = o.observe()
+            tag = f"{case} seed {seeds[i]} ring slot {t}"
+            assert np.array_equal(R["obs_tasks"][t, i].T, ti), f"{tag}: tasks_info"
+            bits = ((R["obs_legal"][t, i][:, :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).reshape(legal.shape[0], -1)[:, :MT]
+            assert np.array_equal(bits.astype(bool), legal), f"{tag}: legal_mask"
+            assert np.array_equal(R["obs_pad"][t, i].astype(bool), pad), f"{tag}: pad mask"
+            assert np.array_equal(R["obs_agents"][t, i], ag), f"{tag}: agent rows"
+            assert np.array_equal(R["obs_flags"][t, i], fl), f"{tag}: event flags"
+            d = o.dims()
+            assert R["obs_reward"][t, i] == o.scalars()[1], f"{tag}: reward"
+            assert R["obs_done"][t, i] == (1 if d["terminated"] else 0) | (2 if d["truncated"] else 0), f"{tag}: done flags"
+            if d["terminated"] or d["truncated"]:
+                t_end = t + 1
+                break
+        assert np.all(R["obs_done"][t_end:, i] == env.OBS_UNWRITTEN), f"{case} seed {seeds[i]}: slots after the last step"
+        compare(snap, i, o, f"{case} seed {seeds[i]} after the recorded rollout")
+    env2 = _env(case, n)
+    env2.rollout(seeds, steps, interval, True, True)
+    assert np.array_equal(m, env2.rollout_metrics())
+    with pytest.raises(Exception):  # all seven rings or none
+        env.rollout_record(seeds, steps, interval, True, obs_rings={k: v for k, v in rings.items() if k != "obs_done"})
+
+
 # ---- fuzzed configurations (knob combinations no registry case has); reference traces in tests/golden/trace_FUZZ* ----
 FUZZ_TRACES = sorted(glob.glob(os.path.join(GOLDEN, "trace_FUZZ*.npz")))
 
