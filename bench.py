@@ -289,6 +289,26 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
         env.rollout(None, 1, args.interval, True, write_obs)
     env.sync()
     out["fused_step_api_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
+    # the same one-launch-per-step path with 8x the envs per launch (BASELINE config 3's 32768 on one GPU): a launch ends on its
+    # slowest env (one that replans: ~80 us against a 24 us mean step), so a wider batch amortises that tail
+    try:
+        n_wide = 8 * args.envs
+        ew = BatchedMultiUAVEnv(params_for_case(args.case), n_wide, device=env.device_index)
+        sw = np.arange(n_wide, dtype=np.uint64)
+        ew.reset(sw)
+        ew.rollout(None, 1, args.interval, True, write_obs)
+        ew.reset(sw)
+        ew.sync()
+        t1 = time.perf_counter()
+        for _ in range(HORIZON):
+            ew.rollout(None, 1, args.interval, True, write_obs)
+        ew.sync()
+        out["fused_step_api_wide_env_steps_per_s"] = n_wide * HORIZON / (time.perf_counter() - t1)
+        out["fused_step_api_wide_envs"] = n_wide
+        ew.close()
+    except Exception as exc:
+        out["fused_step_api_wide_env_steps_per_s"] = None
+        out["fused_step_api_wide_error"] = repr(exc)
     # obs_ring: the fused rollout in launches of K steps whose per-step observations (+ reward, done) land in slot t of device
     # rings [K][N][...] (muavta_rollout_record) instead of overwriting one buffer — every step's observation stays readable by
     # a consumer on the device, at K steps per launch instead of one

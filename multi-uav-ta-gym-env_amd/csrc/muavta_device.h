@@ -31,6 +31,9 @@
 #ifndef MUAVTA_PACE_PRIO
 #define MUAVTA_PACE_PRIO 4
 #endif
+#ifndef MUAVTA_OBS_SADDR
+#define MUAVTA_OBS_SADDR 1
+#endif
 #ifndef MUAVTA_OBS_PREFETCH
 #define MUAVTA_OBS_PREFETCH 0
 #endif
@@ -2366,6 +2369,34 @@ struct Sim {
   // rows it leaves (initTime, doneTime) of every slot in the scratch tile (obs_times()), where the observation rows of
   // this step pick them up without another trip to memory.  Returns whether it ran.
   DEV double* obs_times() { return X.cost; }  // [2][T] after refresh_task_times() returned true
+  // x / c, correctly rounded, for a divisor that is a small integer times a power of two (1200, 6, max_time_steps,
+  // max_tasks <= 2^15) and inv = RN(1 / c): q = RN(x * inv) is within 2 ulp of x / c; r = x - q * c is exact in the FMA (q * c
+  // has <= 53 + 15 bits and cancels against x to a few units); q + r * inv then differs from x / c by < 2^-51 ulp, and x / c is
+  // never that close to a rounding boundary without being on it: both are multiples of 2^g (g = exponent of half an ulp
+  // of the quotient) divided by c's odd part m, so they are >= 2^g / m apart, and x / c cannot BE a midpoint because x's
+  // last bit sits >= 6 binary places above g.  Three full-rate FMAs instead of the ~12-instruction IEEE division
+  // sequence with its quarter-rate v_rcp_f64 (the observation writer divides ~10 times per step and the kernel is
+  // VALU-issue bound).  x must be finite (div_small_any keeps inf / NaN as the true division would).
+  // *(p + byte_off) for a wave-uniform p, pinned to scalar registers so that the access is emitted in the (SGPR base,
+  // 32-bit VGPR offset) addressing form and not with a 64-bit VALU add per access.
+  template <class V> static DEV V& at_lane(V* p, uint32_t byte_off) {
+#if !MUAVTA_OBS_SADDR
+    return *(V*)((char*)p + byte_off);
+#endif
+    typedef __attribute__((address_space(1))) char GC;
+    GC* q = (GC*)p;  // stays a global (not flat) access
+    asm("" : "+s"(q));
+    return *(V*)(__attribute__((address_space(1))) V*)(q + byte_off);  // zext(32-bit byte offset): what the addressing form takes
+  }
+  static DEV double div_small(double x, double c, double inv) {
+    const double q = x * inv;
+    return __builtin_fma(__builtin_fma(-q, c, x), inv, q);
+  }
+  static DEV double div_small_any(double x, double c, double inv) {
+    const double q = x * inv;
+    const double q1 = __builtin_fma(__builtin_fma(-q, c, x), inv, q);
+    return __builtin_isfinite(q) ? q1 : q;
+  }
   DEV bool refresh_task_times() {
     if (!S.times_dirty) return false;  // uniform: LDS word
     lds_sync();
@@ -2419,7 +2450,8 @@ struct Sim {
       if (!dirty && lane < n) { pti = C.t_init[s0]; ptd = C.t_dtime[s0]; }
     }
     refresh_task_times();
-    const double mts = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1);
+    const double mts = (double)(P.max_time_steps > 1 ? P.max_time_steps : 1), inv_mts = P.inv_mts;
+    constexpr double INV_COORD = 1.0 / MAX_COORD, INV6 = 1.0 / 6.0;
     unsigned long long leg0 = 0ull, leg1 = 0ull;  // lane a: legal bits of agent a (rows 0..63, 64..127)
     PROF(15);
     // lane a keeps agent a's (state, head id, type); the agent loop broadcasts them with v_readlane
@@ -2428,20 +2460,19 @@ struct Sim {
     const bool capm = P.capability_mask != 0;
     for (int base = 0; base < MT; base += WG) {
       const int j = base + lane;
+      const uint32_t ju = (uint32_t)j;  // unsigned lane offset + uniform column pointer: stores take the (SGPR base, VGPR offset) form
       const bool in_n = j < n, in_mt = j < MT;
-      int tid = -1, ty = 0, s = 0;
+      int ty = 0;
       uint32_t typemask = 0;  // agent types for which this row is a valid action (before the capability mask)
-      float r[21];
-#pragma unroll
-      for (int c = 0; c < 21; c++) r[c] = 0.f;
       if (in_n) {
-        s = S.open_slot[j];
-        tid = S.t_id[s];
+        const int s = S.open_slot[j];
+        const int tid = S.t_id[s];
         ty = S.t_type[s];
         typemask = (S.t_flags[s] & TF_ELIGIBLE) ? S.t_elig[s] : 0xffffffffu;
+        float r[21];
         r[0] = (float)tid;
-        r[1] = (float)(S.t_px[s] / MAX_COORD);
-        r[2] = (float)(S.t_py[s] / MAX_COORD);
+        r[1] = (float)div_small(S.t_px[s], MAX_COORD, INV_COORD);
+        r[2] = (float)div_small(S.t_py[s], MAX_COORD, INV_COORD);
         r[3] = (float)S.t_status[s];
         double cur[6], alc[6], ti, td;
         if (MUAVTA_OBS_PREFETCH && base == 0) {
@@ -2455,10 +2486,11 @@ struct Sim {
         }
 #pragma unroll
         for (int c = 0; c < 6; c++) { r[4 + c] = (float)cur[c]; r[10 + c] = (float)alc[c]; }
+        r[16] = r[17] = r[18] = 0.f;
         if (P.include_time_windows) {
-          r[16] = (float)((ti - (double)tnow) / mts);
-          r[17] = (float)((td - (double)tnow) / mts);
-          r[18] = (float)((double)ty / 6.0);
+          r[16] = (float)div_small_any(ti - (double)tnow, mts, inv_mts);
+          r[17] = (float)div_small_any(td - (double)tnow, mts, inv_mts);
+          r[18] = (float)div_small((double)ty, 6.0, INV6);
         }
         double cur_ty = cur[0], alc_ty = alc[0];  // (selects, not cur[ty]: a dynamically indexed local array would live in scratch memory)
 #pragma unroll
@@ -2467,15 +2499,18 @@ struct Sim {
         if (P.saturate_mask && alc_ty >= org) typemask = 0;
         const double unmet = fmax(cur_ty - alc_ty, 0.0);
         r[19] = (float)(unmet / fmax(org, 1e-6));
-        r[20] = (float)fmin(((double)tnow - (double)S.t_created[s]) / mts, 1.0);
-      } else if (!(j == 0 && n == 0)) {
-        r[3] = -1.f;  // pad rows are {"status": -1}; with no open task row 0 is task_idle (all zeros)
-      }
-      if (o_tasks && in_mt) {
+        r[20] = (float)fmin(div_small((double)tnow - (double)S.t_created[s], mts, inv_mts), 1.0);
+        if (o_tasks && in_mt) {
 #pragma unroll
-        for (int c = 0; c < 21; c++) o_tasks[c * MT + j] = r[c];
+          for (int c = 0; c < 21; c++) at_lane(o_tasks + (size_t)(c * MT), ju * 4u) = r[c];
+        }
+      } else if (o_tasks && in_mt) {
+        // pad rows are {"status": -1}; with no open task row 0 is task_idle (all zeros)
+        const float st = (j == 0 && n == 0) ? 0.f : -1.f;
+#pragma unroll
+        for (int c = 0; c < 21; c++) at_lane(o_tasks + (size_t)(c * MT), ju * 4u) = c == 3 ? st : 0.f;
       }
-      if (o_pad && in_mt) o_pad[j] = j < (n == 0 ? 1 : n);
+      if (o_pad && in_mt) o_pad[ju] = j < (n == 0 ? 1 : n);
       PROF(16);
       if (o_legal) {
         // legal_mask without a per-agent loop: one ballot per agent TYPE gives the rows that type may take
@@ -2523,8 +2558,8 @@ struct Sim {
     if (o_agents && lane < nA) {
       const int a = lane;
       float* r = o_agents + a * 9;
-      r[0] = (float)(S.a_px[a] / MAX_COORD);
-      r[1] = (float)(S.a_py[a] / MAX_COORD);
+      r[0] = (float)div_small(S.a_px[a], MAX_COORD, INV_COORD);
+      r[1] = (float)div_small(S.a_py[a], MAX_COORD, INV_COORD);
 #pragma unroll
       for (int c = 0; c < 6; c++) r[2 + c] = (float)S.a_caps[c][a];
       r[8] = (float)head_id(a);
@@ -2536,8 +2571,8 @@ struct Sim {
         else if (S.ev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) r = 1;
       }
       o_flags[0] = f; o_flags[1] = t; o_flags[2] = r;
-      o_flags[3] = (float)((double)tnow / mts);
-      o_flags[4] = (float)((double)n / (double)(P.max_tasks > 1 ? P.max_tasks : 1));
+      o_flags[3] = (float)div_small((double)tnow, mts, inv_mts);
+      o_flags[4] = (float)div_small((double)n, (double)(P.max_tasks > 1 ? P.max_tasks : 1), P.inv_max_tasks);
     }
   }
 

@@ -16,7 +16,11 @@ from .params import MuavtaDims, MuavtaParams
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 SO_PATH = os.environ.get("MUAVTA_SO") or os.path.join(PKG_DIR, "libmuavta.so")  # MUAVTA_SO: diagnostic builds only
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ldl",  # (-Os / -O2 / -O3 within 1.5 % of each other on the 128-VGPR kernel, -Oz -12 %: profiles/ r02 notes)
+# -O3 / -O2 / -Os are within 2 % of each other on the 128-VGPR kernel (-Oz: -12 %).  MachineLICM is switched off: in the one
+# big loop of k_rollout it hoists scalar loads of launch constants and address arithmetic out of the step body, the values then
+# live across the whole step at 104 SGPRs / 128 VGPRs and come back as v_readlane / scratch reloads — VALU issue, which is
+# what bounds the kernel (headline 171 -> 188 M env-steps/s; profiles/r02_codegen_flags.txt).
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ldl", "-mllvm", "-disable-machine-licm",
                 "-ffp-contract=off", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-invalid-offsetof"]
 
 EXPORTS = [
