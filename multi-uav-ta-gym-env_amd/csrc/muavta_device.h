@@ -1390,7 +1390,7 @@ struct Sim {
     double total;
     if (n >= 1) { const int ps = S.a_qslot[a][n - 1]; total = norm2(tx - S.t_px[ps], ty - S.t_py[ps]); }
     else total = norm2(tx - px, ty - py);
-    act_f(3)[k] = -1.0 * total / MAX_COORD;
+    act_f(3)[k] = -div_coord(total);
     bool dup = false;
     for (int q = 0; q < k; q++) dup |= S.act_agent[q] == a;
     if (!dup) X.remaining[k] = a;
@@ -1441,7 +1441,7 @@ struct Sim {
             S.a_commit[a] = 0;
             const double dist_old = norm2(px - S.t_px[hs], py - S.t_py[hs]);
             const double dist_new = norm2(px - tx, py - ty_);
-            d0 = (dist_old - dist_new) / MAX_COORD; nd0 = 1;
+            d0 = div_coord(dist_old - dist_new); nd0 = 1;
           } else {
             q0 = 0.05; nq01 = 1;
             idle_br = true;  // the idle penalty (:866-868) looks at pending_reset, which an earlier action's escort creation sets
@@ -1462,7 +1462,7 @@ struct Sim {
               double total;
               if (qlen >= 1) { const int ps = S.a_qslot[a][qlen - 1]; total = norm2(tx - S.t_px[ps], ty_ - S.t_py[ps]); }
               else total = norm2(tx - px, ty_ - py);
-              d1 = -1.0 * total / MAX_COORD; nd1 = 1;
+              d1 = -div_coord(total); nd1 = 1;
               S.a_qid[a][qlen] = tid; S.a_qslot[a][qlen] = s; C.a_qtime[a][qlen] = time_to_task; S.a_qlen[a] = qlen + 1;
               qs().a_nft[a] = end_time; qs().a_nfx[a] = tx; qs().a_nfy[a] = ty_;
               if (S.a_state[a] != 1 && S.a_state[a] != -1) S.a_state[a] = 1;
@@ -1574,7 +1574,7 @@ struct Sim {
               dist_old = norm2(S.a_px[a] - S.t_px[hs], S.a_py[a] - S.t_py[hs]);
               dist_new = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
             }
-            distance_reward += (dist_old - dist_new) / MAX_COORD;
+            distance_reward += div_coord(dist_old - dist_new);
           } else {
             S_quality_reward += 0.05;
             if (S.pending_reset && P.dynamic_idle_penalty != 0) S_quality_reward -= P.dynamic_idle_penalty;
@@ -1616,7 +1616,7 @@ struct Sim {
           } else {
             total = norm2(qs().a_nfx[a] - S.a_px[a], qs().a_nfy[a] - S.a_py[a]);
           }
-          distance_reward += -1.0 * total / MAX_COORD;
+          distance_reward += -div_coord(total);
         }
         if (S.a_state[a] != 1 && S.a_state[a] != -1) S.a_state[a] = 1;
         if (P.escort_enabled && ty == MUAVTA_REC && is_recon(S.a_type[a]) && !has_escort(a)) create_escort_for(a, s);
@@ -2376,7 +2376,8 @@ struct Sim {
   // of the quotient) divided by c's odd part m, so they are >= 2^g / m apart, and x / c cannot BE a midpoint because x's
   // last bit sits >= 6 binary places above g.  Three full-rate FMAs instead of the ~12-instruction IEEE division
   // sequence with its quarter-rate v_rcp_f64 (the observation writer divides ~10 times per step and the kernel is
-  // VALU-issue bound).  x must be finite (div_small_any keeps inf / NaN as the true division would).
+  // VALU-issue bound).  x must be finite (div_small_any keeps inf / NaN as the true division would) and not -0.0 (the
+  // result would be +0.0: callers with a negated operand negate the quotient instead, which IEEE division commutes with).
   // *(p + byte_off) for a wave-uniform p, pinned to scalar registers so that the access is emitted in the (SGPR base,
   // 32-bit VGPR offset) addressing form and not with a 64-bit VALU add per access.
   template <class V> static DEV V& at_lane(V* p, uint32_t byte_off) {
@@ -2392,6 +2393,7 @@ struct Sim {
     const double q = x * inv;
     return __builtin_fma(__builtin_fma(-q, c, x), inv, q);
   }
+  static DEV double div_coord(double x) { return div_small(x, MAX_COORD, 1.0 / MAX_COORD); }  // x / MAX_COORD, x finite
   static DEV double div_small_any(double x, double c, double inv) {
     const double q = x * inv;
     const double q1 = __builtin_fma(__builtin_fma(-q, c, x), inv, q);
@@ -2687,7 +2689,7 @@ struct Sim {
             const double d = norm2(S.h_px[h] - ax, S.h_py[h] - ay);
             if (d < best) best = d;
           }
-          (TL::OTFC ? X.press : X.spc)[j] = 1.0 - fmin(best / MAX_COORD, 1.0);  // threat pressure of round task j (a cost-tile LDS solve may clobber spc afterwards; the register solver leaves it)
+          (TL::OTFC ? X.press : X.spc)[j] = 1.0 - fmin(div_coord(best), 1.0);  // threat pressure of round task j (a cost-tile LDS solve may clobber spc afterwards; the register solver leaves it)
         }
         lds_sync();
       }
@@ -2707,14 +2709,14 @@ struct Sim {
           if (delivered > 0) {  // _cost (:43-70), left-to-right, priority = 0
             double dist = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
             double missing = fmax(X.resid[s], 1e-6);
-            double base = dist / fmax(MAX_COORD, 1.0) - 0.5 * fmin(delivered, missing) - 0.4 * 0.0 - 0.6 * urgency;
+            double base = div_coord(dist) - 0.5 * fmin(delivered, missing) - 0.4 * 0.0 - 0.6 * urgency;
             double score = 0.0;
             if (mode == 1) {  // urgency_edge_scores (PairCostHybrid.py:68-86) on the edges build_pair_tokens keeps (:42-60)
               const int info = pair_info()[s];
               if ((info & 255) < 32 && X.live_rank[a] < 16 && S.a_caps[S.t_type[s]][a] > 0) {
                 double scar = 0.0;
                 if (vis) scar = 1.0 - fmin((double)(info >> 8) / (double)n_live, 1.0);
-                double v = 0.5 * urgency + 0.3 * scar - 0.4 * (dist / fmax(MAX_COORD, 1.0));
+                double v = 0.5 * urgency + 0.3 * scar - 0.4 * div_coord(dist);
                 v = fmin(fmax(v, -0.35), 0.35);
                 score = (double)(float)v;  // the scores array is float32
               }
@@ -2723,7 +2725,7 @@ struct Sim {
               const int ty = S.t_type[s];
               const bool esc = (S.t_flags[s] & TF_ESCORT) != 0;
               const double cap = S.a_caps[ty][a] > 0 ? S.a_caps[ty][a] : 0.0;
-              double v = 0.45 * urgency + 0.35 * (TL::OTFC ? X.press : X.spc)[jr] * (0.5 + 0.5 * (esc ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
+              double v = 0.45 * urgency + 0.35 * (TL::OTFC ? X.press : X.spc)[jr] * (0.5 + 0.5 * (esc ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * div_coord(dist);
               const bool fighter = is_fighter(S.a_type[a]);
               if (fighter && (esc || ty == MUAVTA_INT)) v += 0.2;
               if (!fighter && ty == MUAVTA_REC) v += 0.2;
@@ -2776,20 +2778,20 @@ struct Sim {
           const double delivered = t.esc_task ? 1.0 : capv;
           if (delivered > 0) {
             const double dist = norm2(g.px - t.px, g.py - t.py);
-            const double base = dist / fmax(MAX_COORD, 1.0) - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
+            const double base = div_coord(dist) - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
             double score = 0.0;
             if (mode == 1) {
               if ((t.info & 255) < 32 && g.rank < 16 && capv > 0) {
                 double scar = 0.0;
                 if (vis) scar = 1.0 - fmin((double)(t.info >> 8) / (double)n_live, 1.0);
-                double v = 0.5 * t.urgency + 0.3 * scar - 0.4 * (dist / fmax(MAX_COORD, 1.0));
+                double v = 0.5 * t.urgency + 0.3 * scar - 0.4 * div_coord(dist);
                 v = fmin(fmax(v, -0.35), 0.35);
                 score = (double)(float)v;
               }
             }
             if (mode == 2) {
               const double cap = capv > 0 ? capv : 0.0;
-              double v = 0.45 * t.urgency + 0.35 * t.press * (0.5 + 0.5 * (t.esc_flag ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * (dist / MAX_COORD);
+              double v = 0.45 * t.urgency + 0.35 * t.press * (0.5 + 0.5 * (t.esc_flag ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * div_coord(dist);
               const bool fighter = is_fighter(g.type);
               if (fighter && (t.esc_flag || t.type == MUAVTA_INT)) v += 0.2;
               if (!fighter && t.type == MUAVTA_REC) v += 0.2;
@@ -2947,8 +2949,8 @@ struct Sim {
       if (d < best) best = d;
       n_near += d < 150.0;
     }
-    pressure = 1.0 - fmin(best / MAX_COORD, 1.0);
-    dist_n = fmin(best / MAX_COORD, 1.0);
+    pressure = 1.0 - fmin(div_coord(best), 1.0);
+    dist_n = fmin(div_coord(best), 1.0);
     fighter_pressure = fmin((double)n_near / 4.0, 1.0);
   }
   DEV void tokens(const TokPtrs& K, int env) {
