@@ -144,7 +144,9 @@ def roofline(case, envs, n_agents_tile, kernel_ms):
         "kernel": "k_rollout", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": B,
         "achieved_is": "algorithmic bytes (SURVEY 8d) / kernel time, not HBM traffic",
         "measured_hbm_GBs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-        "limiter": "latency / issue: env state is LDS-resident for the whole rollout, order-dependent phases run on one lane",
+        "limiter": ("VALU issue: env state is LDS-resident for the whole rollout, ~1900 VALU instructions per env-step of which the "
+                    "order-dependent phases run on one lane; 4 waves per SIMD keep its VALU port ~75 % busy "
+                    "(4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, profiles/)"),
     }
 
 

@@ -294,6 +294,9 @@ __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp
 #endif
 #ifndef MUAVTA_PHASE_ATTR
 #define MUAVTA_PHASE_ATTR __forceinline__
+#define MUAVTA_PHASE_INLINED 1  // the body sees the kernel's own `smem`: LDS addresses fold to constants + lane offsets
+#else
+#define MUAVTA_PHASE_INLINED 0
 #endif
 enum { PH_ALLOC = 1, PH_STEP = 2, PH_OBS = 4 };
 // muavta_rollout_record: per-step training data of the fused rollout in caller-owned rings [n_slots][N][...] — the token
@@ -310,7 +313,11 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds
                                                 const RecordPtrs<TL>& rec, int slot, int oslot) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
+#if MUAVTA_PHASE_INLINED
+  Lds<TL> L(smem);
+#else
   Lds<TL> L((unsigned char*)(AS3 unsigned char*)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base));
+#endif
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
   if (phases & PH_STEP) sim.step(true);
   if (phases & PH_OBS) {
@@ -371,7 +378,9 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* 
     lds_sync();
   }
   uint32_t lds_base = (uint32_t)(uintptr_t)(AS3 unsigned char*)smem;
+#if !MUAVTA_PHASE_INLINED
   asm volatile("" : "+v"(lds_base));  // opaque: keeps constant propagation from re-introducing the symbol into the callee
+#endif
   // schedule: [allocate] , n_steps x [step, observation, next allocate] , [observation if it was not written per step] —
   // driven through ONE call site so that an inlined build carries one copy of the body
   for (int k = n_steps > 0 ? 0 : n_steps + 1; k <= n_steps + 1; k++) {
