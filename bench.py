@@ -151,15 +151,26 @@ def roofline(case, envs, n_agents_tile, kernel_ms):
 
 
 def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
+    kernel_ms, seed_ms = [], []
     for _ in range(warmup):
         env.rollout(seeds, HORIZON, interval, True, write_obs)
         env.sync()
-    kernel_ms, seed_ms = [], []
+        seed_ms.append(env.last_seed_ms())  # k_seed on an idle GPU (in the timed loop it runs under the previous launch's tail)
     barrier()
     t0 = time.perf_counter()
+    # launches are queued back to back (the library seeds launch i+1 on its own stream while launch i runs); the per-launch
+    # k_rollout durations come from the handle's ring of HIP event pairs, read every 64 launches and at the end
+    pending = 0
     for _ in range(steps):
         env.rollout(seeds, HORIZON, interval, True, write_obs)
-        kernel_ms.append(env.last_kernel_ms())  # HIP events on the library's stream; waits for the launch
+        pending += 1
+        if pending == 64:
+            kernel_ms.extend(env.kernel_ms_history(pending).tolist())
+            pending = 0
+    if pending:
+        kernel_ms.extend(env.kernel_ms_history(pending).tolist())
+    env.sync()
+    if not seed_ms:
         seed_ms.append(env.last_seed_ms())
     barrier()
     return time.perf_counter() - t0, float(np.mean(kernel_ms)), float(np.mean(seed_ms))

@@ -371,9 +371,14 @@ int muavta_rollout_record(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps
 /* Duration of the last muavta_rollout launch, measured with HIP events recorded on the handle's own
  * stream around the kernel (ms).  Blocks until that launch has finished. */
 int muavta_last_kernel_ms(MuavtaEnv* env, float* ms);
+/* The same for the last n rollout launches (1 <= n <= 64, oldest first): the handle keeps a ring of event pairs, so a
+ * caller can queue launches back to back — the seeding of launch i+1 then overlaps launch i — and read the per-launch
+ * durations afterwards.  Blocks until the newest of them has finished. */
+int muavta_kernel_ms_history(MuavtaEnv* env, float* ms, int32_t n);
 /* Same for the RNG seeding kernel (CPython init_by_array of the four random.Random streams per env,
  * DroneEnv.py:531-538) that ran in front of that rollout; 0 when the rollout continued without seeds. */
-int muavta_last_seed_ms(MuavtaEnv* env, float* ms);
+int muavta_last_seed_ms(MuavtaEnv* env, float* ms);  /* (seed upload + k_seed run on a second stream of the handle: when launches
+ * are queued back to back the figure includes the time the kernel waited for CUs the previous launch still held) */
 /* Block until everything queued on the handle's stream has finished. */
 int muavta_sync(MuavtaEnv* env);
 /* Metrics written by the last muavta_rollout itself (f64 [N, 30]); no extra launch. */

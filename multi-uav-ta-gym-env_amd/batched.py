@@ -245,6 +245,12 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_last_kernel_ms(self.h, C.byref(ms)))
         return float(ms.value)
 
+    def kernel_ms_history(self, n: int) -> np.ndarray:
+        """Durations (ms) of the last n rollout launches, oldest first (n <= 64); waits for the newest."""
+        out = np.empty(int(n), dtype=np.float32)
+        self._ck(self.L.muavta_kernel_ms_history(self.h, _vp(out), int(n)))
+        return out
+
     def last_seed_ms(self) -> float:
         ms = C.c_float()
         self._ck(self.L.muavta_last_seed_ms(self.h, C.byref(ms)))

@@ -632,7 +632,15 @@ struct MuavtaEnv {
   int alloc_mode = 0;  // MUAVTA_ALLOC_*
   void* d_tok = nullptr;  // muavta_tokens staging (host-buffer variant)
   double* d_rel = nullptr;  // release log [N, 1 + MUAVTA_REL_ROW*T] (muavta_set_release_log)
-  uint32_t* d_seedbuf = nullptr;  // [N][4][624] init_by_array states (k_seed)
+  // Seeding pipeline: seeds upload + k_seed run on their own stream into one of two slots, so that the seeding of launch
+  // i+1 overlaps the tail of launch i (k_seed needs a whole CU's LDS: it moves into CUs as the rollout's envs finish).
+  uint32_t* d_seedbuf[2] = {nullptr, nullptr};  // [N][4][624] init_by_array states (k_seed)
+  uint64_t* h_seeds[2] = {nullptr, nullptr};    // pinned staging of the caller's seeds
+  hipStream_t seed_stream = nullptr;
+  hipEvent_t ev_seed0[2] = {nullptr, nullptr}, ev_seeded[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
+  bool seed_used[2] = {false, false};
+  unsigned seed_seq = 0;
+  int last_seed_slot = 0;
   size_t tok_bytes = 0;
   int n_envs = 0, device = 0;
   int A = 0, T = 0, H = 0, E = 0, R = 0, Q = 0;
@@ -643,7 +651,7 @@ struct MuavtaEnv {
   DevCtx* d_ctx = nullptr;  // device copy of {P, O, tapes}
   uint32_t* d_pace = nullptr;
   uint32_t pace_epoch = 0;
-  uint64_t* d_seeds = nullptr;
+  uint64_t* d_seeds[2] = {nullptr, nullptr};
   int32_t *d_act_agent = nullptr, *d_act_index = nullptr, *d_call_out = nullptr;
   ncclComm_t comm = nullptr;  // muavta_comm_init
   int comm_rank = 0, comm_ranks = 0;
@@ -651,7 +659,9 @@ struct MuavtaEnv {
   double* d_metrics = nullptr;
   ObsPtrs O{};
   hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr;  // evs .. ev0: the seeding kernel, ev0 .. ev1: k_rollout
+  enum { EV_RING = 64 };
+  hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};  // ev0[i] .. ev1[i]: the k_rollout launch number i (mod EV_RING)
+  unsigned long long n_rollouts = 0;
   float last_ms = 0.f;
   bool last_seeded = false;
   bool did_reset = false;
@@ -1042,16 +1052,21 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
 #define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); muavta_destroy(e); return MUAVTA_E_HIP; } } while (0)
   DeviceScope scope_(device);
   CK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-  CK(hipEventCreate(&e->ev0));
-  CK(hipEventCreate(&e->ev1));
-  CK(hipEventCreate(&e->evs));
+  for (int i = 0; i < MuavtaEnv::EV_RING; i++) { CK(hipEventCreate(&e->ev0[i])); CK(hipEventCreate(&e->ev1[i])); }
+  CK(hipStreamCreateWithFlags(&e->seed_stream, hipStreamNonBlocking));
+  for (int b = 0; b < 2; b++) {
+    CK(hipEventCreate(&e->ev_seed0[b])); CK(hipEventCreate(&e->ev_seeded[b])); CK(hipEventCreateWithFlags(&e->ev_consumed[b], hipEventDisableTiming));
+  }
   const size_t N = (size_t)n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
   CK(hipMalloc(&e->blobs, N * e->state_bytes));
   CK(hipMemsetAsync(e->blobs, 0, N * e->state_bytes, e->stream));
   CK(hipMalloc(&e->cold, N * e->cold_bytes));
   CK(hipMemsetAsync(e->cold, 0, N * e->cold_bytes, e->stream));
   CK(hipMalloc(&e->tapes, N * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * sizeof(uint32_t)));
-  CK(hipMalloc(&e->d_seeds, N * sizeof(uint64_t)));
+  for (int b = 0; b < 2; b++) {
+    CK(hipMalloc(&e->d_seeds[b], N * sizeof(uint64_t)));
+    CK(hipHostMalloc((void**)&e->h_seeds[b], N * sizeof(uint64_t), hipHostMallocDefault));
+  }
   CK(hipMalloc(&e->d_act_agent, N * e->A * sizeof(int32_t)));
   CK(hipMalloc(&e->d_act_index, N * e->A * sizeof(int32_t)));
   CK(hipMalloc(&e->d_metrics, N * MUAVTA_N_METRICS * sizeof(double)));
@@ -1084,12 +1099,17 @@ int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   muavta_comm_destroy(e);
   DeviceScope scope_(e->device);
+  if (e->seed_stream) hipStreamSynchronize(e->seed_stream);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); hipFree(e->d_seeds); hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel); if (e->d_seedbuf) hipFree(e->d_seedbuf);
+  hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
-  if (e->ev0) hipEventDestroy(e->ev0);
-  if (e->ev1) hipEventDestroy(e->ev1);
-  if (e->evs) hipEventDestroy(e->evs);
+  for (int i = 0; i < MuavtaEnv::EV_RING; i++) { if (e->ev0[i]) hipEventDestroy(e->ev0[i]); if (e->ev1[i]) hipEventDestroy(e->ev1[i]); }
+  for (int b = 0; b < 2; b++) {
+    if (e->ev_seed0[b]) hipEventDestroy(e->ev_seed0[b]);
+    if (e->ev_seeded[b]) hipEventDestroy(e->ev_seeded[b]);
+    if (e->ev_consumed[b]) hipEventDestroy(e->ev_consumed[b]);
+  }
+  if (e->seed_stream) hipStreamDestroy(e->seed_stream);
   if (e->stream) hipStreamDestroy(e->stream);
   delete e;
   return MUAVTA_OK;
@@ -1104,31 +1124,47 @@ int muavta_dims(const MuavtaEnv* e, MuavtaDims* d) {
   return MUAVTA_OK;
 }
 
-// seeds are in e->d_seeds: run the seeding kernel on the handle's stream
-static int seed_streams(MuavtaEnv* e, const uint32_t** out) {
-  *out = nullptr;
+// Upload `seeds` and run the seeding kernel on the seed stream into the next slot; the handle's stream waits for it.
+// The caller launches the consumer on e->stream and then calls seeding_consumed(e, slot).
+static int enqueue_seeding(MuavtaEnv* e, const uint64_t* seeds, const uint64_t** ds, const uint32_t** sb, int* slot) {
   const size_t N = (size_t)e->n_envs;
-  if (!e->d_seedbuf) {
-    HIPCHK(e, hipMalloc((void**)&e->d_seedbuf, N * 4 * 624 * sizeof(uint32_t)));
+  const int b = (int)(e->seed_seq++ & 1u);
+  if (e->seed_used[b]) {
+    HIPCHK(e, hipEventSynchronize(e->ev_seeded[b]));                        // the staging copy of two calls ago has left h_seeds[b]
+    HIPCHK(e, hipStreamWaitEvent(e->seed_stream, e->ev_consumed[b], 0));    // ... and its consumer has read d_seeds / d_seedbuf[b]
   }
+  memcpy(e->h_seeds[b], seeds, N * sizeof(uint64_t));
+  HIPCHK(e, hipMemcpyAsync(e->d_seeds[b], e->h_seeds[b], N * sizeof(uint64_t), hipMemcpyHostToDevice, e->seed_stream));
+  if (!e->d_seedbuf[b]) HIPCHK(e, hipMalloc((void**)&e->d_seedbuf[b], N * 4 * 624 * sizeof(uint32_t)));
   const size_t seed_lds = (size_t)624 * SEED_LD * 4 + 16 * 3 * 8;
   // (per device, and cheap: set it on every call rather than track which devices have seen it)
   HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seed_lds));
-  hipLaunchKernelGGL(k_seed, dim3((unsigned)((N + 15) / 16)), dim3(WG), seed_lds, e->stream, (const uint64_t*)e->d_seeds, (int)N,
-                     (int)(e->P.num_obstacles > 0), e->d_seedbuf);
+  HIPCHK(e, hipEventRecord(e->ev_seed0[b], e->seed_stream));
+  hipLaunchKernelGGL(k_seed, dim3((unsigned)((N + 15) / 16)), dim3(WG), seed_lds, e->seed_stream, (const uint64_t*)e->d_seeds[b], (int)N,
+                     (int)(e->P.num_obstacles > 0), e->d_seedbuf[b]);
   HIPCHK(e, hipGetLastError());
-  *out = e->d_seedbuf;
+  HIPCHK(e, hipEventRecord(e->ev_seeded[b], e->seed_stream));
+  HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_seeded[b], 0));
+  e->seed_used[b] = true;
+  e->last_seed_slot = b;
+  *ds = e->d_seeds[b]; *sb = e->d_seedbuf[b]; *slot = b;
+  return MUAVTA_OK;
+}
+static int seeding_consumed(MuavtaEnv* e, int slot) {
+  HIPCHK(e, hipEventRecord(e->ev_consumed[slot], e->stream));
   return MUAVTA_OK;
 }
 
 int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
   if (!e || !seeds) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
-  HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
+  const uint64_t* ds = nullptr;
   const uint32_t* sb = nullptr;
-  { int rc = seed_streams(e, &sb); if (rc) return rc; }
-  DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (const uint64_t*)e->d_seeds, sb));
+  int slot = 0;
+  { int rc = enqueue_seeding(e, seeds, &ds, &sb, &slot); if (rc) return rc; }
+  DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, ds, sb));
   HIPCHK(e, hipGetLastError());
+  { int rc = seeding_consumed(e, slot); if (rc) return rc; }
   e->did_reset = true;
   e->host_valid = false;
   return MUAVTA_OK;
@@ -1220,19 +1256,18 @@ static int rollout_impl(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, in
   if (!seeds && !e->did_reset) { e->err = "rollout without seeds before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
   const uint64_t* ds = nullptr;
-  if (seeds) {
-    HIPCHK(e, hipMemcpyAsync(e->d_seeds, seeds, (size_t)e->n_envs * sizeof(uint64_t), hipMemcpyHostToDevice, e->stream));
-    ds = e->d_seeds;
-  }
   const uint32_t* sb = nullptr;
-  HIPCHK(e, hipEventRecord(e->evs, e->stream));
-  if (ds) { int rc = seed_streams(e, &sb); if (rc) return rc; }
+  int slot = -1;
+  if (seeds) { int rc = enqueue_seeding(e, seeds, &ds, &sb, &slot); if (rc) return rc; }
   e->last_seeded = ds != nullptr;
-  HIPCHK(e, hipEventRecord(e->ev0, e->stream));
+  const int evi = (int)(e->n_rollouts % MuavtaEnv::EV_RING);
+  HIPCHK(e, hipEventRecord(e->ev0[evi], e->stream));
   static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
   DISPATCH(e, launch_rollout<TL>(e, ds, n_steps, interval, use_vis, write_obs, sb, extra_lds, rec));
   HIPCHK(e, hipGetLastError());
-  HIPCHK(e, hipEventRecord(e->ev1, e->stream));
+  HIPCHK(e, hipEventRecord(e->ev1[evi], e->stream));
+  e->n_rollouts++;
+  if (slot >= 0) { int rc = seeding_consumed(e, slot); if (rc) return rc; }
   e->did_reset = true;
   e->host_valid = false;
   return MUAVTA_OK;
@@ -1285,9 +1320,24 @@ int muavta_sync(MuavtaEnv* e) {
 int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
   if (!e || !ms) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
-  HIPCHK(e, hipEventSynchronize(e->ev1));
-  HIPCHK(e, hipEventElapsedTime(ms, e->ev0, e->ev1));
+  if (!e->n_rollouts) { e->err = "no rollout launched yet"; return MUAVTA_E_STATE; }
+  const int evi = (int)((e->n_rollouts - 1) % MuavtaEnv::EV_RING);
+  HIPCHK(e, hipEventSynchronize(e->ev1[evi]));
+  HIPCHK(e, hipEventElapsedTime(ms, e->ev0[evi], e->ev1[evi]));
   e->last_ms = *ms;
+  return MUAVTA_OK;
+}
+
+int muavta_kernel_ms_history(MuavtaEnv* e, float* ms, int32_t n) {  // durations of the last n rollout launches, oldest first
+  if (!e || !ms || n < 1 || n > MuavtaEnv::EV_RING) { if (e) e->err = "muavta_kernel_ms_history: 1 <= n <= 64"; return MUAVTA_E_ARG; }
+  if ((unsigned long long)n > e->n_rollouts) { e->err = "fewer rollouts launched than asked for"; return MUAVTA_E_STATE; }
+  DeviceScope scope_(e->device);
+  for (int k = 0; k < n; k++) {
+    const int evi = (int)((e->n_rollouts - (unsigned long long)n + (unsigned long long)k) % MuavtaEnv::EV_RING);
+    HIPCHK(e, hipEventSynchronize(e->ev1[evi]));
+    HIPCHK(e, hipEventElapsedTime(&ms[k], e->ev0[evi], e->ev1[evi]));
+  }
+  e->last_ms = ms[n - 1];
   return MUAVTA_OK;
 }
 
@@ -1296,8 +1346,8 @@ int muavta_last_seed_ms(MuavtaEnv* e, float* ms) {  // the RNG seeding kernel th
   DeviceScope scope_(e->device);
   *ms = 0.f;
   if (!e->last_seeded) return MUAVTA_OK;
-  HIPCHK(e, hipEventSynchronize(e->ev0));
-  HIPCHK(e, hipEventElapsedTime(ms, e->evs, e->ev0));
+  HIPCHK(e, hipEventSynchronize(e->ev_seeded[e->last_seed_slot]));
+  HIPCHK(e, hipEventElapsedTime(ms, e->ev_seed0[e->last_seed_slot], e->ev_seeded[e->last_seed_slot]));
   return MUAVTA_OK;
 }
 

@@ -31,6 +31,7 @@ EXPORTS = [
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
     "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
+    "muavta_kernel_ms_history",
 ]
 
 
@@ -107,6 +108,7 @@ def lib() -> C.CDLL:
     L.muavta_avoid_obstacles.argtypes = [i32, vp, vp, i32, vp, i32, vp]
     L.muavta_device_ptrs.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.muavta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    L.muavta_kernel_ms_history.argtypes = [vp, vp, C.c_int32]
     L.muavta_last_seed_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.muavta_comm_uid.argtypes = [vp]
     L.muavta_comm_init.argtypes = [vp, i32, i32, vp]

@@ -851,6 +851,37 @@ def test_observation_rings_of_the_fused_rollout_vs_oracle(case, interval):
         env.rollout_record(seeds, steps, interval, True, obs_rings={k: v for k, v in rings.items() if k != "obs_done"})
 
 
+def test_queued_rollouts_overlap_seeding_and_keep_their_event_pairs():
+    """Rollouts queued back to back (the seeding of launch i+1 runs on the handle's second stream under launch i, through two
+    slots) give the same metrics as synchronised ones, for alternating seed sets; kernel_ms_history returns one duration per
+    launch, the newest equal to last_kernel_ms."""
+    case, n = "WPS_hard_x2", 64
+    env = _env(case, n)
+    sets = [np.arange(k * 100, k * 100 + n, dtype=np.uint64) for k in range(5)]
+    want = []
+    for sd in sets:
+        env.rollout(sd, 150, 20, True, True)
+        env.sync()
+        want.append(env.rollout_metrics())
+    env2 = _env(case, n)
+    got = []
+    for sd in sets:
+        env2.rollout(sd, 150, 20, True, True)   # no sync in between
+        got.append(None)
+    ms = env2.kernel_ms_history(len(sets))
+    assert ms.shape == (len(sets),) and np.all(ms > 0) and abs(float(ms[-1]) - env2.last_kernel_ms()) < 1e-6
+    assert np.array_equal(env2.rollout_metrics(), want[-1])
+    # interleaved: queue two launches, read the metrics of each through a fresh handle's synchronous run
+    env3 = _env(case, n)
+    for k, sd in enumerate(sets):
+        env3.rollout(sd, 150, 20, True, True)
+        env3.reset(sets[(k + 1) % len(sets)])  # a reset in between takes the other seeding slot
+        env3.rollout(sd, 150, 20, True, False)
+        assert np.array_equal(env3.rollout_metrics(), want[k]), f"seed set {k}"
+    with pytest.raises(Exception):
+        env3.kernel_ms_history(65)
+
+
 # ---- fuzzed configurations (knob combinations no registry case has); reference traces in tests/golden/trace_FUZZ* ----
 FUZZ_TRACES = sorted(glob.glob(os.path.join(GOLDEN, "trace_FUZZ*.npz")))
 
