@@ -2117,19 +2117,30 @@ struct Sim {
       const unsigned long long nextr = rm & todo;                         // pending retirements
       const unsigned long long seg = nextr ? (todo & ((nextr & (0ull - nextr)) - 1ull)) : todo;  // entries before the next one
       if (seg) {
-        // _escort_fighters_near(recon, escort_radius) non-empty? (:1746-1764) for every entry of the segment
+        // _escort_fighters_near(recon, escort_radius) non-empty? (:1746-1764) for every entry of the segment.  A fighter heads
+        // for ONE task, so it can only cover the entry whose escort task that is: each fighter lane finds its entry, runs one
+        // distance test (`norm <= radius` on the squared form against the host-side threshold, as in the sensing pass),
+        // and the entries collect their fighters' verdicts by ballot.
         const bool fighter = lane < P.n_agents && S.a_state[lane] != -1 && escort_type(S.a_type[lane]) && S.a_qlen[lane] > 0;
         const int head = fighter ? S.a_qid[lane][0] : -1;
-        const double fx = fighter ? S.a_px[lane] : 0.0, fy = fighter ? S.a_py[lane] : 0.0;
-        unsigned long long cov = 0ull;
-        for (unsigned long long m = seg; m; m &= m - 1ull) {
+        const unsigned long long live_m = __ballot(esc_live);
+        int myk = -1, my_recon = 0;
+        for (unsigned long long m = seg & live_m; m; m &= m - 1ull) {
           const int k = __ffsll((long long)m) - 1;
           const int ek = __builtin_amdgcn_readlane(eid, k), rk = __builtin_amdgcn_readlane(recon, k);
-          const bool lv = (__ballot(esc_live) >> k) & 1ull;
-          bool near = false;
-          if (lv && fighter && head == ek) near = norm2(fx - S.a_px[rk], fy - S.a_py[rk]) <= P.escort_radius;
-          if (__ballot(near) != 0ull) cov |= 1ull << k;
+          if (head == ek) { myk = k; my_recon = rk; }
         }
+        bool near = false;
+        if (fighter && myk >= 0) {
+          const double dx = S.a_px[lane] - S.a_px[my_recon], dy = S.a_py[lane] - S.a_py[my_recon];
+          near = fma(dy, dy, dx * dx) <= P.escort_sq_bound;
+        }
+        unsigned long long cov = 0ull;
+        if (__ballot(near) != 0ull)
+          for (unsigned long long m = seg & live_m; m; m &= m - 1ull) {
+            const int k = __ffsll((long long)m) - 1;
+            if (__ballot(near && myk == k) != 0ull) cov |= 1ull << k;
+          }
         if ((seg >> lane) & 1ull) {
           if (esc_live) { S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon]; }  // follow the protected UAV
         }

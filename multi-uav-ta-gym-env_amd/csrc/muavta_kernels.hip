@@ -746,15 +746,17 @@ int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
   for (int t = 0; t < 7; t++) d->speed[t] = MAX_SPEED[t] / p->simulation_frame_rate * 0.02;
   d->threat_prob = 0.7 / p->simulation_frame_rate * 0.02;
   d->reward_norm_factor = (possible * 1 + possible) / 1000;
-  {  // sqrt is correctly rounded and monotone, so `sqrt(v) <= r` is a threshold test on v; find the threshold
-    const double r = p->sense_radius;
+  // sqrt is correctly rounded and monotone, so `sqrt(v) <= r` is a threshold test on v; find the threshold
+  auto sq_bound = [](double r) {
     double v = r * r;
     if (r > 0) {
       while (std::sqrt(v) > r) v = std::nextafter(v, 0.0);
       while (std::sqrt(std::nextafter(v, INFINITY)) <= r) v = std::nextafter(v, INFINITY);
     }
-    d->sense_sq_bound = v;
-  }
+    return v;
+  };
+  d->sense_sq_bound = sq_bound(p->sense_radius);
+  d->escort_sq_bound = sq_bound(p->escort_radius);
   d->fail_rate = p->fail_rate; d->arrival_rate = p->arrival_rate; d->dynamic_idle_penalty = p->dynamic_idle_penalty;
   d->sense_radius = p->sense_radius; d->miss_penalty = p->miss_penalty; d->on_time_bonus = p->on_time_bonus;
   d->reassign_penalty = p->reassign_penalty; d->escort_radius = p->escort_radius; d->escort_requirement = p->escort_requirement;

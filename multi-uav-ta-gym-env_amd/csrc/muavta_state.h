@@ -50,6 +50,7 @@ struct DevParams {
   double fail_rate, arrival_rate, dynamic_idle_penalty, sense_radius, miss_penalty, on_time_bonus,
       reassign_penalty, escort_radius, escort_requirement, escort_intercept_radius, mutual_support_radius;
   double rw[8];
+  double escort_sq_bound;   // the same threshold for escort_radius (coverage test of _sync_escorts)
   double inv_mts, inv_max_tasks;  // RN(1 / max(max_time_steps, 1)), RN(1 / max(max_tasks, 1)): Sim::div_small
 };
 
