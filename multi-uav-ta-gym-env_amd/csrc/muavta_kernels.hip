@@ -371,6 +371,9 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* 
 #ifdef MUAVTA_PROF
   sim.prof_begin();
 #endif
+#ifdef MUAVTA_DIAG_TIMES
+  if (threadIdx.x == 0 && env < 65536) as_global(ctx.pace)[(1u << 19) + env] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
   if (seeds) {
     sim.reset(seeds[env], seedbuf + (size_t)env * 4 * 624);
   } else {
@@ -425,6 +428,12 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* 
   copy16(blob, L.S, sizeof(EnvState<TL>));
 #ifdef MUAVTA_PROF
   sim.prof_flush();
+#endif
+#ifdef MUAVTA_DIAG_TIMES  // tools/end_times_probe.py: when each env's wave ended and on which SIMD (rows of the pace table no SIMD key reaches)
+  if (threadIdx.x == 0 && env < 65536) {
+    as_global(ctx.pace)[(1u << 19) + 65536 + env] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    as_global(ctx.pace)[(1u << 19) + 131072 + env] = __builtin_amdgcn_s_getreg(4 | (31 << 11)) | (__builtin_amdgcn_s_getreg(20 | (3 << 11)) << 16);
+  }
 #endif
 }
 
@@ -1298,6 +1307,15 @@ int muavta_rollout_record(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, 
   return rollout_impl(e, seeds, n_steps, interval, use_vis, write_obs, rec);
 }
 
+#ifdef MUAVTA_DIAG_TIMES
+int muavta_diag_times(MuavtaEnv* e, uint32_t* out, int32_t n) {  // diagnostic build only: [3][n] start, end (10 ns units), hw ids
+  DeviceScope scope_(e->device);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  for (int k = 0; k < 3; k++)
+    HIPCHK(e, hipMemcpy(out + (size_t)k * n, e->d_pace + (1u << 19) + 65536u * k, (size_t)n * 4, hipMemcpyDeviceToHost));
+  return MUAVTA_OK;
+}
+#endif
 #ifdef MUAVTA_PROF
 int muavta_prof_read(unsigned long long* out, int reset) {  // diagnostic build only
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 48 * sizeof(unsigned long long)) != hipSuccess) return MUAVTA_E_HIP;
