@@ -34,7 +34,7 @@ def drive(case, n):
 
 def report(tag, case, n):
     groups = {}  # (group, counter) -> [values]
-    for sub in ("a", "b"):
+    for sub in ("a", "b", "c", "d"):
         fs = glob.glob(os.path.join(ROOT, "gpurun_out", "valu", f"{tag}_{sub}", "*", "*_counter_collection.csv"))
         if not fs:
             continue
@@ -57,6 +57,20 @@ def report(tag, case, n):
             groups.setdefault((g, r["Counter_Name"]), []).append(float(r["Counter_Value"]))
     names = sorted({g for g, _ in groups})
     ctrs = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_ACTIVE_INST_ANY", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"]
+    if any(c in ("FETCH_SIZE", "WRITE_SIZE") for _, c in groups):  # traffic passes (tools/valu_meter.sh <tag> <case> <n> traffic)
+        from muavta_amd.batched import BatchedMultiUAVEnv
+        from muavta_amd.params import params_for_case
+        p = params_for_case(case)
+        A, MT = p.n_agents, p.max_tasks
+        obs_bytes = 21 * MT * 4 + A * ((MT + 63) // 64) * 8 + MT + A * 9 * 4 + 5 * 4 + 8 + 1
+        print(f"{case}, {n} envs; KB per env-step as the counters report them (x 1024 B); known byte counts: one observation = {obs_bytes} B per env, "
+              "the LDS image (read and written once per k_step / k_allocate / k_observe launch, 16 B per lane) = see lds_bytes_per_env")
+        for g in names:
+            steps = n * (150 if "150" in g else 1)
+            f = np.mean(groups[(g, "FETCH_SIZE")]) * 1024 / steps if (g, "FETCH_SIZE") in groups else float("nan")
+            w = np.mean(groups[(g, "WRITE_SIZE")]) * 1024 / steps if (g, "WRITE_SIZE") in groups else float("nan")
+            print(f"{g:34s} FETCH_SIZE {f:10.1f} B   WRITE_SIZE {w:10.1f} B   per env-step")
+        return
     print(f"{case}, {n} envs; per env-step means (SQ_ACTIVE_* and SQ_WAVE_CYCLES count 4-cycle quads)")
     print(f"{'group':34s}" + "".join(f"{c.replace('SQ_', ''):>17s}" for c in ctrs))
     for g in names:
