@@ -52,9 +52,9 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def measured_traffic(case: str, envs: int):
-    """HBM bytes per k_rollout launch from the rocprofv3 --pmc passes (tools/collect_profiles.sh), or None when the
-    committed figure was taken on other kernel sources."""
+def pmc_entry(case: str, envs: int):
+    """The committed rocprofv3 --pmc summary of k_rollout for this (case, envs) (tools/collect_profiles.sh ->
+    tools/summarize_profiles.py -> profiles/pmc_traffic.json), or None when it was taken on other kernel sources."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         d = json.load(open(path))
@@ -62,8 +62,14 @@ def measured_traffic(case: str, envs: int):
         return None
     e = d.get(f"{case}:{envs}")
     if isinstance(e, dict) and e.get("source_hash") == source_hash():
-        return e.get("bytes_per_launch")
+        return e
     return None
+
+
+def measured_traffic(case: str, envs: int):
+    """HBM bytes per k_rollout launch from the PMC passes, or None (see pmc_entry)."""
+    e = pmc_entry(case, envs)
+    return e.get("bytes_per_launch") if e else None
 
 
 def host_cpu():
@@ -97,6 +103,22 @@ def host_cpu():
             pass
     cores = visible if quota is None else max(1, min(visible, int(quota + 0.5)))
     return model, max(1, cores), visible
+
+
+def oracle_check(case: str, interval: int, seeds, gpu_metrics, n_check: int = 256):
+    """The timed GPU batch against the CPU oracle on a subsample (part of the cpu_baseline leg: the only place bench.py may touch
+    oracle/): all 30 metrics of `n_check` envs spread over the batch must be bit-equal.  Returns the `quality` additions."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orc
+
+    idx = np.unique(np.linspace(0, len(seeds) - 1, min(n_check, len(seeds))).astype(np.int64))
+    want = orc.parallel_metrics(case, [int(seeds[i]) for i in idx], interval)
+    got = np.asarray(gpu_metrics)[idx]
+    bad = np.nonzero(~np.all(got == want, axis=1))[0]
+    if len(bad):
+        raise SystemExit(f"bench: GPU metrics differ from the CPU oracle for seeds {[int(seeds[idx[b]]) for b in bad[:8]]} of {case}")
+    return {"oracle_checked": True, "oracle_checked_envs": int(len(idx)),
+            "oracle_mean_S_WPS_of_checked": float(want[:, 4].mean()), "gpu_mean_S_WPS_of_checked": float(got[:, 4].mean())}
 
 
 def cpu_baseline(case: str, interval: int, seconds: float):
@@ -135,18 +157,33 @@ def _cpu_worker(case, interval, seconds, seed0):
 
 
 def roofline(case, envs, n_agents_tile, kernel_ms):
+    """SURVEY 8(d) roofline of k_rollout (kept exactly as defined there: algorithmic bytes / kernel time against HBM peak) plus
+    what the counters say actually bounds the kernel: `issue` (instruction issue per env-step and VALU-port occupancy) and
+    `hbm_measured_frac` (PMC traffic / kernel time / peak).  The PMC-derived fields are null unless profiles/pmc_traffic.json
+    holds a collection taken on exactly these kernel sources (source_hash)."""
     B = ALGO_BYTES_PER_ENV_STEP.get(n_agents_tile)
     achieved = (envs * HORIZON * B) / (kernel_ms * 1e-3) / 1e9 if B else None
-    traffic = measured_traffic(case, envs)
+    e = pmc_entry(case, envs)
+    traffic = e.get("bytes_per_launch") if e else None
+    measured = (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None
+    issue = None
+    if e and e.get("issue"):
+        issue = dict(e["issue"])
+        issue["source"] = "profiles/" + str(e.get("profile"))
+        issue["source_hash"] = e.get("source_hash")
     return {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
         "kernel": "k_rollout", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": B,
-        "achieved_is": "algorithmic bytes (SURVEY 8d) / kernel time, not HBM traffic",
-        "measured_hbm_GBs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-        "limiter": ("VALU issue: env state is LDS-resident for the whole rollout, ~1900 VALU instructions per env-step of which the "
-                    "order-dependent phases run on one lane; 4 waves per SIMD keep its VALU port ~75 % busy "
-                    "(4 x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, profiles/)"),
+        "achieved_is": ("algorithmic bytes (SURVEY 8d: 2*S_state + S_obs + S_act per env-step) / kernel time, not HBM traffic. Values "
+                        "above 1.0 are possible: the fused kernel keeps the env state in LDS for the whole rollout and never moves the "
+                        "2*S_state per step the formula charges; that the timed work is the whole workload is shown by `quality` "
+                        "equalling the CPU oracle (quality.oracle_checked)"),
+        "measured_hbm_GBs": measured, "hbm_measured_frac": (measured / HBM_PEAK_GBS) if measured else None,
+        "issue": issue,
+        "limiter": ("instruction issue, not memory: the env state is LDS-resident, the order-dependent phases of a step execute with one "
+                    "lane enabled, and the waves sharing a SIMD keep its VALU port busy most of the launch (`issue.valu_port_busy` = "
+                    "waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from the matching PMC pass)"),
     }
 
 
@@ -267,11 +304,16 @@ def main():
                                       + (" (muavta_allreduce_metrics)" if args.abi_collective else " (torch.distributed nccl backend)" if dist is not None else "")},
             "roofline": roofline(args.case, args.envs, env.dims.tile_agents, mean_kernel_ms),
             "seed_kernel_ms": mean_seed_ms,
+            # launches are queued back to back, so launch i+1's seeding (upload + k_seed on a second stream) runs under launch i's
+            # tail; an isolated batch pays k_seed in front of the rollout kernel:
+            "value_unpipelined": total_envs * HORIZON / ((mean_kernel_ms + mean_seed_ms) * 1e-3),
+            "value_unpipelined_is": "whole-job env-steps/s of ONE isolated batch: envs x 150 / (k_rollout ms + k_seed ms on an idle GPU)",
             "quality": {"mean_S_WPS": summary["mean_S_WPS"], "std_S_WPS": summary["std_S_WPS"], "on_time_rate": summary["on_time_rate"],
                         "n_envs": summary["n_envs"], "capacity_flagged_envs": 0},
         }
         out.update(extras)
         if world == 1 and not args.no_cpu_baseline:
+            out["quality"].update(oracle_check(args.case, args.interval, seeds, m))
             out["cpu_baseline"] = cpu_baseline(args.case, args.interval, args.cpu_seconds)
         print(json.dumps(out))
     if dist is not None:
@@ -357,7 +399,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
         from muavta_amd.il import il_record, il_stream
 
         n_il = min(args.envs, 1024)
-        e3 = BatchedMultiUAVEnv(params_for_case(args.case), n_il, device=0)
+        e3 = BatchedMultiUAVEnv(params_for_case(args.case), n_il, device=env.device_index)
         s3 = np.arange(n_il, dtype=np.uint64)
         rings = il_record(e3, s3, HORIZON, args.interval)  # warm-up (allocates the rings)
         t1 = time.perf_counter()
@@ -378,7 +420,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     if args.case == "WPS_hard_x2":
         tiles = {}
         for case, n, interval in OTHER_TILES:
-            e2 = BatchedMultiUAVEnv(params_for_case(case), n, device=0)
+            e2 = BatchedMultiUAVEnv(params_for_case(case), n, device=env.device_index)
             s2 = np.arange(n, dtype=np.uint64)
             el, kms, sms = time_rollouts(e2, s2, interval, True, 5, 2, barrier)
             flagged = int(np.count_nonzero(e2.get("ERROR")))

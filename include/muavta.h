@@ -241,14 +241,17 @@ int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
  *   MUAVTA_OP_UAV_ALLOCATE        UAV.allocate(task, time_step) (DroneEnvComponents.py:55-95): iargs = {agent, task id, time_step};
  *                                 out[0] = its return value (1 = queued now, 0 = already queued / task concluded)
  *   MUAVTA_OP_CREATE_ESCORT       MultiUAVEnv._create_escort_for(recon, rec_task) (DroneEnv.py:1888-1917): iargs = {recon agent, Rec
- *                                 task id}; out[0] = id of the (new or existing) escort task, -1 = None (escorts disabled)
+ *                                 task id, 0 = None: protected_task stays None}; out[0] = id of the (new or existing) escort task,
+ *                                 -1 = None (escorts disabled)
  *   MUAVTA_OP_SYNC_ESCORTS        MultiUAVEnv._sync_escorts() (:1964-2000)
  *   MUAVTA_OP_RETIRE_ESCORT       MultiUAVEnv._retire_escort(escort_task, failed) (:1938-1950): iargs = {escort task id, failed}
  *   MUAVTA_OP_ESCORT_FIGHTERS_NEAR  MultiUAVEnv._escort_fighters_near(agent, radius) (:1746-1764): iargs = {agent}, darg = radius
  *                                 (< 0: escort_radius); out[0] = n, out[1..n] = UAV.id nearest first
  *   MUAVTA_OP_ACTION_VALID        MultiUAVEnv._is_task_action_valid(agent, task) (:341-363): iargs = {agent, task id}; out[0] = 0/1
  *   MUAVTA_OP_SET_QUEUE           `agent.tasks = [t0, t1, ...]` (plain list assignment, e.g. test_escort.py:95: no Task bookkeeping):
- *                                 iargs = {agent, n <= 6, id0 .. id5}; [task_idle] (id 0) is the empty queue
+ *                                 iargs = {agent, n <= 6, id0 .. id5}; [task_idle] (id 0) is the empty queue.  iargs[7] = 1 with
+ *                                 n = 0 is UAV.allocate(task_idle) (DroneEnvComponents.py:59-60,85-92): besides `tasks = [idle]` it
+ *                                 resets next_free_time = 0, next_free_position = position, re_eval = False, last_task = None
  * Runs on the handle's stream and synchronises.  Returns MUAVTA_E_ARG for ids outside the env. */
 typedef enum MuavtaOp {
   MUAVTA_OP_UAV_ALLOCATE = 0, MUAVTA_OP_CREATE_ESCORT, MUAVTA_OP_SYNC_ESCORTS, MUAVTA_OP_RETIRE_ESCORT,
@@ -355,6 +358,10 @@ int muavta_device_ptrs(MuavtaEnv* env, void** state, void** obs_tasks, void** ob
  * [n_steps][N], obs_done u8 [n_steps][N] (bit 0 terminated, bit 1 truncated) instead of overwriting the handle's single
  * observation buffer each step; the handle's buffer receives the final observation once, at the end.  An env whose episode
  * ended at step t < n_steps - 1 leaves its later slots unwritten: obs_done is pre-filled with MUAVTA_OBS_UNWRITTEN for that.
+ * Token rings of such an env (early_terminate, or n_steps beyond max_time_steps): the reference's episode loops stop at `done`
+ * (train_pair_cost.py:108,139), so the slots after the last step carry no sample — they are written as all-pad rows (masks 1,
+ * ids -1, features / edge_valid / expert_mask 0, n_urgent 0, replanned 0) and s_wps carries the final value forward (the
+ * step reward of those slots is exactly 0); no slot of any ring is left uninitialised.
  * Asynchronous on the handle's stream (muavta_sync / an event before reading). */
 #define MUAVTA_OBS_UNWRITTEN 0x80
 typedef struct MuavtaRecord {
@@ -381,6 +388,13 @@ int muavta_last_seed_ms(MuavtaEnv* env, float* ms);  /* (seed upload + k_seed ru
  * are queued back to back the figure includes the time the kernel waited for CUs the previous launch still held) */
 /* Block until everything queued on the handle's stream has finished. */
 int muavta_sync(MuavtaEnv* env);
+/* Order the handle's (non-blocking) stream after another stream of the same device: everything queued on the handle from now on
+ * starts only after the work `other_stream` (a hipStream_t; NULL = the legacy default stream) holds at the time of the call.
+ * For callers that hand the library device buffers another stream may still be using — e.g. ring tensors a caching allocator
+ * recycled while earlier kernels that read them are queued on the framework's stream (torch.cuda.current_stream().cuda_stream)
+ * — before muavta_rollout_record / muavta_tokens_device overwrite them.  The other direction is muavta_sync or an event on the
+ * stream muavta_device_ptrs returns.  The reference has no counterpart: it is single-threaded host code. */
+int muavta_wait_stream(MuavtaEnv* env, void* other_stream);
 /* Metrics written by the last muavta_rollout itself (f64 [N, 30]); no extra launch. */
 int muavta_rollout_metrics(MuavtaEnv* env, double* out);
 /* Rebuild the observation tensors from the current state (after muavta_set / muavta_set_state). */

@@ -240,6 +240,15 @@ class BatchedMultiUAVEnv:
     def sync(self):
         self._ck(self.L.muavta_sync(self.h))
 
+    def wait_stream(self, stream_handle: Optional[int] = None):
+        """Order the handle's stream after `stream_handle` (a hipStream_t as an integer, e.g. `torch.cuda.current_stream().cuda_stream`;
+        None = torch's current stream on this device): call it before handing the library tensors that stream may still be using."""
+        if stream_handle is None:
+            import torch
+
+            stream_handle = torch.cuda.current_stream(self.device_index).cuda_stream
+        self._ck(self.L.muavta_wait_stream(self.h, C.c_void_p(int(stream_handle))))
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float()
         self._ck(self.L.muavta_last_kernel_ms(self.h, C.byref(ms)))

@@ -633,7 +633,7 @@ struct Sim {
     S.t_flags[s] |= TF_ESCORT | TF_ELIGIBLE;
     S.t_elig[s] = P.escort_mask;
     S.t_prot_agent[s] = recon;
-    S.t_prot_id[s] = S.t_id[rec_slot];
+    S.t_prot_id[s] = rec_slot >= 0 ? (int)S.t_id[rec_slot] : -1;  // rec_slot < 0: protected_task = None (out-of-step callers only)
     S.t_prot_slot[s] = rec_slot;
     S.t_required[s] = P.escort_required_agents;
     S.t_created[s] = tnow;
@@ -3167,6 +3167,24 @@ struct Sim {
         o_am[i] = 1; o_aid[i] = -1;
       }
     }
+  }
+  // Token-ring slot of an env whose episode has ended (muavta_rollout_record): an all-pad sample that is never a training
+  // row — masks 1, ids -1, features / edge_valid / expert_mask 0, n_urgent 0, replanned 0.  The reference's episode loops
+  // stop at `done` (train_pair_cost.py:108,139), so there is nothing to restate; the slots just must not stay uninitialised.
+  DEV void tokens_pad(const TokPtrs& K, int env) {
+    const int kind = K.kind, MT = K.max_tasks, MA = K.max_agents;
+    const int Dt = kind == 0 ? 13 : kind == 1 ? 9 : 22, Da = kind == 0 ? 12 : kind == 1 ? 11 : 16;
+    float* o_tf = K.task_feats + (size_t)env * MT * Dt;
+    float* o_af = K.agent_feats + (size_t)env * MA * Da;
+    float* o_ev = K.edge_valid + (size_t)env * MA * MT;
+    for (int i = lane; i < MT * Dt; i += WG) o_tf[i] = 0.f;
+    for (int i = lane; i < MA * Da; i += WG) o_af[i] = 0.f;
+    for (int i = lane; i < MA * MT; i += WG) o_ev[i] = 0.f;
+    if (K.expert_mask) { float* o_em = K.expert_mask + (size_t)env * MA * MT; for (int i = lane; i < MA * MT; i += WG) o_em[i] = 0.f; }
+    for (int i = lane; i < MT; i += WG) { K.task_mask[(size_t)env * MT + i] = 1; K.task_ids[(size_t)env * MT + i] = -1; }
+    for (int i = lane; i < MA; i += WG) { K.agent_mask[(size_t)env * MA + i] = 1; K.agent_ids[(size_t)env * MA + i] = -1; }
+    if (lane == 0 && K.n_urgent) K.n_urgent[env] = 0;
+    if (lane == 0 && K.replanned) K.replanned[env] = 0;
   }
   // out[0..n) = f(k) for the k in [0, count) with pred(k), order preserved (ballot + popcount); returns n
   template <class Out, class Pred, class Val>

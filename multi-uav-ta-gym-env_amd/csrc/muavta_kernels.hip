@@ -308,6 +308,14 @@ struct RecordPtrs {
   ObsPtrs O;       // O.tasks == nullptr: no observation rings
   int n_envs;
 };
+template <class TL>
+__device__ __forceinline__ typename Sim<TL>::TokPtrs global_tok_ptrs(typename Sim<TL>::TokPtrs K) {  // kernel-argument pointers as global (not FLAT) accesses
+  K.task_feats = as_global(K.task_feats); K.task_mask = as_global(K.task_mask); K.task_ids = as_global(K.task_ids);
+  K.agent_feats = as_global(K.agent_feats); K.agent_mask = as_global(K.agent_mask); K.agent_ids = as_global(K.agent_ids);
+  K.edge_valid = as_global(K.edge_valid); K.n_urgent = as_global(K.n_urgent); K.expert_mask = as_global(K.expert_mask);
+  K.replanned = as_global(K.replanned);
+  return K;
+}
 template <class TL, bool REC>
 __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds_base, int phases, int interval, int use_vis, int mode,
                                                 const RecordPtrs<TL>& rec, int slot, int oslot) {
@@ -336,11 +344,7 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds
   if ((phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) {
     sim.allocate(interval, use_vis, mode);
     if (REC && rec.K.task_feats) {  // the sample of step `slot`: tokens + labels of the plan just staged, S_WPS before the step
-      typename Sim<TL>::TokPtrs K = rec.K;
-      K.task_feats = as_global(K.task_feats); K.task_mask = as_global(K.task_mask); K.task_ids = as_global(K.task_ids);
-      K.agent_feats = as_global(K.agent_feats); K.agent_mask = as_global(K.agent_mask); K.agent_ids = as_global(K.agent_ids);
-      K.edge_valid = as_global(K.edge_valid); K.n_urgent = as_global(K.n_urgent); K.expert_mask = as_global(K.expert_mask);
-      K.replanned = as_global(K.replanned);
+      const typename Sim<TL>::TokPtrs K = global_tok_ptrs<TL>(rec.K);
       cold_sync();
       sim.tokens(K, slot * rec.n_envs + env);
       if (threadIdx.x == 0) as_global(rec.s_wps)[(size_t)slot * rec.n_envs + env] = sim.s_wps();
@@ -390,7 +394,23 @@ __global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* 
     int ph;
     if (k == 0) ph = PH_ALLOC;
     else if (k <= n_steps) {
-      if (L.S->terminated || L.S->truncated) { k = n_steps; continue; }  // uniform: read from LDS after a barrier
+      if (L.S->terminated || L.S->truncated) {  // uniform: read from LDS after a barrier
+        if constexpr (REC) {
+          // the episode ended during step k - 1: the allocate of that step was skipped, so token slots k-1 .. n_steps-1 have no
+          // sample.  They become all-pad rows with replanned = 0 and carry the final S_WPS forward (zero step reward), instead
+          // of staying uninitialised ring memory (the observation rings mark theirs with MUAVTA_OBS_UNWRITTEN).
+          if (rec.K.task_feats) {
+            const typename Sim<TL>::TokPtrs K = global_tok_ptrs<TL>(rec.K);
+            const double fin = sim.s_wps();
+            for (int sl = k - 1; sl < n_steps; sl++) {
+              sim.tokens_pad(K, sl * rec.n_envs + env);
+              if (threadIdx.x == 0) as_global(rec.s_wps)[(size_t)sl * rec.n_envs + env] = fin;
+            }
+          }
+        }
+        k = n_steps;
+        continue;
+      }
       ph = PH_STEP | (write_obs ? PH_OBS : 0) | (k < n_steps ? PH_ALLOC : 0);
     } else ph = (write_obs && !(REC && rec.O.tasks)) ? 0 : PH_OBS;  // with observation rings the handle's buffer gets the final one
 #if MUAVTA_PACE_PRIO
@@ -503,7 +523,7 @@ __global__ __launch_bounds__(WG) void k_call(const DevCtx* __restrict__ ctxp, Ca
     case MUAVTA_OP_CREATE_ESCORT: {
       const int s = slot_of(a.i[1]);
       if (lane == 0) {
-        if (ctx.P.escort_enabled && s >= 0) sim.create_escort_for(ag, s);
+        if (ctx.P.escort_enabled && (s >= 0 || a.i[1] == 0)) sim.create_escort_for(ag, s);  // rec_task None (id 0): protected_task = None
         const int k = sim.escort_lookup(ag);
         out[0] = (ctx.P.escort_enabled && k >= 0) ? (int)S.esc_id[k] : -1;
       }
@@ -539,6 +559,10 @@ __global__ __launch_bounds__(WG) void k_call(const DevCtx* __restrict__ ctxp, Ca
           n++;
         }
         S.a_qlen[ag] = (i8)n;
+        if (a.i[7] == 1 && n == 0) {  // UAV.allocate(task_idle) (DroneEnvComponents.py:59-60,85-92): more than the list assignment
+          S.a_reeval[ag] = 0; S.a_last_id[ag] = -1; S.a_last_slot[ag] = -1;
+          sim.qs().a_nft[ag] = 0.0; sim.qs().a_nfx[ag] = S.a_px[ag]; sim.qs().a_nfy[ag] = S.a_py[ag];
+        }
       }
     } break;
     default: break;
@@ -1139,7 +1163,7 @@ int muavta_dims(const MuavtaEnv* e, MuavtaDims* d) {
 // The caller launches the consumer on e->stream and then calls seeding_consumed(e, slot).
 static int enqueue_seeding(MuavtaEnv* e, const uint64_t* seeds, const uint64_t** ds, const uint32_t** sb, int* slot) {
   const size_t N = (size_t)e->n_envs;
-  const int b = (int)(e->seed_seq++ & 1u);
+  const int b = (int)(e->seed_seq & 1u);  // (the slot sequence only advances once the kernel is queued: a failed call leaves it alone)
   if (e->seed_used[b]) {
     HIPCHK(e, hipEventSynchronize(e->ev_seeded[b]));                        // the staging copy of two calls ago has left h_seeds[b]
     HIPCHK(e, hipStreamWaitEvent(e->seed_stream, e->ev_consumed[b], 0));    // ... and its consumer has read d_seeds / d_seedbuf[b]
@@ -1157,6 +1181,7 @@ static int enqueue_seeding(MuavtaEnv* e, const uint64_t* seeds, const uint64_t**
   HIPCHK(e, hipEventRecord(e->ev_seeded[b], e->seed_stream));
   HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_seeded[b], 0));
   e->seed_used[b] = true;
+  e->seed_seq++;
   e->last_seed_slot = b;
   *ds = e->d_seeds[b]; *sb = e->d_seedbuf[b]; *slot = b;
   return MUAVTA_OK;
@@ -1176,6 +1201,7 @@ int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
   DISPATCH(e, hipLaunchKernelGGL(k_reset<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, ds, sb));
   HIPCHK(e, hipGetLastError());
   { int rc = seeding_consumed(e, slot); if (rc) return rc; }
+  e->last_seeded = true;  // muavta_last_seed_ms reports this reset's k_seed
   e->did_reset = true;
   e->host_valid = false;
   return MUAVTA_OK;
@@ -1334,6 +1360,18 @@ int muavta_sync(MuavtaEnv* e) {
   if (!e) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_wait_stream(MuavtaEnv* e, void* other_stream) {  // work queued on the handle from now on starts after what `other_stream` holds now
+  if (!e) return MUAVTA_E_ARG;
+  DeviceScope scope_(e->device);
+  hipEvent_t ev = nullptr;
+  HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t r = hipEventRecord(ev, (hipStream_t)other_stream);
+  if (r == hipSuccess) r = hipStreamWaitEvent(e->stream, ev, 0);
+  hipEventDestroy(ev);  // (destruction is deferred by the runtime until the event has completed)
+  if (r != hipSuccess) { e->err = std::string("muavta_wait_stream: ") + hipGetErrorString(r); return MUAVTA_E_HIP; }
   return MUAVTA_OK;
 }
 
@@ -1507,9 +1545,19 @@ int muavta_comm_init(MuavtaEnv* e, int32_t rank, int32_t n_ranks, const uint8_t*
   DeviceScope scope_(e->device);
   ncclUniqueId id;
   memcpy(&id, uid, sizeof(id));
-  NCCLCHK(e, R->CommInitRank(&e->comm, n_ranks, id, rank));
+  // staging first: a failure below must not leave a communicator behind that has nowhere to stage (a retry would be refused
+  // as "already has a communicator" and the next all-reduce would touch a null buffer)
+  void* staging = nullptr;
+  HIPCHK(e, hipMalloc(&staging, (size_t)(64 + 64 * n_ranks + 128) * 8));
+  ncclComm_t comm = nullptr;
+  const ncclResult_t r = R->CommInitRank(&comm, n_ranks, id, rank);
+  if (r != ncclSuccess) {
+    hipFree(staging);
+    e->err = std::string("ncclCommInitRank: ") + R->GetErrorString(r);
+    return MUAVTA_E_HIP;
+  }
+  e->comm = comm; e->d_comm = staging;
   e->comm_rank = rank; e->comm_ranks = n_ranks;
-  HIPCHK(e, hipMalloc(&e->d_comm, (size_t)(64 + 64 * n_ranks + 128) * 8));
   return MUAVTA_OK;
 }
 int muavta_allreduce_metrics(MuavtaEnv* e, const double* f_partials, int32_t nf, const int64_t* counters, int32_t nc, double* f_total, int64_t* c_total) {

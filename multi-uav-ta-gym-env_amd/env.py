@@ -312,7 +312,7 @@ class UAVView:
         if task.id == 0:  # the idle task: `self.tasks = [task]`, next_free_* reset, returns False (:85-92)
             if any(t.id == 0 for t in self.tasks):
                 return False
-            self._env._b.call("set_queue", [self.id, 0])
+            self._env._b.call("set_queue", [self.id, 0, 0, 0, 0, 0, 0, 1])  # iargs[7] = 1: the allocate(idle) resets as well
             self._env._after_call()
             return False
         out = self._env._b.call("uav_allocate", [self.id, int(task.id), int(time_step)])
@@ -665,8 +665,14 @@ class MultiUAVEnv:
         return out
 
     def _is_task_action_valid(self, agent, task) -> bool:  # :341-363
-        if task is None or task.id == 0:
-            return task is not None and task.status != 2
+        if task is None or task.status == 2:
+            return False
+        if task.id == 0:  # task_idle = Task(0, ..., "Hold", {"Hold": 0.0}) (:589): never resident on the device
+            if agent.tasks and agent.tasks[0].id == 0:
+                return True
+            if self.capability_mask and agent.currentCap2Task[0] <= 0:
+                return False
+            return not self.saturate_mask  # allocatedReqs[Hold] (0.0) >= orgReqs[Hold] (0.0)
         return bool(self._b.call("action_valid", [agent.id, int(task.id)])[0])
 
     def _create_escort_for(self, recon_agent, rec_task):  # :1888-1917

@@ -61,8 +61,12 @@ def il_record(env: BatchedMultiUAVEnv, seeds, n_steps: int = 150, interval: int 
         tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32, np.float64: torch.float64}
         rings = {name: torch.empty(shape, dtype=tdt[dtype], device=dev) for name, (shape, dtype) in shapes.items()}
     env.set_allocator("hungarian_gated")
+    # the rings live in torch's caching allocator and are written by the handle's own (non-blocking) stream: whatever torch's
+    # current stream still has queued on these blocks — a previous training step reading the old batch, or the kernels that
+    # used a block the allocator has just recycled — must be done before the rollout overwrites them
+    env.wait_stream(torch.cuda.current_stream(dev).cuda_stream)
     env.rollout_record(np.asarray(seeds, dtype=np.uint64), n_steps, interval, False, rings, kind, max_tasks, max_agents)
-    env.sync()
+    env.sync()  # ... and the read-after-write direction: the rings are complete before torch's stream touches them
     out = dict(rings)
     diff = rings["s_wps"][1:] - rings["s_wps"][:-1]
     out["step_reward"] = torch.div(diff, torch.full_like(diff, 20.0))  # tensor / tensor: IEEE division (a scalar divisor becomes a multiplication by its reciprocal)

@@ -31,7 +31,7 @@ EXPORTS = [
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
     "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
-    "muavta_kernel_ms_history",
+    "muavta_kernel_ms_history", "muavta_wait_stream",
 ]
 
 
@@ -117,6 +117,7 @@ def lib() -> C.CDLL:
     L.muavta_rollout_record.argtypes = [vp, u64p, i32, i32, i32, i32, vp]
     L.muavta_call.argtypes = [vp, i32, i32, vp, C.c_double, vp]
     L.muavta_sync.argtypes = [vp]
+    L.muavta_wait_stream.argtypes = [vp, vp]
     L.muavta_refresh_observation.argtypes = [vp]
     L.muavta_set_allocator.argtypes = [vp, i32]
     L.muavta_set_release_log.argtypes = [vp, i32]

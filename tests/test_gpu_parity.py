@@ -1110,3 +1110,77 @@ def test_bench_under_torchrun_world_size_1(extra):
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["total_envs"] == 512 and out["quality"]["n_envs"] == 512
     want = orc.parallel_metrics("WPS_hard_x2", np.arange(512), 20)
     assert out["quality"]["mean_S_WPS"] == float(want[:, 4].sum()) / 512
+
+
+def test_il_record_rings_of_an_episode_that_ends_early_are_fully_written():
+    """muavta_rollout_record when episodes end before n_steps (early_terminate, and n_steps beyond max_time_steps): the
+    reference's episode loops stop at `done` (train_pair_cost.py:108,139), so the slots behind an env's last step are
+    all-pad rows with replanned = 0 and a zero step reward — never uninitialised ring memory (rings pre-filled with NaN /
+    0x7f bytes here) — and the slots up to the end equal the per-step stream."""
+    import torch
+    from muavta_amd.batched import BatchedMultiUAVEnv
+    from muavta_amd.il import il_record, il_stream
+    n, steps, interval, kind, mt, ma = 48, 160, 20, "pair", 32, 16   # 160 > max_time_steps = 150: every env is truncated at 150
+    p = params_for_case("WPS_easy")
+    p.early_terminate = 1
+    env = BatchedMultiUAVEnv(p, n)
+    seeds = np.arange(300, 300 + n)
+    tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32, np.float64: torch.float64}
+    rings = {}
+    for name, (shape, dtype) in env.record_shapes(kind, steps, mt, ma).items():
+        t = torch.empty(shape, dtype=tdt[dtype], device="cuda")
+        t.fill_(float("nan")) if t.is_floating_point() else t.fill_(0x7f)
+        rings[name] = t
+    rec = il_record(env, seeds, steps, interval, kind, mt, ma, rings=rings)
+    assert not env.get("ERROR").any()
+    got = {k: v.cpu().numpy() for k, v in rec.items()}
+    ended_at = env.get("SCALARS")[:, 0].astype(int)          # time_steps when the episode ended
+    assert ended_at.max() <= 150 and (ended_at < 150).any(), "no env of the batch terminated early: pick other seeds"
+    for k in ("task_feats", "agent_feats", "edge_valid", "expert_mask", "s_wps", "step_reward"):
+        assert np.isfinite(got[k]).all(), f"{k} holds uninitialised values"
+    env2 = BatchedMultiUAVEnv(p, n)
+    for t, b in il_stream(env2, seeds, 150, interval, kind, mt, ma, with_reward=True):
+        live = ended_at > t                                   # sample t exists iff the episode has not ended after t steps
+        for key in ("task_feats", "task_mask", "task_ids", "agent_feats", "agent_mask", "agent_ids", "edge_valid", "n_urgent", "expert_mask", "replanned"):
+            assert np.array_equal(got[key][t][live], b[key][live]), f"t={t}: {key}"
+        if t:
+            assert np.array_equal(got["step_reward"][t - 1][ended_at >= t], b["step_reward"][ended_at >= t]), f"t={t}: step reward"
+    for i in range(n):
+        e = ended_at[i]
+        assert (got["replanned"][e:, i] == 0).all() and (got["n_urgent"][e:, i] == 0).all()
+        assert (got["task_mask"][e:, i] == 1).all() and (got["agent_mask"][e:, i] == 1).all()
+        assert (got["task_ids"][e:, i] == -1).all() and (got["agent_ids"][e:, i] == -1).all()
+        assert not got["task_feats"][e:, i].any() and not got["agent_feats"][e:, i].any() and not got["edge_valid"][e:, i].any() and not got["expert_mask"][e:, i].any()
+        assert (got["s_wps"][e:, i] == got["s_wps"][steps, i]).all() and not got["step_reward"][e:, i].any()
+    assert np.array_equal(got["s_wps"][steps], env.rollout_metrics()[:, 4])
+
+
+def test_config5_global_indices_0_8191_in_eight_shards():
+    """BASELINE config 5 as the 8-GPU job shards it: global env indices 0..8191 of WPS_burst64, 1024 per shard (= per GPU).
+    Every env produces a result (ERROR == 0) and all 30 metrics equal the oracle's."""
+    case, shard = "WPS_burst64", 1024
+    env = _env(case, shard)
+    want = orc.parallel_metrics(case, np.arange(8192), 20)
+    for r in range(8):
+        seeds = np.arange(r * shard, (r + 1) * shard, dtype=np.uint64)
+        env.rollout(seeds, 150, 20, True, True)
+        got, err = env.rollout_metrics(), env.get("ERROR")
+        assert not err.any(), f"shard {r}: envs {seeds[np.nonzero(err)[0][:8]]} overflowed the tile (codes {np.unique(err[err != 0])})"
+        bad = np.nonzero(~np.all(got == want[r * shard:(r + 1) * shard], axis=1))[0]
+        assert len(bad) == 0, f"shard {r}: seeds {seeds[bad[:8]]} differ"
+
+
+@pytest.mark.parametrize("name,mode,n", [("hungarian", 0, 4096), ("urgency_coalition", 2, 1024)])
+def test_config4_bench_seed_range(name, mode, n):
+    """BASELINE config 4 on the seeds bench.py actually runs (global env index 0..4095), and the same sweep under
+    Urgency-Coalition at 1024 envs: ERROR == 0 and 30 metrics bit-equal to the oracle for every env."""
+    case, interval = "WPS_escort24", 12
+    env = _env(case, n)
+    env.set_allocator(name)
+    seeds = np.arange(n, dtype=np.uint64)
+    env.rollout(seeds, 150, interval, True, True)
+    got, err = env.rollout_metrics(), env.get("ERROR")
+    assert not err.any(), f"{name}: envs {seeds[np.nonzero(err)[0][:8]]} overflowed the tile (codes {np.unique(err[err != 0])})"
+    want = orc.parallel_metrics(case, seeds, interval, 1, mode)
+    bad = np.nonzero(~np.all(got == want, axis=1))[0]
+    assert len(bad) == 0, f"{name}: seeds {seeds[bad[:8]]} differ"

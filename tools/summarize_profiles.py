@@ -8,7 +8,7 @@ per-env HBM record and single-lane tape words — stated as uncalibrated in DESI
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 from bench import source_hash
@@ -54,7 +54,20 @@ for src in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*")
         tp = os.path.join(dst, "pmc_traffic.json")
         d = json.load(open(tp)) if os.path.exists(tp) else {}
         d = {k: v for k, v in d.items() if isinstance(v, dict) or k == "_note"}
-        d[f"{case}:{envs}"] = {"bytes_per_launch": traffic, "source_hash": source_hash(), "profile": f"{tag}_{case}_pmc_k_rollout.csv"}
+        entry = {"bytes_per_launch": traffic, "source_hash": source_hash(), "profile": f"{tag}_{case}_pmc_k_rollout.csv"}
+        if "SQ_INSTS_VALU" in mean and "SQ_WAVE_CYCLES" in mean and "SQ_ACTIVE_INST_VALU" in mean:
+            # issue side (bench.py: roofline.issue).  Waves per SIMD: one single-wave workgroup per env over 256 CUs x 4 SIMDs,
+            # all resident at once for the BASELINE sizes; the VALU port of a SIMD serves its waves one at a time, so its occupancy
+            # over the launch is waves_per_simd x (a wave's VALU-active cycles / its resident cycles), both in quad-cycles
+            wps = max(1.0, min(envs / 1024.0, 8.0))
+            entry["issue"] = {
+                "valu_per_env_step": mean["SQ_INSTS_VALU"] / steps, "salu_per_env_step": mean.get("SQ_INSTS_SALU", 0) / steps,
+                "lds_per_env_step": mean.get("SQ_INSTS_LDS", 0) / steps, "branch_per_env_step": mean.get("SQ_INSTS_BRANCH", 0) / steps,
+                "wave_quad_cycles_per_env_step": mean["SQ_WAVE_CYCLES"] / steps, "waves_per_simd": wps,
+                "valu_port_busy": wps * mean["SQ_ACTIVE_INST_VALU"] / mean["SQ_WAVE_CYCLES"],
+                "wait_any_frac": mean.get("SQ_WAIT_ANY", 0) / mean["SQ_WAVE_CYCLES"],
+            }
+        d[f"{case}:{envs}"] = entry
         d["_note"] = "HBM bytes per k_rollout launch = (FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes (tools/collect_profiles.sh); valid for the kernel sources with this source_hash only"
         json.dump(d, open(tp, "w"), indent=1)
         print(case, "traffic bytes/launch", traffic)
