@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
+#include <type_traits>
 
 #include "muavta_state.h"
 
@@ -2814,9 +2815,11 @@ struct Sim {
         return c;
       };
       bool feasible = false;
-      cost_vec c0;
-      cost_vec_hi c1;
-      if constexpr (TL::REGC) {
+      CostCol col;
+      // REGC: one LSAP column per lane with its costs in registers, whenever the columns fit the wave (always on the 16- and
+      // 24-agent tiles; up to 64 columns on the 64-agent tile, whose kernels are built for 256 VGPRs: four 16-row tuples)
+      const bool reg_cols = TL::REGC && (T <= WG || Cc <= WG);
+      if (reg_cols) {
         // lane = LSAP column (a task, or an agent when scipy transposes): its whole cost column goes straight into
         // uniformly indexed registers, one row per iteration — no A x T tile in LDS.  pair_cost() split in two: the column's
         // side (task or agent fields) is read from LDS ONCE per lane, the row's side is the same for every lane (broadcast
@@ -2830,7 +2833,7 @@ struct Sim {
             const AS g = load_as(a);
             double c = 0.0;
             if (incol) { c = pair_eval(a, g, my_s, ts); feasible |= c < 1e5 / 2; }
-            if constexpr (A > 16) { if (i < 16) c0[i] = c; else c1[i - 16] = c; } else c0[i] = c;
+            col.set(i, c);
           }
         } else {
           const int my_a = incol ? X.freeA[lane] : X.freeA[0];
@@ -2840,7 +2843,7 @@ struct Sim {
             const TS ts = load_ts(sl, i);
             double c = 0.0;
             if (incol) { c = pair_eval(my_a, g, sl, ts); feasible |= c < 1e5 / 2; }
-            if constexpr (A > 16) { if (i < 16) c0[i] = c; else c1[i - 16] = c; } else c0[i] = c;
+            col.set(i, c);
           }
         }
       } else {
@@ -2855,25 +2858,9 @@ struct Sim {
       if (__ballot(feasible) == 0ull) break;
       lds_sync();
       PROF(12);
-      if constexpr (TL::REGC) lsap_reg_core(Rr, Cc, c0, c1);
-      else if constexpr (TL::OTFC) {
-        if (Cc <= WG) {
-          // up to 64 columns: the register-resident solver with one column per lane, its cost in row i evaluated on the fly from
-          // the column's cached operands and row i's broadcast operands — no cost tile, no LDS traffic for v / spc / path / remaining
-          const bool incol = lane < Cc;
-          if (!tr) {
-            const int my_s = (int)S.open_slot[X.roundT[incol ? lane : 0]];
-            const TS ts = load_ts(my_s, incol ? lane : 0);
-            lsap_reg_solve(Rr, Cc, [&](int i) -> double { const int a = X.freeA[i]; const AS g = load_as(a); return pair_eval(a, g, my_s, ts); });
-          } else {
-            const int my_a = X.freeA[incol ? lane : 0];
-            const AS g = load_as(my_a);
-            lsap_reg_solve(Rr, Cc, [&](int i) -> double { const int sl = S.open_slot[X.roundT[i]]; const TS ts = load_ts(sl, i); return pair_eval(my_a, g, sl, ts); });
-          }
-        } else {  // element (row i, column j) of scipy's (possibly transposed) matrix, evaluated when scanned
-          lsap(Rr, Cc, [&](int i, int j) { return tr ? pair_cost(X.freeA[j], S.open_slot[X.roundT[i]], i) : pair_cost(X.freeA[i], S.open_slot[X.roundT[j]], j); });
-        }
-      }
+      if (reg_cols) lsap_reg_solve(Rr, Cc, [&](int i) -> double { return col.get(i); });
+      else if constexpr (TL::OTFC)  // beyond 64 columns: element (row i, column j) of scipy's (possibly transposed) matrix, evaluated when scanned
+        lsap(Rr, Cc, [&](int i, int j) { return tr ? pair_cost(X.freeA[j], S.open_slot[X.roundT[i]], i) : pair_cost(X.freeA[i], S.open_slot[X.roundT[j]], j); });
       else if constexpr (T <= WG && A <= 32) lsap_reg(Rr, Cc);
       else lsap(Rr, Cc);
       PROF(13);
@@ -3220,12 +3207,37 @@ struct Sim {
   DEV double readlane_f64(double v, int l) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
   }
+  // v_min_f64 as such.  fmin() compiles to llvm.minnum, which has to quiet a signalling NaN: every operand the compiler cannot
+  // prove canonical — anything that came through a DPP move or a v_readlane — gets a v_max_f64 x, x, x in front, which doubled
+  // the VALU count of the wave-wide minimum.  The operands here are finite costs or +inf, never NaN.
+  static DEV double vmin(double a, double b) {
+    double d;
+    asm("v_min_f64 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+  }
+  // row_bcast:15 into rows 1 and 3 / row_bcast:31 into rows 2 and 3 (GFX9 DPP); the rows a step does not write keep `keep`
+  DEV double dpp_bcast(double v, double keep, const int which) {
+    int lo, hi;
+    if (which == 15) {
+      lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), 0x142, 0xa, 0xf, false);
+      hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), 0x142, 0xa, 0xf, false);
+    } else {
+      lo = __builtin_amdgcn_update_dpp(__double2loint(keep), __double2loint(v), 0x143, 0xc, 0xf, false);
+      hi = __builtin_amdgcn_update_dpp(__double2hiint(keep), __double2hiint(v), 0x143, 0xc, 0xf, false);
+    }
+    return __hiloint2double(hi, lo);
+  }
+  // wave-wide minimum (uniform result): four exchange steps inside each 16-lane row, then the row broadcasts carry the row
+  // minima up to lane 63 — 18 VALU + 2 v_readlane (was: 12 + 8 v_readlane + 3 v_min + 9 canonicalising v_max).  In the rows a
+  // broadcast step does not write the partner operand stays the previous step's (a value of the lane's own row, >= its minimum).
   DEV double wave_min(double v) {
-    v = fmin(v, dpp_xchg(v, 0));
-    v = fmin(v, dpp_xchg(v, 1));
-    v = fmin(v, dpp_xchg(v, 2));
-    v = fmin(v, dpp_xchg(v, 3));
-    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
+    double t = dpp_xchg(v, 0); v = vmin(v, t);
+    t = dpp_xchg(v, 1); v = vmin(v, t);
+    t = dpp_xchg(v, 2); v = vmin(v, t);
+    t = dpp_xchg(v, 3); v = vmin(v, t);
+    t = dpp_bcast(v, t, 15); v = vmin(v, t);
+    t = dpp_bcast(v, t, 31); v = vmin(v, t);
+    return readlane_f64(v, 63);
   }
   DEV void lsap(int nr, int nc) { const double* c = X.cost; lsap(nr, nc, [c, nc](int i, int j) { return c[i * nc + j]; }); }
   template <class CostAt>
@@ -3309,109 +3321,49 @@ struct Sim {
   // and lane r owns row r's u[r] / col4row[r]; no LDS traffic inside the solve.  scipy's `remaining` array is kept
   // only as each column's POSITION in it (filled in reverse, swap-removed), which is all its tie rule looks at:
   // among the minima take the unassigned column at the LAST position if there is one, else the FIRST position.
+  // A lane's LSAP cost column in registers: 16-row tuples indexed with a uniform row number (s_set_gpr_idx) — one tuple up
+  // to 16 agents, a second of 8 (<= 24 agents) or 16 rows, four on the 64-agent tile (128 VGPRs of its 256).
   typedef double cost_vec __attribute__((ext_vector_type(16)));
-  // rows 16 .. A-1 of a column: 8 registers pairs are enough up to 24 agents (16 fewer VGPRs held through the solve)
-  typedef double cost_vec_hi __attribute__((ext_vector_type((A > 24) ? 16 : 8)));
-  DEV void lsap_reg(int nr, int nc) {  // cost tile staged in X.cost (R x C row-major)
-    cost_vec c0;
-    cost_vec_hi c1;
-#pragma unroll
-    for (int i = 0; i < 16; i++) { c0[i] = (i < nr && lane < nc) ? X.cost[i * nc + lane] : 0.0; }
-    if (A > 16) {
-#pragma unroll
-      for (int i = 0; i < ((A > 24) ? 16 : 8); i++) { c1[i] = (16 + i < nr && lane < nc) ? X.cost[(16 + i) * nc + lane] : 0.0; }
+  typedef double cost_vec8 __attribute__((ext_vector_type(8)));
+  struct CostCol {
+    cost_vec v0;
+    typename std::conditional<(A > 24), cost_vec, cost_vec8>::type v1;
+    cost_vec v2, v3;
+    DEV double get(int i) const {  // i uniform
+      if constexpr (A <= 16) return v0[i];
+      else if constexpr (A <= 32) { if (i < 16) return v0[i]; return v1[i - 16]; }
+      else { if (i < 16) return v0[i]; if (i < 32) return v1[i - 16]; if (i < 48) return v2[i - 32]; return v3[i - 48]; }
     }
-    lsap_reg_core(nr, nc, c0, c1);
-  }
-  DEV void lsap_reg_core(int nr, int nc, const cost_vec& c0, const cost_vec_hi& c1) {
-    const double INF = __builtin_huge_val();
-    double u_r = 0, vj = 0;  // lane r < nr: u[r];  lane j < nc: v[j]
-    int c4r = -1, r4c = -1;  // lane r: col4row[r];  lane j: row4col[j]
-    const bool incol = lane < nc;
-    for (int cur = 0; cur < nr; cur++) {
-      int pos = nc - 1 - lane;  // scipy fills `remaining` in reverse: column j sits at position nc-1-j
-      double sp = INF;
-      int pth = -1;
-      bool active = incol;
-      unsigned long long SRmask = 0ull, SCmask = 0ull;
-      double minVal = 0;
-      int i = cur, nrem = nc, sink = -1;
-      while (sink == -1) {
-        SRmask |= 1ull << i;
-        const double ui = readlane_f64(u_r, i);
-        const double ci = (A > 16 && i >= 16) ? c1[i - 16] : c0[i];
-        double val = INF;
-        bool un = false;
-        if (active) {
-          const double r = minVal + ci - ui - vj;
-          if (r < sp) { sp = r; pth = i; }
-          val = sp;
-          un = r4c == -1;
-        }
-        const double m = wave_min(val);  // (a variant that skips the DPP rows without columns measured 3.5 % SLOWER: r02p)
-        if (m == INF) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }
-        const unsigned long long eq = __ballot(active && val == m);
-        const unsigned long long equ = __ballot(active && val == m && un);
-        int sel;
-        if (equ) {
-          sel = 63 - __clzll((long long)equ);
-          if (equ & (equ - 1ull)) {  // several unassigned minima: the one at the last position
-            int best = -1;
-            for (unsigned long long t = equ; t; t &= t - 1ull) {
-              const int b = __ffsll((long long)t) - 1;
-              const int pb = __builtin_amdgcn_readlane(pos, b);
-              if (pb > best) { best = pb; sel = b; }
-            }
-          }
-        } else {
-          sel = __ffsll((long long)eq) - 1;
-          if (eq & (eq - 1ull)) {    // several (assigned) minima: the one at the first position
-            int best = 1 << 30;
-            for (unsigned long long t = eq; t; t &= t - 1ull) {
-              const int b = __ffsll((long long)t) - 1;
-              const int pb = __builtin_amdgcn_readlane(pos, b);
-              if (pb < best) { best = pb; sel = b; }
-            }
-          }
-        }
-        minVal = m;
-        const int rj = __builtin_amdgcn_readlane(r4c, sel), psel = __builtin_amdgcn_readlane(pos, sel);
-        SCmask |= 1ull << sel;
-        if (pos == nrem - 1) pos = psel;  // remaining[index] = remaining[--num_remaining]
-        if (lane == sel) active = false;
-        nrem--;
-        if (rj == -1) sink = sel; else i = rj;
-      }
-      // dual updates (u over the scanned rows, v over the scanned columns)
-      const double spc_of_my_col = __shfl(sp, c4r < 0 ? 0 : c4r);  // rows in SR other than cur are assigned
-      if (lane < nr) {
-        if (lane == cur) u_r += minVal;
-        else if ((SRmask >> lane) & 1ull) u_r += minVal - spc_of_my_col;
-      }
-      if (incol && ((SCmask >> lane) & 1ull)) vj -= minVal - sp;
-      // augmentation along `path` (uniform walk)
-      int jj = sink;
-      while (true) {
-        const int r = __builtin_amdgcn_readlane(pth, jj);
-        if (lane == jj) r4c = r;
-        const int t = __builtin_amdgcn_readlane(c4r, r);
-        if (lane == r) c4r = jj;
-        jj = t;
-        if (r == cur) break;
-      }
+    DEV void set(int i, double c) {
+      if constexpr (A <= 16) v0[i] = c;
+      else if constexpr (A <= 32) { if (i < 16) v0[i] = c; else v1[i - 16] = c; }
+      else { if (i < 16) v0[i] = c; else if (i < 32) v1[i - 16] = c; else if (i < 48) v2[i - 32] = c; else v3[i - 48] = c; }
     }
-    if (lane < nr) X.col4row[lane] = c4r;
-    if (incol) X.row4col[lane] = r4c;
-    lds_sync();
+  };
+  DEV void lsap_reg(int nr, int nc) {  // cost tile staged in X.cost (R x C row-major), nr <= nc <= 64
+    CostCol col;
+    for (int i = 0; i < nr; i++) col.set(i, lane < nc ? X.cost[i * nc + lane] : 0.0);
+    lsap_reg_solve(nr, nc, [&](int i) -> double { return col.get(i); });
   }
-  // cost_row(i): this lane's (= this column's) cost in row i, for a uniform i — a register of the column built beforehand, or
-  // evaluated on the fly from the column's cached operands and the row's broadcast operands (64-agent tile)
+  // scipy.optimize.linear_sum_assignment (rectangular_lsap.cpp) with the search state in REGISTERS, nr <= nc <= 64: lane j owns
+  // COLUMN j for the whole solve — cost_row(i) is its cost in (uniform) row i, v[j], row4col[j], the shortest-path cost and
+  // predecessor — and lane r owns row r's u[r] / col4row[r]; no LDS traffic inside the solve.  scipy's `remaining` array is kept
+  // only as each column's POSITION in it (filled in reverse, swap-removed), which is all its tie rule looks at: among the
+  // minima take the unassigned column at the LAST position if there is one, else the FIRST position.
+  // Per scan step (r3): the set of unassigned columns is a uniform bit mask kept on the scalar side (it only changes when a
+  // path is augmented), the ballots are taken straight from compares (a ballot of a combined predicate costs a v_cndmask +
+  // v_cmp to materialise it), the wave-wide minimum is 18 VALU (wave_min): ~40 VALU per step, from ~75.
   template <class CostRow>
-  DEV void lsap_reg_solve(int nr, int nc, CostRow cost_row) {
+  DEV void lsap_reg_solve(int nr_, int nc_, CostRow cost_row) {
+    // the problem size is uniform, but it was counted in loops whose trip count came out of LDS, which makes it divergent in the
+    // compiler's eyes — and with it the column masks, the selected column and the row being scanned (VALU selects instead of
+    // scalar code, a 16-way select chain instead of an indexed register read)
+    const int nr = __builtin_amdgcn_readfirstlane(nr_), nc = __builtin_amdgcn_readfirstlane(nc_);
     const double INF = __builtin_huge_val();
     double u_r = 0, vj = 0;  // lane r < nr: u[r];  lane j < nc: v[j]
     int c4r = -1, r4c = -1;  // lane r: col4row[r];  lane j: row4col[j]
     const bool incol = lane < nc;
+    unsigned long long unassigned = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);  // uniform: columns j with row4col[j] == -1
     for (int cur = 0; cur < nr; cur++) {
       int pos = nc - 1 - lane;  // scipy fills `remaining` in reverse: column j sits at position nc-1-j
       double sp = INF;
@@ -3423,19 +3375,15 @@ struct Sim {
       while (sink == -1) {
         SRmask |= 1ull << i;
         const double ui = readlane_f64(u_r, i);
-        const double ci = cost_row(i);
-        double val = INF;
-        bool un = false;
-        if (active) {
-          const double r = minVal + ci - ui - vj;
-          if (r < sp) { sp = r; pth = i; }
-          val = sp;
-          un = r4c == -1;
-        }
-        const double m = wave_min(val);  // (a variant that skips the DPP rows without columns measured 3.5 % SLOWER: r02p)
-        if (m == INF) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }
-        const unsigned long long eq = __ballot(active && val == m);
-        const unsigned long long equ = __ballot(active && val == m && un);
+        const double r = minVal + cost_row(i) - ui - vj;
+        const bool upd = active && r < sp;
+        sp = upd ? r : sp;
+        pth = upd ? i : pth;
+        const double val = active ? sp : INF;
+        const double m = wave_min(val);
+        if (__double2hiint(m) == 0x7ff00000) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }  // m == +inf (never NaN): a scalar compare of the high word
+        const unsigned long long eq = __builtin_amdgcn_ballot_w64(val == m);  // scanned columns and lanes beyond nc hold +inf > m
+        const unsigned long long equ = eq & unassigned;
         int sel;
         if (equ) {
           sel = 63 - __clzll((long long)equ);
@@ -3459,12 +3407,12 @@ struct Sim {
           }
         }
         minVal = m;
-        const int rj = __builtin_amdgcn_readlane(r4c, sel), psel = __builtin_amdgcn_readlane(pos, sel);
+        const int psel = __builtin_amdgcn_readlane(pos, sel);
         SCmask |= 1ull << sel;
         if (pos == nrem - 1) pos = psel;  // remaining[index] = remaining[--num_remaining]
         if (lane == sel) active = false;
         nrem--;
-        if (rj == -1) sink = sel; else i = rj;
+        if (equ) sink = sel; else i = __builtin_amdgcn_readlane(r4c, sel);  // an unassigned column ends the search
       }
       // dual updates (u over the scanned rows, v over the scanned columns)
       const double spc_of_my_col = __shfl(sp, c4r < 0 ? 0 : c4r);  // rows in SR other than cur are assigned
@@ -3474,6 +3422,7 @@ struct Sim {
       }
       if (incol && ((SCmask >> lane) & 1ull)) vj -= minVal - sp;
       // augmentation along `path` (uniform walk)
+      unassigned &= ~(1ull << sink);
       int jj = sink;
       while (true) {
         const int r = __builtin_amdgcn_readlane(pth, jj);

@@ -111,10 +111,12 @@ static_assert(Lds<Tile24>::bytes() <= 10240, "Tile24 no longer fits 16 workgroup
 static_assert(sizeof(EnvState<Tile16>) % 16 == 0 && sizeof(EnvState<Tile24>) % 16 == 0 && sizeof(EnvState<Tile64>) % 16 == 0, "blob copies move 16 B per lane");
 static_assert(sizeof(EnvCold<Tile16>) % 16 == 0 && sizeof(EnvCold<Tile24>) % 16 == 0 && sizeof(EnvCold<Tile64>) % 16 == 0, "cold records are 16 B aligned");
 
-// Minimum waves per SIMD the register allocator must leave room for in the fused rollout (4 => at most 128 VGPRs, which is
-// what 16 single-wave workgroups per CU need).
-#ifndef MUAVTA_MIN_WAVES
-#define MUAVTA_MIN_WAVES 4
+// Minimum waves per SIMD the register allocator must leave room for in the fused rollout / step kernels: Tile::MIN_WAVES (4 =>
+// at most 128 VGPRs, which is what 16 single-wave workgroups per CU need; 2 => 256 VGPRs on the 64-agent tile).
+#ifdef MUAVTA_MIN_WAVES  // (experiments: one value for every tile)
+#define TILE_MIN_WAVES(TL) MUAVTA_MIN_WAVES
+#else
+#define TILE_MIN_WAVES(TL) TL::MIN_WAVES
 #endif
 
 // ---- RNG seeding, one LANE per stream --------------------------------------------------------------------------
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(WG) void k_reset(const DevCtx* __restrict__ ctxp, c
 
 // act_agent == nullptr: use the actions staged in the blob by k_allocate
 template <class TL>
-__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_step(const DevCtx* __restrict__ ctxp, const int32_t* act_agent, const int32_t* act_index, int act_cap,
+__global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_step(const DevCtx* __restrict__ ctxp, const int32_t* act_agent, const int32_t* act_index, int act_cap,
                                              double* rel_log) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const DevParams& P = ctx.P;
@@ -355,7 +357,7 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds
 }
 
 template <class TL, bool REC>
-__global__ __launch_bounds__(WG, MUAVTA_MIN_WAVES) void k_rollout(const DevCtx* __restrict__ ctxp, const uint64_t* seeds, int n_steps, int interval, int use_vis,
+__global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx* __restrict__ ctxp, const uint64_t* seeds, int n_steps, int interval, int use_vis,
                                                 int mode, int write_obs, double* metrics, const uint32_t* seedbuf, RecordPtrs<TL> rec, int epoch) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;

@@ -57,8 +57,8 @@ struct DevParams {
 template <int A_, int T_, int H_, int R_, int E_, int Q_, bool REGC_ = false, bool OTFC_ = false, bool SLIM_ = false>
 struct Tile {
   static constexpr bool SLIM = SLIM_;  // next_free_* / orgReqs / doneReqs / mission areas live in the HBM record instead of LDS (the 24-agent tile: 16 envs per CU need <= 10 KiB)
-  static constexpr bool REGC = REGC_;  // the allocator builds the LSAP cost columns in registers: no A x T cost tile in LDS
-  static constexpr bool OTFC = OTFC_;  // the (LDS) solver evaluates cost elements on the fly: no A x T cost tile either
+  static constexpr bool REGC = REGC_;  // the allocator builds the LSAP cost columns in registers (while they fit one per lane): no A x T cost tile in LDS
+  static constexpr bool OTFC = OTFC_;  // beyond 64 columns the (LDS) solver evaluates cost elements on the fly: no A x T cost tile either
   static constexpr bool NO_COST_TILE = REGC_ || OTFC_;
   static constexpr int A = A_;  // agents
   static constexpr int T = T_;  // live task slots
@@ -67,6 +67,10 @@ struct Tile {
   static constexpr int E = E_;  // events per list
   static constexpr int Q = Q_;  // agent queue depth (reference max measured: 7 / 10 / 5 on the three tiles)
   static constexpr int KW = (T_ + 31) / 32;  // known-mask words per agent
+  // waves per SIMD the fused kernels are compiled for (the VGPR budget is 512 / this).  16 envs of the small tiles share a
+  // CU: four single-wave workgroups per SIMD, 128 VGPRs.  The 64-agent tile is bound by LDS to 4-5 envs per CU — at most two
+  // waves on a SIMD — so its kernels get 256 VGPRs and keep a whole 64-row LSAP cost column per lane in registers.
+  static constexpr int MIN_WAVES = A_ > 32 ? 2 : 4;
   static_assert(A_ <= 64 && T_ <= 128 && H_ <= 64, "ids of agents / slots / threats are stored in int8");
 };
 
@@ -182,7 +186,7 @@ struct alignas(16) EnvState : QueueSide<TL::A, TL::T, !TL::SLIM> {
 // measured over 4096 seeds.
 typedef Tile<16, 40, 16, 48, 40, 10, true> Tile16;
 typedef Tile<24, 48, 24, 88, 32, 12, true, false, true> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
-typedef Tile<64, 128, 48, 128, 96, 8, false, true> Tile64;
+typedef Tile<64, 128, 48, 128, 96, 8, true, true> Tile64;  // register cost columns up to 64 LSAP columns, on-the-fly LDS solver beyond
 
 #define MUAVTA_REL_ROW 29  // doubles per release-log row (include/muavta.h: MUAVTA_F_RELEASE_LOG)
 #define MUAVTA_RNG_STREAMS 4
