@@ -184,13 +184,15 @@ DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
 }
 
 #ifdef MUAVTA_PROF
-__device__ unsigned long long g_prof[48];
-// per-phase cycle accumulators of a diagnostic build: 48 + 1 (last stamp) u64 words in LDS right behind the Scratch tile
-#define MUAVTA_PROF_LDS_BYTES 400
-#define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_lds()[i] += t_ - prof_lds()[48]; prof_lds()[48] = t_; } } while (0)
+enum { PROF_N = 64 };  // slots 0..47: cycle accumulators, 48..63: event counters (x1000)
+__device__ unsigned long long g_prof[PROF_N];
+// per-phase cycle accumulators of a diagnostic build: 64 + 1 (last stamp) u64 words in LDS right behind the Scratch tile
+#define MUAVTA_PROF_LDS_BYTES 528
+#define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_lds()[i] += t_ - prof_lds()[PROF_N]; prof_lds()[PROF_N] = t_; } } while (0)
 #define PROF_COUNT(i, n) do { if (threadIdx.x == 0) prof_lds()[i] += (n); } while (0)
 #else
 #define PROF(i) do { } while (0)
+#define PROF_COUNT(i, n) do { } while (0)
 #endif
 
 template <class TL>
@@ -198,8 +200,8 @@ struct Sim {
   typedef EnvState<TL> State;
 #ifdef MUAVTA_PROF
   DEV unsigned long long* prof_lds() { return reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(&X) + sizeof(Scratch<TL>)); }
-  DEV void prof_begin() { if (threadIdx.x < 48) prof_lds()[threadIdx.x] = 0; if (threadIdx.x == 0) prof_lds()[48] = clock64(); lds_sync(); }
-  DEV void prof_flush() { lds_sync(); if (threadIdx.x < 48) atomicAdd(&g_prof[threadIdx.x], prof_lds()[threadIdx.x]); }
+  DEV void prof_begin() { if (threadIdx.x < PROF_N) prof_lds()[threadIdx.x] = 0; if (threadIdx.x == 0) prof_lds()[PROF_N] = clock64(); lds_sync(); }
+  DEV void prof_flush() { lds_sync(); if (threadIdx.x < PROF_N) atomicAdd(&g_prof[threadIdx.x], prof_lds()[threadIdx.x]); }
 #endif
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   typedef EnvCold<TL> Cold;
@@ -765,6 +767,7 @@ struct Sim {
   // returns whether the call changed any state: a repeat of the same event right after a call that changed nothing
   // is a no-op (f(S) == S), which the drain loop uses to skip the tail of a burst's identical Reset_Allocation events
   DEV bool release_all_tasks_coop(int for_type) {
+    PROF_COUNT(53, 1000);
     const int ft = for_type < 0 ? for_type + 6 : for_type;  // python negative index -> caps[-1] == Det
     const int a = lane;
     bool match = false, busy = false, chg = false;
@@ -1210,11 +1213,29 @@ struct Sim {
     {  // update_threats (:1725-1744): lanes advance every threat up to the first one that engages or leaves the area,
        // lane 0 plays that one as the reference does, and the wave resumes behind it
       unsigned long long livemask = 0ull;
-      for (int start = 0;;) {
-        const int first = update_threats_parallel(start, livemask);
+      if (!P.escort_enabled) {
+        // Without escorts a threat's turn reads nothing another threat's turn writes (own record, own Int task, agent POSITIONS —
+        // an engagement changes agents' states and queues, which only _retarget_threat_via_escort looks at): one pass decides
+        // every threat, the non-event ones commit at once, and lane 0 replays the event threats in env.threats order (the
+        // shared RNG stream and the counters see them in the reference's sequence).
+        const unsigned long long em = update_threats_parallel(0, livemask, true);
         lds_sync();
         PROF(23);
+        PROF_COUNT(54, 1000);
+        if (em) {
+          PROF_COUNT(55, 1000 * __popcll(em));
+          if (lane == 0)
+            for (unsigned long long m = em; m; m &= m - 1ull) update_threats_serial(__ffsll((long long)m) - 1, livemask);
+          lds_sync();
+        }
+      } else
+      for (int start = 0;;) {
+        const int first = (int)update_threats_parallel(start, livemask, false);
+        lds_sync();
+        PROF(23);
+        PROF_COUNT(54, 1000);
         if (first >= S.n_active_threats) break;
+        PROF_COUNT(55, 1000);
         if (lane == 0) update_threats_serial(first, livemask);
         lds_sync();
         start = first + 1;
@@ -1921,7 +1942,8 @@ struct Sim {
   // (env.threats order) commit their lane's result; lane 0 replays the reference loop from the event on.
   // Returns (first serial index, snapshot mask of threats with status != 2).
   // lanes [start, n): the threats behind the last serially replayed one; `livemask` is taken once, at start == 0
-  DEV int update_threats_parallel(int start, unsigned long long& livemask) {
+  // all_at_once (no escorts): every non-event threat commits and the mask of event threats is returned instead of the first one
+  DEV unsigned long long update_threats_parallel(int start, unsigned long long& livemask, bool all_at_once) {
     static_assert(H <= 64, "one threat per lane");
     const int n = S.n_active_threats;
     const int k = lane;
@@ -1970,12 +1992,12 @@ struct Sim {
     }
     const unsigned long long em = __ballot(evt);
     const int first = em ? __ffsll((long long)em) - 1 : n;
-    if (active && k < first) {
+    if (active && (all_at_once ? !evt : k < first)) {
       S.h_px[h] = npx; S.h_py[h] = npy;
       S.h_target[h] = tgt; S.h_intercept[h] = icpt;
       if (live_task) { S.t_px[slot] = npx; S.t_py[slot] = npy; }
     }
-    return first;
+    return all_at_once ? em : (unsigned long long)first;
   }
   DEV void update_threats_serial(int first, unsigned long long livemask) {  // the reference's loop body for ONE threat
     const int n = first + 1 < S.n_active_threats ? first + 1 : S.n_active_threats;
@@ -2113,7 +2135,9 @@ struct Sim {
     }
     const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     unsigned long long rm = __ballot(retire), todo = all;
+    PROF_COUNT(56, 1000); PROF_COUNT(57, 1000 * n);
     while (todo) {
+      PROF_COUNT(58, 1000);
       const unsigned long long low = todo & (0ull - todo);                 // lowest pending entry
       const unsigned long long nextr = rm & todo;                         // pending retirements
       const unsigned long long seg = nextr ? (todo & ((nextr & (0ull - nextr)) - 1ull)) : todo;  // entries before the next one
@@ -2406,6 +2430,7 @@ struct Sim {
     return __builtin_fma(__builtin_fma(-q, c, x), inv, q);
   }
   static DEV double div_coord(double x) { return div_small(x, MAX_COORD, 1.0 / MAX_COORD); }  // x / MAX_COORD, x finite
+  static DEV double div40(double x) { return div_small(x, 40.0, 1.0 / 40.0); }  // remaining / 40.0 of the urgency terms (x: a small non-negative integer)
   static DEV double div_small_any(double x, double c, double inv) {
     const double q = x * inv;
     const double q1 = __builtin_fma(__builtin_fma(-q, c, x), inv, q);
@@ -2681,6 +2706,7 @@ struct Sim {
     lds_sync();
     PROF(11);
     if (!go) return;
+    PROF_COUNT(52, 1000);
     int n_act = 0;
     while (true) {
       // round_tasks: open tasks (that had residual > 0 initially) with residual > 1e-9, in last_tasks_info order
@@ -2715,7 +2741,7 @@ struct Sim {
           if (S.t_flags[s] & TF_DEADLINE) {
             int remaining = S.t_deadline[s] - tnow;
             remaining = remaining > 0 ? remaining : 0;
-            urgency = 1.0 - fmin((double)remaining / 40.0, 1.0);
+            urgency = 1.0 - fmin(div40((double)remaining), 1.0);
           }
           double delivered = is_escort_task(s) ? 1.0 : S.a_caps[S.t_type[s]][a];
           if (delivered > 0) {  // _cost (:43-70), left-to-right, priority = 0
@@ -2752,7 +2778,10 @@ struct Sim {
       // pair_cost() split in two for the solvers that keep one column per lane: the column's side (task or agent fields) is
       // read from LDS ONCE per lane, the row's side is the same for every lane (broadcast reads, issued together).  Same arithmetic.
       struct TS { double px, py, urgency, missing, press; int type, info; bool elig_on, esc_task, esc_flag; uint32_t elig; };
-      struct AS { double px, py; int type, rank; uint32_t k0, k1, k2, k3; };
+      // (the known mask as two 64-bit halves: a four-way select of 32-bit words by a per-lane index is turned into an indexed load
+      // from a stack copy of the struct by the optimiser — scratch stores and a dependent scratch load per cost element on the
+      // 64-agent tile; a two-way select and a 64-bit shift stay in registers)
+      struct AS { double px, py; int type, rank; uint32_t k0, k1; unsigned long long k23; };
       auto load_ts = [&](int sl, int jr) {
         TS t;
         const int fl = S.t_flags[sl];
@@ -2763,7 +2792,7 @@ struct Sim {
         if (fl & TF_DEADLINE) {
           int remaining = S.t_deadline[sl] - tnow;
           remaining = remaining > 0 ? remaining : 0;
-          t.urgency = 1.0 - fmin((double)remaining / 40.0, 1.0);
+          t.urgency = 1.0 - fmin(div40((double)remaining), 1.0);
         }
         t.missing = fmax(X.resid[sl], 1e-6);
         t.info = mode == 1 ? pair_info()[sl] : 0;
@@ -2774,19 +2803,18 @@ struct Sim {
         AS g;
         g.px = S.a_px[a]; g.py = S.a_py[a]; g.type = S.a_type[a];
         g.k0 = S.known[a][0]; g.k1 = KW > 1 ? S.known[a][KW > 1 ? 1 : 0] : 0u;
-        g.k2 = KW > 2 ? S.known[a][KW > 2 ? 2 : 0] : 0u; g.k3 = KW > 3 ? S.known[a][KW > 3 ? 3 : 0] : 0u;
+        g.k23 = (KW > 2 ? (unsigned long long)S.known[a][KW > 2 ? 2 : 0] : 0ull) | ((KW > 3 ? (unsigned long long)S.known[a][KW > 3 ? 3 : 0] : 0ull) << 32);
         g.rank = mode == 1 ? (int)X.live_rank[a] : 0;
         return g;
       };
-      auto pair_eval = [&](int a, const AS& g, int sl, const TS& t) -> double {  // == pair_cost(a, sl, jr)
+      auto pair_eval_cap = [&](const AS& g, int sl, const TS& t, double capv) -> double {  // == pair_cost(a, sl, jr); capv = S.a_caps[t.type][a]
         double c = 1e6;
-        uint32_t kword;
-        if constexpr (KW <= 2) kword = (sl >> 5) ? g.k1 : g.k0;
-        else { const int kw = sl >> 5; kword = kw == 0 ? g.k0 : kw == 1 ? g.k1 : kw == 2 ? g.k2 : g.k3; }
-        bool ok = !(vis && !((kword >> (sl & 31)) & 1u));
+        bool known;
+        if constexpr (KW <= 2) known = ((((sl >> 5) ? g.k1 : g.k0) >> (sl & 31)) & 1u) != 0;
+        else { const unsigned long long w = (sl & 64) ? g.k23 : ((unsigned long long)g.k0 | ((unsigned long long)g.k1 << 32)); known = ((w >> (sl & 63)) & 1ull) != 0; }
+        bool ok = !(vis && !known);
         if (ok && t.elig_on && !((t.elig >> g.type) & 1u)) ok = false;
         if (ok) {
-          const double capv = S.a_caps[t.type][a];
           const double delivered = t.esc_task ? 1.0 : capv;
           if (delivered > 0) {
             const double dist = norm2(g.px - t.px, g.py - t.py);
@@ -2814,6 +2842,7 @@ struct Sim {
         }
         return c;
       };
+      auto pair_eval = [&](int a, const AS& g, int sl, const TS& t) -> double { return pair_eval_cap(g, sl, t, S.a_caps[t.type][a]); };
       bool feasible = false;
       CostCol col;
       // REGC: one LSAP column per lane with its costs in registers, whenever the columns fit the wave (always on the 16- and
@@ -2825,26 +2854,71 @@ struct Sim {
         // side (task or agent fields) is read from LDS ONCE per lane, the row's side is the same for every lane (broadcast
         // reads, issued together), so an iteration costs one LDS round trip instead of a chain of six.  Same arithmetic.
         const bool incol = lane < Cc;
+        if constexpr (A > 32) {
+          // The 64-agent tile runs one wave per SIMD: what a row costs is its dependent chain, not its instruction count.  Lane r
+          // fetches ROW r's operands up front (every row at once, one LDS round trip), and the row loop broadcasts them with
+          // v_readlane: no LDS access on the loop's chain, two rows in flight.  Same arithmetic as pair_cost().
+          auto pack = [](const TS& t) { return t.type | (t.elig_on ? 8 : 0) | (t.esc_task ? 16 : 0) | (t.esc_flag ? 32 : 0) | (int)(t.elig << 8); };
+          if (!tr) {  // rows = free agents, lane = task column
+            const int my_s = incol ? (int)S.open_slot[X.roundT[lane]] : (int)S.open_slot[X.roundT[0]];
+            const TS ts = load_ts(my_s, incol ? lane : 0);
+            const int ra = X.freeA[lane < Rr ? lane : 0];
+            const AS gr = load_as(ra);
+            const int rpk = gr.type | (gr.rank << 8);
+            build_cols(col, Rr, [&](int i) -> double {
+              AS g;
+              const int a = __builtin_amdgcn_readlane(ra, i), pk = __builtin_amdgcn_readlane(rpk, i);
+              g.px = readlane_f64(gr.px, i); g.py = readlane_f64(gr.py, i); g.type = pk & 255; g.rank = pk >> 8;
+              g.k0 = __builtin_amdgcn_readlane(gr.k0, i); g.k1 = __builtin_amdgcn_readlane(gr.k1, i);
+              g.k23 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gr.k23, i) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gr.k23 >> 32), i) << 32);
+              double c = 0.0;
+              if (incol) { c = pair_eval_cap(g, my_s, ts, S.a_caps[ts.type][a]); feasible |= c < 1e5 / 2; }
+              return c;
+            });
+          } else {  // rows = round tasks, lane = free-agent column
+            const int my_a = incol ? X.freeA[lane] : X.freeA[0];
+            const AS g = load_as(my_a);
+            typedef double caps_vec __attribute__((ext_vector_type(8)));
+            caps_vec mycaps;
+#pragma unroll
+            for (int c6 = 0; c6 < 6; c6++) mycaps[c6] = S.a_caps[c6][my_a];
+            const int rj = lane < Rr ? lane : 0;
+            const int rsl = S.open_slot[X.roundT[rj]];
+            const TS tr_ = load_ts(rsl, rj);
+            const int rpk = pack(tr_);
+            build_cols(col, Rr, [&](int i) -> double {
+              TS t;
+              const int sl = __builtin_amdgcn_readlane(rsl, i), pk = __builtin_amdgcn_readlane(rpk, i);
+              t.px = readlane_f64(tr_.px, i); t.py = readlane_f64(tr_.py, i); t.urgency = readlane_f64(tr_.urgency, i);
+              t.missing = readlane_f64(tr_.missing, i); t.press = mode == 2 ? readlane_f64(tr_.press, i) : 0.0;
+              t.info = mode == 1 ? __builtin_amdgcn_readlane(tr_.info, i) : 0;
+              t.type = pk & 7; t.elig_on = (pk & 8) != 0; t.esc_task = (pk & 16) != 0; t.esc_flag = (pk & 32) != 0; t.elig = (uint32_t)pk >> 8;
+              double c = 0.0;
+              if (incol) { c = pair_eval_cap(g, sl, t, mycaps[t.type]); feasible |= c < 1e5 / 2; }
+              return c;
+            });
+          }
+        } else
         if (!tr) {
           const int my_s = incol ? (int)S.open_slot[X.roundT[lane]] : (int)S.open_slot[X.roundT[0]];
           const TS ts = load_ts(my_s, incol ? lane : 0);
-          for (int i = 0; i < Rr; i++) {
+          build_cols(col, Rr, [&](int i) -> double {
             const int a = X.freeA[i];
             const AS g = load_as(a);
             double c = 0.0;
             if (incol) { c = pair_eval(a, g, my_s, ts); feasible |= c < 1e5 / 2; }
-            col.set(i, c);
-          }
+            return c;
+          });
         } else {
           const int my_a = incol ? X.freeA[lane] : X.freeA[0];
           const AS g = load_as(my_a);
-          for (int i = 0; i < Rr; i++) {
+          build_cols(col, Rr, [&](int i) -> double {
             const int sl = S.open_slot[X.roundT[i]];
             const TS ts = load_ts(sl, i);
             double c = 0.0;
             if (incol) { c = pair_eval(my_a, g, sl, ts); feasible |= c < 1e5 / 2; }
-            col.set(i, c);
-          }
+            return c;
+          });
         }
       } else {
         for (int p = lane; p < nr * nc; p += WG) {  // one (agent, task) pair per lane
@@ -2933,7 +3007,7 @@ struct Sim {
     if (!(S.t_flags[s] & TF_DEADLINE)) return 0.0;
     int remaining = S.t_deadline[s] - tnow;
     remaining = remaining > 0 ? remaining : 0;
-    return 1.0 - fmin((double)remaining / 40.0, 1.0);
+    return 1.0 - fmin(div40((double)remaining), 1.0);
   }
   DEV void threat_stats(int s, double& pressure, double& dist_n, double& fighter_pressure) const {  // AttentionEscort.py:46-66
     const int pa = S.t_prot_agent[s];
@@ -3340,9 +3414,21 @@ struct Sim {
       else { if (i < 16) v0[i] = c; else if (i < 32) v1[i - 16] = c; else if (i < 48) v2[i - 32] = c; else v3[i - 48] = c; }
     }
   };
+  // col[i] = cost(i) for the rows i < n of a column, one register tuple per loop: a loop that picks the tuple by a branch on i
+  // makes the register allocator copy a whole tuple around every indexed write (8-16 v_mov_b64 per row on the larger tiles)
+  template <class RowCost>
+  DEV void build_cols(CostCol& col, int n_, RowCost cost) {
+    const int n = __builtin_amdgcn_readfirstlane(n_);
+    for (int i = 0; i < (n < 16 ? n : 16); i++) col.v0[i] = cost(i);
+    if constexpr (A > 16) for (int i = 16; i < (n < 32 ? n : 32); i++) col.v1[i - 16] = cost(i);
+    if constexpr (A > 32) {
+      for (int i = 32; i < (n < 48 ? n : 48); i++) col.v2[i - 32] = cost(i);
+      for (int i = 48; i < n; i++) col.v3[i - 48] = cost(i);
+    }
+  }
   DEV void lsap_reg(int nr, int nc) {  // cost tile staged in X.cost (R x C row-major), nr <= nc <= 64
     CostCol col;
-    for (int i = 0; i < nr; i++) col.set(i, lane < nc ? X.cost[i * nc + lane] : 0.0);
+    build_cols(col, nr, [&](int i) -> double { return lane < nc ? X.cost[i * nc + lane] : 0.0; });
     lsap_reg_solve(nr, nc, [&](int i) -> double { return col.get(i); });
   }
   // scipy.optimize.linear_sum_assignment (rectangular_lsap.cpp) with the search state in REGISTERS, nr <= nc <= 64: lane j owns
@@ -3364,6 +3450,10 @@ struct Sim {
     int c4r = -1, r4c = -1;  // lane r: col4row[r];  lane j: row4col[j]
     const bool incol = lane < nc;
     unsigned long long unassigned = nc >= 64 ? ~0ull : ((1ull << nc) - 1ull);  // uniform: columns j with row4col[j] == -1
+    PROF_COUNT(48, 1000); PROF_COUNT(50, 1000 * nr); PROF_COUNT(51, 1000 * nc);
+#ifdef MUAVTA_PROF
+    int prof_iters = 0;
+#endif
     for (int cur = 0; cur < nr; cur++) {
       int pos = nc - 1 - lane;  // scipy fills `remaining` in reverse: column j sits at position nc-1-j
       double sp = INF;
@@ -3373,6 +3463,9 @@ struct Sim {
       double minVal = 0;
       int i = cur, nrem = nc, sink = -1;
       while (sink == -1) {
+#ifdef MUAVTA_PROF
+        prof_iters++;
+#endif
         SRmask |= 1ull << i;
         const double ui = readlane_f64(u_r, i);
         const double r = minVal + cost_row(i) - ui - vj;
@@ -3435,6 +3528,7 @@ struct Sim {
     }
     if (lane < nr) X.col4row[lane] = c4r;
     if (incol) X.row4col[lane] = r4c;
+    PROF_COUNT(49, 1000 * prof_iters);
     lds_sync();
   }
 

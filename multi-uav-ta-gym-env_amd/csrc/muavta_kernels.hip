@@ -288,7 +288,7 @@ __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp
 // base as a number and rebuilds typed pointers.  An iteration is  step -> observation write -> NEXT step's allocate:
 // the function's return waits for all memory operations, and this way the observation stores have drained by then.
 #ifdef MUAVTA_PROF
-#define PROF_AT(sim, i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); (sim).prof_lds()[i] += t_ - (sim).prof_lds()[48]; (sim).prof_lds()[48] = t_; } } while (0)
+#define PROF_AT(sim, i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); (sim).prof_lds()[i] += t_ - (sim).prof_lds()[PROF_N]; (sim).prof_lds()[PROF_N] = t_; } } while (0)
 #define PROF_EXTRA_LDS MUAVTA_PROF_LDS_BYTES
 #else
 #define PROF_AT(sim, i) do { } while (0)
@@ -1346,8 +1346,8 @@ int muavta_diag_times(MuavtaEnv* e, uint32_t* out, int32_t n) {  // diagnostic b
 #endif
 #ifdef MUAVTA_PROF
 int muavta_prof_read(unsigned long long* out, int reset) {  // diagnostic build only
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), 48 * sizeof(unsigned long long)) != hipSuccess) return MUAVTA_E_HIP;
-  if (reset) { unsigned long long z[48] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return MUAVTA_E_HIP; }
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), PROF_N * sizeof(unsigned long long)) != hipSuccess) return MUAVTA_E_HIP;
+  if (reset) { unsigned long long z[PROF_N] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return MUAVTA_E_HIP; }
   return MUAVTA_OK;
 }
 #endif

@@ -20,7 +20,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 interval = 12 if "escort" in case else 20
 env = BatchedMultiUAVEnv(params_for_case(case), n)
 L = native.lib()
-buf = (C.c_ulonglong * 48)()
+buf = (C.c_ulonglong * 64)()
 env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, True); env.sync()
 L.muavta_prof_read(buf, 1)
 env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, True); env.sync()
@@ -29,10 +29,19 @@ names = {0: "(loop gap)", 1: "rng_refill", 2: "drain+release", 3: "actions", 4: 
          7: "sense", 8: "serial_c reveals/expire/reward", 9: "finish gc+open", 10: "(pre-alloc)", 11: "alloc gate", 12: "cost build",
          13: "lsap", 14: "accept", 15: "(pre-obs)", 16: "obs rows->LDS", 17: "obs rows stream", 18: "obs legal->LDS", 19: "obs legal stream", 20: "obs agents/flags/result", 21: "b: np.sum + penalty terms", 22: "b: generate_threat", 23: "b: threats parallel", 24: "b: threats serial replay", 25: "b: arrivals", 6: "b: escorts+sync", 26: "move: parallel pass", 4: "move: serial replay", 28: "c: prechecks", 29: "c: lists", 8: "c: serial_c (reward)", 32: "c: ballots", 33: "actions: precompute", 3: "actions: serial_a", 34: "move: compute (in 26)", 35: "finish: gc loop (slow path)", 36: "c: serial_c head", 37: "c: serial_c weighted sum", 38: "c: serial_c divisions", 30: "(count x1000) end-of-step slow path entered", 31: "(count x1000) ... with retired slots present", 40: "(count x1000) movement passes", 41: "(count x1000) movement events", 39: "reset: (entry)", 42: "reset: master init_by_array", 43: "reset: agent stream twist+tape", 44: "reset: seed draws + 2-3 init_by_array (parallel lanes)", 45: "reset: tgt/mission streams twist+tape", 46: "reset: zero blob", 47: "reset: serial entity creation"}
 v = np.array(list(buf), dtype=np.float64)
-tot = v.sum()
+counts = v[48:].copy()
+v = v[:48]
+for i in (30, 31, 40, 41):  # event counters that live among the cycle slots
+    counts = np.append(counts, v[i]); v[i] = 0
 v[10] = 0  # (pre-alloc) only holds the first stamp's absolute clock
 tot = v.sum()
 print(f"{case} n={n}: kernel {env.last_kernel_ms():.2f} ms; cycles/env-step (lane 0) {tot / n / 150:.0f} (each stamp costs ~500 cycles of s_memtime latency)")
 for i in range(48):
     if v[i] == 0: continue
     print(f"  {str(names.get(i, i)):40s} {100 * v[i] / tot:6.2f} %   {v[i] / n / 150:9.0f} cyc/step")
+cnames = ["LSAP solves", "LSAP scan steps (inner iterations)", "LSAP rows (sum)", "LSAP columns (sum)", "replans (allocate ran)", "releaseAllTasks calls",
+          "threat passes", "threat events (serial replays)", "escort syncs with entries", "escort map entries (sum)", "escort sync loop iterations", "", "", "", "", "",
+          "end-of-step slow path entered", "... with retired slots present", "movement passes", "movement events"]
+print("  per env-step event counts:")
+for nm, c in zip(cnames, counts):
+    if nm and c: print(f"    {nm:40s} {c / 1000 / n / 150:8.3f}")
