@@ -97,6 +97,7 @@ struct alignas(16) Scratch {
   int16_t path[T], col4row[A], row4col[T], remaining[T], freeA[A], roundT[T];
   uint8_t SR[A], SC[T];
   uint8_t live_rank[A];                  // Urgency-Pair: rank of an agent among the live ones (255 = beyond the token pad)
+  int32_t retarget_h;                    // threat whose get_closest_agent() the serial replay of its engagement left to the wave (-1: none)
   int16_t pair_info_big[T > 64 ? T : 1]; // Urgency-Pair per-slot (rank, n_know) when `remaining` is busy (LDS LSAP, T > 64)
 };
 
@@ -305,13 +306,23 @@ struct Sim {
       const uint4 c = *reinterpret_cast<const uint4*>(&S.rng_idx[0]);
       if ((c.x & 0xffffu) < 624u && (c.y & 0xffffu) < 624u && (c.z & 0xffffu) < 624u && (c.w & 0xffffu) < 624u) return;
     }
+    rng_refill_slow(tape, (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)&S.rng_idx[0]);
+  }
+  // The regeneration itself, OUT OF LINE: a stream consumes a 624-word block only in long or busy episodes, but inlined into the
+  // step loop its per-lane tape addresses (eleven 64-bit values) were computed at the top of EVERY step and spilled to scratch
+  // on the 24-agent tile.  Takes the tape pointer and the LDS address of S.rng_idx by value (no `this`: a Sim whose address
+  // escapes to a call would have to live in memory).
+  static __device__ __noinline__ void rng_refill_slow(uint32_t* tape_, uint32_t lds_rng_idx) {
+    uint32_t* tape = (uint32_t*)(__attribute__((address_space(1))) uint32_t*)tape_;
+    uint32_t* idx = (uint32_t*)(__attribute__((address_space(3))) uint32_t*)(uintptr_t)lds_rng_idx;
+    const int lane = threadIdx.x & (WG - 1);
     for (int st = 0; st < 4; st++) {
-      uint32_t p = S.rng_idx[st];
+      uint32_t p = idx[st];
       uint32_t blk = (p >> 16) & 1u, off = p & 0xffffu;
       if (off >= 624u) {  // block `blk` fully consumed: it becomes twist(other)
         uint32_t* base = tape + st * MUAVTA_RNG_WORDS;
         mt_twist(base + (blk ^ 1u) * 624u, base + blk * 624u);
-        if (lane == 0) S.rng_idx[st] = ((blk ^ 1u) << 16) | (off - 624u);
+        if (lane == 0) idx[st] = ((blk ^ 1u) << 16) | (off - 624u);
         __syncthreads();
       }
     }
@@ -939,6 +950,32 @@ struct Sim {
     fail(MUAVTA_ERR_POSITION);
     ox = 0; oy = 0;
   }
+  // get_closest_agent with one agent per lane (all lanes call it): the serial scan takes `d < min` strictly, i.e. the FIRST agent
+  // at the minimal distance — here the lowest lane among those equal to the wave-wide minimum.  On lane 0 the scan is a chain of
+  // n_agents LDS round trips and square roots (16,000 cycles per failed engagement on the 64-agent tile).
+  DEV int closest_agent_coop(double x, double y) {
+    const double INF = __builtin_huge_val();
+    const int a = lane < P.n_agents ? lane : 0;
+    const int st = S.a_state[a], ty = S.a_type[a];
+    const bool valid = lane < P.n_agents && st != -1 && st != 4;
+    const double d = norm2(S.a_px[a] - x, S.a_py[a] - y);
+    const bool fighter = is_fighter(ty);
+    const double dW = (valid && !fighter) ? d : INF;
+    const double mW = wave_min(dW);
+    if (__double2hiint(mW) != 0x7ff00000) return __ffsll((long long)__builtin_amdgcn_ballot_w64(dW == mW)) - 1;
+    const double dF = (valid && fighter) ? d : INF;
+    const double mF = wave_min(dF);
+    if (__double2hiint(mF) != 0x7ff00000) return __ffsll((long long)__builtin_amdgcn_ballot_w64(dF == mF)) - 1;
+    return -1;
+  }
+  // the retarget an engagement replayed on lane 0 asked for (handle_threat_engagement): all lanes, uniform
+  DEV void resolve_retarget() {
+    const int h = __builtin_amdgcn_readfirstlane(X.retarget_h);
+    if (h < 0) return;
+    const int tgt = closest_agent_coop(S.h_px[h], S.h_py[h]);
+    if (lane == 0) { S.h_target[h] = tgt; S.h_mission[h] = tgt; X.retarget_h = -1; }
+    lds_sync();
+  }
   DEV int closest_agent(double x, double y) const {  // get_closest_agent (:1691-1723)
     double minF = __builtin_huge_val(), minW = __builtin_huge_val();
     int cF = -1, cW = -1;
@@ -1213,6 +1250,7 @@ struct Sim {
     {  // update_threats (:1725-1744): lanes advance every threat up to the first one that engages or leaves the area,
        // lane 0 plays that one as the reference does, and the wave resumes behind it
       unsigned long long livemask = 0ull;
+      if (lane == 0) X.retarget_h = -1;  // (scratch: set before any replay of this phase can post a request, read behind an lds_sync)
       if (!P.escort_enabled) {
         // Without escorts a threat's turn reads nothing another threat's turn writes (own record, own Int task, agent POSITIONS —
         // an engagement changes agents' states and queues, which only _retarget_threat_via_escort looks at): one pass decides
@@ -1224,9 +1262,11 @@ struct Sim {
         PROF_COUNT(54, 1000);
         if (em) {
           PROF_COUNT(55, 1000 * __popcll(em));
-          if (lane == 0)
-            for (unsigned long long m = em; m; m &= m - 1ull) update_threats_serial(__ffsll((long long)m) - 1, livemask);
-          lds_sync();
+          for (unsigned long long m = em; m; m &= m - 1ull) {
+            if (lane == 0) update_threats_serial(__ffsll((long long)m) - 1, livemask);
+            lds_sync();
+            resolve_retarget();
+          }
         }
       } else
       for (int start = 0;;) {
@@ -1238,6 +1278,7 @@ struct Sim {
         PROF_COUNT(55, 1000);
         if (lane == 0) update_threats_serial(first, livemask);
         lds_sync();
+        resolve_retarget();
         start = first + 1;
       }
       if (lane == 0) step_serial_b2();
@@ -1929,9 +1970,8 @@ struct Sim {
         S.h_status[h] = 0;
         threat_task_retire(h, false);
       } else {
-        int tgt = closest_agent(S.h_px[h], S.h_py[h]);
-        S.h_target[h] = tgt;
-        S.h_mission[h] = tgt;
+        X.retarget_h = h;  // threat.target = threat.mission_target = get_closest_agent(position): left to the whole wave (resolve_retarget),
+                           // nothing reads either field before the caller gets there
       }
     }
   }
@@ -3459,7 +3499,7 @@ struct Sim {
       double sp = INF;
       int pth = -1;
       bool active = incol;
-      unsigned long long SRmask = 0ull, SCmask = 0ull;
+      unsigned long long SRmask = 0ull;
       double minVal = 0;
       int i = cur, nrem = nc, sink = -1;
       while (sink == -1) {
@@ -3501,19 +3541,19 @@ struct Sim {
         }
         minVal = m;
         const int psel = __builtin_amdgcn_readlane(pos, sel);
-        SCmask |= 1ull << sel;
         if (pos == nrem - 1) pos = psel;  // remaining[index] = remaining[--num_remaining]
         if (lane == sel) active = false;
         nrem--;
         if (equ) sink = sel; else i = __builtin_amdgcn_readlane(r4c, sel);  // an unassigned column ends the search
       }
-      // dual updates (u over the scanned rows, v over the scanned columns)
-      const double spc_of_my_col = __shfl(sp, c4r < 0 ? 0 : c4r);  // rows in SR other than cur are assigned
-      if (lane < nr) {
-        if (lane == cur) u_r += minVal;
-        else if ((SRmask >> lane) & 1ull) u_r += minVal - spc_of_my_col;
+      // dual updates (u over the scanned rows, v over the scanned columns = the ones that left `remaining`)
+      const unsigned long long others = SRmask & ~(1ull << cur);
+      if (others) {  // (uniform) most searches end in their first row: no other row was scanned, nothing to gather
+        const double spc_of_my_col = __shfl(sp, c4r < 0 ? 0 : c4r);  // rows in SR other than cur are assigned
+        if ((others >> lane) & 1ull) u_r += minVal - spc_of_my_col;
       }
-      if (incol && ((SCmask >> lane) & 1ull)) vj -= minVal - sp;
+      if (lane == cur) u_r += minVal;
+      if (incol && !active) vj -= minVal - sp;
       // augmentation along `path` (uniform walk)
       unassigned &= ~(1ull << sink);
       int jj = sink;

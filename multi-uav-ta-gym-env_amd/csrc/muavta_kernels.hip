@@ -104,6 +104,17 @@ struct Lds {
 };
 
 #define smem muavta_smem
+#ifdef MUAVTA_PROF
+#define PROF_AT(sim, i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); (sim).prof_lds()[i] += t_ - (sim).prof_lds()[PROF_N]; (sim).prof_lds()[PROF_N] = t_; } } while (0)
+#define PROF_EXTRA_LDS MUAVTA_PROF_LDS_BYTES
+#else
+#define PROF_AT(sim, i) do { } while (0)
+#define PROF_EXTRA_LDS 0
+#endif
+// The fused kernels own a STATIC LDS block of their tile's size: its address is a compile-time constant (0), so LDS addresses
+// fold into the ds_* offset fields.  With the dynamic `extern __shared__` array every address was formed as `0 + x` at run
+// time (v_add_u32 v, 0, v / s_add_i32 s, 0, imm: 2 % of the kernel's VALU instructions).  They are launched with no dynamic LDS.
+#define KERNEL_LDS(TL) __shared__ __align__(16) unsigned char lds_own[Lds<TL>::bytes() + PROF_EXTRA_LDS]
 // Residency on a CU is bound by LDS bytes per env (160 KiB per CU, 1 KiB granule): 16 envs of the 16-agent tile
 // (BASELINE configs 2 and 3: 4096 envs = 16 per CU, one round) need <= 10 KiB each.
 static_assert(Lds<Tile16>::bytes() <= 10240, "Tile16 no longer fits 16 workgroups per CU");
@@ -229,7 +240,8 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_step(const DevCtx* _
   const DevCtx& ctx = ctx_ref(ctxp);
   const DevParams& P = ctx.P;
   const int env = blockIdx.x;
-  Lds<TL> L(smem);
+  KERNEL_LDS(TL);
+  Lds<TL> L(lds_own);
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
   copy16(L.S, blob, sizeof(EnvState<TL>));
   lds_sync();
@@ -287,13 +299,6 @@ __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp
 // reference becomes a load from the dynamic-LDS offset table) nor take generic pointers (FLAT accesses): it gets the LDS
 // base as a number and rebuilds typed pointers.  An iteration is  step -> observation write -> NEXT step's allocate:
 // the function's return waits for all memory operations, and this way the observation stores have drained by then.
-#ifdef MUAVTA_PROF
-#define PROF_AT(sim, i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); (sim).prof_lds()[i] += t_ - (sim).prof_lds()[PROF_N]; (sim).prof_lds()[PROF_N] = t_; } } while (0)
-#define PROF_EXTRA_LDS MUAVTA_PROF_LDS_BYTES
-#else
-#define PROF_AT(sim, i) do { } while (0)
-#define PROF_EXTRA_LDS 0
-#endif
 #ifndef MUAVTA_PHASE_ATTR
 #define MUAVTA_PHASE_ATTR __forceinline__
 #define MUAVTA_PHASE_INLINED 1  // the body sees the kernel's own `smem`: LDS addresses fold to constants + lane offsets
@@ -319,12 +324,12 @@ __device__ __forceinline__ typename Sim<TL>::TokPtrs global_tok_ptrs(typename Si
   return K;
 }
 template <class TL, bool REC>
-__device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, uint32_t lds_base, int phases, int interval, int use_vis, int mode,
+__device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned char* lds_own, uint32_t lds_base, int phases, int interval, int use_vis, int mode,
                                                 const RecordPtrs<TL>& rec, int slot, int oslot) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
 #if MUAVTA_PHASE_INLINED
-  Lds<TL> L(smem);
+  Lds<TL> L(lds_own);
 #else
   Lds<TL> L((unsigned char*)(AS3 unsigned char*)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base));
 #endif
@@ -361,7 +366,8 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
                                                 int mode, int write_obs, double* metrics, const uint32_t* seedbuf, RecordPtrs<TL> rec, int epoch) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const int env = blockIdx.x;
-  Lds<TL> L(smem);
+  KERNEL_LDS(TL);
+  Lds<TL> L(lds_own);
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
 #if MUAVTA_PACE_PRIO
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
     copy16(L.S, blob, sizeof(EnvState<TL>));
     lds_sync();
   }
-  uint32_t lds_base = (uint32_t)(uintptr_t)(AS3 unsigned char*)smem;
+  uint32_t lds_base = (uint32_t)(uintptr_t)(AS3 unsigned char*)lds_own;
 #if !MUAVTA_PHASE_INLINED
   asm volatile("" : "+v"(lds_base));  // opaque: keeps constant propagation from re-introducing the symbol into the callee
 #endif
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
       if (threadIdx.x < 16) seen = __hip_atomic_load(pace_row + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
-    if (ph) rollout_phase<TL, REC>(ctxp, lds_base, ph, interval, use_vis, mode, rec, k < n_steps ? k : n_steps,
+    if (ph) rollout_phase<TL, REC>(ctxp, lds_own, lds_base, ph, interval, use_vis, mode, rec, k < n_steps ? k : n_steps,
                                    (REC && rec.O.tasks && k >= 1 && k <= n_steps) ? k - 1 : -1);
 #if MUAVTA_PACE_PRIO
     if (PACED && k >= 1 && k <= n_steps) {  // consumed a step later: the load's latency stays off the env's dependent chain
@@ -1220,7 +1226,7 @@ static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
     da = e->d_act_agent; di = e->d_act_index;
   }
   if (e->d_rel) HIPCHK(e, hipMemsetAsync(e->d_rel, 0, (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double), e->stream));
-  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, da, di, e->A, e->d_rel));
+  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), 0, e->stream, (const DevCtx*)e->d_ctx, da, di, e->A, e->d_rel));  // (static LDS)
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   return MUAVTA_OK;
@@ -1282,10 +1288,10 @@ static void launch_rollout(MuavtaEnv* e, const uint64_t* ds, int n_steps, int in
       R.O.flags = rec->obs_flags; R.O.reward = rec->obs_reward; R.O.done = rec->obs_done;
     }
     R.n_envs = e->n_envs;
-    hipLaunchKernelGGL((k_rollout<TL, true>), dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds + PROF_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, ds,
+    hipLaunchKernelGGL((k_rollout<TL, true>), dim3(e->n_envs), dim3(WG), extra_lds, e->stream, (const DevCtx*)e->d_ctx, ds,
                        n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch);
   } else {
-    hipLaunchKernelGGL((k_rollout<TL, false>), dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + extra_lds + PROF_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, ds,
+    hipLaunchKernelGGL((k_rollout<TL, false>), dim3(e->n_envs), dim3(WG), extra_lds, e->stream, (const DevCtx*)e->d_ctx, ds,
                        n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch);
   }
 }
