@@ -722,6 +722,46 @@ struct Sim {
     }
     return n;
   }
+  // closest_escort() for ONE PROTECTED UAV PER LANE (`need` / `prot` vary by lane; all lanes call it).  The serial form walks the
+  // escort map and then the whole fleet per call — per threat lane that was n_agents LDS round trips and a square root whenever
+  // any lane's filter passed.  Here lane k holds map entry k and lane a holds agent a; both are broadcast with v_readlane in
+  // uniform loops, and the distance is only evaluated for an agent that heads some needed escort task.  Same arithmetic, same
+  // order (agents ascending: the FIRST at the minimal distance wins).
+  DEV void closest_escort_lanes(bool need, int prot, double radius, int& best, int& count) {
+    best = -1; count = 0;
+    if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;
+    const int ne = __builtin_amdgcn_readfirstlane(S.n_escorts), nA = P.n_agents;
+    int eid = -1;  // the live escort task of this lane's protected UAV (escort_lookup + ref_retired)
+    {
+      const int ke = lane < ne ? lane : 0;
+      const int ea = lane < ne ? (int)S.esc_agent[ke] : -1, ei = S.esc_id[ke], es = S.esc_slot[ke];
+      const int elive = (lane < ne && !ref_retired(ei, es)) ? ei : -1;
+      bool found = false;
+      for (int k = 0; k < ne; k++) {
+        const int ak = __builtin_amdgcn_readlane(ea, k), ik = __builtin_amdgcn_readlane(elive, k);
+        if (need && !found && prot == ak) { eid = ik; found = true; }
+      }
+    }
+    const bool want = need && eid >= 0;
+    if (__builtin_amdgcn_ballot_w64(want) == 0ull) return;
+    const int fa = lane < nA ? lane : 0;
+    const bool fok = lane < nA && S.a_state[fa] != -1 && escort_type(S.a_type[fa]) && S.a_qlen[fa] > 0;
+    const int fhead = fok ? (int)S.a_qid[fa][0] : -1;
+    const double fx = S.a_px[fa], fy = S.a_py[fa];
+    const double px = S.a_px[prot], py = S.a_py[prot];
+    double bd = 0;
+    for (int a = 0; a < nA; a++) {
+      const int ha = __builtin_amdgcn_readlane(fhead, a);
+      if (ha < 0) continue;
+      const bool mt = want && eid == ha;
+      if (__builtin_amdgcn_ballot_w64(mt) == 0ull) continue;
+      const double d = norm2(readlane_f64(fx, a) - px, readlane_f64(fy, a) - py);
+      if (mt && d <= radius) {
+        if (count == 0 || d < bd) { bd = d; best = a; }
+        count++;
+      }
+    }
+  }
   DEV int closest_escort(int prot, double radius, int* count) {  // first element + count of the list above
     int k = escort_lookup(prot);
     *count = 0;
@@ -823,33 +863,33 @@ struct Sim {
         qs().a_nft[a] = (double)tnow; qs().a_nfx[a] = S.a_px[a]; qs().a_nfy[a] = S.a_py[a];
         S.a_commit[a] = 0;
       }
+      // Task side: who dropped which slot travels through per-slot agent masks in the scratch tile (LDS atomics), and a slot
+      // lane walks only the agents that dropped IT, in ascending order — not every busy agent's HQ dropped entries (r2: 2 x HQ
+      // v_readlane + compares per busy agent and pass, ~600 VALU per call on the 24-agent tile).
+      typedef typename BucketMask<A>::type DropMask;
+      DropMask* dropm = reinterpret_cast<DropMask*>(X.cost);
+      static_assert(sizeof(DropMask) * T <= sizeof(double) * Scratch<TL>::COSTN, "drop masks overflow the scratch cost tile");
+      for (int sl = lane; sl < T; sl += WG) dropm[sl] = 0;
+      lds_sync();
+#pragma unroll
+      for (int i = 0; i < HQ; i++)
+        if (rsl[i] >= 0 && S.t_id[rsl[i]] == rid[i]) atomicOr(&dropm[rsl[i]], (DropMask)1 << a);  // (a live reference: the slot still holds that id)
+      lds_sync();
       for (int base = 0; base < T; base += WG) {
         const int sl = base + lane;
-        const bool live_slot = sl < T && S.t_id[sl] >= 0 && S.t_status[sl] != 2;  // removeAgentCap ignores concluded tasks
-        const int my_id = sl < T ? S.t_id[sl] : -1;
-        double al[6];
-        int nd = 0;
-        bool touched = false;
-        for (unsigned long long m = bm; m; m &= m - 1ull) {
-          const int b = __ffsll((long long)m) - 1;
-          bool hit = false;
+        DropMask m = sl < T ? dropm[sl] : (DropMask)0;
+        if (m != 0 && S.t_status[sl] == 2) m = 0;  // removeAgentCap ignores concluded tasks
+        if (m != 0) {
+          double al[6];
 #pragma unroll
-          for (int i = 0; i < HQ; i++) {
-            const int bs = __builtin_amdgcn_readlane(rsl[i], b), bi = __builtin_amdgcn_readlane(rid[i], b);
-            hit |= live_slot && bs == sl && bi == my_id;
-          }
-          if (hit) {
-            if (!touched) {
-#pragma unroll
-              for (int c = 0; c < 6; c++) al[c] = C.t_alloc[c][sl];
-              touched = true;
-            }
+          for (int c = 0; c < 6; c++) al[c] = C.t_alloc[c][sl];
+          int nd = 0;
+          for (; m != 0; m &= m - 1) {
+            const int b = (sizeof(DropMask) > 4 ? __ffsll((long long)m) : __ffs((int)m)) - 1;
 #pragma unroll
             for (int c = 0; c < 6; c++) al[c] -= S.a_caps[c][b];
             nd++;
           }
-        }
-        if (touched) {
 #pragma unroll
           for (int c = 0; c < 6; c++) C.t_alloc[c][sl] = al[c];
           S.t_ndet[sl] -= nd;
@@ -1476,9 +1516,12 @@ struct Sim {
     const int k = lane;
     const bool mine = k < n_act;
     const int a = mine ? S.act_agent[k] : -1, s = mine ? S.act_slot[k] : -1;
-    {  // uniform bail-outs: a terminator inside the list, or an agent named twice
+    {  // uniform bail-outs: a terminator inside the list, or an agent named twice — every lane leaves its action number in its
+       // agent's cell of a scratch row: where two lanes name one agent, at least one of them reads back the other's number
       bool bad = mine && a < 0;
-      for (int q = 0; q < n_act; q++) bad |= mine && q < k && S.act_agent[q] == a;
+      if (mine && a >= 0) X.SR[a] = (uint8_t)k;
+      lds_sync();
+      bad |= mine && a >= 0 && X.SR[a] != (uint8_t)k;
       if (__ballot(bad) != 0ull) return false;
     }
     // ---- per-action part: own agent + read-only task data ----
@@ -1595,17 +1638,39 @@ struct Sim {
         if (lane == 0) create_escort_for(aj, sj);
       }
     }
-    // ---- rewards: the reference's additions, in its order (uniform loop, operands broadcast with v_readlane) ----
-    for (int j = 0; j < n_act; j++) {
-      const int c01 = __builtin_amdgcn_readlane(nq01, j), c23 = __builtin_amdgcn_readlane(nq23, j);
-      if (__builtin_amdgcn_readlane(n_pen, j) && c01 == 0) action_reward += -1;          // s < 0: nothing else happened
-      if (c01 >= 1) S_quality_reward += readlane_f64(q0, j);
-      if (c01 >= 2) S_quality_reward += readlane_f64(q1, j);
-      if (__builtin_amdgcn_readlane(nd0, j)) distance_reward += readlane_f64(d0, j);
-      if (__builtin_amdgcn_readlane(n_pen, j) && c01 != 0) action_reward += -1;          // invalid action (:878-880)
-      if (c23 >= 1) S_quality_reward += readlane_f64(q2, j);
-      if (c23 >= 2) S_quality_reward += readlane_f64(q3, j);
-      if (__builtin_amdgcn_readlane(nd1, j)) distance_reward += readlane_f64(d1, j);
+    // ---- rewards: the reference's additions, in its order.  Every lane parks its addends behind those of the lanes before it
+    // (counts by ballot + popcount) in two scratch rows; the sums are then plain left-to-right folds over the rows, read four
+    // at a time (uniform addresses: every lane folds the same numbers).  r2 replayed them with ~12 v_readlane per action.
+    // action_reward only ever receives -1 per penalty: -(count) is the same double whatever the order.
+    {
+      const unsigned long long below = (1ull << k) - 1ull;
+      const unsigned long long b1 = __builtin_amdgcn_ballot_w64(nq01 >= 1), b2 = __builtin_amdgcn_ballot_w64(nq01 >= 2),
+                               b3 = __builtin_amdgcn_ballot_w64(nq23 >= 1), b4 = __builtin_amdgcn_ballot_w64(nq23 >= 2),
+                               e1 = __builtin_amdgcn_ballot_w64(nd0 != 0), e2 = __builtin_amdgcn_ballot_w64(nd1 != 0);
+      double* qrow = X.cost;  // <= 4 per action (COSTN >= 4 * A)
+      double* drow = X.v;     // <= 2 per action (T >= 2 * A)
+      static_assert(T >= 2 * A, "distance addends need 2 * A scratch doubles");
+      int qo = __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below) + __popcll(b4 & below);
+      int dn = __popcll(e1 & below) + __popcll(e2 & below);
+      lds_sync();  // (the slot-side reads of the scratch rows above are done)
+      if (nq01 >= 1) qrow[qo++] = q0;
+      if (nq01 >= 2) qrow[qo++] = q1;
+      if (nq23 >= 1) qrow[qo++] = q2;
+      if (nq23 >= 2) qrow[qo++] = q3;
+      if (nd0) drow[dn++] = d0;
+      if (nd1) drow[dn++] = d1;
+      const int nQ = __popcll(b1) + __popcll(b2) + __popcll(b3) + __popcll(b4), nD = __popcll(e1) + __popcll(e2);
+      const int nP = __popcll(__builtin_amdgcn_ballot_w64(n_pen != 0));
+      lds_sync();
+      auto fold = [](double acc, const double* row, int n) {
+        int i = 0;
+        for (; i + 4 <= n; i += 4) { const double a0 = row[i], a1 = row[i + 1], a2 = row[i + 2], a3 = row[i + 3]; acc += a0; acc += a1; acc += a2; acc += a3; }
+        for (; i < n; i++) acc += row[i];
+        return acc;
+      };
+      S_quality_reward = fold(S_quality_reward, qrow, nQ);
+      distance_reward = fold(distance_reward, drow, nD);
+      for (int i = 0; i < nP; i++) action_reward += -1;
     }
     cold_sync();
     return true;
@@ -2002,21 +2067,24 @@ struct Sim {
     bool evt = false;
     double npx = 0, npy = 0;
     bool live_task = false;
+    if (P.escort_enabled) {  // _retarget_threat_via_escort (:1766-1779): reads agents only.  One protected UAV per threat lane,
+                             // the escort map and the fleet walked in uniform loops (closest_escort_lanes)
+      const int mission = hmis >= 0 ? hmis : tgt;
+      const int mi = mission >= 0 ? mission : 0;
+      const bool need = active && !(hst == 0 || tgt < 0) && mission >= 0 && S.a_state[mi] != -1 && is_recon(S.a_type[mi]);
+      int e0, cnt;
+      closest_escort_lanes(need, mi, P.escort_intercept_radius, e0, cnt);
+      if (need) {
+        if (cnt == 0) { tgt = mission; icpt = -1; }
+        else { tgt = e0; icpt = e0; }
+      }
+    }
     if (active) {
       const double speed = speed_of(hty);
       if (hst == 0 || tgt < 0) {
         npx = px + speed * 0.0;
         npy = py + speed * -1.0;
       } else {
-        if (P.escort_enabled) {  // _retarget_threat_via_escort (:1766-1779): reads agents only
-          int mission = hmis >= 0 ? hmis : tgt;
-          if (mission >= 0 && S.a_state[mission] != -1 && is_recon(S.a_type[mission])) {
-            int cnt;
-            int e0 = closest_escort(mission, P.escort_intercept_radius, &cnt);
-            if (cnt == 0) { tgt = mission; icpt = -1; }
-            else { tgt = e0; icpt = e0; }
-          }
-        }
         const double ax = S.a_px[tgt], ay = S.a_py[tgt];
         double dx = ax - px, dy = ay - py;
         norm_vector(dx, dy);
