@@ -189,14 +189,16 @@ def roofline(case, envs, n_agents_tile, kernel_ms):
 
 def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
     kernel_ms, seed_ms = [], []
-    for _ in range(warmup):
+    for w in range(warmup):
         env.rollout(seeds, HORIZON, interval, True, write_obs)
         env.sync()
-        seed_ms.append(env.last_seed_ms())  # k_seed on an idle GPU (in the timed loop it runs under the previous launch's tail)
+        if w or warmup == 1:  # (the very first call also allocates the seeding buffers)
+            seed_ms.append(env.last_seed_ms())  # k_seed on an idle GPU (in the timed loop it runs next to the previous launch)
     barrier()
     t0 = time.perf_counter()
     # launches are queued back to back (the library seeds launch i+1 on its own stream while launch i runs); the per-launch
-    # k_rollout durations come from the handle's ring of HIP event pairs, read every 64 launches and at the end
+    # k_rollout durations come from the handle's ring of 64 HIP event pairs.  Reading them back (an event query per launch, ~0.1 ms
+    # each) is bookkeeping, not work: it happens after the closing barrier, and inside the loop only when the ring would wrap.
     pending = 0
     for _ in range(steps):
         env.rollout(seeds, HORIZON, interval, True, write_obs)
@@ -204,13 +206,14 @@ def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
         if pending == 64:
             kernel_ms.extend(env.kernel_ms_history(pending).tolist())
             pending = 0
+    env.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
     if pending:
         kernel_ms.extend(env.kernel_ms_history(pending).tolist())
-    env.sync()
     if not seed_ms:
         seed_ms.append(env.last_seed_ms())
-    barrier()
-    return time.perf_counter() - t0, float(np.mean(kernel_ms)), float(np.mean(seed_ms))
+    return elapsed, float(np.mean(kernel_ms)), float(np.mean(seed_ms))
 
 
 def main():

@@ -136,15 +136,6 @@ static_assert(sizeof(EnvCold<Tile16>) % 16 == 0 && sizeof(EnvCold<Tile24>) % 16 
 // seeds every env's agent stream (Random(seed), DroneEnv.py:531-533) and draws the three stream seeds from it
 // (randint(0, 2^63-1) x 3, :535-538), then the obs / tgt / mission lanes seed theirs.  The reset kernels only load
 // the four 624-word states.  Layout: seedbuf [N][4][624] u32 (per-env block contiguous for the coalesced load there).
-#define SEED_LD 65  // LDS row stride in words: column c of row i sits in bank (i + c) % 32, so both the per-lane
-                    // recurrence (fixed c, running i) and the transposed write-out (fixed c per pass, 64 i's) are conflict-free
-DEV uint32_t seed_next32(const uint32_t* col, int& i) {  // i-th output of the first block after seeding (i < 227)
-  const uint32_t y = (col[i * SEED_LD] & 0x80000000u) | (col[(i + 1) * SEED_LD] & 0x7fffffffu);
-  uint32_t v = col[(i + 397) * SEED_LD] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
-  i++;
-  v ^= (v >> 11); v ^= (v << 7) & 0x9d2c5680u; v ^= (v << 15) & 0xefc60000u; v ^= (v >> 18);
-  return v;
-}
 // init_genrand(19650218), the key-independent half of init_by_array: a compile-time table read through the scalar cache
 struct GenrandTable {
   uint32_t v[624];
@@ -155,69 +146,93 @@ struct GenrandTable {
   }
 };
 __constant__ GenrandTable G_TAB = GenrandTable();
-// init_by_array(key[0..len)) into column `col` of the [624][SEED_LD] LDS tile (same recurrence as mt_seed).  len is 1 or 2
-// (seeds below / from 2^32): key[j] + j alternates k0, k1 + 1 for len 2 and is k0 for len 1.
-DEV void seed_column(uint32_t* col, uint32_t k0, uint32_t k1, int len) {
-  uint32_t prev = 19650218u;
+// init_by_array(key[0..len)) into this lane's 624 words of seedbuf (same recurrence as mt_seed).  len is 1 or 2 (seeds below /
+// from 2^32): key[j] + j alternates k0, k1 + 1 for len 2 and is k0 for len 1.  The kernel needs no LDS (r2 kept a [624][65]-word
+// tile: 162 KB, a whole CU's LDS, which is why k_seed could only start once the previous rollout had drained a CU): the first
+// loop's 624 words go through a scratch buffer in GLOBAL memory, 16 words (four 16-byte vectors) at a time in a lane-
+// interleaved layout [vector][lane] — every store / load instruction of the wave moves 1 KB of consecutive bytes — and the
+// second loop reads them back two chunks ahead of its dependent chain and writes the final state straight into the stream's
+// own 624 words (per-lane 64-byte runs: stores, nobody waits for them).  mt[0] is only ever read as the running `prev` (kept
+// in a register) and ends as 0x80000000; mt[1] is rewritten by the two wrap-around steps.
+typedef uint32_t seed_u4 __attribute__((ext_vector_type(4)));
+DEV void seed_stream(uint32_t* mt, seed_u4* tmp /* this wave's [156][64] vectors, already offset by the lane */, uint32_t k0, uint32_t k1, int len) {
+  seed_u4* mt4 = reinterpret_cast<seed_u4*>(mt);
+  uint32_t prev = 19650218u, m1 = 0;
   const uint32_t add_even = k0, add_odd = len == 2 ? k1 + 1u : k0;  // first loop step i uses j = (i - 1) % len
-#pragma unroll 32
-  for (int i = 1; i < 624; i++) {
-    prev = (G_TAB.v[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (((i - 1) & 1) ? add_odd : add_even);
-    col[i * SEED_LD] = prev;
-  }
-  col[0] = prev;
-  {  // 624th step of the first loop: i wrapped to 1 (mt[0] = mt[623]), j = 623 % len
-    prev = (col[SEED_LD] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (len == 2 ? add_odd : add_even);
-    col[SEED_LD] = prev;
-  }
-  int i = 2;
-  for (; i + 16 <= 624; i += 16) {
+  for (int base = 0; base < 624; base += 16) {  // first loop, i = 1 .. 623
     uint32_t m[16];
 #pragma unroll
-    for (int q = 0; q < 16; q++) m[q] = col[(i + q) * SEED_LD];
+    for (int q = 0; q < 16; q++) {
+      const int i = base + q;
+      if (i != 0) prev = (G_TAB.v[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + (((q - 1) & 1) ? add_odd : add_even);  // (i - 1) & 1 == (q - 1) & 1
+      m[q] = i != 0 ? prev : 0x80000000u;
+      if (i == 1) m1 = prev;
+    }
 #pragma unroll
-    for (int q = 0; q < 16; q++) { prev = (m[q] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)(i + q); m[q] = prev; }
-#pragma unroll
-    for (int q = 0; q < 16; q++) col[(i + q) * SEED_LD] = m[q];
+    for (int v = 0; v < 4; v++) tmp[(base / 4 + v) * WG] = seed_u4{m[4 * v], m[4 * v + 1], m[4 * v + 2], m[4 * v + 3]};
   }
-  for (; i < 624; i++) { prev = (col[i * SEED_LD] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i; col[i * SEED_LD] = prev; }
-  col[0] = prev;  // 623rd iteration of the second loop: i wrapped to 1 with mt[0] = mt[623]
-  prev = (col[SEED_LD] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
-  col[SEED_LD] = prev;
-  col[0] = 0x80000000u;
+  // 624th step of the first loop: i wrapped to 1 (mt[0] = mt[623]), j = 623 % len
+  prev = (m1 ^ ((prev ^ (prev >> 30)) * 1664525u)) + (len == 2 ? add_odd : add_even);
+  m1 = prev;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the chunks are read back below (same lane, same addresses)
+  seed_u4 n0[4], n1[4];  // the next two chunks, in flight
+#pragma unroll
+  for (int v = 0; v < 4; v++) { n0[v] = tmp[v * WG]; n1[v] = tmp[(4 + v) * WG]; }
+  for (int base = 0; base < 624; base += 16) {  // second loop, i = 2 .. 623
+    uint32_t m[16];
+#pragma unroll
+    for (int v = 0; v < 4; v++) { m[4 * v] = n0[v].x; m[4 * v + 1] = n0[v].y; m[4 * v + 2] = n0[v].z; m[4 * v + 3] = n0[v].w; n0[v] = n1[v]; }
+    if (base + 32 < 624) {
+#pragma unroll
+      for (int v = 0; v < 4; v++) n1[v] = tmp[((base + 32) / 4 + v) * WG];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int i = base + q;
+      if (i >= 2) { prev = (m[q] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i; m[q] = prev; }
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) mt4[base / 4 + v] = seed_u4{m[4 * v], m[4 * v + 1], m[4 * v + 2], m[4 * v + 3]};  // (chunk 0 carries mt[0] = 0x80000000 and a stale mt[1])
+  }
+  // 623rd iteration of the second loop: i wrapped to 1 with mt[0] = mt[623]
+  prev = (m1 ^ ((prev ^ (prev >> 30)) * 1566083941u)) - 1u;
+  mt[1] = prev;  // (after the chunk store above: stores of one lane to one address land in order)
 }
-// One workgroup = 16 envs x 4 streams, one lane each.  Phase 1: the agent-stream lanes run init_by_array(seed) and draw
-// the three stream seeds; phase 2: the obs / tgt / mission lanes run theirs.  Then the tile is written out transposed.
-__global__ __launch_bounds__(WG) void k_seed(const uint64_t* seeds, int n, int with_obs, uint32_t* seedbuf) {
-  uint32_t* tile = reinterpret_cast<uint32_t*>(smem);                       // [624][SEED_LD]
-  uint64_t* derived = reinterpret_cast<uint64_t*>(tile + 624 * SEED_LD);   // [16][3]
+// i-th output word of the first block after seeding (i < 227), from this lane's state in global memory
+DEV uint32_t seed_output(const uint32_t* mt, int i) {
+  const uint32_t y = (mt[i] & 0x80000000u) | (mt[i + 1] & 0x7fffffffu);
+  uint32_t v = mt[i + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+  v ^= (v >> 11); v ^= (v << 7) & 0x9d2c5680u; v ^= (v << 15) & 0xefc60000u; v ^= (v >> 18);
+  return v;
+}
+// One wave = 16 envs x 4 streams, one lane each.  Phase 1: the agent-stream lanes run init_by_array(seed) and draw the three
+// stream seeds (Random.randint(0, 2^63-1) == _randbelow(2^63): getrandbits(64) until < 2^63, in the order obs, tgt, mission,
+// DroneEnv.py:535-538); phase 2: the obs / tgt / mission lanes run theirs, the seeds handed over by a lane shuffle.  No LDS and
+// ~40 VGPRs: the waves find room next to a running rollout, so the seeding of the NEXT launch overlaps all of this one.
+__global__ __launch_bounds__(WG) void k_seed(const uint64_t* seeds, int n, int with_obs, uint32_t* seedbuf, uint32_t* seedtmp) {
   const int lane = threadIdx.x, el = lane >> 2, st = lane & 3;
   const int e = blockIdx.x * 16 + el;
-  uint32_t* col = tile + lane;
+  uint32_t* mt = seedbuf + ((size_t)blockIdx.x * WG + lane) * 624;  // [N][4][624]: this lane's stream
+  seed_u4* tmp = reinterpret_cast<seed_u4*>(seedtmp) + (size_t)blockIdx.x * 156 * WG + lane;  // this wave's [156][64] scratch vectors
+  unsigned long long d0 = 0, d1 = 0, d2 = 0;
   if (e < n && st == ST_AGENT) {
     const uint64_t seed = seeds[e];
-    seed_column(col, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1);
-    int i = 0;
-    for (int j = 0; j < 3; j++) {  // Random.randint(0, 2^63-1) == _randbelow(2^63): getrandbits(64) until < 2^63
-      uint64_t r;
-      do {
-        if (i > 220) { r = 0; break; }  // 110 rejections in a row
-        const uint64_t lo = seed_next32(col, i), hi = seed_next32(col, i);
-        r = lo | (hi << 32);
-      } while (r >= (1ull << 63));
-      derived[el * 3 + j] = r;  // drawn in the order obs, tgt, mission (DroneEnv.py:535-538)
+    seed_stream(mt, tmp, (uint32_t)seed, (uint32_t)(seed >> 32), (seed >> 32) ? 2 : 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int i = 0, j = 0;
+    while (j < 3 && i <= 220) {  // (110 rejections in a row: the three seeds stay 0)
+      const uint64_t lo = seed_output(mt, i), hi = seed_output(mt, i + 1);
+      i += 2;
+      const uint64_t r = lo | (hi << 32);
+      if (r < (1ull << 63)) { if (j == 0) d0 = r; else if (j == 1) d1 = r; else d2 = r; j++; }
     }
   }
-  __syncthreads();
+  // the agent lane of each env hands its draws to the env's other lanes
+  const int src = lane & ~3;
+  d0 = __shfl(d0, src); d1 = __shfl(d1, src); d2 = __shfl(d2, src);
   if (e < n && st != ST_AGENT && (st != ST_OBS || with_obs)) {
-    const uint64_t sd = derived[el * 3 + (st == ST_OBS ? 0 : st == ST_TGT ? 1 : 2)];
-    seed_column(col, (uint32_t)sd, (uint32_t)(sd >> 32), (sd >> 32) ? 2 : 1);
-  }
-  __syncthreads();
-  for (int c = 0; c < WG; c++) {  // column c -> seedbuf[(block * 64 + c)][0..624), 64 consecutive words per store
-    if (blockIdx.x * 16 + (c >> 2) >= n) break;
-    uint32_t* dst = seedbuf + ((size_t)blockIdx.x * WG + c) * 624;
-    for (int i = lane; i < 624; i += WG) dst[i] = tile[i * SEED_LD + c];
+    const uint64_t sd = st == ST_OBS ? d0 : st == ST_TGT ? d1 : d2;
+    seed_stream(mt, tmp, (uint32_t)sd, (uint32_t)(sd >> 32), (sd >> 32) ? 2 : 1);
   }
 }
 
@@ -674,8 +689,9 @@ struct MuavtaEnv {
   void* d_tok = nullptr;  // muavta_tokens staging (host-buffer variant)
   double* d_rel = nullptr;  // release log [N, 1 + MUAVTA_REL_ROW*T] (muavta_set_release_log)
   // Seeding pipeline: seeds upload + k_seed run on their own stream into one of two slots, so that the seeding of launch
-  // i+1 overlaps the tail of launch i (k_seed needs a whole CU's LDS: it moves into CUs as the rollout's envs finish).
+  // i+1 overlaps launch i (k_seed uses no LDS and few registers: its waves run next to the rollout's where a SIMD has room).
   uint32_t* d_seedbuf[2] = {nullptr, nullptr};  // [N][4][624] init_by_array states (k_seed)
+  uint32_t* d_seedtmp = nullptr;                // k_seed's lane-interleaved scratch
   uint64_t* h_seeds[2] = {nullptr, nullptr};    // pinned staging of the caller's seeds
   hipStream_t seed_stream = nullptr;
   hipEvent_t ev_seed0[2] = {nullptr, nullptr}, ev_seeded[2] = {nullptr, nullptr}, ev_consumed[2] = {nullptr, nullptr};
@@ -1144,7 +1160,7 @@ int muavta_destroy(MuavtaEnv* e) {
   DeviceScope scope_(e->device);
   if (e->seed_stream) hipStreamSynchronize(e->seed_stream);
   if (e->stream) hipStreamSynchronize(e->stream);
-  hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
+  if (e->d_seedtmp) hipFree(e->d_seedtmp); hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   for (int i = 0; i < MuavtaEnv::EV_RING; i++) { if (e->ev0[i]) hipEventDestroy(e->ev0[i]); if (e->ev1[i]) hipEventDestroy(e->ev1[i]); }
   for (int b = 0; b < 2; b++) {
@@ -1178,13 +1194,12 @@ static int enqueue_seeding(MuavtaEnv* e, const uint64_t* seeds, const uint64_t**
   }
   memcpy(e->h_seeds[b], seeds, N * sizeof(uint64_t));
   HIPCHK(e, hipMemcpyAsync(e->d_seeds[b], e->h_seeds[b], N * sizeof(uint64_t), hipMemcpyHostToDevice, e->seed_stream));
-  if (!e->d_seedbuf[b]) HIPCHK(e, hipMalloc((void**)&e->d_seedbuf[b], N * 4 * 624 * sizeof(uint32_t)));
-  const size_t seed_lds = (size_t)624 * SEED_LD * 4 + 16 * 3 * 8;
-  // (per device, and cheap: set it on every call rather than track which devices have seen it)
-  HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_seed), hipFuncAttributeMaxDynamicSharedMemorySize, (int)seed_lds));
+  const size_t seed_bytes = ((N + 15) / 16) * WG * 624 * sizeof(uint32_t);  // whole waves of 16 envs x 4 streams
+  if (!e->d_seedbuf[b]) HIPCHK(e, hipMalloc((void**)&e->d_seedbuf[b], seed_bytes));
+  if (!e->d_seedtmp) HIPCHK(e, hipMalloc((void**)&e->d_seedtmp, seed_bytes));  // k_seed's scratch (one: its launches are serialised on the seed stream)
   HIPCHK(e, hipEventRecord(e->ev_seed0[b], e->seed_stream));
-  hipLaunchKernelGGL(k_seed, dim3((unsigned)((N + 15) / 16)), dim3(WG), seed_lds, e->seed_stream, (const uint64_t*)e->d_seeds[b], (int)N,
-                     (int)(e->P.num_obstacles > 0), e->d_seedbuf[b]);
+  hipLaunchKernelGGL(k_seed, dim3((unsigned)((N + 15) / 16)), dim3(WG), 0, e->seed_stream, (const uint64_t*)e->d_seeds[b], (int)N,
+                     (int)(e->P.num_obstacles > 0), e->d_seedbuf[b], e->d_seedtmp);
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev_seeded[b], e->seed_stream));
   HIPCHK(e, hipStreamWaitEvent(e->stream, e->ev_seeded[b], 0));
