@@ -219,8 +219,8 @@ def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--envs", type=int, default=4096, help="env instances per GPU")
     ap.add_argument("--case", default="WPS_hard_x2")
     ap.add_argument("--interval", type=int, default=None, help="replan interval (default 20; 12 for the escort cases)")
@@ -346,7 +346,27 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     for _ in range(HORIZON):
         env.rollout(None, 1, args.interval, True, write_obs)
     env.sync()
-    out["fused_step_api_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
+    out["fused_step_api_one_stream_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
+    # the same per-step path with the batch split into sub-batches on their own streams (muavta_set_parts): one launch per part and
+    # env step, all asynchronous — a part's launch still ends on its slowest env, but the other parts' launches fill the device
+    # meanwhile (and a host-side planner would decide for one part while the others are being stepped)
+    best = (out["fused_step_api_one_stream_env_steps_per_s"], 1)
+    for parts in (2, 4, 8):
+        env.set_parts(parts)
+        env.reset(seeds)
+        env.sync()
+        t1 = time.perf_counter()
+        for _ in range(HORIZON):
+            for p in range(parts):
+                env.rollout_part(p, 1, args.interval, True, write_obs)
+        env.sync()
+        rate = args.envs * HORIZON / (time.perf_counter() - t1)
+        out[f"fused_step_api_{parts}_parts_env_steps_per_s"] = rate
+        best = max(best, (rate, parts))
+    env.set_parts(0)
+    out["fused_step_api_env_steps_per_s"], out["fused_step_api_parts"] = best
+    out["fused_step_api_is"] = (f"one k_rollout(1 step) launch per sub-batch and env step, {best[1]} sub-batch(es) on their own streams "
+                                "(muavta_rollout_part); 150 env steps of the whole batch, host-timed")
     # the same one-launch-per-step path with 8x the envs per launch (BASELINE config 3's 32768 on one GPU): a launch ends on its
     # slowest env (one that replans: ~80 us against a 24 us mean step), so a wider batch amortises that tail
     try:

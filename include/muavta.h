@@ -375,6 +375,29 @@ typedef struct MuavtaRecord {
 int muavta_rollout_record(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps, int32_t replan_interval, int32_t use_visibility,
                           int32_t write_obs, const MuavtaRecord* rec);
 
+/* Sub-batches.  The reference's loop is "observe -> decide -> env.step" for ONE env (experiments/wps_eval.py:112-133,273); a batch
+ * stepped by one launch per env step ends every launch on its slowest env (one that replans) while the host can do nothing.
+ * muavta_set_parts splits the handle's env range into n_parts contiguous parts (0 or 1: off; at most 8), each with its own
+ * stream: the *_part calls below are the per-step entry points for ONE part — asynchronous on that part's stream, so the host can
+ * decide for part A while the device steps part B, and the parts' launches overlap on the device.  Results are identical to the
+ * whole-batch calls (env instances are independent).  The whole-batch entry points stay valid at any time: they are ordered
+ * after everything the parts have queued, and a later *_part call is ordered after them (event waits on the device).
+ *   muavta_part_range      first env index and env count of a part (contiguous, sizes differ by at most one)
+ *   muavta_rollout_part    muavta_rollout(env, NULL, n_steps, ...) for the part's envs: the device-side planner + n_steps fused steps
+ *   muavta_allocate_part   muavta_allocate for the part; act_* (may be NULL) receive [count, action_cap] rows and make the call wait
+ *   muavta_step_part       muavta_step for the part with [count, action_cap] action rows, or (both NULL) muavta_step_staged
+ *   muavta_observe_part    the part's rows of muavta_observe + muavta_step_result ([count, ...]; NULL = skip); waits for that part only
+ *   muavta_wait_part       block until the part's stream is idle (part < 0: every part)
+ * The per-env release log (muavta_set_release_log) is a whole-batch facility and must be off for muavta_step_part. */
+int muavta_set_parts(MuavtaEnv* env, int32_t n_parts);
+int muavta_part_range(const MuavtaEnv* env, int32_t part, int32_t* first, int32_t* count);
+int muavta_rollout_part(MuavtaEnv* env, int32_t part, int32_t n_steps, int32_t replan_interval, int32_t use_visibility, int32_t write_obs);
+int muavta_allocate_part(MuavtaEnv* env, int32_t part, int32_t replan_interval, int32_t use_visibility, int32_t* act_agent, int32_t* act_index);
+int muavta_step_part(MuavtaEnv* env, int32_t part, const int32_t* act_agent, const int32_t* act_index);
+int muavta_observe_part(MuavtaEnv* env, int32_t part, float* tasks, uint64_t* legal, uint8_t* pad, float* agents, float* flags, double* reward,
+                        uint8_t* done);
+int muavta_wait_part(MuavtaEnv* env, int32_t part);
+
 /* Duration of the last muavta_rollout launch, measured with HIP events recorded on the handle's own
  * stream around the kernel (ms).  Blocks until that launch has finished. */
 int muavta_last_kernel_ms(MuavtaEnv* env, float* ms);

@@ -237,6 +237,64 @@ class BatchedMultiUAVEnv:
                 raise ValueError(f"seeds must have shape ({self.n_envs},)")
         self._ck(self.L.muavta_rollout_record(self.h, _vp(s), int(n_steps), int(replan_interval), int(use_visibility), int(write_obs), C.byref(rec)))
 
+    # ------------------------------------------------------------------ sub-batches on their own streams
+    def set_parts(self, n_parts: int):
+        """Split the env range into `n_parts` contiguous parts with a stream each (0 / 1: off): the *_part calls step one part
+        asynchronously, so the host can decide for one part while the device steps another (include/muavta.h)."""
+        self._ck(self.L.muavta_set_parts(self.h, int(n_parts)))
+        self.n_parts = 0 if n_parts <= 1 else int(n_parts)
+
+    def part_range(self, part: int):
+        f, c = C.c_int32(), C.c_int32()
+        self._ck(self.L.muavta_part_range(self.h, int(part), C.byref(f), C.byref(c)))
+        return int(f.value), int(c.value)
+
+    def rollout_part(self, part: int, n_steps: int = 1, replan_interval: int = 20, use_visibility: bool = True, write_obs: bool = True):
+        self._ck(self.L.muavta_rollout_part(self.h, int(part), int(n_steps), int(replan_interval), int(use_visibility), int(write_obs)))
+
+    def allocate_part(self, part: int, replan_interval: int = 20, use_visibility: bool = True, fetch: bool = True):
+        if not fetch:
+            self._ck(self.L.muavta_allocate_part(self.h, int(part), int(replan_interval), int(use_visibility), None, None))
+            return None
+        _, cnt = self.part_range(part)
+        aa = np.empty((cnt, self.A_tile), dtype=np.int32)
+        ai = np.empty((cnt, self.A_tile), dtype=np.int32)
+        self._ck(self.L.muavta_allocate_part(self.h, int(part), int(replan_interval), int(use_visibility), _vp(aa), _vp(ai)))
+        return aa, ai
+
+    def step_part(self, part: int, act_agent: Optional[np.ndarray] = None, act_index: Optional[np.ndarray] = None):
+        """act_*: int32 [count of the part, action_cap]; both None: the actions `allocate_part` staged on the device."""
+        if act_agent is None:
+            self._ck(self.L.muavta_step_part(self.h, int(part), None, None))
+            return
+        _, cnt = self.part_range(part)
+        aa = np.ascontiguousarray(act_agent, dtype=np.int32)
+        ai = np.ascontiguousarray(act_index, dtype=np.int32)
+        if aa.shape != (cnt, self.A_tile) or ai.shape != (cnt, self.A_tile):
+            raise ValueError(f"actions of part {part} must have shape {(cnt, self.A_tile)}")
+        self._ck(self.L.muavta_step_part(self.h, int(part), _vp(aa), _vp(ai)))
+
+    def observe_part(self, part: int):
+        """The part's rows of `observe()` plus (reward, terminated, truncated); waits for that part's stream only."""
+        _, n = self.part_range(part)
+        A, MT = self.n_agents, self.max_tasks
+        tasks = np.empty((n, 21, MT), dtype=np.float32)
+        legal = np.empty((n, A, self.dims.legal_words), dtype=np.uint64)
+        pad = np.empty((n, MT), dtype=np.uint8)
+        agents = np.empty((n, A, 9), dtype=np.float32)
+        flags = np.empty((n, 5), dtype=np.float32)
+        r = np.empty(n, dtype=np.float64)
+        d = np.empty(n, dtype=np.uint8)
+        self._ck(self.L.muavta_observe_part(self.h, int(part), _vp(tasks), _vp(legal), _vp(pad), _vp(agents), _vp(flags), _vp(r), _vp(d)))
+        tasks = np.ascontiguousarray(tasks.transpose(0, 2, 1))
+        bits = (legal[..., :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)
+        legal = bits.reshape(n, A, -1)[:, :, :MT]
+        return ({"tasks": tasks, "legal_mask": legal.astype(bool), "mask": pad.astype(bool), "agents": agents, "event_flags": flags},
+                r, (d & 1).astype(bool), (d & 2).astype(bool))
+
+    def wait_part(self, part: int = -1):
+        self._ck(self.L.muavta_wait_part(self.h, int(part)))
+
     def sync(self):
         self._ck(self.L.muavta_sync(self.h))
 

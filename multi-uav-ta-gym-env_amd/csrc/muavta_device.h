@@ -3569,8 +3569,8 @@ struct Sim {
       bool active = incol;
       unsigned long long SRmask = 0ull;
       double minVal = 0;
-      int i = cur, nrem = nc, sink = -1;
-      while (sink == -1) {
+      int i = cur, nrem = nc, sink;
+      for (;;) {
 #ifdef MUAVTA_PROF
         prof_iters++;
 #endif
@@ -3612,7 +3612,8 @@ struct Sim {
         if (pos == nrem - 1) pos = psel;  // remaining[index] = remaining[--num_remaining]
         if (lane == sel) active = false;
         nrem--;
-        if (equ) sink = sel; else i = __builtin_amdgcn_readlane(r4c, sel);  // an unassigned column ends the search
+        if (equ) { sink = sel; break; }  // an unassigned column ends the search
+        i = __builtin_amdgcn_readlane(r4c, sel);
       }
       // dual updates (u over the scanned rows, v over the scanned columns = the ones that left `remaining`)
       const unsigned long long others = SRmask & ~(1ull << cur);

@@ -251,10 +251,10 @@ __global__ __launch_bounds__(WG) void k_reset(const DevCtx* __restrict__ ctxp, c
 // act_agent == nullptr: use the actions staged in the blob by k_allocate
 template <class TL>
 __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_step(const DevCtx* __restrict__ ctxp, const int32_t* act_agent, const int32_t* act_index, int act_cap,
-                                             double* rel_log) {
+                                             double* rel_log, int env_base) {
   const DevCtx& ctx = ctx_ref(ctxp);
   const DevParams& P = ctx.P;
-  const int env = blockIdx.x;
+  const int env = env_base + blockIdx.x;  // (env_base: the first env of a sub-batch launched on its own stream, muavta_*_part)
   KERNEL_LDS(TL);
   Lds<TL> L(lds_own);
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
@@ -287,9 +287,9 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_step(const DevCtx* _
 
 template <class TL>
 __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp, int interval, int use_vis, int mode,
-                                                 int32_t* out_agent, int32_t* out_index, int act_cap) {
+                                                 int32_t* out_agent, int32_t* out_index, int act_cap, int env_base) {
   const DevCtx& ctx = ctx_ref(ctxp);
-  const int env = blockIdx.x;
+  const int env = env_base + blockIdx.x;
   Lds<TL> L(smem);
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
   copy16(L.S, blob, sizeof(EnvState<TL>));
@@ -339,10 +339,9 @@ __device__ __forceinline__ typename Sim<TL>::TokPtrs global_tok_ptrs(typename Si
   return K;
 }
 template <class TL, bool REC>
-__device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned char* lds_own, uint32_t lds_base, int phases, int interval, int use_vis, int mode,
+__device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned char* lds_own, uint32_t lds_base, int env, int phases, int interval, int use_vis, int mode,
                                                 const RecordPtrs<TL>& rec, int slot, int oslot) {
   const DevCtx& ctx = ctx_ref(ctxp);
-  const int env = blockIdx.x;
 #if MUAVTA_PHASE_INLINED
   Lds<TL> L(lds_own);
 #else
@@ -378,9 +377,9 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned cha
 
 template <class TL, bool REC>
 __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx* __restrict__ ctxp, const uint64_t* seeds, int n_steps, int interval, int use_vis,
-                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf, RecordPtrs<TL> rec, int epoch) {
+                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf, RecordPtrs<TL> rec, int epoch, int env_base) {
   const DevCtx& ctx = ctx_ref(ctxp);
-  const int env = blockIdx.x;
+  const int env = env_base + blockIdx.x;
   KERNEL_LDS(TL);
   Lds<TL> L(lds_own);
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
@@ -443,7 +442,7 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
       if (threadIdx.x < 16) seen = __hip_atomic_load(pace_row + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
-    if (ph) rollout_phase<TL, REC>(ctxp, lds_own, lds_base, ph, interval, use_vis, mode, rec, k < n_steps ? k : n_steps,
+    if (ph) rollout_phase<TL, REC>(ctxp, lds_own, lds_base, env, ph, interval, use_vis, mode, rec, k < n_steps ? k : n_steps,
                                    (REC && rec.O.tasks && k >= 1 && k <= n_steps) ? k - 1 : -1);
 #if MUAVTA_PACE_PRIO
     if (PACED && k >= 1 && k <= n_steps) {  // consumed a step later: the load's latency stays off the env's dependent chain
@@ -716,6 +715,16 @@ struct MuavtaEnv {
   double* d_metrics = nullptr;
   ObsPtrs O{};
   hipStream_t stream = nullptr;
+  // sub-batches (muavta_set_parts): contiguous env ranges, each stepped on its own stream so that the host can decide for one part
+  // while the device steps another, and so that one part's slowest env does not hold up the others' launches
+  enum { MAX_PARTS = 8 };
+  int n_parts = 0;
+  hipStream_t part_stream[MAX_PARTS] = {};
+  hipEvent_t part_ev[MAX_PARTS] = {};
+  hipEvent_t ev_fork = nullptr;
+  bool part_busy[MAX_PARTS] = {};         // the part's stream holds work the main stream has not been ordered after yet
+  bool part_fork_needed[MAX_PARTS] = {};  // the main stream got work since the part's stream last waited for it
+  int32_t *d_part_agent = nullptr, *d_part_index = nullptr;  // action staging of the parts (one [N, A] pair, each part its rows)
   enum { EV_RING = 64 };
   hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};  // ev0[i] .. ev1[i]: the k_rollout launch number i (mod EV_RING)
   unsigned long long n_rollouts = 0;
@@ -726,6 +735,7 @@ struct MuavtaEnv {
   bool host_valid = false;
   std::string err;
 };
+static int join_parts(MuavtaEnv* e);  // (sub-batches: defined with the other part helpers in front of the C ABI)
 
 namespace {
 
@@ -829,6 +839,7 @@ size_t blob_bytes() { return sizeof(EnvState<TL>); }
 
 int sync_host(MuavtaEnv* e) {
   if (e->host_valid) return MUAVTA_OK;
+  if (e->n_parts) { int rc_ = join_parts(e); if (rc_) return rc_; }
   e->host_blobs.resize((size_t)e->n_envs * e->state_bytes);
   e->host_cold.resize((size_t)e->n_envs * e->cold_bytes);
   HIPCHK(e, hipMemcpyAsync(e->host_blobs.data(), e->blobs, e->host_blobs.size(), hipMemcpyDeviceToHost, e->stream));
@@ -1065,6 +1076,43 @@ int check_errors(MuavtaEnv* e) {  // scan the per-env error words after a synchr
 
 }  // namespace
 
+// ---- sub-batches on their own streams (muavta_set_parts) ------------------------------------------------------------------
+// Ordering between the handle's main stream and the part streams: an entry point that works on the main stream first makes it
+// wait for whatever the part streams still hold (join_parts) and flags every part to wait for the main stream before its next
+// launch (fork_part).  Both are event waits on the device: the host never blocks.
+static int join_parts(MuavtaEnv* e) {
+  for (int p = 0; p < e->n_parts; p++) {
+    if (e->part_busy[p]) {
+      HIPCHK(e, hipEventRecord(e->part_ev[p], e->part_stream[p]));
+      HIPCHK(e, hipStreamWaitEvent(e->stream, e->part_ev[p], 0));
+      e->part_busy[p] = false;
+    }
+    e->part_fork_needed[p] = true;
+  }
+  return MUAVTA_OK;
+}
+#define MAIN_OP(e) do { if ((e)->n_parts) { int rc_ = join_parts(e); if (rc_) return rc_; } } while (0)
+static int fork_part(MuavtaEnv* e, int p) {
+  if (e->part_fork_needed[p]) {
+    HIPCHK(e, hipEventRecord(e->ev_fork, e->stream));
+    HIPCHK(e, hipStreamWaitEvent(e->part_stream[p], e->ev_fork, 0));
+    e->part_fork_needed[p] = false;
+  }
+  e->part_busy[p] = true;
+  return MUAVTA_OK;
+}
+static void part_range(const MuavtaEnv* e, int p, int* first, int* count) {
+  const long long N = e->n_envs, k = e->n_parts > 0 ? e->n_parts : 1;
+  const int lo = (int)(N * p / k), hi = (int)(N * (p + 1) / k);
+  *first = lo; *count = hi - lo;
+}
+static int check_part(MuavtaEnv* e, int p, const char* who) {
+  if (!e) return MUAVTA_E_ARG;
+  if (e->n_parts < 1 || p < 0 || p >= e->n_parts) { e->err = std::string(who) + ": no such part (muavta_set_parts first)"; return MUAVTA_E_ARG; }
+  if (!e->did_reset) { e->err = std::string(who) + " before reset"; return MUAVTA_E_STATE; }
+  return MUAVTA_OK;
+}
+
 // ====================================================================================================
 // C ABI
 // ====================================================================================================
@@ -1159,6 +1207,12 @@ int muavta_destroy(MuavtaEnv* e) {
   muavta_comm_destroy(e);
   DeviceScope scope_(e->device);
   if (e->seed_stream) hipStreamSynchronize(e->seed_stream);
+  for (int p = 0; p < MuavtaEnv::MAX_PARTS; p++) {
+    if (e->part_stream[p]) { hipStreamSynchronize(e->part_stream[p]); hipStreamDestroy(e->part_stream[p]); }
+    if (e->part_ev[p]) hipEventDestroy(e->part_ev[p]);
+  }
+  if (e->ev_fork) hipEventDestroy(e->ev_fork);
+  hipFree(e->d_part_agent); hipFree(e->d_part_index);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->d_seedtmp) hipFree(e->d_seedtmp); hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
@@ -1217,6 +1271,7 @@ static int seeding_consumed(MuavtaEnv* e, int slot) {
 int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
   if (!e || !seeds) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   const uint64_t* ds = nullptr;
   const uint32_t* sb = nullptr;
   int slot = 0;
@@ -1233,6 +1288,7 @@ int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
 static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
   if (!e->did_reset) { e->err = "step before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   const int32_t *da = nullptr, *di = nullptr;
   if (aa) {
     size_t bytes = (size_t)e->n_envs * e->A * sizeof(int32_t);
@@ -1241,7 +1297,7 @@ static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
     da = e->d_act_agent; di = e->d_act_index;
   }
   if (e->d_rel) HIPCHK(e, hipMemsetAsync(e->d_rel, 0, (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double), e->stream));
-  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), 0, e->stream, (const DevCtx*)e->d_ctx, da, di, e->A, e->d_rel));  // (static LDS)
+  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), 0, e->stream, (const DevCtx*)e->d_ctx, da, di, e->A, e->d_rel, 0));  // (static LDS)
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   return MUAVTA_OK;
@@ -1271,8 +1327,9 @@ int muavta_allocate(MuavtaEnv* e, int32_t interval, int32_t use_vis, int32_t* ac
   if (!e) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "allocate before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, interval, use_vis, e->alloc_mode,
-                                 e->d_act_agent, e->d_act_index, e->A));
+                                 e->d_act_agent, e->d_act_index, e->A, 0));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   if (act_agent && act_index) {
@@ -1288,7 +1345,7 @@ static int token_dims(int kind, int* dt, int* da);
 }  // extern "C" (the launcher below is a template)
 template <class TL>
 static void launch_rollout(MuavtaEnv* e, const uint64_t* ds, int n_steps, int interval, int use_vis, int write_obs, const uint32_t* sb, size_t extra_lds,
-                           const MuavtaRecord* rec) {
+                           const MuavtaRecord* rec, hipStream_t stream, int env_base, int n_launch) {
   RecordPtrs<TL> R;
   memset(&R, 0, sizeof(R));
   const int epoch = (int)(e->pace_epoch++ % 65535u) + 1;  // 1..65535: the zero-filled table matches no launch
@@ -1303,11 +1360,11 @@ static void launch_rollout(MuavtaEnv* e, const uint64_t* ds, int n_steps, int in
       R.O.flags = rec->obs_flags; R.O.reward = rec->obs_reward; R.O.done = rec->obs_done;
     }
     R.n_envs = e->n_envs;
-    hipLaunchKernelGGL((k_rollout<TL, true>), dim3(e->n_envs), dim3(WG), extra_lds, e->stream, (const DevCtx*)e->d_ctx, ds,
-                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch);
+    hipLaunchKernelGGL((k_rollout<TL, true>), dim3(n_launch), dim3(WG), extra_lds, stream, (const DevCtx*)e->d_ctx, ds,
+                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch, env_base);
   } else {
-    hipLaunchKernelGGL((k_rollout<TL, false>), dim3(e->n_envs), dim3(WG), extra_lds, e->stream, (const DevCtx*)e->d_ctx, ds,
-                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch);
+    hipLaunchKernelGGL((k_rollout<TL, false>), dim3(n_launch), dim3(WG), extra_lds, stream, (const DevCtx*)e->d_ctx, ds,
+                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch, env_base);
   }
 }
 extern "C" {
@@ -1315,6 +1372,7 @@ static int rollout_impl(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, in
   if (!e || n_steps < 0) return MUAVTA_E_ARG;
   if (!seeds && !e->did_reset) { e->err = "rollout without seeds before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   const uint64_t* ds = nullptr;
   const uint32_t* sb = nullptr;
   int slot = -1;
@@ -1323,7 +1381,7 @@ static int rollout_impl(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, in
   const int evi = (int)(e->n_rollouts % MuavtaEnv::EV_RING);
   HIPCHK(e, hipEventRecord(e->ev0[evi], e->stream));
   static const size_t extra_lds = getenv("MUAVTA_EXTRA_LDS") ? (size_t)atoi(getenv("MUAVTA_EXTRA_LDS")) : 0;  // occupancy experiments only
-  DISPATCH(e, launch_rollout<TL>(e, ds, n_steps, interval, use_vis, write_obs, sb, extra_lds, rec));
+  DISPATCH(e, launch_rollout<TL>(e, ds, n_steps, interval, use_vis, write_obs, sb, extra_lds, rec, e->stream, 0, e->n_envs));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1[evi], e->stream));
   e->n_rollouts++;
@@ -1356,6 +1414,117 @@ int muavta_rollout_record(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, 
   return rollout_impl(e, seeds, n_steps, interval, use_vis, write_obs, rec);
 }
 
+// ---- sub-batches ---------------------------------------------------------------------------------------------------------
+int muavta_set_parts(MuavtaEnv* e, int32_t n_parts) {
+  if (!e || n_parts < 0 || n_parts > MuavtaEnv::MAX_PARTS || n_parts > e->n_envs) { if (e) e->err = "muavta_set_parts: 0 .. 8 parts, at most one per env"; return MUAVTA_E_ARG; }
+  DeviceScope scope_(e->device);
+  MAIN_OP(e);  // whatever the old parts hold is ordered in front of the main stream
+  if (n_parts == 1) n_parts = 0;
+  for (int p = 0; p < n_parts; p++) {
+    if (!e->part_stream[p]) HIPCHK(e, hipStreamCreateWithFlags(&e->part_stream[p], hipStreamNonBlocking));
+    if (!e->part_ev[p]) HIPCHK(e, hipEventCreateWithFlags(&e->part_ev[p], hipEventDisableTiming));
+    e->part_busy[p] = false; e->part_fork_needed[p] = true;
+  }
+  if (n_parts && !e->ev_fork) HIPCHK(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  if (n_parts && !e->d_part_agent) {
+    HIPCHK(e, hipMalloc((void**)&e->d_part_agent, (size_t)e->n_envs * e->A * sizeof(int32_t)));
+    HIPCHK(e, hipMalloc((void**)&e->d_part_index, (size_t)e->n_envs * e->A * sizeof(int32_t)));
+  }
+  e->n_parts = n_parts;
+  return MUAVTA_OK;
+}
+int muavta_part_range(const MuavtaEnv* e, int32_t part, int32_t* first, int32_t* count) {
+  if (!e || !first || !count || part < 0 || part >= (e->n_parts > 0 ? e->n_parts : 1)) return MUAVTA_E_ARG;
+  int f, c;
+  part_range(e, part, &f, &c);
+  *first = f; *count = c;
+  return MUAVTA_OK;
+}
+int muavta_rollout_part(MuavtaEnv* e, int32_t part, int32_t n_steps, int32_t interval, int32_t use_vis, int32_t write_obs) {
+  { int rc = check_part(e, part, "muavta_rollout_part"); if (rc) return rc; }
+  if (n_steps < 0) return MUAVTA_E_ARG;
+  DeviceScope scope_(e->device);
+  { int rc = fork_part(e, part); if (rc) return rc; }
+  int first, count;
+  part_range(e, part, &first, &count);
+  DISPATCH(e, launch_rollout<TL>(e, nullptr, n_steps, interval, use_vis, write_obs, nullptr, 0, nullptr, e->part_stream[part], first, count));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
+  return MUAVTA_OK;
+}
+int muavta_step_part(MuavtaEnv* e, int32_t part, const int32_t* act_agent, const int32_t* act_index) {
+  { int rc = check_part(e, part, "muavta_step_part"); if (rc) return rc; }
+  if (e->d_rel) { e->err = "muavta_step_part: the release log is a whole-batch facility (muavta_set_release_log off)"; return MUAVTA_E_STATE; }
+  int first, count;
+  part_range(e, part, &first, &count);
+  if (act_agent && act_index) {
+    for (int n = 0; n < count; n++)
+      for (int k = 0; k < e->A; k++) {
+        const int a = act_agent[(size_t)n * e->A + k];
+        if (a < 0) break;
+        if (a >= e->P.n_agents) { e->err = "muavta_step_part: agent id out of range"; return MUAVTA_E_ARG; }
+      }
+  } else if (act_agent || act_index) return MUAVTA_E_ARG;
+  DeviceScope scope_(e->device);
+  { int rc = fork_part(e, part); if (rc) return rc; }
+  hipStream_t st = e->part_stream[part];
+  const int32_t *da = nullptr, *di = nullptr;
+  if (act_agent) {  // rows first .. first + count of the staging pair; NULL: the actions muavta_allocate_part staged in the blob
+    const size_t off = (size_t)first * e->A, bytes = (size_t)count * e->A * sizeof(int32_t);
+    HIPCHK(e, hipMemcpyAsync(e->d_part_agent + off, act_agent, bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipMemcpyAsync(e->d_part_index + off, act_index, bytes, hipMemcpyHostToDevice, st));
+    da = e->d_part_agent; di = e->d_part_index;
+  }
+  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(count), dim3(WG), 0, st, (const DevCtx*)e->d_ctx, da, di, e->A, (double*)nullptr, first));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
+  return MUAVTA_OK;
+}
+int muavta_allocate_part(MuavtaEnv* e, int32_t part, int32_t interval, int32_t use_vis, int32_t* act_agent, int32_t* act_index) {
+  { int rc = check_part(e, part, "muavta_allocate_part"); if (rc) return rc; }
+  DeviceScope scope_(e->device);
+  { int rc = fork_part(e, part); if (rc) return rc; }
+  int first, count;
+  part_range(e, part, &first, &count);
+  hipStream_t st = e->part_stream[part];
+  DISPATCH(e, hipLaunchKernelGGL(k_allocate<TL>, dim3(count), dim3(WG), Lds<TL>::bytes(), st, (const DevCtx*)e->d_ctx, interval, use_vis, e->alloc_mode,
+                                 e->d_part_agent, e->d_part_index, e->A, first));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
+  if (act_agent && act_index) {
+    const size_t off = (size_t)first * e->A, bytes = (size_t)count * e->A * sizeof(int32_t);
+    HIPCHK(e, hipMemcpyAsync(act_agent, e->d_part_agent + off, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(act_index, e->d_part_index + off, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));
+  }
+  return MUAVTA_OK;
+}
+int muavta_observe_part(MuavtaEnv* e, int32_t part, float* tasks, uint64_t* legal, uint8_t* pad, float* agents, float* flags, double* reward, uint8_t* done) {
+  { int rc = check_part(e, part, "muavta_observe_part"); if (rc) return rc; }
+  DeviceScope scope_(e->device);
+  { int rc = fork_part(e, part); if (rc) return rc; }
+  int first, count;
+  part_range(e, part, &first, &count);
+  hipStream_t st = e->part_stream[part];
+  const size_t F = (size_t)first, C = (size_t)count, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents, kw = (mt + 63) / 64;
+  if (tasks) HIPCHK(e, hipMemcpyAsync(tasks, e->O.tasks + F * mt * 21, C * mt * 21 * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (legal) HIPCHK(e, hipMemcpyAsync(legal, e->O.legal + F * nA * kw, C * nA * kw * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+  if (pad) HIPCHK(e, hipMemcpyAsync(pad, e->O.pad + F * mt, C * mt, hipMemcpyDeviceToHost, st));
+  if (agents) HIPCHK(e, hipMemcpyAsync(agents, e->O.agents + F * nA * 9, C * nA * 9 * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (flags) HIPCHK(e, hipMemcpyAsync(flags, e->O.flags + F * 5, C * 5 * sizeof(float), hipMemcpyDeviceToHost, st));
+  if (reward) HIPCHK(e, hipMemcpyAsync(reward, e->O.reward + F, C * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (done) HIPCHK(e, hipMemcpyAsync(done, e->O.done + F, C, hipMemcpyDeviceToHost, st));
+  HIPCHK(e, hipStreamSynchronize(st));
+  return MUAVTA_OK;
+}
+int muavta_wait_part(MuavtaEnv* e, int32_t part) {  // part < 0: every part
+  if (!e || part >= e->n_parts) return MUAVTA_E_ARG;
+  DeviceScope scope_(e->device);
+  for (int p = 0; p < e->n_parts; p++)
+    if (part < 0 || p == part) HIPCHK(e, hipStreamSynchronize(e->part_stream[p]));
+  return MUAVTA_OK;
+}
+
 #ifdef MUAVTA_DIAG_TIMES
 int muavta_diag_times(MuavtaEnv* e, uint32_t* out, int32_t n) {  // diagnostic build only: [3][n] start, end (10 ns units), hw ids
   DeviceScope scope_(e->device);
@@ -1382,6 +1551,7 @@ int muavta_set_allocator(MuavtaEnv* e, int32_t mode) {
 int muavta_sync(MuavtaEnv* e) {
   if (!e) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
 }
@@ -1436,6 +1606,7 @@ int muavta_observe(MuavtaEnv* e, float* tasks, uint64_t* legal, uint8_t* pad, fl
   if (!e) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "observe before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   const size_t N = (size_t)e->n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
   if (tasks) HIPCHK(e, hipMemcpyAsync(tasks, e->O.tasks, N * mt * 21 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
   if (legal) HIPCHK(e, hipMemcpyAsync(legal, e->O.legal, N * nA * ((mt + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
@@ -1462,6 +1633,7 @@ int muavta_tokens_device(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t 
       !task_ids || !agent_feats || !agent_mask || !agent_ids || !edge_valid) { if (e) e->err = "muavta_tokens: bad argument"; return MUAVTA_E_ARG; }
   if (!e->did_reset) { e->err = "tokens before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   DISPATCH(e, launch_tokens<TL>(e, kind, max_tasks, max_agents, task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned));
   HIPCHK(e, hipGetLastError());
   return MUAVTA_OK;
@@ -1505,6 +1677,7 @@ int muavta_call(MuavtaEnv* e, int32_t env_index, int32_t op, const int32_t* iarg
   if (has_agent && (a.i[0] < 0 || a.i[0] >= e->P.n_agents)) { e->err = "muavta_call: agent id out of range"; return MUAVTA_E_ARG; }
   if (op == MUAVTA_OP_SET_QUEUE && (a.i[1] < 0 || a.i[1] > 6)) { e->err = "muavta_call(SET_QUEUE): at most 6 tasks"; return MUAVTA_E_ARG; }
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   if (!e->d_call_out) HIPCHK(e, hipMalloc((void**)&e->d_call_out, MUAVTA_CALL_OUT * sizeof(int32_t)));
   DISPATCH(e, hipLaunchKernelGGL(k_call<TL>, dim3(1), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, a, e->d_call_out));
   HIPCHK(e, hipGetLastError());
@@ -1626,6 +1799,7 @@ int muavta_comm_destroy(MuavtaEnv* e) {
 int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
   if (!e) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   if (enable && !e->d_rel) {
     const size_t bytes = (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double);
@@ -1641,6 +1815,7 @@ int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
 int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from the current state (after muavta_set)
   if (!e) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   DISPATCH(e, hipLaunchKernelGGL(k_observe<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;  // (the kernel refreshes the derived initTime / doneTime rows of the HBM record)
@@ -1650,6 +1825,7 @@ int muavta_refresh_observation(MuavtaEnv* e) {  // rebuild the obs tensors from 
 int muavta_step_result(MuavtaEnv* e, double* reward, uint8_t* done) {
   if (!e) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   if (reward) HIPCHK(e, hipMemcpyAsync(reward, e->O.reward, (size_t)e->n_envs * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   if (done) HIPCHK(e, hipMemcpyAsync(done, e->O.done, (size_t)e->n_envs, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1660,6 +1836,7 @@ int muavta_metrics(MuavtaEnv* e, double* out) {
   if (!e || !out) return MUAVTA_E_ARG;
   if (!e->did_reset) { e->err = "metrics before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   DISPATCH(e, hipLaunchKernelGGL(k_metrics<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, e->d_metrics));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
@@ -1677,6 +1854,7 @@ int muavta_get(MuavtaEnv* e, MuavtaField field, void* dst, size_t bytes) {
     const size_t want = (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double);
     if (!e->d_rel) { e->err = "release log is off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
     if (bytes != want) { e->err = "muavta_get(RELEASE_LOG): wrong size"; return MUAVTA_E_ARG; }
+    MAIN_OP(e);
     HIPCHK(e, hipMemcpyAsync(dst, e->d_rel, want, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return MUAVTA_OK;
@@ -1703,6 +1881,7 @@ int muavta_set(MuavtaEnv* e, MuavtaField field, const void* src, size_t bytes) {
 int muavta_get_state(MuavtaEnv* e, void* dst, size_t bytes) {  // [N x EnvState | N x EnvCold]
   if (!e || !dst || bytes != (size_t)e->n_envs * (e->state_bytes + e->cold_bytes)) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   HIPCHK(e, hipMemcpyAsync(dst, e->blobs, (size_t)e->n_envs * e->state_bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipMemcpyAsync((char*)dst + (size_t)e->n_envs * e->state_bytes, e->cold, (size_t)e->n_envs * e->cold_bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1711,6 +1890,7 @@ int muavta_get_state(MuavtaEnv* e, void* dst, size_t bytes) {  // [N x EnvState 
 int muavta_set_state(MuavtaEnv* e, const void* src, size_t bytes) {
   if (!e || !src || bytes != (size_t)e->n_envs * (e->state_bytes + e->cold_bytes)) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   HIPCHK(e, hipMemcpyAsync(e->blobs, src, (size_t)e->n_envs * e->state_bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync(e->cold, (const char*)src + (size_t)e->n_envs * e->state_bytes, (size_t)e->n_envs * e->cold_bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1722,6 +1902,7 @@ int muavta_get_rng(MuavtaEnv* e, void* dst, size_t bytes) {  // raw MT tapes, fo
   size_t need = e ? (size_t)e->n_envs * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * 4 : 0;
   if (!e || !dst || bytes != need) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   HIPCHK(e, hipMemcpyAsync(dst, e->tapes, bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
@@ -1730,6 +1911,7 @@ int muavta_set_rng(MuavtaEnv* e, const void* src, size_t bytes) {
   size_t need = e ? (size_t)e->n_envs * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS * 4 : 0;
   if (!e || !src || bytes != need) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   HIPCHK(e, hipMemcpyAsync(e->tapes, src, bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
@@ -1749,6 +1931,7 @@ int muavta_device_ptrs(MuavtaEnv* e, void** state, void** obs_tasks, void** obs_
 int muavta_rollout_metrics(MuavtaEnv* e, double* out) {  // metrics written by the last muavta_rollout (no extra kernel)
   if (!e || !out) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  MAIN_OP(e);
   HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;

@@ -31,7 +31,8 @@ EXPORTS = [
     "muavta_rollout_metrics", "muavta_refresh_observation", "muavta_get_rng", "muavta_set_rng", "muavta_abi_sizes",
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
     "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
-    "muavta_kernel_ms_history", "muavta_wait_stream",
+    "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
+    "muavta_step_part", "muavta_observe_part", "muavta_wait_part",
 ]
 
 
@@ -118,6 +119,13 @@ def lib() -> C.CDLL:
     L.muavta_call.argtypes = [vp, i32, i32, vp, C.c_double, vp]
     L.muavta_sync.argtypes = [vp]
     L.muavta_wait_stream.argtypes = [vp, vp]
+    L.muavta_set_parts.argtypes = [vp, i32]
+    L.muavta_part_range.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.muavta_rollout_part.argtypes = [vp, i32, i32, i32, i32, i32]
+    L.muavta_allocate_part.argtypes = [vp, i32, i32, i32, vp, vp]
+    L.muavta_step_part.argtypes = [vp, i32, vp, vp]
+    L.muavta_observe_part.argtypes = [vp, i32] + [vp] * 7
+    L.muavta_wait_part.argtypes = [vp, i32]
     L.muavta_refresh_observation.argtypes = [vp]
     L.muavta_set_allocator.argtypes = [vp, i32]
     L.muavta_set_release_log.argtypes = [vp, i32]

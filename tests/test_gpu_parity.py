@@ -1184,3 +1184,59 @@ def test_config4_bench_seed_range(name, mode, n):
     want = orc.parallel_metrics(case, seeds, interval, 1, mode)
     bad = np.nonzero(~np.all(got == want, axis=1))[0]
     assert len(bad) == 0, f"{name}: seeds {seeds[bad[:8]]} differ"
+
+
+@pytest.mark.parametrize("case,interval,n,parts", [("WPS_hard", 20, 6, 2), ("WPS_escort", 12, 5, 3)])
+def test_stepwise_bit_exact_vs_oracle_through_the_part_entry_points(case, interval, n, parts):
+    """muavta_set_parts: the batch split into parts stepped on their own streams — allocate_part / step_part with host-side
+    action rows (decided per part, the other parts' launches in flight), observe_part — every field of every env against the
+    oracle after every step, exactly as the whole-batch stepwise test does."""
+    env = _env(case, n)
+    seeds = np.arange(40, 40 + n, dtype=np.uint64)
+    env.reset(seeds)
+    env.set_parts(parts)
+    ranges = [env.part_range(p) for p in range(parts)]
+    assert sum(c for _, c in ranges) == n and ranges[0][0] == 0
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    for o, s in zip(oracles, seeds):
+        o.reset(int(s))
+    for t in range(150):
+        for p, (first, count) in enumerate(ranges):           # decide for part p while the parts before it are being stepped
+            aa, ai = env.allocate_part(p, interval, True)
+            for i in range(count):
+                oa, oi = oracles[first + i].allocate(interval, 1)
+                k = len(oa)
+                assert np.array_equal(aa[i, :k], oa) and np.array_equal(ai[i, :k], oi) and (k == aa.shape[1] or aa[i, k] == -1), f"{case} t={t} env {first + i}: plan"
+                oracles[first + i].step(oa, oi)
+            env.step_part(p, aa, ai)
+        obs_parts = [env.observe_part(p) for p in range(parts)]
+        snap = Snapshot(env)                                    # whole-batch reads: ordered after every part's stream
+        for p, (first, count) in enumerate(ranges):
+            o_p, r_p, term_p, trunc_p = obs_parts[p]
+            for key in ("tasks", "legal_mask", "mask", "agents", "event_flags"):
+                assert np.array_equal(o_p[key], snap.obs[key][first:first + count]), f"{case} t={t} part {p}: observe_part {key}"
+            assert np.array_equal(r_p, snap.reward[first:first + count]) and np.array_equal(trunc_p, snap.trunc[first:first + count])
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"{case} parts seed {seeds[i]} t={t + 1}")
+
+
+@pytest.mark.parametrize("case,interval,n", [("WPS_hard_x2", 20, 1024), ("WPS_escort24", 12, 256)])
+def test_rollout_by_parts_equals_the_whole_batch_rollout(case, interval, n):
+    """150 x rollout_part(1 step) on four parts (the device-side planner, one launch per part and env step, all asynchronous) ends in
+    the same state, observations and metrics as one fused 150-step rollout of the whole batch."""
+    seeds = np.arange(7000, 7000 + n, dtype=np.uint64)
+    ref = _env(case, n)
+    ref.rollout(seeds, 150, interval, True, True)
+    want_m, want_obs, want_state = ref.rollout_metrics(), ref.observe(), ref.get_state()
+    env = _env(case, n)
+    env.reset(seeds)
+    env.set_parts(4)
+    for t in range(150):
+        for p in range(4):
+            env.rollout_part(p, 1, interval, True, True)
+    got_obs = env.observe()
+    assert np.array_equal(env.metrics(), want_m) and not env.get("ERROR").any()
+    for key in want_obs:
+        assert np.array_equal(got_obs[key], want_obs[key]), key
+    env.set_parts(0)
+    assert np.array_equal(env.get_state(), want_state)

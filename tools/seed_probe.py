@@ -22,3 +22,13 @@ for K in (1, 2, 10, 20):
     env.sync(); wall = (time.perf_counter() - t0) * 1e3
     km = env.kernel_ms_history(K)
     print(f"  {K:2d} queued: wall/launch {wall / K:.3f} ms, k_rollout mean {km.mean():.3f} (min {km.min():.3f} max {km.max():.3f}), last k_seed span {env.last_seed_ms():.3f} ms")
+import json
+res = []
+for rep in range(12):
+    env.sync(); t0 = time.perf_counter()
+    for _ in range(20):
+        env.rollout(seeds, 150, interval, True, True)
+    env.sync(); wall = (time.perf_counter() - t0) * 1e3
+    km = env.kernel_ms_history(20)
+    res.append((round(wall / 20, 3), round(float(km.mean()), 3), round(env.last_seed_ms(), 3)))
+print("  12 x 20 queued (wall/launch, k_rollout mean, last k_seed span):", res)
