@@ -384,11 +384,24 @@ struct Sim {
     return m ? __ffs((int)m) - 1 : -1;
   }
   DEV void queue_erase(int a, int k) {
-    int n = S.a_qlen[a];
+    const int n = S.a_qlen[a];
     for (int i = k; i + 1 < n; i++) {
       S.a_qid[a][i] = S.a_qid[a][i + 1];
       S.a_qslot[a][i] = S.a_qslot[a][i + 1];
-      C.a_qtime[a][i] = C.a_qtime[a][i + 1];
+    }
+    // the travel times live in the HBM record: up to four entries per pass with all the loads in front of the stores — a
+    // load-then-store per entry is one memory round trip (~1 us) per entry on this serial path
+    for (int i = k; i + 1 < n; i += 4) {
+      const int r = n - 1 - i;
+      double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+      if (r >= 1) t0 = C.a_qtime[a][i + 1];
+      if (r >= 2) t1 = C.a_qtime[a][i + 2];
+      if (r >= 3) t2 = C.a_qtime[a][i + 3];
+      if (r >= 4) t3 = C.a_qtime[a][i + 4];
+      if (r >= 1) C.a_qtime[a][i] = t0;
+      if (r >= 2) C.a_qtime[a][i + 1] = t1;
+      if (r >= 3) C.a_qtime[a][i + 2] = t2;
+      if (r >= 4) C.a_qtime[a][i + 3] = t3;
     }
     S.a_qlen[a] = n - 1;
   }
@@ -669,19 +682,48 @@ struct Sim {
     int s = S.esc_slot[k], id = S.esc_id[k];
     // an escort that expired by its hard window keeps its map entry forever (status == 2 -> early return)
     if (ref_retired(id, s)) return;
-    // _release_escort_agents (:1919-1936)
+    // _release_escort_agents (:1919-1936): agent.desAllocate(escort) for every holder, in agents_obj order.  Every holder's
+    // Task.removeAgentCap works on the SAME task: allocatedReqs is fetched once, the holders' capabilities are subtracted in order
+    // in registers, and the result is stored once (a read-modify-write per holder is a memory round trip per holder).
+    double al[6] = {0, 0, 0, 0, 0, 0};
+    bool loaded = false;
+    int nd = 0;
     for (int a = 0; a < P.n_agents; a++) {
       if (!((holders >> a) & 1ull)) continue;
       if (S.a_state[a] == -1 || S.a_qlen[a] == 0) continue;
-      if (des_allocate(a, id)) {
-        if (S.a_qlen[a] == 0) {
-          S.a_state[a] = 0;
-          S.a_commit[a] = 0;
-          qs().a_nft[a] = (double)tnow;
-          qs().a_nfx[a] = S.a_px[a];
-          qs().a_nfy[a] = S.a_py[a];
+      const int kq = queue_find(a, id);
+      if (kq < 0 || id == 0) continue;
+      {  // des_allocate_at(a, kq) with the task side deferred
+        const int slot = S.a_qslot[a][kq];
+        queue_erase(a, kq);
+        qs().a_nft[a] = (double)tnow;
+        qs().a_nfx[a] = S.a_px[a];
+        qs().a_nfy[a] = S.a_py[a];
+        S.a_commit[a] = 0;
+        if (ref_valid(id, slot) && S.t_status[slot] != 2) {  // (slot == s: the one slot that holds this id)
+          if (!loaded) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) al[c] = C.t_alloc[c][s];
+            loaded = true;
+          }
+#pragma unroll
+          for (int c = 0; c < 6; c++) al[c] -= S.a_caps[c][a];
+          nd++;
         }
       }
+      if (S.a_qlen[a] == 0) {
+        S.a_state[a] = 0;
+        S.a_commit[a] = 0;
+        qs().a_nft[a] = (double)tnow;
+        qs().a_nfx[a] = S.a_px[a];
+        qs().a_nfy[a] = S.a_py[a];
+      }
+    }
+    if (loaded) {
+#pragma unroll
+      for (int c = 0; c < 6; c++) C.t_alloc[c][s] = al[c];
+      S.t_ndet[s] -= nd;
+      S.times_dirty = 1;
     }
     S.t_status[s] = 2;
     int recon = S.t_prot_agent[s];
@@ -696,6 +738,68 @@ struct Sim {
     }
     if (failed) S.escort_failed++; else S.escort_completed++;
     push_event(MUAVTA_EV_ESCORT_RETIRED, id);
+  }
+  // _retire_escort (:1938-1950) of the escort that protects `recon`, with the whole wave (all lanes call it, uniform arguments):
+  // every holder erases ITS OWN queue entry (lane = agent: agent.desAllocate touches the agent's own fields), Task.removeAgentCap
+  // of the holders runs on one lane in agents_obj order (one fetch of allocatedReqs, one store), and the map entries behind the
+  // retired one move up one lane each.  On lane 0 the same work is a chain of dependent LDS round trips: the map look-up, a pass
+  // over the fleet, a five-array shift of the map (12-17 thousand cycles per retirement on the 24-agent tile).
+  DEV void retire_escort_coop(int recon, bool failed) {
+    cold_sync();  // the holders' lanes read queue-time rows other lanes wrote in earlier phases
+    const int ne = __builtin_amdgcn_readfirstlane(S.n_escorts), nA = P.n_agents;
+    const unsigned long long emk = __builtin_amdgcn_ballot_w64(lane < ne && S.esc_agent[lane < ne ? lane : 0] == recon);  // escort_lookup(recon)
+    if (emk == 0ull) return;
+    const int kk = __ffsll((long long)emk) - 1;
+    const int s = S.esc_slot[kk], id = S.esc_id[kk];
+    // an escort that expired by its hard window keeps its map entry forever (status == 2 -> early return)
+    if (ref_retired(id, s)) return;
+    // _release_escort_agents (:1919-1936)
+    bool capped = false;
+    if (lane < nA && S.a_state[lane] != -1 && S.a_qlen[lane] > 0) {
+      const int a = lane;
+      const int kq = queue_find(a, id);
+      if (kq >= 0) {
+        const int slot = S.a_qslot[a][kq];
+        queue_erase(a, kq);
+        qs().a_nft[a] = (double)tnow;
+        qs().a_nfx[a] = S.a_px[a];
+        qs().a_nfy[a] = S.a_py[a];
+        S.a_commit[a] = 0;
+        capped = ref_valid(id, slot) && S.t_status[slot] != 2;
+        if (S.a_qlen[a] == 0) S.a_state[a] = 0;  // (commit_until / next_free_* were just set to the same values)
+      }
+    }
+    const unsigned long long cm = __builtin_amdgcn_ballot_w64(capped);
+    // the map entries behind kk, one per lane, before anybody rewrites them
+    const int me = lane < ne ? lane : 0;
+    const int m_agent = S.esc_agent[me], m_id = S.esc_id[me], m_slot = S.esc_slot[me], m_pid = S.esc_pid[me], m_pslot = S.esc_pslot[me];
+    lds_sync();
+    if (lane == 0) {
+      if (cm) {  // Task.removeAgentCap of every holder, agents ascending
+        double al[6];
+#pragma unroll
+        for (int c = 0; c < 6; c++) al[c] = C.t_alloc[c][s];
+        for (unsigned long long m = cm; m; m &= m - 1ull) {
+          const int a = __ffsll((long long)m) - 1;
+#pragma unroll
+          for (int c = 0; c < 6; c++) al[c] -= S.a_caps[c][a];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; c++) C.t_alloc[c][s] = al[c];
+        S.t_ndet[s] -= __popcll(cm);
+        S.times_dirty = 1;
+      }
+      S.t_status[s] = 2;
+      S.esc_mask &= ~(1ull << recon);  // (== S.t_prot_agent[s]: the map is keyed by the protected UAV)
+      S.n_escorts = ne - 1;
+      if (failed) S.escort_failed++; else S.escort_completed++;
+      push_event(MUAVTA_EV_ESCORT_RETIRED, id);
+    }
+    if (lane > kk && lane < ne) {
+      S.esc_agent[lane - 1] = m_agent; S.esc_id[lane - 1] = m_id; S.esc_slot[lane - 1] = m_slot;
+      S.esc_pid[lane - 1] = m_pid; S.esc_pslot[lane - 1] = m_pslot;
+    }
+    cold_sync();
   }
   DEV void retire_escort_for(int recon, bool failed) {  // :1952-1957
     int k = escort_lookup(recon);
@@ -1815,17 +1919,30 @@ struct Sim {
               px = S.t_px[cs]; py = S.t_py[cs];
             } else if ((tnow - S.a_task_start[a]) >= task_duration(ty) && ty != MUAVTA_HOLD && ty != MUAVTA_DEF &&
                        ty != MUAVTA_INT && ty != MUAVTA_DET) {
-              // task concluded by this agent (:1079-1107)
+              // task concluded by this agent (:1079-1107).  Everything this block needs from the HBM record is requested first, in
+              // one batch (doneReqs / orgReqs live there on the SLIM tile, the requirement vectors on every tile): one memory round
+              // trip instead of one per read-modify-write.
               S.a_px[a] = px; S.a_py[a] = py;  // taskDone reads agent.position
+              const double org_cs = qs().t_org[cs];
+              double done_cs = qs().t_done[cs], cur6[6], al6[6];
+#pragma unroll
+              for (int c = 0; c < 6; c++) { cur6[c] = C.t_cur[c][cs]; al6[c] = C.t_alloc[c][cs]; }
               bool was_head = task_done(a, cid, ty);
-              qs().t_done[cs] += S.a_caps[ty][a];
-              for (int c = 0; c < 6; c++) C.t_cur[c][cs] -= S.a_caps[c][a];
-              if (was_head) remove_agent_cap(cs, a);
-              if (qs().t_done[cs] >= qs().t_org[cs]) {
+              done_cs += S.a_caps[ty][a];
+              qs().t_done[cs] = done_cs;
+#pragma unroll
+              for (int c = 0; c < 6; c++) C.t_cur[c][cs] = cur6[c] - S.a_caps[c][a];
+              if (was_head && S.t_status[cs] != 2) {  // remove_agent_cap(cs, a)
+#pragma unroll
+                for (int c = 0; c < 6; c++) C.t_alloc[c][cs] = al6[c] - S.a_caps[c][a];
+                S.t_ndet[cs] -= 1;
+                S.times_dirty = 1;
+              }
+              if (done_cs >= org_cs) {
                 const bool esc = S.t_flags[cs] & TF_ESCORT;
                 if (!esc && !(S.t_flags[cs] & TF_REACHED)) { S.t_flags[cs] |= TF_REACHED; S.n_reached++; }
-                quality_reward += qs().t_org[cs] * 2;
-                S.F_Reward += qs().t_org[cs] * 1 / P.reward_norm_factor;
+                quality_reward += org_cs * 2;
+                S.F_Reward += org_cs * 1 / P.reward_norm_factor;
                 if (!esc) mark_outcome_slot(cs, true);
                 S.t_status[cs] = 2;
                 if (ty == MUAVTA_REC && is_recon(S.a_type[a])) {  // _on_protected_rec_done (:1959-1962)
@@ -2227,6 +2344,7 @@ struct Sim {
     // recon UAV and Rec task, which no other entry's retirement touches, so that is decided up front; coverage of
     // the entries BETWEEN two retirements is then evaluated in one pass (fighters' queues only change at a
     // retirement), one fighter per lane, instead of one map entry at a time.
+    PROF(59);
     const int n = S.n_escorts;
     if (n == 0) return;
     int recon = -1, es = -1, eid = -1;
@@ -2280,14 +2398,15 @@ struct Sim {
         if (lane == 0) { S.escort_required_steps += __popcll(seg); S.escort_covered_steps += __popcll(cov); }
         todo &= ~seg;
         lds_sync();
+        PROF(60);
       } else {
         const int k = __ffsll((long long)low) - 1;
         const int rk = __builtin_amdgcn_readlane(recon, k), ek = __builtin_amdgcn_readlane(eid, k);
         const bool dk = (__ballot(dead) >> k) & 1ull;
-        const unsigned long long holders = __ballot(lane < P.n_agents && S.a_state[lane] != -1 && queue_find(lane, ek) >= 0);
-        if (lane == 0) { const int kk = escort_lookup(rk); if (kk >= 0) retire_escort_entry(kk, dk, holders); }
+        retire_escort_coop(rk, dk);
+        (void)ek;
         todo &= ~low;
-        lds_sync();
+        PROF(61);
       }
     }
   }

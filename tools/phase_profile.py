@@ -30,6 +30,7 @@ names = {0: "(loop gap)", 1: "rng_refill", 2: "drain+release", 3: "actions", 4: 
          13: "lsap", 14: "accept", 15: "(pre-obs)", 16: "obs rows->LDS", 17: "obs rows stream", 18: "obs legal->LDS", 19: "obs legal stream", 20: "obs agents/flags/result", 21: "b: np.sum + penalty terms", 22: "b: generate_threat", 23: "b: threats parallel", 24: "b: threats serial replay", 25: "b: arrivals", 6: "b: escorts+sync", 26: "move: parallel pass", 4: "move: serial replay", 28: "c: prechecks", 29: "c: lists", 8: "c: serial_c (reward)", 32: "c: ballots", 33: "actions: precompute", 3: "actions: serial_a", 34: "move: compute (in 26)", 35: "finish: gc loop (slow path)", 36: "c: serial_c head", 37: "c: serial_c weighted sum", 38: "c: serial_c divisions", 30: "(count x1000) end-of-step slow path entered", 31: "(count x1000) ... with retired slots present", 40: "(count x1000) movement passes", 41: "(count x1000) movement events", 39: "reset: (entry)", 42: "reset: master init_by_array", 43: "reset: agent stream twist+tape", 44: "reset: seed draws + 2-3 init_by_array (parallel lanes)", 45: "reset: tgt/mission streams twist+tape", 46: "reset: zero blob", 47: "reset: serial entity creation"}
 v = np.array(list(buf), dtype=np.float64)
 counts = v[48:].copy()
+extra = {59: "escorts: arrivals + creation (in b: escorts+sync)", 60: "escorts: segment passes", 61: "escorts: retirements"}
 v = v[:48]
 for i in (30, 31, 40, 41):  # event counters that live among the cycle slots
     counts = np.append(counts, v[i]); v[i] = 0
@@ -42,6 +43,8 @@ for i in range(48):
 cnames = ["LSAP solves", "LSAP scan steps (inner iterations)", "LSAP rows (sum)", "LSAP columns (sum)", "replans (allocate ran)", "releaseAllTasks calls",
           "threat passes", "threat events (serial replays)", "escort syncs with entries", "escort map entries (sum)", "escort sync loop iterations", "", "", "", "", "",
           "end-of-step slow path entered", "... with retired slots present", "movement passes", "movement events"]
+for i, nm in extra.items():
+    if counts[i - 48]: print(f"  {nm:40s} {100 * counts[i - 48] / tot:6.2f} %   {counts[i - 48] / n / 150:9.0f} cyc/step   (cycles; part of the slot named in brackets)"); counts[i - 48] = 0
 print("  per env-step event counts:")
 for nm, c in zip(cnames, counts):
     if nm and c: print(f"    {nm:40s} {c / 1000 / n / 150:8.3f}")
