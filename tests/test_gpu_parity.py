@@ -1240,3 +1240,33 @@ def test_rollout_by_parts_equals_the_whole_batch_rollout(case, interval, n):
         assert np.array_equal(got_obs[key], want_obs[key]), key
     env.set_parts(0)
     assert np.array_equal(env.get_state(), want_state)
+
+
+def test_compat_install_without_a_factory_resolves_to_the_hip_library():
+    """`compat.install()` with no `backend_factory` (the product default) must build its envs on libmuavta.so — the injection hook
+    is for this repository's CPU tests only.  A fresh interpreter: installs the aliases, imports the reference's module names,
+    runs a short episode through the facade and reports which backend and which shared objects it ended up with."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import muavta_amd.compat as compat
+compat.install()
+from mUAV_TA.DroneEnv import MultiUAVEnv
+from mUAV_TA.MultiDroneEnvUtils import agentEnvOptions
+env = MultiUAVEnv(agentEnvOptions(agents={"F1": 2, "R1": 2}, tasks={"Att": 2, "Rec": 2}, multiple_tasks_per_agent=True, max_time_steps=30))
+obs, _ = env.reset(seed=3)
+for _ in range(5):
+    obs, rew, term, trunc, info = env.step({a: 0 for a in env.agents})
+maps = open("/proc/self/maps").read()
+print(json.dumps({"backend": type(env._b).__module__ + "." + type(env._b).__name__, "libmuavta": "libmuavta.so" in maps,
+                  "oracle": "liboracle" in maps, "oracle_modules": [m for m in sys.modules if m in ("orc", "oracle_backend")], "t": env.time_steps}))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "MUAVTA_SO"}
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["backend"].endswith("batched.BatchedMultiUAVEnv") and got["libmuavta"] and not got["oracle"] and not got["oracle_modules"] and got["t"] == 5, got
