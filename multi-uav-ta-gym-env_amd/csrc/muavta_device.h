@@ -941,8 +941,10 @@ struct Sim {
     uint32_t avail = 0;
     {  // available_agents: set of type indices of the matched agents
       const int ty = a < P.n_agents ? S.a_type[a] : 0;
+      // (ballots straight from a compare: the ballot of a combined predicate costs a v_cndmask + v_cmp to materialise it)
+      const int tym = match ? ty : -1;
 #pragma unroll
-      for (int t = 0; t <= MUAVTA_F2; t++) if (__ballot(match && ty == t) != 0ull) avail |= 1u << t;
+      for (int t = 0; t <= MUAVTA_F2; t++) if (__builtin_amdgcn_ballot_w64(tym == t) != 0ull) avail |= 1u << t;
     }
     lds_sync();
     if (Q <= 16) {
@@ -1687,7 +1689,7 @@ struct Sim {
     // actions that will create an escort (and with it set pending_reset) further down, in action order
     const bool creates = P.escort_enabled && succ && ty == MUAVTA_REC && is_recon(S.a_type[a]) && !has_escort(a);
     const unsigned long long cm = __ballot(creates);
-    if (idle_br && P.dynamic_idle_penalty != 0 && (pending0 || (cm & ((1ull << k) - 1ull)) != 0ull)) { q1 = -P.dynamic_idle_penalty; nq01 = 2; }
+    if (idle_br && P.dynamic_idle_penalty != 0 && (pending0 || prefix_count(cm) != 0)) { q1 = -P.dynamic_idle_penalty; nq01 = 2; }
     // ---- task side: Task.addAgentCap in action order over the lanes that share a slot ----
     const unsigned long long sm = __ballot(succ);
     if (sm) {
@@ -1747,15 +1749,14 @@ struct Sim {
     // at a time (uniform addresses: every lane folds the same numbers).  r2 replayed them with ~12 v_readlane per action.
     // action_reward only ever receives -1 per penalty: -(count) is the same double whatever the order.
     {
-      const unsigned long long below = (1ull << k) - 1ull;
       const unsigned long long b1 = __builtin_amdgcn_ballot_w64(nq01 >= 1), b2 = __builtin_amdgcn_ballot_w64(nq01 >= 2),
                                b3 = __builtin_amdgcn_ballot_w64(nq23 >= 1), b4 = __builtin_amdgcn_ballot_w64(nq23 >= 2),
                                e1 = __builtin_amdgcn_ballot_w64(nd0 != 0), e2 = __builtin_amdgcn_ballot_w64(nd1 != 0);
       double* qrow = X.cost;  // <= 4 per action (COSTN >= 4 * A)
       double* drow = X.v;     // <= 2 per action (T >= 2 * A)
       static_assert(T >= 2 * A, "distance addends need 2 * A scratch doubles");
-      int qo = __popcll(b1 & below) + __popcll(b2 & below) + __popcll(b3 & below) + __popcll(b4 & below);
-      int dn = __popcll(e1 & below) + __popcll(e2 & below);
+      int qo = prefix_count(b1) + prefix_count(b2) + prefix_count(b3) + prefix_count(b4);  // (k == lane)
+      int dn = prefix_count(e1) + prefix_count(e2);
       lds_sync();  // (the slot-side reads of the scratch rows above are done)
       if (nq01 >= 1) qrow[qo++] = q0;
       if (nq01 >= 2) qrow[qo++] = q1;
@@ -2387,10 +2388,11 @@ struct Sim {
           near = fma(dy, dy, dx * dx) <= P.escort_sq_bound;
         }
         unsigned long long cov = 0ull;
+        const int neark = near ? myk : -2;
         if (__ballot(near) != 0ull)
           for (unsigned long long m = seg & live_m; m; m &= m - 1ull) {
             const int k = __ffsll((long long)m) - 1;
-            if (__ballot(near && myk == k) != 0ull) cov |= 1ull << k;
+            if (__builtin_amdgcn_ballot_w64(neark == k) != 0ull) cov |= 1ull << k;
           }
         if ((seg >> lane) & 1ull) {
           if (esc_live) { S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon]; }  // follow the protected UAV
@@ -2430,7 +2432,7 @@ struct Sim {
         c = S.t_status[s] != 2 && !(fl & TF_KNOWN_ALL) && (S.t_created[s] > 0 || (fl & TF_DEADLINE));
       }
       const unsigned long long m = __ballot(c);
-      if (c) cand[nc + __popcll(m & ((1ull << lane) - 1ull))] = s;
+      if (c) cand[nc + prefix_count(m)] = s;
       nc += __popcll(m);
     }
     if (nc == 0) return;
@@ -2480,7 +2482,7 @@ struct Sim {
         }
         lds_sync();  // every lane holds its entry before the survivors are packed to the front
         if (k < n && !due) {
-          const int d = w + __popcll(km & below);
+          const int d = w + prefix_count(km);
           S.pend_time[d] = pt; S.pend_id[d] = pid; S.pend_slot[d] = (uint8_t)psl; S.pend_know[d] = pk;
         }
         w += __popcll(km);
@@ -2609,8 +2611,8 @@ struct Sim {
         const unsigned long long am = __ballot(alive), om = __ballot(open);
         const unsigned long long below = (1ull << lane) - 1ull;
         lds_sync();  // every lane has read its t_order entry before any is overwritten
-        if (alive) S.t_order[w + __popcll(am & below)] = s;
-        if (open) { const int row = no + __popcll(om & below); S.open_slot[row] = s; S.t_row[s] = (uint8_t)row; }
+        if (alive) S.t_order[w + prefix_count(am)] = s;
+        if (open) { const int row = no + prefix_count(om); S.open_slot[row] = s; S.t_row[s] = (uint8_t)row; }
         w += __popcll(am);
         no += __popcll(om);
       }
@@ -2784,14 +2786,15 @@ struct Sim {
         unsigned long long okm = 0ull;
 #pragma unroll
         for (int t = 0; t <= MUAVTA_F2; t++) {
-          const unsigned long long m = __ballot(in_n && ((typemask >> t) & 1u));
+          const unsigned long long m = __builtin_amdgcn_ballot_w64((typemask & (1u << t)) != 0u);  // (typemask is 0 beyond the open rows)
           if (my_ty == t) okm = m;
         }
         if (capm) {  // capability mask: rows whose task type the agent has capability for
+          const int tyx = in_n ? ty : -1;
           unsigned long long capok = 0ull;
 #pragma unroll
           for (int tt = 0; tt < 6; tt++) {
-            const unsigned long long m = __ballot(in_n && ty == tt);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(tyx == tt);
             if (lane < nA && S.a_caps[tt][lane] > 0) capok |= m;
           }
           okm &= capok;
@@ -2914,7 +2917,7 @@ struct Sim {
         if (mode == 1) {
           const unsigned long long um = __ballot(under);
           if (under) {
-            const int rank = n_under + __popcll(um & ((1ull << lane) - 1ull));
+            const int rank = n_under + prefix_count(um);
             int n_know = 0;
             if (vis) for (int b = 0; b < P.n_agents; b++) n_know += (S.known[b][s >> 5] >> (s & 31)) & 1u;
             pair_info()[s] = (rank < 32 ? rank : 255) | (n_know << 8);
@@ -2925,7 +2928,7 @@ struct Sim {
       if (mode == 1 && lane < P.n_agents) {
         const bool lv = S.a_state[lane] != -1;
         const unsigned long long lm = __ballot(lv);
-        const int rk = __popcll(lm & ((1ull << lane) - 1ull));
+        const int rk = prefix_count(lm);
         X.live_rank[lane] = (lv && rk < 16) ? (uint8_t)rk : (uint8_t)255;
       }
       if (nr == 0 || __ballot(any_open) == 0ull) go = false;
@@ -3190,12 +3193,12 @@ struct Sim {
         const unsigned long long below = (1ull << lane) - 1ull;
         lds_sync();  // freeA fully read before it is compacted in place
         if (acc) {
-          const int n = n_act + n_acc + __popcll(am & below);
+          const int n = n_act + n_acc + prefix_count(am);
           S.act_agent[n] = a; S.act_slot[n] = s; S.act_index[n] = oi;
           const double delivered = is_escort_task(s) ? 1.0 : S.a_caps[S.t_type[s]][a];
           X.resid[s] = fmax(X.resid[s] - delivered, 0.0);
         }
-        if (keep) X.freeA[n_left + __popcll(km & below)] = a;
+        if (keep) X.freeA[n_left + prefix_count(km)] = a;
         n_acc += __popcll(am);
         n_left += __popcll(km);
       }
@@ -3474,6 +3477,11 @@ struct Sim {
     if (lane == 0 && K.n_urgent) K.n_urgent[env] = 0;
     if (lane == 0 && K.replanned) K.replanned[env] = 0;
   }
+  // number of set bits of a (uniform) lane mask below this lane: v_mbcnt_lo / v_mbcnt_hi, two VALU instructions
+  // (`prefix_count(m)` is a 64-bit shift, a 64-bit subtract, two ANDs and two bit counts)
+  static DEV int prefix_count(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+  }
   // out[0..n) = f(k) for the k in [0, count) with pred(k), order preserved (ballot + popcount); returns n
   template <class Out, class Pred, class Val>
   DEV int compact_to(Out* out, int count, Pred pred, Val val) {
@@ -3482,7 +3490,7 @@ struct Sim {
       const int k = base + lane;
       const bool p = k < count && pred(k);
       const unsigned long long m = __ballot(p);
-      if (p) out[n + __popcll(m & ((1ull << lane) - 1ull))] = (Out)val(k);
+      if (p) out[n + prefix_count(m)] = (Out)val(k);
       n += __popcll(m);
     }
     return n;
