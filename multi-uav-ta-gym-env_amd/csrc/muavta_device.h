@@ -1191,7 +1191,7 @@ struct Sim {
       for (int i = lane; i < (int)(sizeof(State) / 4); i += WG) w[i] = 0;
     }
     lds_sync();
-    if (lane == 0) { S.rng_idx[ST_AGENT] = agent_cursor; S.error = err0; }
+    if (lane == 0) { S.rng_idx[ST_AGENT] = agent_cursor; S.error = err0; S.obs_rows = -1; }
     lds_sync();
     PROF(46);
     if (lane == 0) reset_serial();
@@ -2703,14 +2703,18 @@ struct Sim {
     return true;
   }
 
-  DEV void write_obs(float* o_tasks, unsigned long long* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags) {
+  // handle_buffer: the tensors are the handle's single observation buffer (overwritten in place every step), not a ring slot —
+  // its pad rows are only rewritten where live rows have just disappeared (S.obs_rows)
+  DEV void write_obs(float* o_tasks, unsigned long long* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags, bool handle_buffer = false) {
     cold_sync();  // the rows below read the requirement vectors the serial phases of this step may have changed
     const int MT = P.max_tasks, nA = P.n_agents;
-    const int n = S.n_open;
+    const int n = __builtin_amdgcn_readfirstlane(S.n_open);
+    const int pad_known = handle_buffer ? __builtin_amdgcn_readfirstlane(S.obs_rows) : -1;
+    const int pad_until = pad_known < 0 ? MT : pad_known;  // pad rows below this index have to be (re)written
     // The HBM rows of the first 64 observation rows are requested NOW, so that their latency runs under the rebuild of the
     // task times below (LDS work); (initTime, doneTime) then come from the scratch tile when they were rebuilt.
     double pc[6], pa[6], pti = 0, ptd = 0;
-    const bool dirty = S.times_dirty != 0;
+    const bool dirty = __builtin_amdgcn_readfirstlane(S.times_dirty) != 0;  // (uniform: a scalar branch picks LDS or HBM below, not a per-lane pointer select)
     if (MUAVTA_OBS_PREFETCH) {
       const int s0 = lane < n ? (int)S.open_slot[lane] : 0;
 #pragma unroll
@@ -2760,23 +2764,30 @@ struct Sim {
           r[17] = (float)div_small_any(td - (double)tnow, mts, inv_mts);
           r[18] = (float)div_small((double)ty, 6.0, INV6);
         }
-        double cur_ty = cur[0], alc_ty = alc[0];  // (selects, not cur[ty]: a dynamically indexed local array would live in scratch memory)
-#pragma unroll
-        for (int c = 1; c < 6; c++) if (ty == c) { cur_ty = cur[c]; alc_ty = alc[c]; }
+        // the row of the task's own type: two more loads with a per-lane row index (a select chain over the six rows loaded above
+        // costs ~30 VALU; a dynamically indexed local array would live in scratch memory)
+        const double cur_ty = C.t_cur[ty][s], alc_ty = C.t_alloc[ty][s];
         const double org = qs().t_org[s];
         if (P.saturate_mask && alc_ty >= org) typemask = 0;
         const double unmet = fmax(cur_ty - alc_ty, 0.0);
         r[19] = (float)(unmet / fmax(org, 1e-6));
         r[20] = (float)fmin(div_small((double)tnow - (double)S.t_created[s], mts, inv_mts), 1.0);
         if (o_tasks && in_mt) {
+          // feature-major: column c of row j at (c * MT + j) * 4 — one base in scalar registers, the lane's byte offset stepped by
+          // the column stride (one VALU add per store; a column pointer per store was five SALU instructions)
+          uint32_t off = ju * 4u;
+          const uint32_t cstride = (uint32_t)MT * 4u;
 #pragma unroll
-          for (int c = 0; c < 21; c++) at_lane(o_tasks + (size_t)(c * MT), ju * 4u) = r[c];
+          for (int c = 0; c < 21; c++) { at_lane(o_tasks, off) = r[c]; off += cstride; }
         }
-      } else if (o_tasks && in_mt) {
-        // pad rows are {"status": -1}; with no open task row 0 is task_idle (all zeros)
+      } else if (o_tasks && in_mt && (j < pad_until || j == 0)) {
+        // pad rows are {"status": -1}; with no open task row 0 is task_idle (all zeros).  Rows the buffer already holds as pad rows
+        // are left alone.
         const float st = (j == 0 && n == 0) ? 0.f : -1.f;
+        uint32_t off = ju * 4u;
+        const uint32_t cstride = (uint32_t)MT * 4u;
 #pragma unroll
-        for (int c = 0; c < 21; c++) at_lane(o_tasks + (size_t)(c * MT), ju * 4u) = c == 3 ? st : 0.f;
+        for (int c = 0; c < 21; c++) { at_lane(o_tasks, off) = c == 3 ? st : 0.f; off += cstride; }
       }
       if (o_pad && in_mt) o_pad[ju] = j < (n == 0 ? 1 : n);
       PROF(16);
@@ -2843,6 +2854,7 @@ struct Sim {
       o_flags[3] = (float)div_small((double)tnow, mts, inv_mts);
       o_flags[4] = (float)div_small((double)n, (double)(P.max_tasks > 1 ? P.max_tasks : 1), P.inv_max_tasks);
     }
+    if (handle_buffer && o_tasks && lane == 0) S.obs_rows = n > 0 ? n : 1;  // rows from here on hold pad rows now
   }
 
   // ====================================================================================================

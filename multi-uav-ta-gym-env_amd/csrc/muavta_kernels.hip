@@ -74,10 +74,10 @@ template <class TL> __device__ __forceinline__ EnvCold<TL>* cold_of(const DevCtx
 __device__ __forceinline__ uint32_t* tape_of(const DevCtx& c, int env) { return as_global(c.tapes) + (size_t)env * MUAVTA_RNG_STREAMS * MUAVTA_RNG_WORDS; }
 
 template <class TL>
-__device__ __forceinline__ void obs_for_env(Sim<TL>& sim, const DevParams& P, const ObsPtrs& O, int env) {
+__device__ __forceinline__ void obs_for_env(Sim<TL>& sim, const DevParams& P, const ObsPtrs& O, int env, bool handle_buffer = true) {
   const size_t mt = (size_t)P.max_tasks, nA = (size_t)P.n_agents;
   sim.write_obs(O.tasks + (size_t)env * mt * 21, O.legal + (size_t)env * nA * ((mt + 63) >> 6), O.pad + (size_t)env * mt,
-                O.agents + (size_t)env * nA * 9, O.flags + (size_t)env * 5);
+                O.agents + (size_t)env * nA * 9, O.flags + (size_t)env * 5, handle_buffer);
   if (threadIdx.x == 0) {
     O.reward[env] = sim.S.last_reward;
     O.done[env] = (uint8_t)((sim.S.terminated ? 1 : 0) | (sim.S.truncated ? 2 : 0));
@@ -352,14 +352,16 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned cha
   if (phases & PH_OBS) {
     ObsPtrs O = obs_ptrs(ctx);
     int at = env;
+    bool handle_buffer = true;
     if constexpr (REC) {
-      if (oslot >= 0) {  // slot `oslot` of the caller's observation rings instead of the handle's single buffer
+      if (oslot >= 0) {  // slot `oslot` of the caller's observation rings instead of the handle's single buffer (a fresh buffer: every row is written)
+        handle_buffer = false;
         O.tasks = as_global(rec.O.tasks); O.legal = as_global(rec.O.legal); O.pad = as_global(rec.O.pad); O.agents = as_global(rec.O.agents);
         O.flags = as_global(rec.O.flags); O.reward = as_global(rec.O.reward); O.done = as_global(rec.O.done);
         at = oslot * rec.n_envs + env;
       }
     }
-    obs_for_env(sim, ctx.P, O, at);
+    obs_for_env(sim, ctx.P, O, at, handle_buffer);
   }
   lds_sync();
   if ((phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) {
@@ -499,6 +501,12 @@ __global__ __launch_bounds__(WG) void k_observe(const DevCtx* __restrict__ ctxp)
   lds_sync();
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, nullptr);
   obs_for_env(sim, ctx.P, obs_ptrs(ctx), env);
+  lds_sync();
+  if (threadIdx.x == 0) {  // the only fields this kernel changes in the record: which rows of the buffer hold pad rows now, and the
+    EnvState<TL>* blob = blob_of<TL>(ctx, env);   // task times it rebuilt on the way (refresh_task_times)
+    blob->obs_rows = L.S->obs_rows;
+    blob->times_dirty = L.S->times_dirty;
+  }
 }
 
 template <class TL>
@@ -1059,6 +1067,12 @@ int gather(MuavtaEnv* e, MuavtaField f, void* dst, size_t bytes, bool scatter) {
 #undef BAD
 #undef RW
   return MUAVTA_OK;
+}
+
+template <class TL>
+void forget_obs_rows(MuavtaEnv* e) {  // the host rewrote the blobs: what the observation buffer holds no longer follows from them
+  EnvState<TL>* blobs = reinterpret_cast<EnvState<TL>*>(e->host_blobs.data());
+  for (int n = 0; n < e->n_envs; n++) blobs[n].obs_rows = -1;
 }
 
 template <class TL>
@@ -1872,6 +1886,7 @@ int muavta_set(MuavtaEnv* e, MuavtaField field, const void* src, size_t bytes) {
   if (rc) return rc;
   DISPATCH(e, rc = gather<TL>(e, field, const_cast<void*>(src), bytes, true));
   if (rc) return rc;
+  DISPATCH(e, forget_obs_rows<TL>(e));
   HIPCHK(e, hipMemcpyAsync(e->blobs, e->host_blobs.data(), e->host_blobs.size(), hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync(e->cold, e->host_cold.data(), e->host_cold.size(), hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1891,7 +1906,9 @@ int muavta_set_state(MuavtaEnv* e, const void* src, size_t bytes) {
   if (!e || !src || bytes != (size_t)e->n_envs * (e->state_bytes + e->cold_bytes)) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
   MAIN_OP(e);
-  HIPCHK(e, hipMemcpyAsync(e->blobs, src, (size_t)e->n_envs * e->state_bytes, hipMemcpyHostToDevice, e->stream));
+  e->host_blobs.assign((const unsigned char*)src, (const unsigned char*)src + (size_t)e->n_envs * e->state_bytes);
+  DISPATCH(e, forget_obs_rows<TL>(e));  // (the observation buffer belongs to another moment than the restored state)
+  HIPCHK(e, hipMemcpyAsync(e->blobs, e->host_blobs.data(), (size_t)e->n_envs * e->state_bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipMemcpyAsync(e->cold, (const char*)src + (size_t)e->n_envs * e->state_bytes, (size_t)e->n_envs * e->cold_bytes, hipMemcpyHostToDevice, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   e->host_valid = false;

@@ -178,6 +178,8 @@ struct alignas(16) EnvState : QueueSide<TL::A, TL::T, !TL::SLIM> {
   uint32_t rng_win[4][8];             // the next 8 raw words of each stream, prefetched at the step boundary
   uint32_t rng_win_at[4];             // cursor value the window was filled at
   int32_t times_dirty;                // some allocationDetails changed since initTime/doneTime were rebuilt
+  int32_t obs_rows;                   // rows [obs_rows, max_tasks) of the HANDLE's observation task tensor are known to hold pad rows
+                                      // ({"status": -1}); -1: unknown (after a reset, or when the host rewrote the state)
 };
 
 // Standard tiles (BASELINE.json configs).  The 16-agent tile has 40 task slots — the bound at which the reference stops
