@@ -12,7 +12,9 @@ PLAN = [("WPS_easy", "hungarian", 0, 20, 8192), ("WPS_hard", "hungarian", 0, 20,
         ("WPS_attn", "hungarian", 0, 20, 4096), ("WPS_attn_AWACS", "hungarian", 0, 20, 4096), ("D2_popup_threats", "hungarian", 0, 20, 4096),
         ("WPS_hard_x2", "hungarian", 0, 20, 32768), ("WPS_escort", "hungarian", 0, 12, 8192), ("WPS_escort24", "hungarian", 0, 12, 4096),
         ("WPS_burst64", "hungarian", 0, 20, 1024), ("WPS_hard", "urgency_pair", 1, 20, 8192), ("WPS_attn", "urgency_pair", 1, 20, 4096),
-        ("WPS_escort", "urgency_coalition", 2, 12, 8192), ("WPS_escort24", "urgency_coalition", 2, 12, 2048), ("WPS_hard", "hungarian_gated", 3, 20, 8192)]
+        ("WPS_escort", "urgency_coalition", 2, 12, 8192), ("WPS_escort24", "urgency_coalition", 2, 12, 2048), ("WPS_hard", "hungarian_gated", 3, 20, 8192),
+        ("WPS_attn_XL", "hungarian", 0, 20, 1024), ("WPS_attn_L", "hungarian", 0, 20, 1024), ("WPS_burst64", "urgency_coalition", 2, 12, 512),
+        ("WPS_burst64", "urgency_pair", 1, 20, 512), ("WPS_attn_XL", "urgency_pair", 1, 20, 512)]
 base = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 for case, name, mode, interval, n in PLAN:
     env = BatchedMultiUAVEnv(params_for_case(case), n)
