@@ -333,6 +333,12 @@ enum { MUAVTA_LSAP_AUTO = 0, MUAVTA_LSAP_LDS = 1, MUAVTA_LSAP_REGISTERS = 2 };
 int muavta_lsap_impl(int32_t device, const double* cost, int32_t n_problems, int32_t n_rows, int32_t n_cols, int64_t* row_ind,
                      int64_t* col_ind, int32_t impl);
 
+/* Diagnostic: the kernels' square root and division (sequences restricted to the simulation's operand range, see
+ * fsqrt / fdiv in csrc/muavta_device.h) evaluated on the device for n operand pairs: out_sqrt[i] = sqrt(x[i]),
+ * out_div[i] = x[i] / y[i], out_div_neg[i] = -x[i] / y[i] (through the shared-reciprocal form).  Inside the documented
+ * domain the results equal the IEEE-754 correctly rounded ones bit for bit; the parity tests pin that against numpy. */
+int muavta_domain_math(int32_t device, const double* x, const double* y, int32_t n, double* out_sqrt, double* out_div, double* out_div_neg);
+
 /* core_sim.SimCore.avoid_obstacles (core_sim/src/sim_core.rs:25-59) for n (position, movement)
  * pairs against one obstacle list, evaluated on the device. */
 int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double* movement, int32_t n,

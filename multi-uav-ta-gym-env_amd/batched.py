@@ -443,3 +443,18 @@ def avoid_obstacles(agent_pos, obstacles, movement, device: int = 0):
     if rc != 0:
         raise MuavtaError(f"muavta_avoid_obstacles failed ({rc}): {L.muavta_last_error(None).decode()}")
     return out
+
+
+def domain_math(x, y, device: int = 0):
+    """The kernels' range-restricted sqrt / division on the device (diagnostic, `muavta_domain_math`):
+    returns (sqrt(x), x / y, -x / y) as the device computes them."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+    if x.shape != y.shape:
+        raise ValueError("x and y must have the same length")
+    outs = [np.empty_like(x) for _ in range(3)]
+    L = native.lib()
+    rc = L.muavta_domain_math(int(device), _vp(x), _vp(y), x.shape[0], *[_vp(o) for o in outs])
+    if rc != 0:
+        raise MuavtaError(f"muavta_domain_math failed ({rc}): {L.muavta_last_error(None).decode()}")
+    return tuple(outs)

@@ -79,7 +79,41 @@ DEV double engage_range(int t) { return t == MUAVTA_F1 ? 40.0 : t == MUAVTA_F2 ?
 DEV double threat_attack(int t) { return 0.2; }                          // UavCapTable[T1/T2][Att]
 DEV double threat_defence(int t) { return t == MUAVTA_T1 ? 0.5 : 0.4; }  // UavCapTable[T1/T2][Def]
 
-DEV double norm2(double x, double y) { return sqrt(fma(y, y, x * x)); }  // np.linalg.norm of a 2-vector
+// Correctly rounded f64 square root and division for operands of this simulation's range: the very instruction sequences
+// the compiler expands `sqrt` and `/` into (v_rsq_f64 / v_rcp_f64 seed + FMA refinement + one correction step), without the
+// range scaling in front (v_div_scale_f64 x2 / v_cmp + v_ldexp x2 + v_cndmask) and the special-case fix-up behind
+// (v_div_fixup_f64).  Those only act on operands the simulation cannot produce — a radicand below 2^-767, a numerator below
+// 2^-970 that is not zero, a zero / denormal / infinite divisor, exponents >= 768 apart — so inside the domain every
+// intermediate is the same and so is the result, bit for bit (tests/test_gpu_parity.py::test_domain_sqrt_div_bit_exact pins
+// them against numpy on the GPU).  sqrt: 13 VALU instead of 20; division: 8 instead of 11, and a second quotient by the same
+// divisor costs 3 (the reciprocal refinement is shared).  The kernels are VALU-issue bound.
+//   fsqrt(x):       x is +0, -0, +inf, NaN, or >= 2^-767  (sums of squares of coordinate differences: 0 or >= 2^-200)
+//   frcp_nr(d):     d finite, 2^-250 <= |d| <= 2^250       (distances >= 1e-12 where the callers guard, speeds, counts)
+//   fdiv_r(n,d,r):  n == 0 (either sign: +0 results, callers never hold -0) or 2^-250 <= |n| <= 2^250;  r = frcp_nr(d)
+DEV double fsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = y * 0.5;
+  const double e = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, e, g); h = __builtin_fma(h, e, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return __builtin_amdgcn_class(x, 0x260) ? x : g;  // -0, +0, +inf: the radicand itself
+}
+DEV double frcp_nr(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  double e = __builtin_fma(-d, r, 1.0);
+  r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-d, r, 1.0);
+  return __builtin_fma(r, e, r);
+}
+DEV double fdiv_r(double n, double d, double r) {
+  const double q = n * r;
+  return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+DEV double fdiv(double n, double d) { return fdiv_r(n, d, frcp_nr(d)); }
+DEV double norm2(double x, double y) { return fsqrt(fma(y, y, x * x)); }  // np.linalg.norm of a 2-vector
 DEV bool is_recon(int t) { return t == MUAVTA_R1 || t == MUAVTA_R2; }
 DEV bool is_fighter(int t) { return t == MUAVTA_F1 || t == MUAVTA_F2; }
 
@@ -474,7 +508,7 @@ struct Sim {
     S.a_reeval[a] = 0;
     S.a_last_id[a] = -1;
     S.a_last_slot[a] = -1;
-    double time_to_task = pre_time >= 0 ? pre_time : norm2(qs().a_nfx[a] - S.t_px[s], qs().a_nfy[a] - S.t_py[s]) / speed_of(S.a_type[a]);
+    double time_to_task = pre_time >= 0 ? pre_time : fdiv(norm2(qs().a_nfx[a] - S.t_px[s], qs().a_nfy[a] - S.t_py[s]), speed_of(S.a_type[a]));
     double start_time = (qs().a_nft[a] - (double)tnow) > 0 ? qs().a_nft[a] : (double)tnow;
     double dur = (double)task_duration(S.t_type[s]);
     double end_time = start_time + time_to_task + dur;
@@ -1046,7 +1080,8 @@ struct Sim {
   DEV void norm_vector(double& x, double& y) {  // EnvUtils.norm_vector (MultiDroneEnvUtils.py:168-177)
     double m = norm2(x, y);
     if (m == 0) { x = 0; y = 0; return; }
-    x = x / m; y = y / m;
+    const double r = frcp_nr(m);  // (m > 0: a norm of finite coordinates)
+    x = fdiv_r(x, m, r); y = fdiv_r(y, m, r);
   }
   // core_sim SimCore::avoid_obstacles (core_sim/src/sim_core.rs:25-59); Rust `%` == fmod
   DEV void avoid_obstacles(double px, double py, double mx, double my, double& ax, double& ay) {
@@ -1381,7 +1416,7 @@ struct Sim {
       double d = 0.0;
       if (lane < P.n_agents) {
         double dx = S.a_px[lane] - prev_x, dy = S.a_py[lane] - prev_y;
-        d = sqrt(dx * dx + dy * dy);
+        d = fsqrt(dx * dx + dy * dy);
         S.a_dist[lane] += d;
         X.u[lane] = d;
       }
@@ -1525,7 +1560,7 @@ struct Sim {
           const double dist = norm2(dx, dy);
           double ux = 0, uy = 0;
           const bool zero = to_task ? (fabs(dist) < 1e-12) : (dist == 0);
-          if (!zero) { ux = dx / dist; uy = dy / dist; }
+          if (!zero) { const double r = frcp_nr(dist); ux = fdiv_r(dx, dist, r); uy = fdiv_r(dy, dist, r); }
           double ndx, ndy;
           displacement(px, py, ux, uy, speed, ndx, ndy);
           if (to_task) {
@@ -1594,7 +1629,7 @@ struct Sim {
     if (S.a_qlen[a] > 0) { const int hs = S.a_qslot[a][0]; d_old = norm2(px - S.t_px[hs], py - S.t_py[hs]); }
     act_f(0)[k] = d_old;
     act_f(1)[k] = norm2(px - tx, py - ty);
-    act_f(2)[k] = norm2(qs().a_nfx[a] - tx, qs().a_nfy[a] - ty) / speed_of(S.a_type[a]);
+    act_f(2)[k] = fdiv(norm2(qs().a_nfx[a] - tx, qs().a_nfy[a] - ty), speed_of(S.a_type[a]));
     const int n = S.a_qlen[a];  // after the append the queue holds n + 1 entries; tasks[-2] is the current last one
     double total;
     if (n >= 1) { const int ps = S.a_qslot[a][n - 1]; total = norm2(tx - S.t_px[ps], ty - S.t_py[ps]); }
@@ -1663,7 +1698,7 @@ struct Sim {
           if (!action_valid(a, s)) n_pen = 1;
           else if (!(queue_find(a, tid) >= 0 || S.t_status[s] == 2)) {  // UAV.allocate (DroneEnvComponents.py:55-96)
             S.a_reeval[a] = 0; S.a_last_id[a] = -1; S.a_last_slot[a] = -1;
-            const double time_to_task = norm2(qs().a_nfx[a] - tx, qs().a_nfy[a] - ty_) / speed_of(S.a_type[a]);
+            const double time_to_task = fdiv(norm2(qs().a_nfx[a] - tx, qs().a_nfy[a] - ty_), speed_of(S.a_type[a]));
             const double start_time = (qs().a_nft[a] - (double)tnow) > 0 ? qs().a_nft[a] : (double)tnow;
             ty = S.t_type[s];
             const double end_time = start_time + time_to_task + (double)task_duration(ty);
@@ -1894,7 +1929,7 @@ struct Sim {
           double dx = S.t_px[cs] - px, dy = S.t_py[cs] - py;
           const double dist = norm2(dx, dy);
           double ux = 0, uy = 0;
-          if (!(fabs(dist) < 1e-12)) { ux = dx / dist; uy = dy / dist; }
+          if (!(fabs(dist) < 1e-12)) { const double r = frcp_nr(dist); ux = fdiv_r(dx, dist, r); uy = fdiv_r(dy, dist, r); }
           if (S.a_state[a] == 1) {  // navigating (:1012-1048)
             if (ty == MUAVTA_INT) {
               if (dist < engage) {

@@ -633,6 +633,15 @@ __global__ __launch_bounds__(WG) void k_lsap(const double* cost, int nr, int nc,
   }
 }
 
+__global__ void k_domain_math(const double* x, const double* y, int n, double* out_sqrt, double* out_div, double* out_div2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out_sqrt[i] = fsqrt(x[i]);
+  out_div[i] = fdiv(x[i], y[i]);
+  const double r = frcp_nr(y[i]);
+  out_div2[i] = fdiv_r(-x[i], y[i], r);
+}
+
 __global__ void k_avoid(const double* pos, const double* mov, int n, const double* obst, int n_obs, double* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -802,6 +811,8 @@ int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
   if (nA < 1) { *err = "no agents"; return MUAVTA_E_ARG; }
   if (p->num_obstacles < 0 || p->num_obstacles > 8) { *err = "num_obstacles must be in 0..8"; return MUAVTA_E_ARG; }
   if (p->max_time_steps < 1) { *err = "max_time_steps must be >= 1"; return MUAVTA_E_ARG; }
+  // (agent speeds = MAX_SPEED / frame_rate * 0.02 are divisors of the kernels' range-restricted division, see fdiv)
+  if (!(p->simulation_frame_rate >= 1e-9 && p->simulation_frame_rate <= 1e9)) { *err = "simulation_frame_rate must be in [1e-9, 1e9]"; return MUAVTA_E_ARG; }
   // time steps, deadlines (t + window_length), reveal times (t + threat_delay), commit locks (t + commit_horizon) and task
   // ids (a few per step) are stored in 16 bits on the device
   if (p->max_time_steps > 20000 || p->window_length > 10000 || p->threat_delay > 10000 || p->commit_horizon > 10000 || p->window_length < -10000 ||
@@ -1998,6 +2009,27 @@ int muavta_lsap_impl(int32_t device, const double* cost, int32_t n, int32_t nr, 
       g_create_error = "muavta_lsap: cost matrix " + std::to_string(i) + " is infeasible";
       return MUAVTA_E_ARG;
     }
+  return MUAVTA_OK;
+}
+
+int muavta_domain_math(int32_t device, const double* x, const double* y, int32_t n, double* out_sqrt, double* out_div, double* out_div_neg) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "muavta_domain_math: no HIP device"; return MUAVTA_E_NO_DEVICE; }
+  if (!x || !y || !out_sqrt || !out_div || !out_div_neg || n < 1) return MUAVTA_E_ARG;
+  double* d[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); for (double* q : d) hipFree(q); return MUAVTA_E_HIP; } } while (0)
+  DeviceScope scope_(device);
+  const size_t bytes = (size_t)n * sizeof(double);
+  for (double*& q : d) CK(hipMalloc(&q, bytes));
+  CK(hipMemcpy(d[0], x, bytes, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d[1], y, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_domain_math, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], d[1], n, d[2], d[3], d[4]);
+  CK(hipGetLastError());
+  CK(hipMemcpy(out_sqrt, d[2], bytes, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(out_div, d[3], bytes, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(out_div_neg, d[4], bytes, hipMemcpyDeviceToHost));
+#undef CK
+  for (double* q : d) hipFree(q);
   return MUAVTA_OK;
 }
 

@@ -278,6 +278,33 @@ def test_full_size_properties_cfg2():
     assert np.array_equal(m1, env.rollout_metrics())
 
 
+def test_domain_sqrt_div_bit_exact():
+    """fsqrt / fdiv (csrc/muavta_device.h): the compiler's sqrt and division sequences without range scaling and fix-ups must be
+    the IEEE-754 correctly rounded results (numpy's) on everything the simulation can feed them: coordinates and their
+    differences, squared distances, distances from 1e-12 up, speeds, zero numerators and radicands."""
+    from muavta_amd.batched import domain_math
+
+    rng = np.random.default_rng(20261004)
+    n = 1 << 20
+    pos = rng.uniform(0.0, 1200.0, size=(4, n))
+    dx, dy = pos[0] - pos[1], pos[2] - pos[3]
+    sq = dy * dy + dx * dx
+    xs = [sq, dx, dy, np.sqrt(sq), rng.uniform(0, 2000, n), np.ldexp(rng.uniform(1, 2, n), rng.integers(-200, 40, n)),  # radicands / numerators
+          np.zeros(64), np.array([1e-24, 1e-12, 1.0, 4.0, 1200.0 ** 2 * 2, np.inf]), np.ldexp(1.0, np.arange(-240, 240, dtype=np.int64))]
+    ys = [np.sqrt(sq) + 1e-12, np.sqrt(sq) + 1e-12, rng.uniform(1e-12, 1e-6, n), rng.choice([0.1, 0.16, 0.4, 0.3, 0.28, 0.24, 10.0, 16.0], n),  # divisors
+          rng.uniform(1e-3, 2000, n), np.ldexp(rng.uniform(1, 2, n), rng.integers(-40, 40, n)),
+          rng.uniform(0.1, 50, 64), np.array([1e-12, 3.0, 7.0, 0.1, 1e-6, 1.0]), np.ldexp(1.0, -np.arange(-240, 240, dtype=np.int64) // 4) * 3.0]
+    for x, y in zip(xs, ys):
+        s, _, _ = domain_math(np.abs(x), y)
+        assert np.array_equal(s.view(np.uint64), np.sqrt(np.abs(x)).view(np.uint64))
+        fin = np.isfinite(x)
+        _, q, qn = domain_math(x, y)
+        assert np.array_equal(q[fin].view(np.uint64), (x[fin] / y[fin]).view(np.uint64))
+        nz = fin & (x != 0)  # (a zero numerator gives +0 whatever its sign: callers never hold -0)
+        assert np.array_equal(qn[nz].view(np.uint64), (-x[nz] / y[nz]).view(np.uint64))
+        assert np.all(qn[fin & (x == 0)] == 0)
+
+
 def test_lsap_known_answers_and_ties():
     from muavta_amd.batched import lsap
     g = np.load(os.path.join(GOLDEN, "lsap_cases.npz"))
