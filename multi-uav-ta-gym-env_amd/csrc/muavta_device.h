@@ -35,6 +35,9 @@
 #ifndef MUAVTA_OBS_SADDR
 #define MUAVTA_OBS_SADDR 1
 #endif
+#ifndef MUAVTA_LDS_ZERO_REG  // 1: the rollout phases address the LDS block through one pinned zero register (muavta_kernels.hip: lds_zero) — measured slower
+#define MUAVTA_LDS_ZERO_REG 0
+#endif
 #ifndef MUAVTA_OBS_PREFETCH
 #define MUAVTA_OBS_PREFETCH 0
 #endif

@@ -114,6 +114,16 @@ struct Lds {
 // The fused kernels own a STATIC LDS block of their tile's size: its address is a compile-time constant (0), so LDS addresses
 // fold into the ds_* offset fields.  With the dynamic `extern __shared__` array every address was formed as `0 + x` at run
 // time (v_add_u32 v, 0, v / s_add_i32 s, 0, imm: 2 % of the kernel's VALU instructions).  They are launched with no dynamic LDS.
+// Experiment (MUAVTA_LDS_ZERO_REG=1, off): a DS instruction takes its address from a VGPR, so every access at a constant address
+// is preceded by its own rematerialised `v_mov_b32 v, 0` (887 in the 16-agent rollout kernel, 6 % of its static VALU
+// instructions).  Addressing the block through ONE pinned zero register the compiler cannot see through removes 400 of them,
+// but loads at uniform addresses then stop being uniform values: 560 scalar branches become exec-mask regions and 490 address
+// adds move from the SALU to the VALU.  Measured r3: 219 M env-steps/s against 231 M (config 2), 55.0 against 57.1 M (config 4).
+#if MUAVTA_LDS_ZERO_REG
+static __device__ __forceinline__ uint32_t lds_zero() { uint32_t z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+#else
+static __device__ __forceinline__ uint32_t lds_zero() { return 0u; }
+#endif
 #define KERNEL_LDS(TL) __shared__ __align__(16) unsigned char lds_own[Lds<TL>::bytes() + PROF_EXTRA_LDS]
 // Residency on a CU is bound by LDS bytes per env (160 KiB per CU, 1 KiB granule): 16 envs of the 16-agent tile
 // (BASELINE configs 2 and 3: 4096 envs = 16 per CU, one round) need <= 10 KiB each.
@@ -256,7 +266,7 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_step(const DevCtx* _
   const DevParams& P = ctx.P;
   const int env = env_base + blockIdx.x;  // (env_base: the first env of a sub-batch launched on its own stream, muavta_*_part)
   KERNEL_LDS(TL);
-  Lds<TL> L(lds_own);
+  Lds<TL> L(lds_own + lds_zero());
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
   copy16(L.S, blob, sizeof(EnvState<TL>));
   lds_sync();
@@ -343,7 +353,7 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned cha
                                                 const RecordPtrs<TL>& rec, int slot, int oslot) {
   const DevCtx& ctx = ctx_ref(ctxp);
 #if MUAVTA_PHASE_INLINED
-  Lds<TL> L(lds_own);
+  Lds<TL> L(lds_own + lds_zero());
 #else
   Lds<TL> L((unsigned char*)(AS3 unsigned char*)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_base));
 #endif
