@@ -1639,6 +1639,8 @@ struct Sim {
     else total = norm2(tx - px, ty - py);
     act_f(3)[k] = -div_coord(total);
     bool dup = false;
+    // (kept rolled: unrolled 32-fold with one scalar accumulator pair per element it alone spilled 90 SGPRs)
+#pragma clang loop unroll(disable) vectorize(disable)
     for (int q = 0; q < k; q++) dup |= S.act_agent[q] == a;
     if (!dup) X.remaining[k] = a;
   }

@@ -18,12 +18,20 @@ from muavta_amd.params import params_for_case
 case = sys.argv[1] if len(sys.argv) > 1 else "WPS_hard_x2"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 interval = 12 if "escort" in case else 20
-env = BatchedMultiUAVEnv(params_for_case(case), n)
+obs = True
+if case == "QUIET":  # tools/quiet_probe.py's last line: config 2 with nothing happening (no threats / arrivals / failures / sensing, one task, no re-plan, no observation)
+    from muavta_amd.params import params_from_config
+    from muavta_amd.scenarios import CASE_SPECS, WPS_ENV_FLAGS
+    spec = dict(CASE_SPECS["WPS_hard_x2"]); spec.update(threats_list=[], arrival_rate=0.0, fail_rate=0.0, sense_radius=0.0, threat_delay=0, tasks={"Att": 0, "Rec": 1, "Hold": 0})
+    env = BatchedMultiUAVEnv(params_from_config(spec, dict(WPS_ENV_FLAGS), tile_agents=16, tile_tasks=40, tile_threats=16), n)
+    interval, obs = 1000, False
+else:
+    env = BatchedMultiUAVEnv(params_for_case(case), n)
 L = native.lib()
 buf = (C.c_ulonglong * 64)()
-env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, True); env.sync()
+env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, obs); env.sync()
 L.muavta_prof_read(buf, 1)
-env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, True); env.sync()
+env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, obs); env.sync()
 L.muavta_prof_read(buf, 1)
 names = {0: "(loop gap)", 1: "rng_refill", 2: "drain+release", 3: "actions", 4: "movement", 5: "dist", 6: "serial_b threats/arrivals/escorts",
          7: "sense", 8: "serial_c reveals/expire/reward", 9: "finish gc+open", 10: "(pre-alloc)", 11: "alloc gate", 12: "cost build",
