@@ -190,6 +190,11 @@ int muavta_reset(MuavtaEnv* env, const uint64_t* seeds);
  * list, act_index[i, k] = index into env.last_tasks_info (the open list returned by the previous
  * observation).  Leading dims are [n_envs, action_cap]. */
 int muavta_step(MuavtaEnv* env, const int32_t* act_agent, const int32_t* act_index);
+/* The same with rows of any length: [n_envs, list_cap] (list_cap 1..32767).  The reference's actions dict takes a LIST of
+ * indices per agent (DroneEnv.py:822-825) and applies the items one after the other; rows longer than action_cap are applied
+ * action_cap items at a time on the device, in order, inside the one step.  muavta_step(e, a, i) == muavta_step_lists(e, a, i,
+ * action_cap). */
+int muavta_step_lists(MuavtaEnv* env, const int32_t* act_agent, const int32_t* act_index, int32_t list_cap);
 
 /* HungarianAllocator.allocate_tasks(get_live_agents(), _open_tasks(env), time_steps, events,
  * agent_known_ids=agent_visibility_map()) + _apply_assign  (HungarianAllocator.py:72-208,

@@ -70,18 +70,22 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_reset(self.h, _vp(s)))
 
     def step(self, act_agent: np.ndarray, act_index: np.ndarray):
-        """act_* : int32 [n_envs, action_cap]; act_agent -1 terminates an env's list."""
+        """act_* : int32 [n_envs, cap]; act_agent -1 terminates an env's list.  cap is the tile's action_cap, or any
+        length for list-valued actions (`muavta_step_lists`: applied in order inside the one step)."""
         aa = np.ascontiguousarray(act_agent, dtype=np.int32)
         ai = np.ascontiguousarray(act_index, dtype=np.int32)
-        want = (self.n_envs, self.A_tile)
-        if aa.shape != want or ai.shape != want:
-            raise ValueError(f"actions must have shape {want}")
-        self._ck(self.L.muavta_step(self.h, _vp(aa), _vp(ai)))
+        if aa.ndim != 2 or aa.shape != ai.shape or aa.shape[0] != self.n_envs or aa.shape[1] < 1:
+            raise ValueError(f"actions must have shape ({self.n_envs}, cap), cap >= 1")
+        if aa.shape[1] == self.A_tile:
+            self._ck(self.L.muavta_step(self.h, _vp(aa), _vp(ai)))
+        else:
+            self._ck(self.L.muavta_step_lists(self.h, _vp(aa), _vp(ai), aa.shape[1]))
 
     def pack_actions(self, per_env):
-        """[(agent_id, open_index), ...] per env -> the two padded arrays `step` takes."""
-        aa = np.full((self.n_envs, self.A_tile), -1, dtype=np.int32)
-        ai = np.zeros((self.n_envs, self.A_tile), dtype=np.int32)
+        """[(agent_id, open_index), ...] per env -> the two padded arrays `step` takes (as wide as the longest list needs)."""
+        cap = max([self.A_tile] + [len(acts) for acts in per_env])
+        aa = np.full((self.n_envs, cap), -1, dtype=np.int32)
+        ai = np.zeros((self.n_envs, cap), dtype=np.int32)
         for n, acts in enumerate(per_env):
             for k, (a, i) in enumerate(acts):
                 aa[n, k], ai[n, k] = a, i

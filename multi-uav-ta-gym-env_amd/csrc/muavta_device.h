@@ -247,6 +247,11 @@ struct Sim {
   Cold& C;     // HBM (L2-resident): requirement vectors, queue-entry times, init/done times, obstacles
   Scratch<TL>& X;
   double* rel_log = nullptr;  // optional per-env release log in HBM (muavta_set_release_log)
+  // muavta_step_lists: the (agent, index) items of this env beyond the ones staged in S.act_* (which hold TL::A at a time), still
+  // in the caller's rows in HBM: this env's row, its length and the next item to stage.  nullptr everywhere else.
+  const int32_t* more_agent = nullptr;
+  const int32_t* more_index = nullptr;
+  int more_cap = 0, more_pos = 0;
   int tnow;                   // env.time_steps in a (uniform) register: it changes once per step, and every LDS read of it is ~100 cycles of latency
   const DevParams& P;
   uint32_t* tape;  // [4][1248] in HBM
@@ -595,13 +600,49 @@ struct Sim {
     }
     S.free_slots[s >> 5] |= bit;
   }
+  // One list item -> S.act_*[n] (lane 0; index -> slot through the open list the previous observation returned, which no phase
+  // before the end of the step rewrites).  Agent ids beyond the fleet are skipped (the host entry points reject them).
+  DEV bool stage_item(int n, int a, int idx) {
+    if (a >= P.n_agents) return false;
+    if (idx < 0) idx += S.n_open;  // python negative indexing into last_tasks_info
+    S.act_agent[n] = (i8)a;
+    S.act_slot[n] = (idx >= 0 && idx < S.n_open) ? (i8)S.open_slot[idx] : (i8)-1;
+    S.act_index[n] = (i16)(idx < -32768 ? -32768 : idx > 32767 ? 32767 : idx);
+    return true;
+  }
+  // the next up-to-A items of a long list (wave-uniform result: how many were staged)
+  DEV int stage_more() {
+    lds_sync();
+    if (lane == 0) {
+      int n = 0;
+      while (more_pos < more_cap && n < A) {
+        const int a = more_agent[more_pos];
+        if (a < 0) { more_pos = more_cap; break; }
+        if (stage_item(n, a, more_index[more_pos])) n++;
+        more_pos++;
+      }
+      S.n_act = n;
+    }
+    lds_sync();
+    return S.n_act;
+  }
+  DEV bool pending_item_names_slot(int s) const {  // (lane 0) an item not staged yet names slot s
+    if (!more_agent) return false;
+    for (int k = more_pos; k < more_cap; k++) {
+      if (more_agent[k] < 0) break;
+      int idx = more_index[k];
+      if (idx < 0) idx += S.n_open;
+      if (idx >= 0 && idx < S.n_open && S.open_slot[idx] == s) return true;
+    }
+    return false;
+  }
   DEV int reclaim_slot_serial() {
     for (int k = 0; k < S.n_order; k++) {
       int s = S.t_order[k];
       if (S.t_status[s] != 2 || !slot_unreferenced(S.t_id[s])) continue;
       bool staged = false;  // actions still to be applied this step may name it (-> invalid-action penalty)
       for (int j = 0; j < S.n_act; j++) staged |= (S.act_slot[j] == s);
-      if (staged) continue;
+      if (staged || pending_item_names_slot(s)) continue;
       release_slot(s);
       for (int i = k; i + 1 < S.n_order; i++) S.t_order[i] = S.t_order[i + 1];
       S.n_order--;
@@ -1390,12 +1431,17 @@ struct Sim {
         }
     }
     PROF(2);
-    if (S.n_act > 0 && !apply_actions_parallel(r_action, r_distance, r_squality)) {
-      precompute_actions();
-      lds_sync();
-      PROF(33);
-      if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
-      cold_sync();
+    for (;;) {
+      if (S.n_act > 0 && !apply_actions_parallel(r_action, r_distance, r_squality)) {
+        precompute_actions();
+        lds_sync();
+        PROF(33);
+        if (lane == 0) step_serial_a(r_action, r_distance, r_quality, r_squality);
+        cold_sync();
+      }
+      // a list longer than the staging arrays (muavta_step_lists) is applied A items at a time, in order: the loop of
+      // DroneEnv.py:813-933 is sequential, so chunks applied one after the other are the same sequence
+      if (!more_agent || stage_more() == 0) break;
     }
     PROF(3);
     // movement (:965-1129): lanes commit every agent up to the first "event" agent, lane 0 plays that one

@@ -272,21 +272,13 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_step(const DevCtx* _
   lds_sync();
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, P, tape_of(ctx, env));
   if (rel_log) sim.rel_log = rel_log + (size_t)env * (1 + MUAVTA_REL_ROW * TL::T);
-  if (act_agent && threadIdx.x == 0) {
-    EnvState<TL>& S = *L.S;
-    int n = 0;
-    for (int k = 0; k < act_cap && n < TL::A; k++) {
-      int a = act_agent[(size_t)env * act_cap + k];
-      if (a < 0) break;
-      if (a >= P.n_agents) continue;  // (muavta_step rejects these on the host; never index the agent arrays with one)
-      int idx = act_index[(size_t)env * act_cap + k];
-      if (idx < 0) idx += S.n_open;  // python negative indexing into last_tasks_info
-      S.act_agent[n] = (i8)a;
-      S.act_slot[n] = (idx >= 0 && idx < S.n_open) ? (i8)S.open_slot[idx] : (i8)-1;
-      S.act_index[n] = (i16)(idx < -32768 ? -32768 : idx > 32767 ? 32767 : idx);
-      n++;
-    }
-    S.n_act = n;
+  if (act_agent) {
+    // the env's row of (agent, index) items: the first TL::A of them are staged here, a longer row (muavta_step_lists) is
+    // consumed by the action phase A items at a time
+    sim.more_agent = act_agent + (size_t)env * act_cap; sim.more_index = act_index + (size_t)env * act_cap;
+    sim.more_cap = act_cap; sim.more_pos = 0;
+    sim.stage_more();
+    if (act_cap <= TL::A) sim.more_agent = nullptr;  // (uniform: nothing beyond the staged items)
   }
   lds_sync();
   sim.step(true);
@@ -736,6 +728,8 @@ struct MuavtaEnv {
   uint32_t pace_epoch = 0;
   uint64_t* d_seeds[2] = {nullptr, nullptr};
   int32_t *d_act_agent = nullptr, *d_act_index = nullptr, *d_call_out = nullptr;
+  int32_t *d_list_agent = nullptr, *d_list_index = nullptr;  // muavta_step_lists rows [N][list_cap] (grown on demand)
+  int list_cap = 0;
   ncclComm_t comm = nullptr;  // muavta_comm_init
   int comm_rank = 0, comm_ranks = 0;
   void* d_comm = nullptr;     // [64 f64 send | 64 x n_ranks f64 recv | 64 i64 send | 64 i64 recv]
@@ -1249,7 +1243,7 @@ int muavta_destroy(MuavtaEnv* e) {
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   hipFree(e->d_part_agent); hipFree(e->d_part_index);
   if (e->stream) hipStreamSynchronize(e->stream);
-  if (e->d_seedtmp) hipFree(e->d_seedtmp); hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
+  if (e->d_seedtmp) hipFree(e->d_seedtmp); hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); if (e->d_list_agent) hipFree(e->d_list_agent); if (e->d_list_index) hipFree(e->d_list_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   for (int i = 0; i < MuavtaEnv::EV_RING; i++) { if (e->ev0[i]) hipEventDestroy(e->ev0[i]); if (e->ev1[i]) hipEventDestroy(e->ev1[i]); }
   for (int b = 0; b < 2; b++) {
@@ -1320,38 +1314,57 @@ int muavta_reset(MuavtaEnv* e, const uint64_t* seeds) {
   return MUAVTA_OK;
 }
 
-static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai) {
+static int step_impl(MuavtaEnv* e, const int32_t* aa, const int32_t* ai, int cap = 0) {
   if (!e->did_reset) { e->err = "step before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
   MAIN_OP(e);
   const int32_t *da = nullptr, *di = nullptr;
+  if (cap <= 0) cap = e->A;
   if (aa) {
-    size_t bytes = (size_t)e->n_envs * e->A * sizeof(int32_t);
-    HIPCHK(e, hipMemcpyAsync(e->d_act_agent, aa, bytes, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->d_act_index, ai, bytes, hipMemcpyHostToDevice, e->stream));
-    da = e->d_act_agent; di = e->d_act_index;
+    size_t bytes = (size_t)e->n_envs * cap * sizeof(int32_t);
+    int32_t *ba = e->d_act_agent, *bi = e->d_act_index;
+    if (cap > e->A) {  // rows longer than the handle's action buffers: muavta_step_lists
+      if (cap > e->list_cap) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->d_list_agent) hipFree(e->d_list_agent);
+        if (e->d_list_index) hipFree(e->d_list_index);
+        e->d_list_agent = e->d_list_index = nullptr; e->list_cap = 0;
+        HIPCHK(e, hipMalloc(&e->d_list_agent, bytes));
+        HIPCHK(e, hipMalloc(&e->d_list_index, bytes));
+        e->list_cap = cap;
+      }
+      ba = e->d_list_agent; bi = e->d_list_index;
+    }
+    HIPCHK(e, hipMemcpyAsync(ba, aa, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(bi, ai, bytes, hipMemcpyHostToDevice, e->stream));
+    da = ba; di = bi;
   }
   if (e->d_rel) HIPCHK(e, hipMemsetAsync(e->d_rel, 0, (size_t)e->n_envs * (1 + MUAVTA_REL_ROW * e->T) * sizeof(double), e->stream));
-  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), 0, e->stream, (const DevCtx*)e->d_ctx, da, di, e->A, e->d_rel, 0));  // (static LDS)
+  DISPATCH(e, hipLaunchKernelGGL(k_step<TL>, dim3(e->n_envs), dim3(WG), 0, e->stream, (const DevCtx*)e->d_ctx, da, di, cap, e->d_rel, 0));  // (static LDS)
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   return MUAVTA_OK;
 }
 
-int muavta_step(MuavtaEnv* e, const int32_t* act_agent, const int32_t* act_index) {
+int muavta_step_lists(MuavtaEnv* e, const int32_t* act_agent, const int32_t* act_index, int32_t list_cap) {
   if (!e || !act_agent || !act_index) return MUAVTA_E_ARG;
+  if (list_cap < 1 || list_cap > 32767) { e->err = "muavta_step_lists: list_cap must be in 1..32767"; return MUAVTA_E_ARG; }
   // agent ids index the per-agent arrays of the env blob on the device: reject anything outside [0, n_agents) up front
   // (the reference's actions dict is keyed by agent name: an unknown name is a KeyError there, DroneEnv.py:813-816)
   for (int n = 0; n < e->n_envs; n++)
-    for (int k = 0; k < e->A; k++) {
-      const int a = act_agent[(size_t)n * e->A + k];
+    for (int k = 0; k < list_cap; k++) {
+      const int a = act_agent[(size_t)n * list_cap + k];
       if (a < 0) break;
       if (a >= e->P.n_agents) {
         e->err = "muavta_step: env " + std::to_string(n) + " names agent id " + std::to_string(a) + ", valid ids are 0.." + std::to_string(e->P.n_agents - 1);
         return MUAVTA_E_ARG;
       }
     }
-  return step_impl(e, act_agent, act_index);
+  return step_impl(e, act_agent, act_index, list_cap);
+}
+int muavta_step(MuavtaEnv* e, const int32_t* act_agent, const int32_t* act_index) {
+  if (!e) return MUAVTA_E_ARG;
+  return muavta_step_lists(e, act_agent, act_index, e->A);
 }
 int muavta_step_staged(MuavtaEnv* e) {
   if (!e) return MUAVTA_E_ARG;

@@ -539,8 +539,6 @@ class MultiUAVEnv:
             a = self.agent_by_name[name]
             for i in (idxs if isinstance(idxs, list) else [idxs]):
                 items.append((a.id, int(i)))
-        if len(items) > self._b.A_tile:
-            raise ValueError(f"at most {self._b.A_tile} (agent, index) items per step on this tile")
         aa, ai = self._b.pack_actions([items])
         self._b.step(aa, ai)
         self._steps += 1

@@ -32,7 +32,7 @@ EXPORTS = [
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
     "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
-    "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math",
+    "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_step_lists",
 ]
 
 
@@ -91,6 +91,7 @@ def lib() -> C.CDLL:
     L.muavta_dims.argtypes = [vp, C.POINTER(MuavtaDims)]
     L.muavta_reset.argtypes = [vp, u64p]
     L.muavta_step.argtypes = [vp, vp, vp]
+    L.muavta_step_lists.argtypes = [vp, vp, vp, i32]
     L.muavta_allocate.argtypes = [vp, i32, i32, vp, vp]
     L.muavta_step_staged.argtypes = [vp]
     L.muavta_rollout.argtypes = [vp, u64p, i32, i32, i32, i32]

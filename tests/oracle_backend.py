@@ -20,8 +20,9 @@ class OracleBackend:
         self.o.reset(int(seeds[0]))
 
     def pack_actions(self, per_env):
-        aa = np.full((1, self.A_tile), -1, dtype=np.int32)
-        ai = np.zeros((1, self.A_tile), dtype=np.int32)
+        cap = max(self.A_tile, len(per_env[0]))  # (as the product: as wide as the longest list needs)
+        aa = np.full((1, cap), -1, dtype=np.int32)
+        ai = np.zeros((1, cap), dtype=np.int32)
         for k, (a, i) in enumerate(per_env[0]):
             aa[0, k], ai[0, k] = a, i
         return aa, ai

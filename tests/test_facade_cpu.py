@@ -76,6 +76,32 @@ def test_facade_episode_matches_golden(case, seed):
     assert env.compute_s_wps() == g["metrics"][4] and env.compute_s_esc() == g["metrics"][5]
 
 
+def test_facade_takes_list_valued_actions_of_any_length():
+    """env.step({name: [index, ...]}) as the reference takes it (DroneEnv.py:813-838), more items per step than the tile's
+    action_cap: the facade flattens the dict in order and the episode equals the reference's (tests/golden/lists_*.npz)."""
+    import itertools
+    from test_oracle_golden import lists_params
+    path = os.path.join(GOLDEN, "lists_WPS_hard_s0.npz")
+    g, p = lists_params(path)
+    flags = dict(WPS_ENV_FLAGS, multiple_tasks_per_agent=bool(int(g["multi"])))
+    env = MultiUAVEnv(CASE_SPECS["WPS_hard"], backend=OracleBackend(p), flags=flags)
+    env.reset(seed=int(g["seed"]))
+    acts = g["actions"]
+    longest = 0
+    for t in range(g["pos"].shape[0] - 1):
+        ga = acts[acts[:, 0] == t]
+        actions = {}
+        for aid, grp in itertools.groupby(ga, key=lambda r: int(r[1])):  # (an agent appears once per step in these traces)
+            idxs = [int(r[2]) for r in grp]
+            actions[env.agents_obj[aid].name] = idxs if len(idxs) > 1 else idxs[0]
+        longest = max(longest, len(ga))
+        obs, rew, term, trunc, infos = env.step(actions)
+        assert rew[env.agents_obj[0].name] == g["reward"][t + 1]
+        assert np.array_equal(np.array([a.position for a in env.agents_obj]), g["pos"][t + 1])
+        assert [x.id for x in env.last_tasks_info] == list(g["open_ids"][g["open_ptr"][t + 1]:g["open_ptr"][t + 2]])
+    assert longest > env._b.A_tile
+
+
 def test_object_views_identity_and_visibility():
     env, p = _facade("WPS_hard")
     env.reset(seed=3)

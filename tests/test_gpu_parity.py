@@ -419,6 +419,88 @@ def test_invalid_and_out_of_range_actions():
             compare(snap, i, o, f"random actions seed {i} t={t + 1}")
 
 
+@pytest.mark.parametrize("case,tasks_per_agent", [("WPS_hard", True), ("WPS_hard", False), ("WPS_escort", True)])
+def test_list_valued_actions_longer_than_the_tile(case, tasks_per_agent):
+    """The reference's actions dict maps an agent to a LIST of indices and applies the items in order (DroneEnv.py:813-838):
+    rows longer than the tile's action_cap go through muavta_step_lists, which applies them action_cap items at a time inside the
+    one step.  Random lists of up to 3.5 x action_cap items (repeated agents, repeated tasks, invalid indices, dead agents),
+    state compared with the oracle after every step."""
+    from muavta_amd.params import params_from_config
+    from muavta_amd.scenarios import CASE_SPECS, TILES, WPS_ENV_FLAGS
+    from muavta_amd.batched import BatchedMultiUAVEnv
+    flags = dict(WPS_ENV_FLAGS)
+    flags["reward_weights"] = dict(flags["reward_weights"], action=1.0, distance=0.5, s_quality=1.0)
+    flags["multiple_tasks_per_agent"] = tasks_per_agent
+    ta, tt, th = TILES[case]
+    p = params_from_config(CASE_SPECS[case], flags, tile_agents=ta, tile_tasks=tt, tile_threats=th)
+    n = 4
+    env = BatchedMultiUAVEnv(p, n)
+    env.reset(np.arange(50, 50 + n, dtype=np.uint64))
+    oracles = [orc.OracleEnv(p) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(50 + i)
+    rng = np.random.default_rng(7)
+    longest, compared, full = 0, 0, set()
+    for t in range(40):
+        acts = []
+        for i in range(n):
+            if i == 0 and t % 2:  # one env keeps short rows: the two entry points interleave on one handle
+                k = int(rng.integers(0, 4))
+                acts.append([(int(rng.integers(0, env.n_agents)), int(rng.integers(0, 12))) for _ in range(k)])
+                continue
+            items = []
+            for a in rng.permutation(env.n_agents)[:int(rng.integers(1, env.n_agents + 1))]:
+                # a list per agent, dict order; few distinct tasks (an agent's queue holds at most Q entries on a tile), some indices invalid
+                items += [(int(a), int(rng.integers(-1, 5)) if rng.random() < 0.9 else 37) for _ in range(int(rng.integers(1, 10)))]
+            acts.append(items[:int(3.5 * env.A_tile)])
+        longest = max(longest, max(len(a) for a in acts))
+        aa, ai = env.pack_actions(acts)
+        env.step(aa, ai)
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            if snap.ERROR[i] == 2:  # this many queued tasks per agent pass the tile's queue depth (flagged, documented): env retired from the comparison
+                full.add(i)
+            if i in full:
+                continue
+            o.step([a for a, _ in acts[i]], [j for _, j in acts[i]])
+            compare(snap, i, o, f"list actions {case} seed {50 + i} t={t + 1}")
+            compared += 1
+    assert longest > 2 * env.n_agents and longest > env.A_tile
+    assert compared >= 100 and len(full) <= 2
+
+
+LIST_TRACES = sorted(glob.glob(os.path.join(GOLDEN, "lists_*.npz")))
+
+
+@pytest.mark.parametrize("path", LIST_TRACES, ids=[os.path.basename(p)[6:-4] for p in LIST_TRACES])
+def test_reference_list_valued_action_traces_on_the_device(path):
+    """The reference's own episodes driven with list-valued actions (tests/golden/lists_*.npz, tools/gen_golden.py --lists; up to
+    76 items in one step): the device applies the same rows through muavta_step_lists and must match the oracle after every step
+    and the reference's positions / rewards directly."""
+    from test_oracle_golden import lists_params
+    from muavta_amd.batched import BatchedMultiUAVEnv
+    g, p = lists_params(path)
+    name = os.path.basename(path)[:-4]
+    env = BatchedMultiUAVEnv(p, 2)  # two copies of the episode: the rows are per env
+    seed = int(g["seed"])
+    env.reset(np.array([seed, seed], dtype=np.uint64))
+    o = orc.OracleEnv(p)
+    o.reset(seed)
+    acts = g["actions"]
+    for t in range(g["pos"].shape[0] - 1):
+        ga = acts[acts[:, 0] == t]
+        items = [(int(a), int(i)) for a, i in ga[:, 1:3]]
+        aa, ai = env.pack_actions([items, items])
+        env.step(aa, ai)
+        o.step(ga[:, 1].astype(np.int32), ga[:, 2].astype(np.int32))
+        snap = Snapshot(env)
+        for i in range(2):
+            compare(snap, i, o, f"{name} t={t + 1}")
+        assert np.array_equal(env.get("AGENT_POS")[0][:p.n_agents], g["pos"][t + 1]), f"{name} t={t + 1}: positions vs the reference"
+        assert env.step_result()[0][0] == g["reward"][t + 1], f"{name} t={t + 1}: reward vs the reference"
+    assert np.all(env.get("ERROR") == 0)
+
+
 def test_agent_ids_outside_the_fleet_are_rejected():
     """An agent id >= n_agents would index the per-agent arrays of the env blob: muavta_step refuses it (MUAVTA_E_ARG)
     and leaves the state untouched (the reference's actions dict is keyed by name: an unknown name is a KeyError)."""

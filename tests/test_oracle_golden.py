@@ -128,6 +128,42 @@ def test_trace_bit_exact(path):
     assert e.dims()["n_replans"] == int(g["n_replans"])
 
 
+LIST_TRACES = sorted(glob.glob(os.path.join(GOLDEN, "lists_*.npz")))
+
+
+def lists_params(path, **tiles):
+    """Params of a list-valued-action trace (tools/gen_golden.py --lists): the registry case under the WPS flags, with the
+    trace's multiple_tasks_per_agent."""
+    from muavta_amd.params import params_from_config
+    from muavta_amd.scenarios import CASE_SPECS, TILES, WPS_ENV_FLAGS
+    g = np.load(path)
+    case = os.path.basename(path)[6:-4].rsplit("_s", 1)[0]
+    flags = dict(WPS_ENV_FLAGS)
+    flags["multiple_tasks_per_agent"] = bool(int(g["multi"]))
+    ta, tt, th = TILES[case]
+    return g, params_from_config(CASE_SPECS[case], flags, tile_agents=tiles.get("tile_agents", ta), tile_tasks=tiles.get("tile_tasks", tt),
+                                 tile_threats=tiles.get("tile_threats", th))
+
+
+@pytest.mark.parametrize("path", LIST_TRACES, ids=[os.path.basename(p)[6:-4] for p in LIST_TRACES])
+def test_list_valued_actions_trace_bit_exact(path):
+    """env.step({agent: [index, ...]}) of the reference (DroneEnv.py:813-838; up to 76 items in one step, repeated tasks,
+    indices beyond the open list, dead agents, with and without multiple_tasks_per_agent): the oracle fed the same flattened
+    items reproduces every step's state, reward, events and observation."""
+    g, p = lists_params(path)
+    name = os.path.basename(path)[:-4]
+    e = orc.OracleEnv(p)
+    e.reset(int(g["seed"]))
+    check_state(e, g, 0, name)
+    acts, evs = g["actions"], g["events"]
+    assert np.bincount(acts[:, 0]).max() > 32
+    for s in range(g["pos"].shape[0] - 1):
+        ga = acts[acts[:, 0] == s]
+        e.step(ga[:, 1].astype(np.int32), ga[:, 2].astype(np.int32))
+        assert np.array_equal(e.events(), evs[evs[:, 0] == s + 1][:, 1:]), f"{name} t={s + 1}: drained events"
+        check_state(e, g, s + 1, name)
+
+
 @pytest.mark.parametrize("path", METRICS, ids=[os.path.basename(p)[8:-4] for p in METRICS])
 def test_metrics_many_seeds(path):
     g = np.load(path)

@@ -378,7 +378,7 @@ def main():
         print("metrics", case, np.stack(rows)[:, 4].mean())
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens", "--il", "--fuzz")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens", "--il", "--fuzz", "--lists")):
     main()
 
 
@@ -701,3 +701,64 @@ def gen_fuzz(n_cfg=14):
 
 if __name__ == "__main__" and "--fuzz" in sys.argv:
     gen_fuzz()
+
+
+# ------------------------------------------------------------------------------------------------
+# List-valued actions: env.step({agent_name: [index, index, ...]}) — the reference applies an agent's items one after the
+# other (DroneEnv.py:822-838).  No allocator here: random lists (repeated tasks, indices beyond the open list, dead agents,
+# more items per step than any tile's action_cap) drive the env; the trace holds the flattened (t, agent id, index) items.
+# ------------------------------------------------------------------------------------------------
+def run_episode_lists(case, seed, steps, multi):
+    spec = CASE_SPECS[case]
+    cfg = make_config(spec, dict(WPS_ENV_FLAGS))
+    cfg.multiple_tasks_per_agent = multi
+    env = MultiUAVEnv(cfg)
+    obs, info = env.reset(seed=seed)
+    rng = np.random.default_rng(1000 + seed)
+    recs, obs_rows, act_rows, ev_rows, rewards = [snapshot(env)], [snapshot_obs(env)], [], [], [0.0]
+    open_ids = [t.id for t in env.last_tasks_info]
+    open_ptr = [0, len(open_ids)]
+    for t in range(steps):
+        actions = {}
+        names = [a.name for a in env.agents_obj]
+        for k in rng.permutation(len(names))[:int(rng.integers(1, len(names) + 1))]:
+            n_items = int(rng.integers(1, 8))
+            idxs = [int(rng.integers(0, 4)) if rng.random() < 0.9 else 37 for _ in range(n_items)]
+            actions[names[k]] = idxs if (n_items > 1 or rng.random() < 0.5) else idxs[0]  # a bare int is a one-item list (:822-823)
+            for i in idxs:
+                act_rows.append((env.time_steps, env.agent_by_name[names[k]].id, i))
+        obs, reward, done, trunc, info = env.step(actions)
+        for ev in info["events"]:
+            ev_rows.append((env.time_steps, EVENT_CODE[ev[0]], int(ev[1])))
+        rewards.append(float(next(iter(reward.values()))))
+        recs.append(snapshot(env)); obs_rows.append(snapshot_obs(env))
+        open_ids += [t.id for t in env.last_tasks_info]; open_ptr.append(len(open_ids))
+        if all(done.values()) or all(trunc.values()):
+            break
+    out = stack(recs, env)
+    out["reward"] = np.array(rewards)
+    out["events"] = np.array(ev_rows, dtype=np.int64).reshape(-1, 3)
+    out["actions"] = np.array(act_rows, dtype=np.int64).reshape(-1, 3)
+    out["obs_tasks"] = np.stack([o[0] for o in obs_rows])
+    out["obs_legal"] = np.packbits(np.stack([o[1] for o in obs_rows]), axis=-1)
+    out["obs_flags"] = np.stack([o[2] for o in obs_rows])
+    out["obs_agent"] = np.stack([o[3] for o in obs_rows])
+    out["open_ptr"] = np.array(open_ptr, dtype=np.int64)
+    out["open_ids"] = np.array(open_ids, dtype=np.int64)
+    out["max_tasks"] = np.int64(env.max_tasks)
+    out["multi"] = np.int64(multi)
+    out["seed"] = np.int64(seed)
+    return out
+
+
+def gen_lists():
+    for case, seed, multi in (("WPS_hard", 0, True), ("WPS_hard", 1, False), ("WPS_escort", 2, True)):
+        tr = run_episode_lists(case, seed, 40, multi)
+        path = os.path.join(OUT, f"lists_{case}_s{seed}.npz")
+        np.savez_compressed(path, **tr)
+        per_step = np.bincount(tr["actions"][:, 0])
+        print(path, os.path.getsize(path) // 1024, "KiB", "steps", tr["pos"].shape[0] - 1, "items per step max", per_step.max())
+
+
+if __name__ == "__main__" and "--lists" in sys.argv:
+    gen_lists()
