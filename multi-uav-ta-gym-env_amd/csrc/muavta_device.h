@@ -1186,10 +1186,10 @@ struct Sim {
     const double d = norm2(S.a_px[a] - x, S.a_py[a] - y);
     const bool fighter = is_fighter(ty);
     const double dW = (valid && !fighter) ? d : INF;
-    const double mW = wave_min(dW);
+    const double mW = wave_min_first(dW, A);  // (A: compile-time — agent lanes only)
     if (__double2hiint(mW) != 0x7ff00000) return __ffsll((long long)__builtin_amdgcn_ballot_w64(dW == mW)) - 1;
     const double dF = (valid && fighter) ? d : INF;
-    const double mF = wave_min(dF);
+    const double mF = wave_min_first(dF, A);
     if (__double2hiint(mF) != 0x7ff00000) return __ffsll((long long)__builtin_amdgcn_ballot_w64(dF == mF)) - 1;
     return -1;
   }
@@ -3646,6 +3646,19 @@ struct Sim {
     t = dpp_bcast(v, t, 31); v = vmin(v, t);
     return readlane_f64(v, 63);
   }
+  // The same when only the first `n` lanes can hold anything but +inf (n wave-uniform): the minimum of a 16-lane row is complete
+  // after the four exchange steps, so up to 16 lanes need no row broadcast (12 VALU) and up to 32 only the first (15 VALU).
+  DEV double wave_min_first(double v, int n) {
+    double t = dpp_xchg(v, 0); v = vmin(v, t);
+    t = dpp_xchg(v, 1); v = vmin(v, t);
+    t = dpp_xchg(v, 2); v = vmin(v, t);
+    t = dpp_xchg(v, 3); v = vmin(v, t);
+    if (n <= 16) return readlane_f64(v, 0);
+    t = dpp_bcast(v, t, 15); v = vmin(v, t);
+    if (n <= 32) return readlane_f64(v, 31);
+    t = dpp_bcast(v, t, 31); v = vmin(v, t);
+    return readlane_f64(v, 63);
+  }
   DEV void lsap(int nr, int nc) { const double* c = X.cost; lsap(nr, nc, [c, nc](int i, int j) { return c[i * nc + j]; }); }
   template <class CostAt>
   DEV void lsap(int nr, int nc, CostAt cost_at) {
@@ -3806,7 +3819,7 @@ struct Sim {
         sp = upd ? r : sp;
         pth = upd ? i : pth;
         const double val = active ? sp : INF;
-        const double m = wave_min(val);
+        const double m = wave_min_first(val, nc);  // (lanes beyond nc hold +inf)
         if (__double2hiint(m) == 0x7ff00000) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }  // m == +inf (never NaN): a scalar compare of the high word
         const unsigned long long eq = __builtin_amdgcn_ballot_w64(val == m);  // scanned columns and lanes beyond nc hold +inf > m
         const unsigned long long equ = eq & unassigned;
