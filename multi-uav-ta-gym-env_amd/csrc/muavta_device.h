@@ -1403,6 +1403,31 @@ struct Sim {
     return res;
   }
 
+  // The same sum for up to 16 elements held one per lane (lane i: element i): the second eight join the first through a row
+  // shift, the tail comes through v_readlane — no scratch row, no LDS round trips.  Same additions in the same order.
+  DEV double np_sum_lanes16(double d, int n_) {
+    const int n = __builtin_amdgcn_readfirstlane(n_);
+    double res;
+    if (n < 8) {
+      res = 0.;
+      for (int i = 0; i < n; i++) res += readlane_f64(d, i);
+      return res;
+    }
+    const int body = n - (n % 8);
+    double r = d;
+    if (body == 16) {  // lanes 0..7: d[j] + d[8 + j]   (row_shl:8, lanes 8..15 read beyond the row: 0)
+      const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(d), 0x108, 0xf, 0xf, true);
+      const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(d), 0x108, 0xf, 0xf, true);
+      r = d + __hiloint2double(hi, lo);
+    }
+    r = r + dpp_xchg(r, 0);
+    r = r + dpp_xchg(r, 1);
+    r = r + dpp_xchg(r, 2);
+    res = readlane_f64(r, 0);
+    for (int i = body; i < n; i++) res += readlane_f64(d, i);
+    return res;
+  }
+
   DEV void step(bool write_obs_flag) {
     PROF(0);
     rng_refill();
@@ -1467,10 +1492,10 @@ struct Sim {
         double dx = S.a_px[lane] - prev_x, dy = S.a_py[lane] - prev_y;
         d = fsqrt(dx * dx + dy * dy);
         S.a_dist[lane] += d;
-        X.u[lane] = d;
+        if constexpr (A > 16) X.u[lane] = d;
       }
-      lds_sync();
-      dist_sum = np_sum_wave(X.u, P.n_agents);  // np.sum(dists) (:1138)
+      if constexpr (A <= 16) dist_sum = np_sum_lanes16(d, P.n_agents);  // np.sum(dists) (:1138)
+      else { lds_sync(); dist_sum = np_sum_wave(X.u, P.n_agents); }
     }
     rng_prefetch_commit(rng_words);
     PROF(5);
@@ -2856,7 +2881,7 @@ struct Sim {
         const double org = qs().t_org[s];
         if (P.saturate_mask && alc_ty >= org) typemask = 0;
         const double unmet = fmax(cur_ty - alc_ty, 0.0);
-        r[19] = (float)(unmet / fmax(org, 1e-6));
+        r[19] = (float)fdiv(unmet, fmax(org, 1e-6));  // (unmet: 0 or a difference of capability sums, org >= 1e-6: inside fdiv's domain)
         r[20] = (float)fmin(div_small((double)tnow - (double)S.t_created[s], mts, inv_mts), 1.0);
         if (o_tasks && in_mt) {
           // feature-major: column c of row j at (c * MT + j) * 4 — one base in scalar registers, the lane's byte offset stepped by
@@ -3819,7 +3844,7 @@ struct Sim {
         sp = upd ? r : sp;
         pth = upd ? i : pth;
         const double val = active ? sp : INF;
-        const double m = wave_min_first(val, nc);  // (lanes beyond nc hold +inf)
+        const double m = wave_min(val);  // (wave_min_first(val, nc) saves 3-6 VALU per scan step for <= 32 columns and loses more to its two scalar branches in the dependent chain: measured r3)
         if (__double2hiint(m) == 0x7ff00000) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }  // m == +inf (never NaN): a scalar compare of the high word
         const unsigned long long eq = __builtin_amdgcn_ballot_w64(val == m);  // scanned columns and lanes beyond nc hold +inf > m
         const unsigned long long equ = eq & unassigned;

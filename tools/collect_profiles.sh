@@ -17,6 +17,7 @@ for ce in $CASES; do
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/sq1" -- python3 $ARGS --steps 4 --warmup 1 > /dev/null 2> "$OUT/sq1.err"
   rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_BRANCH --output-format csv -d "$OUT/sq2" -- python3 $ARGS --steps 4 --warmup 1 > /dev/null 2> "$OUT/sq2.err"
   rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_IFETCH SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM --output-format csv -d "$OUT/sq3" -- python3 $ARGS --steps 4 --warmup 1 > /dev/null 2> "$OUT/sq3.err"
+  rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 --output-format csv -d "$OUT/sq4" -- python3 $ARGS --steps 4 --warmup 1 > /dev/null 2> "$OUT/sq4.err"
   python3 $ARGS > "$OUT/bench.json" 2> "$OUT/bench.err"
   echo "$c done: $(cut -c1-200 "$OUT/bench.json")"
 done

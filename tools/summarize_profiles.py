@@ -24,14 +24,22 @@ for src in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*")
             name = r["Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             g.write(",".join([name.strip('"'), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]]) + "\n")
     pmc, meta = {}, {}
-    for sub in ("fetch", "write", "sq1", "sq2", "sq3"):
+    lanes = None
+    for sub in ("fetch", "write", "sq1", "sq2", "sq3", "sq4"):
         fs = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
         if not fs:
             continue
+        own = {}
         for r in csv.DictReader(open(fs[0])):
             if "k_rollout" not in r["Kernel_Name"]:
                 continue
+            own.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if sub == "sq4" and r["Counter_Name"] in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"):
+                continue  # (already collected in sq1 / sq2; here only as the same-pass denominators of the lane figure below)
             pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+        if sub == "sq4" and "SQ_THREAD_CYCLES_VALU" in own and "SQ_ACTIVE_INST_VALU" in own:
+            # rocprofv3's VALUUtilization: thread-cycles / (instruction cycles x 64) — mean share of the 64 lanes a VALU instruction has enabled
+            lanes = 64.0 * sum(own["SQ_THREAD_CYCLES_VALU"]) / (sum(own["SQ_ACTIVE_INST_VALU"]) * 64.0)
             meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(dst, f"{tag}_{case}_bench.json"), "w"), indent=1)
@@ -49,6 +57,8 @@ for src in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*")
             g.write("# derived: " + ", ".join(f"{k}/SQ_WAVE_CYCLES={mean[k] / wc:.3f}" for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS") if k in mean) + "\n")
             insts = sum(mean.get(k, 0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_BRANCH"))
             g.write(f"# derived: instructions per env-step (VALU+SALU+LDS+SMEM+VMEM+branch) = {insts / steps:.0f}, wave cycles per env-step = {wc / steps:.0f}\n")
+        if lanes is not None:
+            g.write(f"# derived: mean enabled lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, same pass) = {lanes:.2f} of 64\n")
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         traffic = (mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
         tp = os.path.join(dst, "pmc_traffic.json")
@@ -66,6 +76,7 @@ for src in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*")
                 "wave_quad_cycles_per_env_step": mean["SQ_WAVE_CYCLES"] / steps, "waves_per_simd": wps,
                 "valu_port_busy": wps * mean["SQ_ACTIVE_INST_VALU"] / mean["SQ_WAVE_CYCLES"],
                 "wait_any_frac": mean.get("SQ_WAIT_ANY", 0) / mean["SQ_WAVE_CYCLES"],
+                "mean_enabled_lanes_per_valu": lanes,
             }
         d[f"{case}:{envs}"] = entry
         d["_note"] = "HBM bytes per k_rollout launch = (FETCH_SIZE + WRITE_SIZE) * 1024 from separate rocprofv3 --pmc passes (tools/collect_profiles.sh); valid for the kernel sources with this source_hash only"
