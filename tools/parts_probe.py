@@ -4,6 +4,9 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+if os.environ.get("PROBE_TORCH_FIRST"):
+    import torch
+    torch.cuda.set_device(0); torch.cuda.synchronize()
 from muavta_amd.batched import BatchedMultiUAVEnv
 if os.environ.get("PROBE_TORCH"):
     import torch
@@ -12,18 +15,21 @@ from muavta_amd.params import params_for_case
 case, n = "WPS_hard_x2", 4096
 env = BatchedMultiUAVEnv(params_for_case(case), n)
 seeds = np.arange(n, dtype=np.uint64)
-if os.environ.get("PROBE_PRELUDE") == "rollouts":
-    for _ in range(10):
+PRE = os.environ.get("PROBE_PRELUDE", "").split(",")
+if "rollouts" in PRE:
+    for _ in range(int(os.environ.get("PROBE_ROLLOUTS", "10"))):
         env.rollout(seeds, 150, 20, True, True)
     env.sync()
-if os.environ.get("PROBE_PRELUDE") == "stepapi":
+if "history" in PRE:
+    print("history", env.kernel_ms_history(4), env.last_seed_ms(), env.last_kernel_ms())
+if "stepapi" in PRE:
     env.reset(seeds)
     for _ in range(150):
         env.allocate(20, True, fetch=False); env.step_staged()
     env.sync()
-if os.environ.get("PROBE_PRELUDE") == "get":
+if "get" in PRE:
     env.reset(seeds); env.get("ERROR"); env.rollout_metrics()
-if os.environ.get("PROBE_PRELUDE") == "torchops":
+if "torchops" in PRE:
     import torch
     torch.cuda.synchronize(); t = torch.tensor([1.0, 2.0], dtype=torch.float64, device="cuda"); print(float(t[0]))
 for parts in (0, 2, 4):
