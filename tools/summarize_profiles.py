@@ -14,7 +14,7 @@ os.makedirs(dst, exist_ok=True)
 from bench import source_hash
 for src in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*"))):
     case = os.path.basename(src)
-    ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+    ks = sorted(glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # (gpurun merges: newest collection first)
     if not ks:
         continue
     rows = list(csv.DictReader(open(ks[0])))
@@ -26,7 +26,7 @@ for src in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*")
     pmc, meta = {}, {}
     lanes = None
     for sub in ("fetch", "write", "sq1", "sq2", "sq3", "sq4"):
-        fs = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
+        fs = sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)
         if not fs:
             continue
         own = {}
