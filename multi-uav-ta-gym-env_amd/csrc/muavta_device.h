@@ -32,6 +32,18 @@
 #ifndef MUAVTA_PACE_PRIO
 #define MUAVTA_PACE_PRIO 4
 #endif
+#ifndef MUAVTA_PACE_HOLD  // 0 off; n: a wave more than n steps ahead of a neighbour on its SIMD sleeps until it has caught up (muavta_kernels.hip)
+#define MUAVTA_PACE_HOLD 0
+#endif
+#ifndef MUAVTA_PACE_HOLD_WINDOW
+#define MUAVTA_PACE_HOLD_WINDOW 48
+#endif
+#ifndef MUAVTA_PACE_HOLD_SLEEP
+#define MUAVTA_PACE_HOLD_SLEEP 16
+#endif
+#ifndef MUAVTA_PACE_HOLD_POLLS
+#define MUAVTA_PACE_HOLD_POLLS 256
+#endif
 #ifndef MUAVTA_OBS_SADDR
 #define MUAVTA_OBS_SADDR 1
 #endif

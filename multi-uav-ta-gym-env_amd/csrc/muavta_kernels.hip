@@ -458,6 +458,22 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
 #else
       if (__ballot(behind_me) != 0ull) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(MUAVTA_PACE_PRIO);
 #endif
+#if MUAVTA_PACE_HOLD
+      // Holding: a wave more than MUAVTA_PACE_HOLD steps AHEAD of a neighbour on its SIMD sleeps until that neighbour has caught up.
+      // A wave is latency-bound (it uses about a third of the SIMD's issue slots and runs 1.33x faster alone than as one of
+      // four), so an env with heavier steps falls behind whatever its priority and ends the launch running alone; the slots its
+      // neighbours give up while they wait are the only thing that speeds it up.  The furthest-behind wave never waits (progress),
+      // neighbours further behind than the window are ignored (a later workgroup that took over a wave slot of a multi-round
+      // launch), and the polls are bounded.  Timing only.
+      for (int polls = 0; polls < MUAVTA_PACE_HOLD_POLLS; polls++) {
+        const uint32_t st = seen & 0xFFFFu;
+        const bool wait_for = threadIdx.x < 16 && (seen >> 16) == (uint32_t)epoch && st + MUAVTA_PACE_HOLD < (uint32_t)k &&
+                              st + MUAVTA_PACE_HOLD_WINDOW >= (uint32_t)k;
+        if (__ballot(wait_for) == 0ull) break;
+        __builtin_amdgcn_s_sleep(MUAVTA_PACE_HOLD_SLEEP);
+        if (threadIdx.x < 16) seen = __hip_atomic_load(pace_row + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#endif
     }
 #endif
   }
