@@ -236,6 +236,7 @@ DEV void mt_seed(uint32_t* mt, uint32_t k0, uint32_t k1, int len) {
 #ifdef MUAVTA_PROF
 enum { PROF_N = 64 };  // slots 0..47: cycle accumulators, 48..63: event counters (x1000)
 __device__ unsigned long long g_prof[PROF_N];
+__device__ int g_prof_target = -1;  // >= 0: only this env's stamps are accumulated (tools/phase_profile.py --slowest)
 // per-phase cycle accumulators of a diagnostic build: 64 + 1 (last stamp) u64 words in LDS right behind the Scratch tile
 #define MUAVTA_PROF_LDS_BYTES 528
 #define PROF(i) do { if (threadIdx.x == 0) { unsigned long long t_ = clock64(); prof_lds()[i] += t_ - prof_lds()[PROF_N]; prof_lds()[PROF_N] = t_; } } while (0)
@@ -251,7 +252,7 @@ struct Sim {
 #ifdef MUAVTA_PROF
   DEV unsigned long long* prof_lds() { return reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(&X) + sizeof(Scratch<TL>)); }
   DEV void prof_begin() { if (threadIdx.x < PROF_N) prof_lds()[threadIdx.x] = 0; if (threadIdx.x == 0) prof_lds()[PROF_N] = clock64(); lds_sync(); }
-  DEV void prof_flush() { lds_sync(); if (threadIdx.x < PROF_N) atomicAdd(&g_prof[threadIdx.x], prof_lds()[threadIdx.x]); }
+  DEV void prof_flush(int env) { lds_sync(); if (threadIdx.x < PROF_N && (g_prof_target < 0 || g_prof_target == env)) atomicAdd(&g_prof[threadIdx.x], prof_lds()[threadIdx.x]); }
 #endif
   enum { A = TL::A, T = TL::T, H = TL::H, R = TL::R, E = TL::E, Q = TL::Q, KW = TL::KW };
   typedef EnvCold<TL> Cold;

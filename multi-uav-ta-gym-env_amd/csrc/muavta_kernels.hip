@@ -489,7 +489,7 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
   lds_sync();
   copy16(blob, L.S, sizeof(EnvState<TL>));
 #ifdef MUAVTA_PROF
-  sim.prof_flush();
+  sim.prof_flush(env);
 #endif
 #ifdef MUAVTA_DIAG_TIMES  // tools/end_times_probe.py: when each env's wave ended and on which SIMD (rows of the pace table no SIMD key reaches)
   if (threadIdx.x == 0 && env < 65536) {
@@ -1605,6 +1605,7 @@ int muavta_diag_times(MuavtaEnv* e, uint32_t* out, int32_t n) {  // diagnostic b
 }
 #endif
 #ifdef MUAVTA_PROF
+int muavta_prof_target(int env) { return hipMemcpyToSymbol(HIP_SYMBOL(g_prof_target), &env, sizeof(env)) == hipSuccess ? MUAVTA_OK : MUAVTA_E_HIP; }  // diagnostic build only
 int muavta_prof_read(unsigned long long* out, int reset) {  // diagnostic build only
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), PROF_N * sizeof(unsigned long long)) != hipSuccess) return MUAVTA_E_HIP;
   if (reset) { unsigned long long z[PROF_N] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)) != hipSuccess) return MUAVTA_E_HIP; }

@@ -31,12 +31,22 @@ L = native.lib()
 buf = (C.c_ulonglong * 64)()
 env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, obs); env.sync()
 L.muavta_prof_read(buf, 1)
+per_env = 1
+if "--slowest" in sys.argv:  # (build with --build -DMUAVTA_DIAG_TIMES) only the env whose wave ended last: what the launch's critical path spends its time on
+    times = np.zeros((3, n), dtype=np.uint32)
+    L.muavta_diag_times.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    assert L.muavta_diag_times(env.h, times.ctypes.data_as(C.c_void_p), n) == 0
+    dur = (times[1] - times[0]).astype(np.int64)
+    slow = int(np.argmax(dur))
+    print(f"slowest env {slow}: {dur[slow] * 1e-5:.3f} ms; mean env {dur.mean() * 1e-5:.3f} ms")
+    L.muavta_prof_target(slow)
+    per_env = n  # the sums below are of ONE env: undo the division by n
 env.rollout(np.arange(n, dtype=np.uint64), 150, interval, True, obs); env.sync()
 L.muavta_prof_read(buf, 1)
 names = {0: "(loop gap)", 1: "rng_refill", 2: "drain+release", 3: "actions", 4: "movement", 5: "dist", 6: "serial_b threats/arrivals/escorts",
          7: "sense", 8: "serial_c reveals/expire/reward", 9: "finish gc+open", 10: "(pre-alloc)", 11: "alloc gate", 12: "cost build",
          13: "lsap", 14: "accept", 15: "(pre-obs)", 16: "obs rows->LDS", 17: "obs rows stream", 18: "obs legal->LDS", 19: "obs legal stream", 20: "obs agents/flags/result", 21: "b: np.sum + penalty terms", 22: "b: generate_threat", 23: "b: threats parallel", 24: "b: threats serial replay", 25: "b: arrivals", 6: "b: escorts+sync", 26: "move: parallel pass", 4: "move: serial replay", 28: "c: prechecks", 29: "c: lists", 8: "c: serial_c (reward)", 32: "c: ballots", 33: "actions: precompute", 3: "actions: serial_a", 34: "move: compute (in 26)", 35: "finish: gc loop (slow path)", 36: "c: serial_c head", 37: "c: serial_c weighted sum", 38: "c: serial_c divisions", 30: "(count x1000) end-of-step slow path entered", 31: "(count x1000) ... with retired slots present", 40: "(count x1000) movement passes", 41: "(count x1000) movement events", 39: "reset: (entry)", 42: "reset: master init_by_array", 43: "reset: agent stream twist+tape", 44: "reset: seed draws + 2-3 init_by_array (parallel lanes)", 45: "reset: tgt/mission streams twist+tape", 46: "reset: zero blob", 47: "reset: serial entity creation"}
-v = np.array(list(buf), dtype=np.float64)
+v = np.array(list(buf), dtype=np.float64) * per_env
 counts = v[48:].copy()
 extra = {59: "escorts: arrivals + creation (in b: escorts+sync)", 60: "escorts: segment passes", 61: "escorts: retirements"}
 v = v[:48]
