@@ -3839,6 +3839,33 @@ struct Sim {
     int prof_iters = 0;
 #endif
     for (int cur = 0; cur < nr; cur++) {
+      {
+        // A row whose FIRST scan step already finds an unassigned column at the minimum (most rows: nc > nr leaves most columns
+        // free) needs none of the search state below.  Every column is still in `remaining` at its initial position nc-1-j, so
+        // "the unassigned minimum at the LAST position" is the one in the LOWEST lane; only row cur was scanned (no other u
+        // changes), the selected column's v changes by minVal - spc = 0, and the path is the single edge (cur, sink).  Same values
+        // as the general loop (0.0 + c is kept: it turns a cost of -0.0 into +0.0 there as well).  ~45 instructions and 3 branches
+        // instead of ~160 / 20 — on a lone wave (the env that ends a launch of configs 4 and 5) a scan step costs ~1,700 cycles.
+#ifdef MUAVTA_PROF
+        prof_iters++;
+#endif
+        const double r0 = 0.0 + cost_row(cur) - readlane_f64(u_r, cur) - vj;
+        const double val0 = incol ? r0 : INF;
+        const double m0 = wave_min(val0);
+        if (__double2hiint(m0) != 0x7ff00000) {
+          const unsigned long long equ0 = __builtin_amdgcn_ballot_w64(val0 == m0) & unassigned;
+          if (equ0) {
+            const int sink0 = __ffsll((long long)equ0) - 1;
+            if (lane == cur) { u_r += m0; c4r = sink0; }
+            if (lane == sink0) r4c = cur;
+            unassigned &= ~(1ull << sink0);
+            continue;
+          }
+        }
+#ifdef MUAVTA_PROF
+        prof_iters--;  // (the general search below counts this scan step again)
+#endif
+      }
       int pos = nc - 1 - lane;  // scipy fills `remaining` in reverse: column j sits at position nc-1-j
       double sp = INF;
       int pth = -1;
