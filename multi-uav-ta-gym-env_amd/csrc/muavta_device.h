@@ -3173,40 +3173,44 @@ struct Sim {
         g.rank = mode == 1 ? (int)X.live_rank[a] : 0;
         return g;
       };
-      auto pair_eval_cap = [&](const AS& g, int sl, const TS& t, double capv) -> double {  // == pair_cost(a, sl, jr); capv = S.a_caps[t.type][a]
-        double c = 1e6;
+      // == pair_cost(a, sl, jr); capv = S.a_caps[t.type][a].  STRAIGHT-LINE per lane: every lane evaluates the whole expression and the
+      // conditions only select the result.  In SIMT the arithmetic was executed anyway whenever one lane needed it; what the nested
+      // `if`s added was an exec-mask region each (s_and_saveexec + branch + s_or: five per cost element), and on the lone wave that
+      // ends a launch of configs 4 and 5 every taken branch is an instruction-buffer refill.  Same operations on the same operands
+      // for every lane whose result is kept.
+      auto pair_eval_cap = [&](const AS& g, int sl, const TS& t, double capv) -> double {
         bool known;
         if constexpr (KW <= 2) known = ((((sl >> 5) ? g.k1 : g.k0) >> (sl & 31)) & 1u) != 0;
         else { const unsigned long long w = (sl & 64) ? g.k23 : ((unsigned long long)g.k0 | ((unsigned long long)g.k1 << 32)); known = ((w >> (sl & 63)) & 1ull) != 0; }
-        bool ok = !(vis && !known);
-        if (ok && t.elig_on && !((t.elig >> g.type) & 1u)) ok = false;
-        if (ok) {
-          const double delivered = t.esc_task ? 1.0 : capv;
-          if (delivered > 0) {
-            const double dist = norm2(g.px - t.px, g.py - t.py);
-            const double base = div_coord(dist) - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
-            double score = 0.0;
-            if (mode == 1) {
-              if ((t.info & 255) < 32 && g.rank < 16 && capv > 0) {
-                double scar = 0.0;
-                if (vis) scar = 1.0 - fmin((double)(t.info >> 8) / (double)n_live, 1.0);
-                double v = 0.5 * t.urgency + 0.3 * scar - 0.4 * div_coord(dist);
-                v = fmin(fmax(v, -0.35), 0.35);
-                score = (double)(float)v;
-              }
-            }
-            if (mode == 2) {
-              const double cap = capv > 0 ? capv : 0.0;
-              double v = 0.45 * t.urgency + 0.35 * t.press * (0.5 + 0.5 * (t.esc_flag ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * div_coord(dist);
-              const bool fighter = is_fighter(g.type);
-              if (fighter && (t.esc_flag || t.type == MUAVTA_INT)) v += 0.2;
-              if (!fighter && t.type == MUAVTA_REC) v += 0.2;
-              score = fmin(fmax(v, 0.0), 1.0);
-            }
-            if (base < 1e5 / 2) c = base - score;
-          }
+        bool ok = !(vis & !known);
+        ok = ok & !(t.elig_on & !((t.elig >> g.type) & 1u));
+        const double delivered = t.esc_task ? 1.0 : capv;
+        ok = ok & (delivered > 0);
+        const double dist = norm2(g.px - t.px, g.py - t.py);
+        const double dc = div_coord(dist);
+        const double base = dc - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
+        double score = 0.0;
+        if (mode == 1) {  // (uniform)
+          double scar = 0.0;
+          if (vis) scar = 1.0 - fmin((double)(t.info >> 8) / (double)n_live, 1.0);
+          double v = 0.5 * t.urgency + 0.3 * scar - 0.4 * dc;
+          v = fmin(fmax(v, -0.35), 0.35);
+          const bool edge = ((t.info & 255) < 32) & (g.rank < 16) & (capv > 0);
+          score = edge ? (double)(float)v : 0.0;
         }
-        return c;
+        if (mode == 2) {  // (uniform)
+          const double cap = capv > 0 ? capv : 0.0;
+          double v = 0.45 * t.urgency + 0.35 * t.press * (0.5 + 0.5 * (t.esc_flag ? 1.0 : 0.0)) + 0.3 * fmin(cap, 1.0) - 0.25 * dc;
+          const bool fighter = is_fighter(g.type);
+          const double v_f = v + 0.2;
+          v = (fighter & (t.esc_flag | (t.type == MUAVTA_INT))) ? v_f : v;
+          const double v_r = v + 0.2;
+          v = (!fighter & (t.type == MUAVTA_REC)) ? v_r : v;
+          score = fmin(fmax(v, 0.0), 1.0);
+        }
+        ok = ok & (base < 1e5 / 2);
+        const double c = base - score;
+        return ok ? c : 1e6;
       };
       auto pair_eval = [&](int a, const AS& g, int sl, const TS& t) -> double { return pair_eval_cap(g, sl, t, S.a_caps[t.type][a]); };
       bool feasible = false;
@@ -3238,7 +3242,7 @@ struct Sim {
               g.k0 = __builtin_amdgcn_readlane(gr.k0, i); g.k1 = __builtin_amdgcn_readlane(gr.k1, i);
               g.k23 = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gr.k23, i) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gr.k23 >> 32), i) << 32);
               double c = 0.0;
-              if (incol) { c = pair_eval_cap(g, my_s, ts, S.a_caps[ts.type][a]); feasible |= c < 1e5 / 2; }
+              c = pair_eval_cap(g, my_s, ts, S.a_caps[ts.type][a]); feasible |= incol & (c < 1e5 / 2);  // (lanes beyond the columns evaluate column 0's operands; nobody reads their result)
               return c;
             });
           } else {  // rows = round tasks, lane = free-agent column
@@ -3260,7 +3264,7 @@ struct Sim {
               t.info = mode == 1 ? __builtin_amdgcn_readlane(tr_.info, i) : 0;
               t.type = pk & 7; t.elig_on = (pk & 8) != 0; t.esc_task = (pk & 16) != 0; t.esc_flag = (pk & 32) != 0; t.elig = (uint32_t)pk >> 8;
               double c = 0.0;
-              if (incol) { c = pair_eval_cap(g, sl, t, mycaps[t.type]); feasible |= c < 1e5 / 2; }
+              c = pair_eval_cap(g, sl, t, mycaps[t.type]); feasible |= incol & (c < 1e5 / 2);
               return c;
             });
           }
@@ -3272,7 +3276,7 @@ struct Sim {
             const int a = X.freeA[i];
             const AS g = load_as(a);
             double c = 0.0;
-            if (incol) { c = pair_eval(a, g, my_s, ts); feasible |= c < 1e5 / 2; }
+            c = pair_eval(a, g, my_s, ts); feasible |= incol & (c < 1e5 / 2);
             return c;
           });
         } else {
@@ -3282,7 +3286,7 @@ struct Sim {
             const int sl = S.open_slot[X.roundT[i]];
             const TS ts = load_ts(sl, i);
             double c = 0.0;
-            if (incol) { c = pair_eval(my_a, g, sl, ts); feasible |= c < 1e5 / 2; }
+            c = pair_eval(my_a, g, sl, ts); feasible |= incol & (c < 1e5 / 2);
             return c;
           });
         }
