@@ -3877,6 +3877,10 @@ struct Sim {
       unsigned long long SRmask = 0ull;
       double minVal = 0;
       int i = cur, nrem = nc, sink;
+      // The loop body is the step that CONTINUES the search (the minimum sits in an assigned column); the step that ends it — an
+      // unassigned column at the minimum — leaves the loop first and is finished behind it.  One exit, four branches per scan step.
+      unsigned long long equ;
+      double m;
       for (;;) {
 #ifdef MUAVTA_PROF
         prof_iters++;
@@ -3888,30 +3892,18 @@ struct Sim {
         sp = upd ? r : sp;
         pth = upd ? i : pth;
         const double val = active ? sp : INF;
-        const double m = wave_min(val);  // (wave_min_first(val, nc) saves 3-6 VALU per scan step for <= 32 columns and loses more to its two scalar branches in the dependent chain: measured r3)
+        m = wave_min(val);  // (wave_min_first(val, nc) saves 3-6 VALU per scan step for <= 32 columns and loses more to its two scalar branches in the dependent chain: measured r3)
         if (__double2hiint(m) == 0x7ff00000) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }  // m == +inf (never NaN): a scalar compare of the high word
         const unsigned long long eq = __builtin_amdgcn_ballot_w64(val == m);  // scanned columns and lanes beyond nc hold +inf > m
-        const unsigned long long equ = eq & unassigned;
-        int sel;
-        if (equ) {
-          sel = 63 - __clzll((long long)equ);
-          if (equ & (equ - 1ull)) {  // several unassigned minima: the one at the last position
-            int best = -1;
-            for (unsigned long long t = equ; t; t &= t - 1ull) {
-              const int b = __ffsll((long long)t) - 1;
-              const int pb = __builtin_amdgcn_readlane(pos, b);
-              if (pb > best) { best = pb; sel = b; }
-            }
-          }
-        } else {
-          sel = __ffsll((long long)eq) - 1;
-          if (eq & (eq - 1ull)) {    // several (assigned) minima: the one at the first position
-            int best = 1 << 30;
-            for (unsigned long long t = eq; t; t &= t - 1ull) {
-              const int b = __ffsll((long long)t) - 1;
-              const int pb = __builtin_amdgcn_readlane(pos, b);
-              if (pb < best) { best = pb; sel = b; }
-            }
+        equ = eq & unassigned;
+        if (equ) break;  // an unassigned column ends the search
+        int sel = __ffsll((long long)eq) - 1;
+        if (eq & (eq - 1ull)) {    // several (assigned) minima: the one at the first position
+          int best = 1 << 30;
+          for (unsigned long long t = eq; t; t &= t - 1ull) {
+            const int b = __ffsll((long long)t) - 1;
+            const int pb = __builtin_amdgcn_readlane(pos, b);
+            if (pb < best) { best = pb; sel = b; }
           }
         }
         minVal = m;
@@ -3919,8 +3911,21 @@ struct Sim {
         if (pos == nrem - 1) pos = psel;  // remaining[index] = remaining[--num_remaining]
         if (lane == sel) active = false;
         nrem--;
-        if (equ) { sink = sel; break; }  // an unassigned column ends the search
         i = __builtin_amdgcn_readlane(r4c, sel);
+      }
+      {  // the last scan step: among the unassigned minima the one at the last position (positions and `nrem` are not needed any more)
+        int sel = 63 - __clzll((long long)equ);
+        if (equ & (equ - 1ull)) {
+          int best = -1;
+          for (unsigned long long t = equ; t; t &= t - 1ull) {
+            const int b = __ffsll((long long)t) - 1;
+            const int pb = __builtin_amdgcn_readlane(pos, b);
+            if (pb > best) { best = pb; sel = b; }
+          }
+        }
+        minVal = m;
+        if (lane == sel) active = false;
+        sink = sel;
       }
       // dual updates (u over the scanned rows, v over the scanned columns = the ones that left `remaining`)
       const unsigned long long others = SRmask & ~(1ull << cur);
