@@ -44,6 +44,9 @@
 #ifndef MUAVTA_PACE_HOLD_POLLS
 #define MUAVTA_PACE_HOLD_POLLS 256
 #endif
+#ifndef MUAVTA_PRELOAD_ROWS_ABOVE  // tiles with more agents than this fetch the LSAP row operands up front, one row per lane (allocate)
+#define MUAVTA_PRELOAD_ROWS_ABOVE 16
+#endif
 #ifndef MUAVTA_OBS_SADDR
 #define MUAVTA_OBS_SADDR 1
 #endif
@@ -3224,7 +3227,7 @@ struct Sim {
         // side (task or agent fields) is read from LDS ONCE per lane, the row's side is the same for every lane (broadcast
         // reads, issued together), so an iteration costs one LDS round trip instead of a chain of six.  Same arithmetic.
         const bool incol = lane < Cc;
-        if constexpr (A > 32) {
+        if constexpr (A > MUAVTA_PRELOAD_ROWS_ABOVE) {
           // The 64-agent tile runs one wave per SIMD: what a row costs is its dependent chain, not its instruction count.  Lane r
           // fetches ROW r's operands up front (every row at once, one LDS round trip), and the row loop broadcasts them with
           // v_readlane: no LDS access on the loop's chain, two rows in flight.  Same arithmetic as pair_cost().
