@@ -44,9 +44,6 @@
 #ifndef MUAVTA_PACE_HOLD_POLLS
 #define MUAVTA_PACE_HOLD_POLLS 256
 #endif
-#ifndef MUAVTA_PRELOAD_ROWS_ABOVE  // tiles with more agents than this fetch the LSAP row operands up front, one row per lane (allocate)
-#define MUAVTA_PRELOAD_ROWS_ABOVE 16
-#endif
 #ifndef MUAVTA_OBS_SADDR
 #define MUAVTA_OBS_SADDR 1
 #endif
@@ -3227,10 +3224,11 @@ struct Sim {
         // side (task or agent fields) is read from LDS ONCE per lane, the row's side is the same for every lane (broadcast
         // reads, issued together), so an iteration costs one LDS round trip instead of a chain of six.  Same arithmetic.
         const bool incol = lane < Cc;
-        if constexpr (A > MUAVTA_PRELOAD_ROWS_ABOVE) {
-          // The 64-agent tile runs one wave per SIMD: what a row costs is its dependent chain, not its instruction count.  Lane r
+        {
+          // What a row costs the wave that ends a launch is its dependent chain, not its instruction count (§6 of DESIGN.md).  Lane r
           // fetches ROW r's operands up front (every row at once, one LDS round trip), and the row loop broadcasts them with
-          // v_readlane: no LDS access on the loop's chain, two rows in flight.  Same arithmetic as pair_cost().
+          // v_readlane: no LDS access on the loop's chain.  Same arithmetic as pair_cost().  (r3: first on the 64-agent tile only;
+          // the other two tiles read the row's fields inside the loop — two dependent LDS round trips per row — until the end of r3.)
           auto pack = [](const TS& t) { return t.type | (t.elig_on ? 8 : 0) | (t.esc_task ? 16 : 0) | (t.esc_flag ? 32 : 0) | (int)(t.elig << 8); };
           if (!tr) {  // rows = free agents, lane = task column
             const int my_s = incol ? (int)S.open_slot[X.roundT[lane]] : (int)S.open_slot[X.roundT[0]];
@@ -3271,27 +3269,6 @@ struct Sim {
               return c;
             });
           }
-        } else
-        if (!tr) {
-          const int my_s = incol ? (int)S.open_slot[X.roundT[lane]] : (int)S.open_slot[X.roundT[0]];
-          const TS ts = load_ts(my_s, incol ? lane : 0);
-          build_cols(col, Rr, [&](int i) -> double {
-            const int a = X.freeA[i];
-            const AS g = load_as(a);
-            double c = 0.0;
-            c = pair_eval(a, g, my_s, ts); feasible |= incol & (c < 1e5 / 2);
-            return c;
-          });
-        } else {
-          const int my_a = incol ? X.freeA[lane] : X.freeA[0];
-          const AS g = load_as(my_a);
-          build_cols(col, Rr, [&](int i) -> double {
-            const int sl = S.open_slot[X.roundT[i]];
-            const TS ts = load_ts(sl, i);
-            double c = 0.0;
-            c = pair_eval(my_a, g, sl, ts); feasible |= incol & (c < 1e5 / 2);
-            return c;
-          });
         }
       } else {
         for (int p = lane; p < nr * nc; p += WG) {  // one (agent, task) pair per lane
