@@ -3689,6 +3689,30 @@ struct Sim {
     for (int j = lane; j < nc; j += WG) { X.v[j] = 0; X.row4col[j] = -1; X.path[j] = -1; }
     lds_sync();
     for (int cur = 0; cur < nr; cur++) {
+      {
+        // A row whose first scan step already finds an unassigned column at the minimum needs none of the search state (same
+        // reasoning as in lsap_reg_solve: positions are still the initial ones, so the unassigned minimum at the LAST position is
+        // the one with the LOWEST column index; u[cur] += minVal, v unchanged, one path edge).
+        const double ui = X.u[cur];
+        double gmin = INF;
+        int g_un = -1;
+        for (int base = 0; base < nc; base += WG) {
+          const int j = base + lane;
+          double val = INF;
+          bool un = false;
+          if (j < nc) { val = 0.0 + cost_at(cur, j) - ui - X.v[j]; un = X.row4col[j] == -1; }
+          const double m = wave_min(val);
+          const unsigned long long equ = __ballot(j < nc && val == m && un);
+          if (m < gmin) { gmin = m; g_un = equ ? base + __ffsll((long long)equ) - 1 : -1; }
+          else if (m == gmin && g_un < 0 && equ) g_un = base + __ffsll((long long)equ) - 1;
+        }
+        if (gmin != INF && g_un >= 0) {
+          lds_sync();  // every lane has read u / v / row4col
+          if (lane == 0) { X.u[cur] = ui + gmin; X.row4col[g_un] = cur; X.col4row[cur] = g_un; }
+          lds_sync();
+          continue;
+        }
+      }
       for (int it = lane; it < nc; it += WG) { X.remaining[it] = nc - it - 1; X.SC[it] = 0; X.spc[it] = INF; }
       for (int r = lane; r < nr; r += WG) X.SR[r] = 0;
       lds_sync();
