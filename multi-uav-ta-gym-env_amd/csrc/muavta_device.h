@@ -2797,15 +2797,37 @@ struct Sim {
     unsigned long long* tmax = tmin + T;
     for (int s = lane; s < T; s += WG) { tmin[s] = ~0ull; tmax[s] = 0ull; }
     lds_sync();
-    const int nE = P.n_agents * Q;
-    for (int e = lane; e < nE; e += WG) {
-      const int a = e / Q, k = e - a * Q;
-      if (k < S.a_qlen[a]) {
-        const int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
-        if (ref_valid(id, slot) && S.t_status[slot] != 2) {
-          const unsigned long long bits = (unsigned long long)__double_as_longlong(C.a_qtime[a][k]);
-          atomicMin(&tmin[slot], bits);
-          atomicMax(&tmax[slot], bits);
+    if constexpr (A > 32) {
+      // 64 agents x Q entries: one AGENT per lane, as many passes as the longest queue holds entries (3-5, not Q = 12), and the
+      // lane's queue-time row (HBM) is requested in one go in front of them — one memory latency instead of one per pass.
+      const int a = lane < P.n_agents ? lane : 0;
+      const int ql = lane < P.n_agents ? (int)S.a_qlen[a] : 0;
+      double qt[Q];
+#pragma unroll
+      for (int k = 0; k < Q; k++) qt[k] = k < ql ? C.a_qtime[a][k] : 0.0;
+#pragma unroll
+      for (int k = 0; k < Q; k++) {
+        if (__ballot(k < ql) == 0ull) break;
+        if (k < ql) {
+          const int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
+          if (ref_valid(id, slot) && S.t_status[slot] != 2) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(qt[k]);
+            atomicMin(&tmin[slot], bits);
+            atomicMax(&tmax[slot], bits);
+          }
+        }
+      }
+    } else {
+      const int nE = P.n_agents * Q;
+      for (int e = lane; e < nE; e += WG) {
+        const int a = e / Q, k = e - a * Q;
+        if (k < S.a_qlen[a]) {
+          const int id = S.a_qid[a][k], slot = S.a_qslot[a][k];
+          if (ref_valid(id, slot) && S.t_status[slot] != 2) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(C.a_qtime[a][k]);
+            atomicMin(&tmin[slot], bits);
+            atomicMax(&tmax[slot], bits);
+          }
         }
       }
     }
