@@ -3868,6 +3868,7 @@ struct Sim {
 #ifdef MUAVTA_PROF
     int prof_iters = 0;
 #endif
+    bool bad = false;  // (uniform) an infeasible matrix
     for (int cur = 0; cur < nr; cur++) {
       {
         // A row whose FIRST scan step already finds an unassigned column at the minimum (most rows: nc > nr leaves most columns
@@ -3919,7 +3920,10 @@ struct Sim {
         pth = upd ? i : pth;
         const double val = active ? sp : INF;
         m = wave_min(val);  // (wave_min_first(val, nc) saves 3-6 VALU per scan step for <= 32 columns and loses more to its two scalar branches in the dependent chain: measured r3)
-        if (__double2hiint(m) == 0x7ff00000) { if (lane == 0) fail(MUAVTA_ERR_LSAP); lds_sync(); return; }  // m == +inf (never NaN): a scalar compare of the high word
+        // m == +inf (never NaN; a scalar compare of the high word): every remaining column is out of reach — the matrix is infeasible.
+        // No exit here: the unassigned columns then all sit at the "minimum", so the search ends in this step by itself; the flag
+        // is raised behind the solve (a `return` inside the loop made the compiler thread an exit code through every scan step).
+        bad |= __double2hiint(m) == 0x7ff00000;
         const unsigned long long eq = __builtin_amdgcn_ballot_w64(val == m);  // scanned columns and lanes beyond nc hold +inf > m
         equ = eq & unassigned;
         if (equ) break;  // an unassigned column ends the search
@@ -3939,6 +3943,7 @@ struct Sim {
         nrem--;
         i = __builtin_amdgcn_readlane(r4c, sel);
       }
+      if (bad) break;  // (infeasible: no path to augment — the columns at the "minimum" have no predecessor row)
       {  // the last scan step: among the unassigned minima the one at the last position (positions and `nrem` are not needed any more)
         int sel = 63 - __clzll((long long)equ);
         if (equ & (equ - 1ull)) {
@@ -3973,6 +3978,7 @@ struct Sim {
         if (r == cur) break;
       }
     }
+    if (bad && lane == 0) fail(MUAVTA_ERR_LSAP);  // (scipy: ValueError("cost matrix is infeasible"); the assignment written below is meaningless then)
     if (lane < nr) X.col4row[lane] = c4r;
     if (incol) X.row4col[lane] = r4c;
     PROF_COUNT(49, 1000 * prof_iters);
