@@ -3323,7 +3323,10 @@ struct Sim {
           keep = true;
           if (j >= 0) {
             double cij;
-            if constexpr (TL::NO_COST_TILE) cij = pair_cost(a, S.open_slot[X.roundT[j]], j);  // same value the solver saw
+            if constexpr (TL::NO_COST_TILE) {  // same value the solver saw, through the same straight-line evaluator
+              const int sl = S.open_slot[X.roundT[j]];
+              cij = pair_eval_cap(load_as(a), sl, load_ts(sl, j), S.a_caps[S.t_type[sl]][a]);
+            }
             else cij = X.cost[tr ? (j * Cc + i) : (i * Cc + j)];
             if (cij < 1e5 / 2) {
               acc = true; keep = false;
