@@ -292,6 +292,46 @@ int muavta_tokens_device(MuavtaEnv* env, int32_t kind, int32_t max_tasks, int32_
                          int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent,
                          float* expert_mask, int32_t* replanned);
 
+/* The learned hybrids' planner call: HungarianAllocator.allocate_tasks(live, tok["open_tasks"], time_step, events, force,
+ * task_priorities=..., reserved_agent_names=..., agent_known_ids=..., edge_scores=...) with CALLER-COMPUTED inputs
+ * (TaskAllocation/OptimizationBased/HungarianAllocator.py:72-92,123-124,170-179), as PairCostHybrid.plan
+ * (TaskAllocation/Hybrid/PairCostHybrid.py:283-294,312-327), AttentionRAH.plan (AttentionRAH.py:395-453),
+ * AttentionCommit._plan_from_scores (AttentionCommit.py:266-300) and AttentionEscort._plan_from_scores (AttentionEscort.py:472-515)
+ * issue it, followed by _apply_assign (experiments/train_pair_cost.py:46-51).  The inputs are indexed in the token layout the
+ * caller's network consumed — muavta_tokens(_device)(kind, max_tasks, max_agents): row i = i-th live agent, column j = j-th
+ * token task — so the tensors a policy produces from the token tensors go straight back in:
+ *   edge_scores f32 [N, max_agents, max_tasks]  edge_score_dict: cost[i, j] = base - float(score) wherever base < 5e4; pad rows /
+ *                                               columns are ignored; NULL = no scores
+ *   task_pri    f64 [N, max_tasks]              task_priorities[task_ids[j]] (the -0.4 * priority term of _cost); NULL = none
+ *   reserved    u64 [N]                         bit a set <=> UAV.id a is in reserved_agent_names; NULL = none
+ * flags: MUAVTA_SC_EDGE_VALID_ONLY  scores count only where the token builder's edge_valid is 1 (PairCostHybrid.edge_score_dict;
+ *                                   AttentionEscort's takes every non-pad pair: leave the flag off)
+ *        MUAVTA_SC_FULL_TASK_LIST   the allocator gets the token builder's whole open list, not only the max_tasks rows that
+ *                                   became tokens (build_att_tokens' "open_tasks": AttentionRAH / AttentionCommit; build_pair_tokens
+ *                                   and build_escort_tokens hand over the kept rows: leave the flag off)
+ *        MUAVTA_SC_COMMIT           reserved |= committed_names(env); assigned agents that hold a real task are locked for
+ *                                   commit_horizon steps (AttentionCommit.py:24-44, as AttentionEscort._plan_from_scores does)
+ * gate:  MUAVTA_GATE_FORCE      plan now (the caller evaluated its own gate; force=True)
+ *        MUAVTA_GATE_TRAINER    force=True under _should_replan(env, events, replan_interval) with tags Reset_Allocation, New_Threat,
+ *                               Agent_Fail (experiments/train_pair_cost.py:33-43; wps_eval.py:64-74 is the same with 15)
+ *        MUAVTA_GATE_ESCORT     force=True under escort_eval._should_replan (experiments/escort_eval.py:52-58: any event)
+ *        MUAVTA_GATE_ALLOCATOR  force=False: HungarianAllocator.should_replan decides (:27-41)
+ * use_visibility = 0 passes agent_known_ids=None.  Outputs: the staged actions (muavta_step_staged applies them; act_agent /
+ * act_index as in muavta_allocate, host buffers, may be NULL), selected f32 [N, max_agents, max_tasks] = _selected_mask(tok,
+ * result) (PairCostHybrid.py:296-310; may be NULL), replanned i32 [N] = the gate fired (may be NULL).
+ * muavta_allocate_scored takes HOST buffers for all of them and synchronises; muavta_allocate_scored_device takes DEVICE buffers
+ * (e.g. torch tensors on the handle's GPU), runs on the handle's stream and does not synchronise. */
+enum { MUAVTA_GATE_FORCE = 0, MUAVTA_GATE_TRAINER = 1, MUAVTA_GATE_ESCORT = 2, MUAVTA_GATE_ALLOCATOR = 3 };
+enum { MUAVTA_SC_EDGE_VALID_ONLY = 1, MUAVTA_SC_FULL_TASK_LIST = 2, MUAVTA_SC_COMMIT = 4 };
+typedef struct MuavtaScored {
+  int32_t kind, max_tasks, max_agents;  /* MUAVTA_TOK_*, token pads */
+  int32_t gate, flags, replan_interval, use_visibility, reserved0;
+  const float* edge_scores; const double* task_pri; const uint64_t* reserved;
+  float* selected; int32_t* replanned;
+} MuavtaScored;
+int muavta_allocate_scored(MuavtaEnv* env, const MuavtaScored* spec, int32_t* act_agent, int32_t* act_index);
+int muavta_allocate_scored_device(MuavtaEnv* env, const MuavtaScored* spec);
+
 /* The measured path: reset(seeds) followed by n_steps x (allocate -> step) fused in ONE kernel
  * launch, state resident in LDS (run_wps_episode / run_escort_episode with Local-/Coalition-
  * Hungarian, experiments/wps_eval.py:76-291, experiments/escort_eval.py:86-226).  seeds == NULL

@@ -1572,7 +1572,48 @@ struct Env {
   // mode 1: Urgency-Pair (TaskAllocation/Hybrid/PairCostHybrid.py:31-86,520-550 + experiments/wps_eval.py:64-74,
   //         248-254): replan gate _should_replan(env, events, 15), engineered edge scores (float32) for the
   //         first 16 live agents x first 32 underfilled tasks, then HungarianAllocator.allocate_tasks(force=True).
-  int allocate(int interval, int use_visibility, int32_t* act_agent, int32_t* act_index, int cap, int mode = 0) {
+  // mode 4 (scored): HungarianAllocator.allocate_tasks driven the way the learned hybrids drive it — caller-supplied edge scores,
+  //         task priorities and reserved agents, indexed in the token layout (kind, max_tasks, max_agents) the caller built its
+  //         tensors in: PairCostHybrid.plan (PairCostHybrid.py:283-294,312-327), AttentionRAH.plan (AttentionRAH.py:395-453),
+  //         AttentionCommit._plan_from_scores (AttentionCommit.py:266-300), AttentionEscort._plan_from_scores (AttentionEscort.py:
+  //         472-515); consumed by HungarianAllocator.py:79-92,123-124,170-179.
+  struct Scored {
+    int gate, kind, max_tasks, max_agents, flags;
+    const float* scores;    // [max_agents, max_tasks] or null
+    const double* pri;      // [max_tasks] or null
+    uint64_t reserved;      // bit UAV.id
+    float* selected;        // [max_agents, max_tasks] or null: _selected_mask (PairCostHybrid.py:296-310)
+  };
+  // the token builder's task list: build_att_tokens' open_tasks (kind 0/1, AttentionRAH.py:69-73) or build_escort_tokens' sorted
+  // local open list (kind 2, AttentionEscort.py:83-96), untruncated
+  std::vector<int> token_task_list(int kind) const {
+    const bool vis = !(P.sense_radius == 0 && P.threat_delay == 0);
+    std::vector<int> out;
+    if (kind != 2) {
+      for (size_t k = 1; k < tasks.size(); k++) {
+        const Task& t = tasks[k];
+        if (t.status != 2 && t.allocatedReqs[t.type] < t.currentReqs[t.type]) out.push_back((int)k);
+      }
+      return out;
+    }
+    std::vector<int> open_all;
+    for (size_t k = 1; k < tasks.size(); k++) if (tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_all.push_back((int)k);
+    if (!vis) out = open_all;
+    else {
+      for (int tid : open_all) { bool any = false; for (auto& a : agents) if (a.state != -1) any |= known[a.id][tid] != 0; if (any) out.push_back(tid); }
+      if (out.empty()) out = open_all;
+    }
+    std::vector<double> key(tasks.size(), 0.0);
+    for (int tid : out) {
+      const Task& t = tasks[tid];
+      double pr, dn, fp;
+      threat_stats(t, &pr, &dn, &fp);
+      key[tid] = -(1.5 * task_urgency(t) + 1.2 * pr + 0.8 * (t.escort ? 1.0 : 0.0) + 0.5 * (t.type == MUAVTA_INT ? 1.0 : 0.0));
+    }
+    std::stable_sort(out.begin(), out.end(), [&](int x, int y) { return key[x] < key[y]; });
+    return out;
+  }
+  int allocate(int interval, int use_visibility, int32_t* act_agent, int32_t* act_index, int cap, int mode = 0, const Scored* sc = nullptr) {
     last_actions.clear(); last_pairs.clear();
     lsap_costs.clear(); lsap_shapes.clear(); lsap_rows.clear(); lsap_cols.clear();
     interval = std::max(1, interval);
@@ -1584,7 +1625,49 @@ struct Env {
     std::vector<double> score;     // [agent id][task id], 0 where there is no edge
     std::vector<char> reserved(n_agents, 0);
     std::vector<char> in_list(tasks.size(), 1);
-    if (mode == 1) {
+    std::vector<double> pri_of;    // [task id] HungarianAllocator task_priorities (0 where the dict has no entry)
+    std::vector<int> sc_list;      // mode 4: the ordered task list handed to allocate_tasks
+    std::vector<int> sc_kept;      // mode 4: token columns -> task id
+    if (mode == 4) {
+      const bool envvis = !(P.sense_radius == 0 && P.threat_delay == 0);
+      bool gate = true;
+      if (sc->gate == MUAVTA_GATE_TRAINER) {  // train_pair_cost._should_replan (experiments/train_pair_cost.py:33-43; wps_eval.py:64-74 with 15)
+        gate = time_steps == 0 || time_steps % interval == 0;
+        for (auto& ev : done_events) gate |= (ev.tag == MUAVTA_EV_RESET_ALLOCATION || ev.tag == MUAVTA_EV_NEW_THREAT || ev.tag == MUAVTA_EV_AGENT_FAIL);
+      } else if (sc->gate == MUAVTA_GATE_ESCORT) {  // escort_eval._should_replan (experiments/escort_eval.py:52-58)
+        gate = time_steps == 0 || time_steps % interval == 0 || !done_events.empty();
+      } else if (sc->gate == MUAVTA_GATE_ALLOCATOR) {  // force=False: the allocator's own should_replan (:27-41)
+        n_calls++;
+        gate = should_replan(done_events, interval);
+      }
+      if (sc->selected) std::fill(sc->selected, sc->selected + (size_t)sc->max_agents * sc->max_tasks, 0.0f);
+      if (!gate) return finish();
+      if (sc->gate != MUAVTA_GATE_ALLOCATOR) n_calls++;
+      std::vector<int> full = token_task_list(sc->kind);
+      for (size_t j = 0; j < full.size() && (int)j < sc->max_tasks; j++) sc_kept.push_back(full[j]);
+      sc_list = (sc->flags & MUAVTA_SC_FULL_TASK_LIST) ? full : sc_kept;
+      std::fill(in_list.begin(), in_list.end(), 0);
+      for (int tid : sc_list) in_list[tid] = 1;
+      pri_of.assign(tasks.size(), 0.0);
+      if (sc->pri) for (size_t j = 0; j < sc_kept.size(); j++) pri_of[sc_kept[j]] = sc->pri[j];
+      score.assign((size_t)n_agents * tasks.size(), 0.0);
+      if (sc->scores) {
+        for (size_t i = 0; i < live.size() && (int)i < sc->max_agents; i++) {
+          const UAV& a = agents[live[i]];
+          for (size_t j = 0; j < sc_kept.size(); j++) {
+            const Task& t = tasks[sc_kept[j]];
+            if (sc->flags & MUAVTA_SC_EDGE_VALID_ONLY) {  // the token builder's edge_valid (PairCostHybrid.py:42-60; AttentionEscort.py:214-232 has no capability test)
+              if (envvis && !known[a.id][t.id]) continue;
+              if (t.has_eligible && !((t.eligible_mask >> a.type) & 1u)) continue;
+              if (sc->kind != 2 && a.caps[t.type] <= 0) continue;
+            }
+            score[(size_t)a.id * tasks.size() + t.id] = (double)sc->scores[i * sc->max_tasks + j];
+          }
+        }
+      }
+      for (int aid : live) reserved[aid] = (sc->reserved >> aid) & 1ull;
+      if (sc->flags & MUAVTA_SC_COMMIT) for (int aid : live) reserved[aid] |= agents[aid].commit_until > time_steps;  // committed_names (AttentionCommit.py:24-30)
+    } else if (mode == 1) {
       bool gate = time_steps == 0 || time_steps % 15 == 0;
       for (auto& ev : done_events) gate |= (ev.tag == MUAVTA_EV_RESET_ALLOCATION || ev.tag == MUAVTA_EV_NEW_THREAT || ev.tag == MUAVTA_EV_AGENT_FAIL);
       if (!gate) return finish();
@@ -1593,7 +1676,7 @@ struct Env {
       for (size_t k = 1; k < tasks.size(); k++) {
         const Task& t = tasks[k];
         bool under = t.status != 2 && t.allocatedReqs[t.type] < t.currentReqs[t.type];
-        in_list[k] = under;
+        in_list[k] = under && att_open.size() < 32;  // build_pair_tokens hands the allocator the 32 token rows only (PairCostHybrid.py:36,62)
         if (under) att_open.push_back((int)k);
       }
       score.assign((size_t)n_agents * tasks.size(), 0.0);
@@ -1669,6 +1752,9 @@ struct Env {
     }
     gate_step = time_steps;
     std::vector<int> open_tasks;  // the list handed to allocate_tasks, filtered by its own residual test (:113-119)
+    if (mode == 4) {
+      for (int k : sc_list) if (tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_tasks.push_back(k);
+    } else
     for (size_t k = 1; k < tasks.size(); k++)
       if (in_list[k] && tasks[k].status != 2 && residual_demand(tasks[k]) > 0) open_tasks.push_back((int)k);
     bool any_free = false;
@@ -1703,7 +1789,7 @@ struct Env {
           } else {
             double dist = norm2(a.pos.x - t.pos.x, a.pos.y - t.pos.y);
             double missing = std::fmax(residuals[t.id], 1e-6);
-            base_cost = dist / std::fmax(max_coord, 1.0) - 0.5 * std::fmin(delivered, missing) - 0.4 * 0.0 - 0.6 * urgency;
+            base_cost = dist / std::fmax(max_coord, 1.0) - 0.5 * std::fmin(delivered, missing) - 0.4 * (pri_of.empty() ? 0.0 : pri_of[t.id]) - 0.6 * urgency;
           }
           if (base_cost < 1e5 / 2)
             cost[(size_t)i * nc + j] = base_cost - (score.empty() ? 0.0 : (double)score[(size_t)a.id * tasks.size() + t.id]);
@@ -1734,7 +1820,15 @@ struct Env {
     last_plan_step = time_steps;
     n_replans++;
     last_pairs = actions;
-    if (mode == 2 && P.commit_horizon > 0) {  // apply_agent_commits (AttentionCommit.py:33-44): pre-step queue head decides
+    if (mode == 4 && sc->selected) {  // _selected_mask (PairCostHybrid.py:296-310): rows = live[:max_agents], columns = task_ids
+      for (auto& pr : actions) {
+        int i = -1, j = -1;
+        for (size_t q = 0; q < live.size() && (int)q < sc->max_agents; q++) if (live[q] == pr.first) i = (int)q;
+        for (size_t q = 0; q < sc_kept.size(); q++) if (sc_kept[q] == pr.second) j = (int)q;
+        if (i >= 0 && j >= 0) sc->selected[(size_t)i * sc->max_tasks + j] = 1.0f;
+      }
+    }
+    if ((mode == 2 || (mode == 4 && (sc->flags & MUAVTA_SC_COMMIT))) && P.commit_horizon > 0) {  // apply_agent_commits (AttentionCommit.py:33-44): pre-step queue head decides
       for (auto& pr : actions) {
         UAV& a = agents[pr.first];
         if (!a.tasks.empty() && a.tasks[0] != 0) a.commit_until = time_steps + P.commit_horizon;
@@ -1781,6 +1875,12 @@ int orc_tokens_expert(void* h, int kind, int max_tasks, int max_agents, float* t
 }
 int orc_allocate_mode(void* h, int interval, int use_vis, int mode, int32_t* act_agent, int32_t* act_index, int cap) {
   return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap, mode);
+}
+// HungarianAllocator.allocate_tasks with caller-supplied edge scores / priorities / reserved agents (mode 4 above)
+int orc_allocate_scored(void* h, int interval, int use_vis, int gate, int kind, int max_tasks, int max_agents, int flags, const float* scores,
+                        const double* pri, uint64_t reserved, int32_t* act_agent, int32_t* act_index, int cap, float* selected) {
+  Env::Scored sc{gate, kind, max_tasks, max_agents, flags, scores, pri, reserved, selected};
+  return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap, 4, &sc);
 }
 int orc_rollout_mode(void* h, uint64_t seed, int n_steps, int interval, int use_vis, int mode) {
   Env* e = (Env*)h;

@@ -73,6 +73,21 @@ class OracleEnv:
         n = self.L.orc_allocate_mode(self.h, int(interval), int(use_vis), int(mode), _p(aa), _p(ai), self.A)
         return aa[:n].copy(), ai[:n].copy()
 
+    def allocate_scored(self, interval, use_vis, gate, kind, max_tasks, max_agents, flags=0, scores=None, pri=None, reserved=0):
+        """HungarianAllocator.allocate_tasks with caller-supplied edge scores / priorities / reserved agents in token layout.
+        Returns (act_agent, act_index, selected [max_agents, max_tasks])."""
+        aa = np.full(self.A + 1, -1, dtype=np.int32)
+        ai = np.zeros(self.A + 1, dtype=np.int32)
+        sel = np.zeros((max_agents, max_tasks), np.float32)
+        sc = None if scores is None else np.ascontiguousarray(scores, dtype=np.float32)
+        pr = None if pri is None else np.ascontiguousarray(pri, dtype=np.float64)
+        assert sc is None or sc.shape == (max_agents, max_tasks)
+        assert pr is None or pr.shape == (max_tasks,)
+        n = self.L.orc_allocate_scored(self.h, int(interval), int(use_vis), int(gate), int(kind), int(max_tasks), int(max_agents), int(flags),
+                                       None if sc is None else _p(sc), None if pr is None else _p(pr), C.c_uint64(int(reserved)),
+                                       _p(aa), _p(ai), self.A, _p(sel))
+        return aa[:n].copy(), ai[:n].copy(), sel
+
     def rollout_mode(self, seed, n_steps, interval, use_vis, mode):
         return self.L.orc_rollout_mode(self.h, C.c_uint64(seed), int(n_steps), int(interval), int(use_vis), int(mode))
 

@@ -362,3 +362,135 @@ def test_il_loop_vs_reference(path):
         e.step(aa, ai)
         assert e.metrics()[4] == g["s_wps"][t + 1]  # RL step reward = (s_wps[t+1] - s_wps[t]) / 20
     assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"])
+
+
+# ---- caller-supplied planner inputs (a25 / f3 RL half): reference planners driven with seeded network outputs -------------
+GATE_FORCE, GATE_TRAINER, GATE_ESCORT, GATE_ALLOCATOR = 0, 1, 2, 3
+SC_EDGE_VALID_ONLY, SC_FULL_TASK_LIST, SC_COMMIT = 1, 2, 4
+
+
+def _check_lsap(e, g, t, where):
+    """every LSAP call of the oracle's last allocate equals the reference's calls at step t: shapes, every cost, rows, cols"""
+    shapes, costs, rows, cols = e.lsap_calls()
+    idx = np.nonzero(g["lsap_step"] == t)[0]
+    assert len(idx) == len(shapes), f"{where} t={t}: {len(shapes)} LSAP calls, reference {len(idx)}"
+    if not len(idx):
+        return
+    sizes = g["lsap_shape"][:, 0] * g["lsap_shape"][:, 1]
+    mins = g["lsap_shape"].min(axis=1)
+    c0, r0 = int(sizes[:idx[0]].sum()), int(mins[:idx[0]].sum())
+    assert np.array_equal(shapes, g["lsap_shape"][idx]), f"{where} t={t}: LSAP shapes"
+    n, m = int(sizes[idx].sum()), int(mins[idx].sum())
+    assert np.array_equal(costs, g["lsap_cost"][c0:c0 + n]), f"{where} t={t}: cost matrices"
+    assert np.array_equal(rows, g["lsap_row"][r0:r0 + m]) and np.array_equal(cols, g["lsap_col"][r0:r0 + m]), f"{where} t={t}: assignment"
+
+
+def _acts_at(g, t):
+    a = g["actions"][g["actions"][:, 0] == t][:, 1:]
+    return a[np.argsort(a[:, 0], kind="stable")]
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rl_*.npz"))))
+def test_rl_loop_scored_plans_vs_reference(path):
+    """run_rl_episode (experiments/train_pair_cost.py:132-156) with PairCostHybrid.plan(scores=seeded): scored cost matrices,
+    assignments, _selected_mask, actions, tokens / next tokens, step rewards, done, final metrics"""
+    g = np.load(path)
+    case = os.path.basename(path)[3:-4]
+    kind = 1 if int(g["raw"]) else 0
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(int(g["seed"]))
+    steps, k = g["step"].tolist(), 0
+    assert e.metrics()[4] == g["s_wps"][0]
+    pending = None
+    for t in range(len(g["replanned"])):
+        tok = e.tokens(kind, 32, 16)
+        if pending is not None:  # next_tok of the previous transition = tokens after its step
+            assert np.array_equal(tok["task_feats"], g["ntf"][pending]) and np.array_equal(tok["agent_feats"], g["naf"][pending])
+            assert np.array_equal(tok["task_ids"], g["ntid"][pending])
+            pending = None
+        planned = bool(g["replanned"][t])
+        sc = g["scores"][k] if planned else np.zeros((16, 32), np.float32)
+        aa, ai, sel = e.allocate_scored(20, 1, GATE_TRAINER, kind, 32, 16, SC_EDGE_VALID_ONLY, scores=sc)
+        assert (e.scalars_last_plan() == t) == planned, f"{case} t={t}: gate"
+        if planned:
+            assert t == steps[k]
+            assert np.array_equal(tok["task_feats"], g["tf"][k]) and np.array_equal(tok["agent_feats"], g["af"][k])
+            assert np.array_equal(tok["edge_valid"], g["ev"][k]) and np.array_equal(tok["task_ids"], g["tid"][k]) and np.array_equal(tok["agent_ids"], g["aid"][k])
+            _check_lsap(e, g, t, case)
+            assert np.array_equal(sel, g["selected"][k]), f"{case} t={t}: selected mask"
+            want = g["pairs"][g["pairs"][:, 0] == t][:, 1:]
+            assert sorted(map(tuple, e.last_actions().tolist())) == sorted(map(tuple, want.tolist())), f"{case} t={t}: pairs"
+            pending = k
+        else:
+            assert len(aa) == 0 and not sel.any()
+        want_a = _acts_at(g, t)
+        order = np.argsort(aa, kind="stable")
+        assert np.array_equal(np.stack([aa[order], ai[order]], axis=1).reshape(-1, 2), want_a.reshape(-1, 2)), f"{case} t={t}: actions"
+        done = e.step(aa, ai)
+        assert e.metrics()[4] == g["s_wps"][t + 1]
+        if planned:
+            assert (e.metrics()[4] - g["s_wps"][t]) / 20.0 == g["step_r"][k] and bool(done) == bool(g["ep_done"][k])
+            k += 1
+    assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"])
+    assert e.dims()["n_replans"] == int(g["n_replans"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rah_*.npz"))))
+def test_priorities_and_reserved_agents_vs_reference(path):
+    """AttentionRAH.plan (AttentionRAH.py:395-453) with seeded (rho, pri_vec): task_priorities + reserved_agent_names as the
+    planner passed them, over build_att_tokens' UNTRUNCATED open list, under wps_eval._should_replan(15)"""
+    g = np.load(path)
+    case = os.path.basename(path)[4:-4]
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(int(g["seed"]))
+    steps, k = g["step"].tolist(), 0
+    for t in range(len(g["replanned"])):
+        planned = bool(g["replanned"][t])
+        pri = g["pri"][k] if planned else np.zeros(32)
+        res = int(g["reserved"][k]) if planned else 0
+        if planned:
+            assert np.array_equal(e.tokens(0, 32, 16)["task_ids"], g["tid"][k])
+        aa, ai, _ = e.allocate_scored(15, 1, GATE_TRAINER, 0, 32, 16, SC_FULL_TASK_LIST, pri=pri, reserved=res)
+        assert (e.scalars_last_plan() == t) == planned
+        if planned:
+            assert t == steps[k]
+            _check_lsap(e, g, t, case)
+            want = g["pairs"][g["pairs"][:, 0] == t][:, 1:]
+            assert sorted(map(tuple, e.last_actions().tolist())) == sorted(map(tuple, want.tolist())), f"{case} t={t}: pairs"
+            k += 1
+        want_a = _acts_at(g, t)
+        order = np.argsort(aa, kind="stable")
+        assert np.array_equal(np.stack([aa[order], ai[order]], axis=1).reshape(-1, 2), want_a.reshape(-1, 2)), f"{case} t={t}: actions"
+        e.step(aa, ai)
+    assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "esc_*.npz"))))
+def test_escort_scored_plans_vs_reference(path):
+    """AttentionEscort.plan (AttentionEscort.py:472-522) with seeded scores: edges over build_escort_tokens' sorted task list,
+    reserved = committed_names, apply_agent_commits, under escort_eval._should_replan"""
+    g = np.load(path)
+    case = os.path.basename(path)[4:-4]
+    mt, ma, interval = int(g["max_tasks"]), int(g["max_agents"]), int(g["interval"])
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(int(g["seed"]))
+    steps, k = g["step"].tolist(), 0
+    for t in range(len(g["replanned"])):
+        planned = bool(g["replanned"][t])
+        sc = g["scores"][k] if planned else np.zeros((ma, mt), np.float32)
+        if planned:
+            tok = e.tokens(2, mt, ma)
+            assert np.array_equal(tok["task_ids"], g["tid"][k]) and np.array_equal(tok["agent_ids"], g["aid"][k])
+        aa, ai, sel = e.allocate_scored(interval, 1, GATE_ESCORT, 2, mt, ma, SC_COMMIT, scores=sc)
+        assert (e.scalars_last_plan() == t) == planned
+        if planned:
+            assert t == steps[k]
+            _check_lsap(e, g, t, case)
+            assert np.array_equal(sel, g["selected"][k]), f"{case} t={t}: selected mask"
+            assert np.array_equal(e.agent_commit_until(), g["commit"][k]), f"{case} t={t}: commit_until"
+            k += 1
+        want_a = _acts_at(g, t)
+        order = np.argsort(aa, kind="stable")
+        assert np.array_equal(np.stack([aa[order], ai[order]], axis=1).reshape(-1, 2), want_a.reshape(-1, 2)), f"{case} t={t}: actions"
+        e.step(aa, ai)
+    assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"])

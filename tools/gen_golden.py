@@ -762,3 +762,206 @@ def gen_lists():
 
 if __name__ == "__main__" and "--lists" in sys.argv:
     gen_lists()
+
+
+# ------------------------------------------------------------------------------------------------
+# Caller-supplied planner inputs (RL half): HungarianAllocator.allocate_tasks with edge_scores /
+# task_priorities / reserved_agent_names, driven through the reference's own planners with SEEDED network outputs:
+#   rl_<case>.npz    PairCostHybrid.plan(env, hung, events, force=True, scores=<seeded f32 [16, 32]>) inside the loop of
+#                    experiments/train_pair_cost.py:132-156 (run_rl_episode): per plan the scores, _selected_mask, result pairs,
+#                    every LSAP call; per step replanned / actions / S_WPS (step reward = diff / 20) / done; tokens and next tokens
+#   rah_<case>.npz   AttentionRAH.plan with `act` replaced by seeded (rho, pri_vec) under wps_eval._should_replan(15):
+#                    task_priorities + reserved_agent_names as the planner passed them (AttentionRAH.py:395-453)
+#   esc_<case>.npz   AttentionEscort.plan with `act` replaced by seeded scores under escort_eval._should_replan(interval):
+#                    edge_scores over build_escort_tokens' sorted list, reserved = committed_names, apply_agent_commits
+# ------------------------------------------------------------------------------------------------
+def _ids(tok, mt, ma):
+    tid = np.full(mt, -1, dtype=np.int64); tid[:len(tok["task_ids"])] = tok["task_ids"]
+    live = tok["live"][:ma]
+    aid = np.full(ma, -1, dtype=np.int64); aid[:len(live)] = [a.id for a in live]
+    return tid, aid
+
+
+def _pack_lsap(tap):
+    shapes = np.array([c[1].shape for c in tap.calls], dtype=np.int64).reshape(-1, 2)
+    return dict(lsap_step=np.array([c[0] for c in tap.calls], dtype=np.int64), lsap_shape=shapes,
+                lsap_cost=np.concatenate([c[1].ravel() for c in tap.calls]) if tap.calls else np.zeros(0),
+                lsap_row=np.concatenate([c[2] for c in tap.calls]) if tap.calls else np.zeros(0, dtype=np.int64),
+                lsap_col=np.concatenate([c[3] for c in tap.calls]) if tap.calls else np.zeros(0, dtype=np.int64))
+
+
+def gen_rl():
+    import experiments.train_pair_cost as T
+    from TaskAllocation.Hybrid.PairCostHybrid import PairCostHybrid
+
+    for case, seed, raw in (("WPS_hard", 0, False), ("WPS_hard_x2", 1, False), ("WPS_attn", 2, True), ("WPS_burst64", 0, False)):
+        env = make_env(case)
+        policy = PairCostHybrid(use_attention=False, max_tasks=32, max_agents=16, d_model=16, raw_features=raw, device="cpu")
+        tap = LsapTap()
+        HA.linear_sum_assignment = tap
+        try:
+            rng = np.random.default_rng(4200 + seed)
+            obs, info = env.reset(seed=seed)
+            hung = HA.HungarianAllocator(replan_interval=20, max_coord=env.max_coord)
+            done = {a: False for a in env.agents}
+            trunc = {a: False for a in env.agents}
+            rec = {k: [] for k in ("step", "scores", "selected", "tid", "aid", "tf", "af", "ev", "ntf", "naf", "ntid", "step_r", "ep_done")}
+            pairs, acts, replanned, s_wps = [], [], [], [float(env.compute_s_wps())]
+            s_prev = s_wps[0]
+            while not all(done.values()) and not all(trunc.values()):
+                events = _events(info)
+                actions = {}
+                tok = None
+                rp = T._should_replan(env, events)
+                replanned.append(int(rp))
+                tap.step = env.time_steps
+                if rp:
+                    # the net's output stand-in: tanh-range scores, NOT masked by edge_valid (edge_score_dict must do that)
+                    scores = (rng.uniform(-1.0, 1.0, (16, 32)) * 0.35).astype(np.float32)
+                    result, tok, scores, noise, logits, selected = policy.plan(env, hung, events=events, explore=False, force=True, scores=scores)
+                    actions = T._apply_assign(env, result)
+                    t_plan = env.time_steps
+                    for name, task in result:
+                        pairs.append((t_plan, env.agent_by_name[name].id, task.id))
+                    for name, idx in actions.items():
+                        acts.append((t_plan, env.agent_by_name[name].id, idx))
+                obs, reward, done, trunc, info = env.step(actions)
+                s_now = float(env.compute_s_wps())
+                step_r = (s_now - s_prev) / 20.0
+                s_prev = s_now
+                s_wps.append(s_now)
+                ep_done = all(done.values()) or all(trunc.values())
+                if tok is not None:
+                    next_tok = policy.build_tokens(env)
+                    tid, aid = _ids(tok, 32, 16)
+                    ntid, _ = _ids(next_tok, 32, 16)
+                    rec["step"].append(t_plan); rec["scores"].append(scores); rec["selected"].append(selected)
+                    rec["tid"].append(tid); rec["aid"].append(aid); rec["tf"].append(tok["task_feats"]); rec["af"].append(tok["agent_feats"])
+                    rec["ev"].append(tok["edge_valid"]); rec["ntf"].append(next_tok["task_feats"]); rec["naf"].append(next_tok["agent_feats"])
+                    rec["ntid"].append(ntid); rec["step_r"].append(step_r); rec["ep_done"].append(int(ep_done))
+        finally:
+            HA.linear_sum_assignment = linear_sum_assignment
+        out = {k: np.stack([np.asarray(x) for x in v]) for k, v in rec.items()}
+        out.update(_pack_lsap(tap))
+        out.update(pairs=np.array(pairs, dtype=np.int64).reshape(-1, 3), actions=np.array(acts, dtype=np.int64).reshape(-1, 3),
+                   replanned=np.array(replanned, dtype=np.int64), s_wps=np.array(s_wps), seed=np.int64(seed), raw=np.int64(raw),
+                   n_replans=np.int64(hung.n_replans),
+                   metrics=np.array([float(info["metrics"][k]) for k in METRIC_KEYS]))
+        np.savez_compressed(os.path.join(OUT, f"rl_{case}.npz"), **out)
+        print("rl", case, out["scores"].shape, "selected", int(out["selected"].sum()), "pairs", len(pairs), "S_WPS", out["metrics"][4],
+              "max token tasks", int((out["tid"] >= 0).sum(axis=1).max()))
+
+
+def gen_rah():
+    import experiments.wps_eval as W
+    from TaskAllocation.Hybrid.AttentionRAH import AttentionRAH
+
+    for case, seed in (("WPS_hard", 3), ("WPS_hard_x2", 4), ("WPS_attn_XL", 1)):
+        env = make_env(case)
+        policy = AttentionRAH(max_tasks=32, max_agents=16)
+        rng = np.random.default_rng(7700 + seed)
+        policy.act = lambda tok, explore=False: (float(rng.uniform(0.0, 0.3)), rng.uniform(0.0, 1.0, 32).astype(np.float32))
+        tap = LsapTap()
+        HA.linear_sum_assignment = tap
+        try:
+            obs, info = env.reset(seed=seed)
+            hung = HA.HungarianAllocator(replan_interval=20, max_coord=env.max_coord)
+            seen = {}
+            orig = hung.allocate_tasks
+
+            def spy(agents, tasks, **kw):
+                seen["tasks"] = [t.id for t in tasks]; seen["pri"] = dict(kw.get("task_priorities") or {}); seen["res"] = list(kw.get("reserved_agent_names") or [])
+                return orig(agents, tasks, **kw)
+
+            hung.allocate_tasks = spy
+            done = {a: False for a in env.agents}
+            trunc = {a: False for a in env.agents}
+            rec = {k: [] for k in ("step", "pri", "reserved", "tid", "n_list")}
+            pairs, acts, replanned = [], [], []
+            while not all(done.values()) and not all(trunc.values()):
+                events = _events(info)
+                actions = {}
+                rp = W._should_replan(env, events)
+                replanned.append(int(rp))
+                tap.step = env.time_steps
+                if rp:
+                    result, rho, task_pri, tok = policy.plan(env, hung, events=events, force=True)
+                    actions = W._apply_assign(env, result)
+                    tid, _ = _ids(tok, 32, 16)
+                    pri = np.zeros(32)
+                    for j, t in enumerate(tid):
+                        if t >= 0:
+                            pri[j] = seen["pri"][int(t)]
+                    assert set(seen["pri"]) == {int(t) for t in tid if t >= 0}
+                    mask = 0
+                    for name in seen["res"]:
+                        mask |= 1 << env.agent_by_name[name].id
+                    rec["step"].append(env.time_steps); rec["pri"].append(pri); rec["reserved"].append(np.uint64(mask)); rec["tid"].append(tid)
+                    rec["n_list"].append(len(seen["tasks"]))
+                    for name, task in result:
+                        pairs.append((env.time_steps, env.agent_by_name[name].id, task.id))
+                    for name, idx in actions.items():
+                        acts.append((env.time_steps, env.agent_by_name[name].id, idx))
+                obs, reward, done, trunc, info = env.step(actions)
+        finally:
+            HA.linear_sum_assignment = linear_sum_assignment
+        out = {k: np.stack([np.asarray(x) for x in v]) for k, v in rec.items()}
+        out.update(_pack_lsap(tap))
+        out.update(pairs=np.array(pairs, dtype=np.int64).reshape(-1, 3), actions=np.array(acts, dtype=np.int64).reshape(-1, 3),
+                   replanned=np.array(replanned, dtype=np.int64), seed=np.int64(seed),
+                   metrics=np.array([float(info["metrics"][k]) for k in METRIC_KEYS]))
+        np.savez_compressed(os.path.join(OUT, f"rah_{case}.npz"), **out)
+        print("rah", case, out["pri"].shape, "reserved plans", int((out["reserved"] != 0).sum()), "max list", int(out["n_list"].max()), "S_WPS", out["metrics"][4])
+
+
+def gen_esc():
+    import experiments.escort_eval as E
+    from TaskAllocation.Hybrid.AttentionEscort import AttentionEscort
+
+    for case, seed, interval, mt, ma in (("WPS_escort", 1, 12, 32, 16), ("WPS_escort24", 0, 12, 48, 24), ("WPS_hard", 2, 20, 32, 16)):
+        env = make_env(case)
+        policy = AttentionEscort(max_tasks=mt, max_agents=ma, use_attention=False, d_model=16, device="cpu")
+        rng = np.random.default_rng(9100 + seed)
+        policy.act = lambda tok, explore=False: (rng.uniform(0.0, 1.0, (ma, mt)).astype(np.float32), np.zeros((ma, mt), np.float32), np.zeros((ma, mt), np.float32))
+        tap = LsapTap()
+        HA.linear_sum_assignment = tap
+        try:
+            obs, info = env.reset(seed=seed)
+            hung = HA.HungarianAllocator(replan_interval=interval, max_coord=env.max_coord)
+            done = {a: False for a in env.agents}
+            trunc = {a: False for a in env.agents}
+            rec = {k: [] for k in ("step", "scores", "selected", "tid", "aid", "commit")}
+            pairs, acts, replanned = [], [], []
+            while not all(done.values()) and not all(trunc.values()):
+                events = _events(info)
+                actions = {}
+                rp = E._should_replan(env, events, interval)
+                replanned.append(int(rp))
+                tap.step = env.time_steps
+                if rp:
+                    result, tok, scores, noise, logits, selected = policy.plan(env, hung, events=events, explore=False, force=True)
+                    actions = E._apply_assign(env, result)
+                    tid, aid = _ids(tok, mt, ma)
+                    rec["step"].append(env.time_steps); rec["scores"].append(scores); rec["selected"].append(selected); rec["tid"].append(tid); rec["aid"].append(aid)
+                    rec["commit"].append(np.array([int(getattr(a, "commit_until", 0) or 0) for a in env.agents_obj], dtype=np.int64))
+                    for name, task in result:
+                        pairs.append((env.time_steps, env.agent_by_name[name].id, task.id))
+                    for name, idx in actions.items():
+                        acts.append((env.time_steps, env.agent_by_name[name].id, idx))
+                obs, reward, done, trunc, info = env.step(actions)
+        finally:
+            HA.linear_sum_assignment = linear_sum_assignment
+        out = {k: np.stack([np.asarray(x) for x in v]) for k, v in rec.items()}
+        out.update(_pack_lsap(tap))
+        out.update(pairs=np.array(pairs, dtype=np.int64).reshape(-1, 3), actions=np.array(acts, dtype=np.int64).reshape(-1, 3),
+                   replanned=np.array(replanned, dtype=np.int64), seed=np.int64(seed), interval=np.int64(interval),
+                   max_tasks=np.int64(mt), max_agents=np.int64(ma),
+                   metrics=np.array([float(info["metrics"][k]) for k in METRIC_KEYS]))
+        np.savez_compressed(os.path.join(OUT, f"esc_{case}.npz"), **out)
+        print("esc", case, out["scores"].shape, "selected", int(out["selected"].sum()), "pairs", len(pairs), "S_ESC", out["metrics"][5])
+
+
+if __name__ == "__main__" and "--rl" in sys.argv:
+    gen_rl()
+    gen_rah()
+    gen_esc()
