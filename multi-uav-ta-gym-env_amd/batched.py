@@ -106,6 +106,62 @@ class BatchedMultiUAVEnv:
         (the trainers' expert: allocate_tasks(force=True) under _should_replan(env, events, interval), train_pair_cost.py:33-43)."""
         self._ck(self.L.muavta_set_allocator(self.h, {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2, "hungarian_gated": 3}[name]))
 
+    GATES = {"force": 0, "trainer": 1, "escort": 2, "allocator": 3}
+    SC_EDGE_VALID_ONLY, SC_FULL_TASK_LIST, SC_COMMIT = 1, 2, 4
+
+    def allocate_scored(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16, *, edge_scores=None, task_pri=None,
+                        reserved=None, gate: str = "trainer", replan_interval: int = 20, use_visibility: bool = True,
+                        edge_valid_only: Optional[bool] = None, full_task_list: bool = False, commit: bool = False,
+                        want_selected: bool = True, fetch: bool = True, out=None):
+        """`HungarianAllocator.allocate_tasks(..., task_priorities=, reserved_agent_names=, edge_scores=)` with caller-computed
+        inputs in the token layout of `tokens(kind, max_tasks, max_agents)` — what PairCostHybrid.plan / AttentionRAH.plan /
+        AttentionEscort._plan_from_scores do with their network's output (include/muavta.h: muavta_allocate_scored).
+        numpy inputs go through the host entry point; CUDA torch tensors (all of them, plus `out` = {'selected': f32 [N, MA, MT],
+        'replanned': i32 [N]} tensors to fill) through the device one, on the handle's stream, without a copy or a sync.
+        Returns {'selected', 'replanned'[, 'act_agent', 'act_index']}; the plan is staged for `step_staged()`."""
+        k = self.TOKEN_KINDS[kind][0]
+        mt = int(max_tasks if max_tasks is not None else (48 if kind == "escort" else 32))
+        ma, N = int(max_agents), self.n_envs
+        if edge_valid_only is None:
+            edge_valid_only = kind != "escort"
+        flags = (self.SC_EDGE_VALID_ONLY if edge_valid_only else 0) | (self.SC_FULL_TASK_LIST if full_task_list else 0) | (self.SC_COMMIT if commit else 0)
+        spec = native.MuavtaScored(k, mt, ma, self.GATES[gate], flags, int(replan_interval), int(bool(use_visibility)), 0)
+        shapes = {"edge_scores": ((N, ma, mt), 4), "task_pri": ((N, mt), 8), "reserved": ((N,), 8), "selected": ((N, ma, mt), 4), "replanned": ((N,), 4)}
+        ins = {"edge_scores": edge_scores, "task_pri": task_pri, "reserved": reserved}
+        on_device = any(v is not None and hasattr(v, "data_ptr") for v in ins.values()) or out is not None
+        if on_device:
+            tens = dict(ins)
+            tens.update(out or {})
+            for name, t in tens.items():
+                if t is None:
+                    continue
+                shape, size = shapes[name]
+                if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != size:
+                    raise ValueError(f"allocate_scored: {name} must be a contiguous CUDA tensor of shape {shape} with {size}-byte elements")
+                setattr(spec, name, t.data_ptr())
+            self._ck(self.L.muavta_allocate_scored_device(self.h, C.byref(spec)))
+            return out
+        arrs = {}
+        for name, dt in (("edge_scores", np.float32), ("task_pri", np.float64), ("reserved", np.uint64)):
+            if ins[name] is not None:
+                a = np.ascontiguousarray(ins[name], dtype=dt)
+                if a.shape != shapes[name][0]:
+                    raise ValueError(f"allocate_scored: {name} must have shape {shapes[name][0]}")
+                arrs[name] = a
+                setattr(spec, name, a.ctypes.data)
+        res = {"replanned": np.empty(N, dtype=np.int32)}
+        spec.replanned = res["replanned"].ctypes.data
+        if want_selected:
+            res["selected"] = np.empty((N, ma, mt), dtype=np.float32)
+            spec.selected = res["selected"].ctypes.data
+        aa = ai = None
+        if fetch:
+            aa = np.empty((N, self.A_tile), dtype=np.int32)
+            ai = np.empty((N, self.A_tile), dtype=np.int32)
+            res["act_agent"], res["act_index"] = aa, ai
+        self._ck(self.L.muavta_allocate_scored(self.h, C.byref(spec), _vp(aa), _vp(ai)))
+        return res
+
     TOKEN_KINDS = {"pair": (0, 13, 12), "pair_raw": (1, 9, 11), "escort": (2, 22, 16)}
 
     def tokens(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16, out=None):

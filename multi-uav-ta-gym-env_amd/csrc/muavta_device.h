@@ -246,6 +246,16 @@ __device__ int g_prof_target = -1;  // >= 0: only this env's stamps are accumula
 #define PROF_COUNT(i, n) do { } while (0)
 #endif
 
+// muavta_allocate_scored: the caller's planner inputs in token layout (device pointers, kernel arguments), see include/muavta.h
+struct ScoredDev {
+  const float* scores;                  // [N, MA, MT] or null
+  const double* pri;                    // [N, MT] or null
+  const unsigned long long* reserved;   // [N] or null
+  float* selected;                      // [N, MA, MT] or null
+  int32_t* replanned;                   // [N] or null
+  int32_t kind, MT, MA, gate, flags;
+};
+
 template <class TL>
 struct Sim {
   typedef EnvState<TL> State;
@@ -3023,11 +3033,29 @@ struct Sim {
   //   float32 edge scores 0.5*urgency + 0.3*scarcity - 0.4*dist, clipped to +-0.35, for the first 16 live agents x
   //   first 32 underfilled tasks, subtracted from the Hungarian cost; replan gate = experiments/wps_eval.py:64-74.
   DEV int16_t* pair_info() { return T > 64 ? X.pair_info_big : X.remaining; }
-  DEV void allocate(int interval, int use_visibility, int mode = 0) {
+  // mode 4 (SC, muavta_allocate_scored): the caller's edge scores / task priorities / reserved agents, indexed in the token layout
+  //   (sc.kind, sc.MT, sc.MA) — PairCostHybrid.plan, AttentionRAH.plan, AttentionCommit / AttentionEscort._plan_from_scores
+  //   (HungarianAllocator.py:79-92,123-124,170-179).  sc_list: T bytes of LDS behind the scratch tile (the task list handed to
+  //   allocate_tasks, as positions in last_tasks_info, in the token builder's order).  Compiled into k_allocate_scored only.
+  template <bool SC = false>
+  DEV void allocate(int interval, int use_visibility, int mode = 0, const ScoredDev* scp = nullptr, int env = 0, uint8_t* sc_list = nullptr) {
     PROF(10);
     interval = interval < 1 ? 1 : interval;
     if (lane == 0) S.n_act = 0;
     bool go;
+    const bool envvis = !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is not None
+    int n_sc = 0;  // SC: length of sc_list
+    if constexpr (SC) {
+      const ScoredDev& sc = *scp;
+      bool trig = false;
+      for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;
+      if (sc.gate == MUAVTA_GATE_TRAINER) go = tnow == 0 || tnow % interval == 0 || __ballot(trig) != 0ull;   // train_pair_cost.py:33-43
+      else if (sc.gate == MUAVTA_GATE_ESCORT) go = tnow == 0 || tnow % interval == 0 || S.n_dev > 0;           // escort_eval.py:52-58
+      else if (sc.gate == MUAVTA_GATE_ALLOCATOR) go = (tnow - S.last_plan_step >= interval) || (S.n_dev > 0);  // should_replan (:27-41)
+      else go = true;
+      if ((go || sc.gate == MUAVTA_GATE_ALLOCATOR) && lane == 0) S.n_calls++;
+      if (sc.replanned && lane == 0) sc.replanned[env] = go ? 1 : 0;
+    } else
     if (mode == 1) {  // _should_replan(env, events, 15); plan(force=True) bypasses the allocator's own gate
       bool trig = false;
       for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;  // Reset_Allocation, New_Threat, Agent_Fail
@@ -3047,18 +3075,77 @@ struct Sim {
       go = (tnow - S.last_plan_step >= interval) || (S.n_dev > 0);
     }
     if (go && lane == 0) S.gate_step = tnow + 1;
-    const bool vis = use_visibility && !(P.sense_radius == 0 && P.threat_delay == 0);  // agent_visibility_map() is None
+    const bool vis = use_visibility && envvis;  // agent_visibility_map() is None
     int nr = 0, n_live = 1;
     if (go) {
       cold_sync();  // residual demand reads currentReqs / allocatedReqs
+      if constexpr (SC) {
+        const ScoredDev& sc = *scp;
+        if (sc.kind == 2) {  // build_escort_tokens' sorted local open list -> sc_list; columns = its first MT entries
+          const int n_live_raw = compact_to(X.freeA, P.n_agents, [&](int a) { return S.a_state[a] != -1; }, [&](int a) { return a; });
+          const int n_all = compact_to(X.roundT, S.n_order, [&](int k) { const int s = S.t_order[k]; return S.t_status[s] != 2 && residual_demand(s) > 0; },
+                                       [&](int k) { return S.t_order[k]; });
+          lds_sync();
+          const int n_list = escort_sorted_list(envvis, n_live_raw, n_all);
+          const int n_cols = n_list < sc.MT ? n_list : sc.MT;  // columns = the first MT entries = the list handed over
+          n_sc = n_cols;
+          for (int k = lane; k < S.n_open; k += WG) { const int s = S.open_slot[k]; pair_info()[s] = 255; X.resid[s] = 0.0; }  // (after the helper: pair_info may alias X.remaining)
+          lds_sync();
+          for (int j = lane; j < n_cols; j += WG) {
+            const int s = X.path[j];
+            pair_info()[s] = (int16_t)j; X.resid[s] = residual_demand(s); sc_list[j] = (uint8_t)S.t_row[s];
+          }
+          lds_sync();
+        }
+      }
       // live agents -> free list (get_live_agents order), residual demand per open task: one lane each
       // Urgency-Coalition holds committed agents out of the match (committed_names, AttentionCommit.py:24-30)
+      unsigned long long held = 0ull;  // SC: reserved_agent_names (HungarianAllocator.py:91-92)
+      if constexpr (SC) held = scp->reserved ? scp->reserved[env] : 0ull;
       nr = compact_to(X.freeA, P.n_agents,
-                      [&](int a) { return S.a_state[a] != -1 && !(mode == 2 && S.a_commit[a] > tnow); },
+                      [&](int a) { return S.a_state[a] != -1 && !(mode == 2 && S.a_commit[a] > tnow) &&
+                                          !(SC && (((held >> a) & 1ull) || ((scp->flags & MUAVTA_SC_COMMIT) && S.a_commit[a] > tnow))); },
                       [&](int a) { return a; });
       n_live = nr > 1 ? nr : 1;
       bool any_open = false;
       int n_under = 0;
+      if constexpr (SC) {
+        const ScoredDev& sc = *scp;
+        if (lane < P.n_agents) {  // token row of an agent: its rank among the live ones (tok["live"][:max_agents])
+          const bool lv = S.a_state[lane] != -1;
+          const unsigned long long lm = __ballot(lv);
+          const int rk = prefix_count(lm);
+          X.live_rank[lane] = (lv && rk < sc.MA) ? (uint8_t)rk : (uint8_t)255;
+        }
+        if (sc.kind != 2) {  // build_att_tokens' open_tasks (AttentionRAH.py:69-73): underfilled at the type index, env.tasks order
+          const bool full = (sc.flags & MUAVTA_SC_FULL_TASK_LIST) != 0;
+          for (int base = 0; base < S.n_open; base += WG) {
+            const int k = base + lane;
+            bool under = false, inl = false;
+            int s = 0, rank = 0;
+            if (k < S.n_open) {
+              s = S.open_slot[k];
+              const int ty = S.t_type[s];
+              under = C.t_alloc[ty][s] < C.t_cur[ty][s];
+            }
+            const unsigned long long um = __ballot(under);
+            if (k < S.n_open) {
+              rank = n_under + prefix_count(um);
+              inl = under && (full || rank < sc.MT);
+              pair_info()[s] = (int16_t)(!under ? 255 : rank < sc.MT ? rank : 254);  // token column; 254: in the list, no column
+              const double r = inl ? residual_demand(s) : 0.0;
+              X.resid[s] = r;
+              any_open |= r > 0;
+            }
+            const unsigned long long im = __ballot(inl);
+            if (inl) sc_list[n_sc + prefix_count(im)] = (uint8_t)k;
+            n_sc += __popcll(im);
+            n_under += __popcll(um);
+          }
+        } else {
+          any_open = n_sc > 0;  // every entry of the sorted list has residual demand
+        }
+      } else
       for (int base = 0; base < S.n_open; base += WG) {
         const int k = base + lane;
         bool under = false;
@@ -3068,12 +3155,15 @@ struct Sim {
           const int ty = S.t_type[s];
           // Urgency-Pair only plans over build_att_tokens' open_tasks: underfilled at the type index (AttentionRAH.py:69-73)
           under = mode != 1 || C.t_alloc[ty][s] < C.t_cur[ty][s];
-          const double r = under ? residual_demand(s) : 0.0;
+        }
+        const unsigned long long um = mode == 1 ? __ballot(under) : 0ull;
+        if (k < S.n_open) {
+          // (Urgency-Pair hands the allocator the 32 token rows only: tok["open_tasks"] = kept, PairCostHybrid.py:36,62)
+          const double r = (under && !(mode == 1 && n_under + prefix_count(um) >= 32)) ? residual_demand(s) : 0.0;
           X.resid[s] = r;
           any_open |= r > 0;
         }
         if (mode == 1) {
-          const unsigned long long um = __ballot(under);
           if (under) {
             const int rank = n_under + prefix_count(um);
             int n_know = 0;
@@ -3093,12 +3183,14 @@ struct Sim {
     }
     lds_sync();
     PROF(11);
-    if (!go) return;
+    if (!go) { if constexpr (SC) scored_selected(*scp, env, 0); return; }
     PROF_COUNT(52, 1000);
     int n_act = 0;
     while (true) {
       // round_tasks: open tasks (that had residual > 0 initially) with residual > 1e-9, in last_tasks_info order
-      const int nc = compact_to(X.roundT, S.n_open, [&](int k) { return X.resid[S.open_slot[k]] > 1e-9; }, [&](int k) { return k; });
+      int nc;
+      if constexpr (SC) nc = compact_to(X.roundT, n_sc, [&](int i) { return X.resid[S.open_slot[sc_list[i]]] > 1e-9; }, [&](int i) { return (int)sc_list[i]; });
+      else nc = compact_to(X.roundT, S.n_open, [&](int k) { return X.resid[S.open_slot[k]] > 1e-9; }, [&](int k) { return k; });
       lds_sync();
       if (nr == 0 || nc == 0) break;
       const bool tr = nc < nr;              // scipy transposes so that rows <= cols
@@ -3135,8 +3227,19 @@ struct Sim {
           if (delivered > 0) {  // _cost (:43-70), left-to-right, priority = 0
             double dist = norm2(S.a_px[a] - S.t_px[s], S.a_py[a] - S.t_py[s]);
             double missing = fmax(X.resid[s], 1e-6);
-            double base = div_coord(dist) - 0.5 * fmin(delivered, missing) - 0.4 * 0.0 - 0.6 * urgency;
+            double pri = 0.0;
+            if constexpr (SC) { const int col = pair_info()[s]; if (scp->pri && col < scp->MT) pri = scp->pri[(size_t)env * scp->MT + col]; }
+            double base = div_coord(dist) - 0.5 * fmin(delivered, missing) - 0.4 * pri - 0.6 * urgency;
             double score = 0.0;
+            if constexpr (SC) {  // edge_score_dict (PairCostHybrid.py:283-294 / AttentionEscort.py:472-482)
+              const int col = pair_info()[s], row = X.live_rank[a];
+              bool edge = col < scp->MT && row < scp->MA && scp->scores != nullptr;
+              if (edge && (scp->flags & MUAVTA_SC_EDGE_VALID_ONLY)) {
+                if (envvis && !((S.known[a][s >> 5] >> (s & 31)) & 1u)) edge = false;
+                if (scp->kind != 2 && !(S.a_caps[S.t_type[s]][a] > 0)) edge = false;  // (eligibility already holds here)
+              }
+              if (edge) score = (double)scp->scores[((size_t)env * scp->MA + row) * scp->MT + col];
+            }
             if (mode == 1) {  // urgency_edge_scores (PairCostHybrid.py:68-86) on the edges build_pair_tokens keeps (:42-60)
               const int info = pair_info()[s];
               if ((info & 255) < 32 && X.live_rank[a] < 16 && S.a_caps[S.t_type[s]][a] > 0) {
@@ -3165,7 +3268,7 @@ struct Sim {
       static_assert(KW <= 4, "an agent's known mask is cached in four words");
       // pair_cost() split in two for the solvers that keep one column per lane: the column's side (task or agent fields) is
       // read from LDS ONCE per lane, the row's side is the same for every lane (broadcast reads, issued together).  Same arithmetic.
-      struct TS { double px, py, urgency, missing, press; int type, info; bool elig_on, esc_task, esc_flag; uint32_t elig; };
+      struct TS { double px, py, urgency, missing, press, pri; int type, info; bool elig_on, esc_task, esc_flag; uint32_t elig; };
       // (the known mask as two 64-bit halves: a four-way select of 32-bit words by a per-lane index is turned into an indexed load
       // from a stack copy of the struct by the optimiser — scratch stores and a dependent scratch load per cost element on the
       // 64-agent tile; a two-way select and a 64-bit shift stay in registers)
@@ -3183,8 +3286,10 @@ struct Sim {
           t.urgency = 1.0 - fmin(div40((double)remaining), 1.0);
         }
         t.missing = fmax(X.resid[sl], 1e-6);
-        t.info = mode == 1 ? pair_info()[sl] : 0;
+        t.info = (SC || mode == 1) ? pair_info()[sl] : 0;
         t.press = mode == 2 ? (TL::OTFC ? X.press : X.spc)[jr] : 0.0;
+        t.pri = 0.0;
+        if constexpr (SC) { if (scp->pri && t.info < scp->MT) t.pri = scp->pri[(size_t)env * scp->MT + t.info]; }
         return t;
       };
       auto load_as = [&](int a) {
@@ -3192,7 +3297,7 @@ struct Sim {
         g.px = S.a_px[a]; g.py = S.a_py[a]; g.type = S.a_type[a];
         g.k0 = S.known[a][0]; g.k1 = KW > 1 ? S.known[a][KW > 1 ? 1 : 0] : 0u;
         g.k23 = (KW > 2 ? (unsigned long long)S.known[a][KW > 2 ? 2 : 0] : 0ull) | ((KW > 3 ? (unsigned long long)S.known[a][KW > 3 ? 3 : 0] : 0ull) << 32);
-        g.rank = mode == 1 ? (int)X.live_rank[a] : 0;
+        g.rank = (SC || mode == 1) ? (int)X.live_rank[a] : 0;
         return g;
       };
       // == pair_cost(a, sl, jr); capv = S.a_caps[t.type][a].  STRAIGHT-LINE per lane: every lane evaluates the whole expression and the
@@ -3210,8 +3315,17 @@ struct Sim {
         ok = ok & (delivered > 0);
         const double dist = norm2(g.px - t.px, g.py - t.py);
         const double dc = div_coord(dist);
-        const double base = dc - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
+        double base;
+        if constexpr (SC) base = dc - 0.5 * fmin(delivered, t.missing) - 0.4 * t.pri - 0.6 * t.urgency;
+        else base = dc - 0.5 * fmin(delivered, t.missing) - 0.4 * 0.0 - 0.6 * t.urgency;
         double score = 0.0;
+        if constexpr (SC) {  // edge_score_dict: the caller's f32 score of (token row, token column), float()ed
+          bool edge = (t.info < scp->MT) & (g.rank < scp->MA) & (scp->scores != nullptr);
+          if (scp->flags & MUAVTA_SC_EDGE_VALID_ONLY) edge = edge & (!envvis | known) & !(t.elig_on & !((t.elig >> g.type) & 1u)) & ((scp->kind == 2) | (capv > 0));
+          float sv = 0.f;
+          if (edge) sv = scp->scores[((size_t)env * scp->MA + g.rank) * scp->MT + t.info];
+          score = (double)sv;
+        }
         if (mode == 1) {  // (uniform)
           double scar = 0.0;
           if (vis) scar = 1.0 - fmin((double)(t.info >> 8) / (double)n_live, 1.0);
@@ -3284,7 +3398,8 @@ struct Sim {
               const int sl = __builtin_amdgcn_readlane(rsl, i), pk = __builtin_amdgcn_readlane(rpk, i);
               t.px = readlane_f64(tr_.px, i); t.py = readlane_f64(tr_.py, i); t.urgency = readlane_f64(tr_.urgency, i);
               t.missing = readlane_f64(tr_.missing, i); t.press = mode == 2 ? readlane_f64(tr_.press, i) : 0.0;
-              t.info = mode == 1 ? __builtin_amdgcn_readlane(tr_.info, i) : 0;
+              t.info = (SC || mode == 1) ? __builtin_amdgcn_readlane(tr_.info, i) : 0;
+              t.pri = SC ? readlane_f64(tr_.pri, i) : 0.0;
               t.type = pk & 7; t.elig_on = (pk & 8) != 0; t.esc_task = (pk & 16) != 0; t.esc_flag = (pk & 32) != 0; t.elig = (uint32_t)pk >> 8;
               double c = 0.0;
               c = pair_eval_cap(g, sl, t, mycaps[t.type]); feasible |= incol & (c < 1e5 / 2);
@@ -3352,7 +3467,7 @@ struct Sim {
       lds_sync();
       PROF(14);
     }
-    if (mode == 2 && P.commit_horizon > 0 && lane < n_act) {  // apply_agent_commits (AttentionCommit.py:33-44)
+    if ((mode == 2 || (SC && (scp->flags & MUAVTA_SC_COMMIT))) && P.commit_horizon > 0 && lane < n_act) {  // apply_agent_commits (AttentionCommit.py:33-44)
       const int a = S.act_agent[lane];
       if (S.a_qlen[a] > 0) S.a_commit[a] = tnow + P.commit_horizon;  // only agents that hold a real task now
     }
@@ -3362,6 +3477,18 @@ struct Sim {
       S.n_replans++;
     }
     lds_sync();
+    if constexpr (SC) scored_selected(*scp, env, n_act);
+  }
+  // _selected_mask(tok, result) (PairCostHybrid.py:296-310): 1 where the plan pairs token row i with token column j
+  DEV void scored_selected(const ScoredDev& sc, int env, int n_act) {
+    if (!sc.selected) return;
+    float* o = sc.selected + (size_t)env * sc.MA * sc.MT;
+    for (int idx = lane; idx < sc.MA * sc.MT; idx += WG) {
+      const int i = idx / sc.MT, j = idx - i * sc.MT;
+      bool hit = false;
+      for (int k = 0; k < n_act; k++) hit |= (int)X.live_rank[S.act_agent[k]] == i && (int)pair_info()[S.act_slot[k]] == j;
+      o[idx] = hit ? 1.f : 0.f;
+    }
   }
 
   // ====================================================================================================
@@ -3399,6 +3526,44 @@ struct Sim {
     pressure = 1.0 - fmin(div_coord(best), 1.0);
     dist_n = fmin(div_coord(best), 1.0);
     fighter_pressure = fmin((double)n_near / 4.0, 1.0);
+  }
+  // build_escort_tokens' task list (AttentionEscort.py:83-96): of the n_all slots in X.roundT (_open_tasks_residual, env.tasks order)
+  // those known by at least one live agent (X.freeA[0..n_live_raw); all of them if that leaves nothing or visibility is off),
+  // stably sorted by _task_priority_key (:69-74).  Result in X.path, returns its length.  Scratch: X.remaining, X.spc.
+  DEV int escort_sorted_list(bool vis, int n_live_raw, int n_all) {
+    int n_list = n_all;
+    if (vis) {  // local task set: known by at least one live agent; all of open_all if that leaves nothing
+      const int n_loc = compact_to(X.remaining, n_all,
+                                   [&](int k) {
+                                     const int s = X.roundT[k];
+                                     bool any = false;
+                                     for (int i = 0; i < n_live_raw; i++) any |= (S.known[X.freeA[i]][s >> 5] >> (s & 31)) & 1u;
+                                     return any;
+                                   },
+                                   [&](int k) { return X.roundT[k]; });
+      lds_sync();
+      if (n_loc > 0) n_list = n_loc;
+      else for (int k = lane; k < n_all; k += WG) X.remaining[k] = X.roundT[k];
+    } else {
+      for (int k = lane; k < n_all; k += WG) X.remaining[k] = X.roundT[k];
+    }
+    lds_sync();
+    // stable sort by _task_priority_key (:69-74): rank = number of entries that sort before this one
+    for (int k = lane; k < n_list; k += WG) {
+      const int s = X.remaining[k];
+      double pr, dn, fp;
+      threat_stats(s, pr, dn, fp);
+      X.spc[k] = -(1.5 * slot_urgency(s) + 1.2 * pr + 0.8 * ((S.t_flags[s] & TF_ESCORT) ? 1.0 : 0.0) + 0.5 * (S.t_type[s] == MUAVTA_INT ? 1.0 : 0.0));
+    }
+    lds_sync();
+    for (int k = lane; k < n_list; k += WG) {
+      const double key = X.spc[k];
+      int rank = 0;
+      for (int j = 0; j < n_list; j++) rank += (X.spc[j] < key) || (X.spc[j] == key && j < k);
+      X.path[rank] = X.remaining[k];
+    }
+    lds_sync();
+    return n_list;
   }
   DEV void tokens(const TokPtrs& K, int env) {
     const int kind = K.kind, MT = K.max_tasks, MA = K.max_agents;
@@ -3438,37 +3603,7 @@ struct Sim {
     int16_t* list = X.roundT;  // the token rows' task list
     int n_list = n_all;
     if (kind == 2) {
-      if (vis) {  // local task set: known by at least one live agent; all of open_all if that leaves nothing
-        const int n_loc = compact_to(X.remaining, n_all,
-                                     [&](int k) {
-                                       const int s = X.roundT[k];
-                                       bool any = false;
-                                       for (int i = 0; i < n_live_raw; i++) any |= (S.known[X.freeA[i]][s >> 5] >> (s & 31)) & 1u;
-                                       return any;
-                                     },
-                                     [&](int k) { return X.roundT[k]; });
-        lds_sync();
-        if (n_loc > 0) n_list = n_loc;
-        else for (int k = lane; k < n_all; k += WG) X.remaining[k] = X.roundT[k];
-      } else {
-        for (int k = lane; k < n_all; k += WG) X.remaining[k] = X.roundT[k];
-      }
-      lds_sync();
-      // stable sort by _task_priority_key (:69-74): rank = number of entries that sort before this one
-      for (int k = lane; k < n_list; k += WG) {
-        const int s = X.remaining[k];
-        double pr, dn, fp;
-        threat_stats(s, pr, dn, fp);
-        X.spc[k] = -(1.5 * slot_urgency(s) + 1.2 * pr + 0.8 * ((S.t_flags[s] & TF_ESCORT) ? 1.0 : 0.0) + 0.5 * (S.t_type[s] == MUAVTA_INT ? 1.0 : 0.0));
-      }
-      lds_sync();
-      for (int k = lane; k < n_list; k += WG) {
-        const double key = X.spc[k];
-        int rank = 0;
-        for (int j = 0; j < n_list; j++) rank += (X.spc[j] < key) || (X.spc[j] == key && j < k);
-        X.path[rank] = X.remaining[k];
-      }
-      lds_sync();
+      n_list = escort_sorted_list(vis, n_live_raw, n_all);
       list = X.path;
     }
     const int n_kept = n_list < MT ? n_list : MT;

@@ -309,6 +309,34 @@ __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp
   copy16(blob, L.S, sizeof(EnvState<TL>));
 }
 
+// muavta_allocate_scored: k_allocate with the caller's edge scores / priorities / reserved agents (Sim::allocate<true>).  The
+// task list handed to the allocator sits in T bytes of LDS behind the tile.
+enum { SCORED_EXTRA_LDS = 128 };
+template <class TL>
+__global__ __launch_bounds__(WG) void k_allocate_scored(const DevCtx* __restrict__ ctxp, ScoredDev sc, int interval, int use_vis,
+                                                        int32_t* out_agent, int32_t* out_index, int act_cap, int env_base) {
+  static_assert(TL::T <= SCORED_EXTRA_LDS, "the scored allocator's task list is one byte per slot");
+  const DevCtx& ctx = ctx_ref(ctxp);
+  const int env = env_base + blockIdx.x;
+  Lds<TL> L(smem);
+  EnvState<TL>* blob = blob_of<TL>(ctx, env);
+  copy16(L.S, blob, sizeof(EnvState<TL>));
+  lds_sync();
+  sc.scores = as_global(sc.scores); sc.pri = as_global(sc.pri); sc.reserved = as_global(sc.reserved);
+  sc.selected = as_global(sc.selected); sc.replanned = as_global(sc.replanned);
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
+  sim.template allocate<true>(interval, use_vis, 4, &sc, env, smem + Lds<TL>::bytes());
+  lds_sync();
+  if (out_agent) {
+    const EnvState<TL>& S = *L.S;
+    for (int k = threadIdx.x; k < act_cap; k += WG) {
+      out_agent[(size_t)env * act_cap + k] = k < S.n_act ? S.act_agent[k] : -1;
+      out_index[(size_t)env * act_cap + k] = k < S.n_act ? S.act_index[k] : 0;
+    }
+  }
+  copy16(blob, L.S, sizeof(EnvState<TL>));
+}
+
 // The body of the fused rollout, OUT OF LINE on purpose.  Inlined into the 150-step loop of k_rollout the compiler hoists
 // loop invariants across the whole body and the kernel needs 255 VGPRs (+188 B/lane of scratch: two waves per SIMD); as a
 // function of its own the body fits the 128 VGPRs of FOUR waves per SIMD — with 10 KiB of LDS per env that is 16 resident
@@ -785,6 +813,7 @@ int launch_attr(MuavtaEnv* e) {
                         reinterpret_cast<const void*>(&k_rollout<TL, false>), reinterpret_cast<const void*>(&k_rollout<TL, true>), reinterpret_cast<const void*>(&k_metrics<TL>), reinterpret_cast<const void*>(&k_observe<TL>),
                         reinterpret_cast<const void*>(&k_tokens<TL>), reinterpret_cast<const void*>(&k_call<TL>)};
     for (const void* k : ks) HIPCHK(e, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_allocate_scored<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + SCORED_EXTRA_LDS));
   }
   return MUAVTA_OK;
 }
@@ -1417,6 +1446,67 @@ int muavta_allocate(MuavtaEnv* e, int32_t interval, int32_t use_vis, int32_t* ac
 }
 
 static int token_dims(int kind, int* dt, int* da);
+
+// ---- HungarianAllocator.allocate_tasks with the caller's edge scores / priorities / reserved agents ------------------------------
+static int scored_check(MuavtaEnv* e, const MuavtaScored* sp) {
+  int dt, da;
+  if (!e) return MUAVTA_E_ARG;
+  if (!sp || token_dims(sp->kind, &dt, &da) || sp->max_tasks < 1 || sp->max_tasks > 128 || sp->max_agents < 1 || sp->max_agents > 64 ||
+      sp->gate < MUAVTA_GATE_FORCE || sp->gate > MUAVTA_GATE_ALLOCATOR || (sp->flags & ~7) ||
+      (sp->kind == MUAVTA_TOK_ESCORT && (sp->flags & MUAVTA_SC_FULL_TASK_LIST))) {
+    e->err = "muavta_allocate_scored: bad spec (kind 0..2, max_tasks 1..128, max_agents 1..64, gate 0..3, flags 0..7; build_escort_tokens has no untruncated list)";
+    return MUAVTA_E_ARG;
+  }
+  if (!e->did_reset) { e->err = "allocate before reset"; return MUAVTA_E_STATE; }
+  return MUAVTA_OK;
+}
+int muavta_allocate_scored_device(MuavtaEnv* e, const MuavtaScored* sp) {
+  if (int rc = scored_check(e, sp)) return rc;
+  DeviceScope scope_(e->device);
+  MAIN_OP(e);
+  ScoredDev sc{sp->edge_scores, sp->task_pri, (const unsigned long long*)sp->reserved, sp->selected, sp->replanned, sp->kind, sp->max_tasks,
+               sp->max_agents, sp->gate, sp->flags};
+  DISPATCH(e, hipLaunchKernelGGL(k_allocate_scored<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes() + SCORED_EXTRA_LDS, e->stream, (const DevCtx*)e->d_ctx, sc,
+                                 sp->replan_interval, sp->use_visibility, e->d_act_agent, e->d_act_index, e->A, 0));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
+  return MUAVTA_OK;
+}
+int muavta_allocate_scored(MuavtaEnv* e, const MuavtaScored* sp, int32_t* act_agent, int32_t* act_index) {
+  if (int rc = scored_check(e, sp)) return rc;
+  DeviceScope scope_(e->device);
+  const size_t N = (size_t)e->n_envs, MT = (size_t)sp->max_tasks, MA = (size_t)sp->max_agents;
+  const size_t sz[5] = {N * MA * MT * 4, N * MT * 8, N * 8, N * MA * MT * 4, N * 4};  // scores, pri, reserved | selected, replanned
+  size_t off[6] = {0};
+  for (int i = 0; i < 5; i++) off[i + 1] = off[i] + ((sz[i] + 255) & ~(size_t)255);
+  if (off[5] > e->tok_bytes) {  // (shares the staging buffer of muavta_tokens' host variant)
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->d_tok) hipFree(e->d_tok);
+    e->d_tok = nullptr; e->tok_bytes = 0;
+    HIPCHK(e, hipMalloc(&e->d_tok, off[5]));
+    e->tok_bytes = off[5];
+  }
+  char* b = (char*)e->d_tok;
+  const void* in[3] = {sp->edge_scores, sp->task_pri, sp->reserved};
+  for (int i = 0; i < 3; i++)
+    if (in[i]) HIPCHK(e, hipMemcpyAsync(b + off[i], in[i], sz[i], hipMemcpyHostToDevice, e->stream));
+  MuavtaScored d = *sp;
+  d.edge_scores = sp->edge_scores ? (const float*)(b + off[0]) : nullptr;
+  d.task_pri = sp->task_pri ? (const double*)(b + off[1]) : nullptr;
+  d.reserved = sp->reserved ? (const uint64_t*)(b + off[2]) : nullptr;
+  d.selected = sp->selected ? (float*)(b + off[3]) : nullptr;
+  d.replanned = sp->replanned ? (int32_t*)(b + off[4]) : nullptr;
+  if (int rc = muavta_allocate_scored_device(e, &d)) return rc;
+  if (sp->selected) HIPCHK(e, hipMemcpyAsync(sp->selected, b + off[3], sz[3], hipMemcpyDeviceToHost, e->stream));
+  if (sp->replanned) HIPCHK(e, hipMemcpyAsync(sp->replanned, b + off[4], sz[4], hipMemcpyDeviceToHost, e->stream));
+  if (act_agent && act_index) {
+    size_t bytes = N * e->A * sizeof(int32_t);
+    HIPCHK(e, hipMemcpyAsync(act_agent, e->d_act_agent, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(act_index, e->d_act_index, bytes, hipMemcpyDeviceToHost, e->stream));
+  }
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
 }  // extern "C" (the launcher below is a template)
 template <class TL>
 static void launch_rollout(MuavtaEnv* e, const uint64_t* ds, int n_steps, int interval, int use_vis, int write_obs, const uint32_t* sb, size_t extra_lds,

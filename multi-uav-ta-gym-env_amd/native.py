@@ -33,11 +33,20 @@ EXPORTS = [
     "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
     "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_step_lists",
+    "muavta_allocate_scored", "muavta_allocate_scored_device",
 ]
 
 
 class MuavtaError(RuntimeError):
     pass
+
+
+class MuavtaScored(C.Structure):
+    """include/muavta.h: MuavtaScored (muavta_allocate_scored)."""
+    _fields_ = [("kind", C.c_int32), ("max_tasks", C.c_int32), ("max_agents", C.c_int32), ("gate", C.c_int32), ("flags", C.c_int32),
+                ("replan_interval", C.c_int32), ("use_visibility", C.c_int32), ("reserved0", C.c_int32),
+                ("edge_scores", C.c_void_p), ("task_pri", C.c_void_p), ("reserved", C.c_void_p), ("selected", C.c_void_p),
+                ("replanned", C.c_void_p)]
 
 
 def sources():
@@ -133,6 +142,8 @@ def lib() -> C.CDLL:
     L.muavta_set_release_log.argtypes = [vp, i32]
     L.muavta_tokens.argtypes = [vp, i32, i32, i32] + [vp] * 10
     L.muavta_tokens_device.argtypes = [vp, i32, i32, i32] + [vp] * 10
+    L.muavta_allocate_scored.argtypes = [vp, C.POINTER(MuavtaScored), vp, vp]
+    L.muavta_allocate_scored_device.argtypes = [vp, C.POINTER(MuavtaScored)]
     L.muavta_abi_sizes.argtypes = [C.POINTER(i32 * 3)]
     for name in EXPORTS:
         if name != "muavta_last_error":

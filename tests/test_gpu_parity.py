@@ -1379,3 +1379,146 @@ print(json.dumps({"backend": type(env._b).__module__ + "." + type(env._b).__name
     assert out.returncode == 0, out.stderr[-2000:]
     got = json.loads(out.stdout.strip().splitlines()[-1])
     assert got["backend"].endswith("batched.BatchedMultiUAVEnv") and got["libmuavta"] and not got["oracle"] and not got["oracle_modules"] and got["t"] == 5, got
+
+
+# ---- caller-supplied planner inputs: muavta_allocate_scored (a25 inputs, f3 RL half) -----------------------------------------------
+SCORED_FILES = sorted(glob.glob(os.path.join(GOLDEN, "rl_*.npz")) + glob.glob(os.path.join(GOLDEN, "rah_*.npz")) + glob.glob(os.path.join(GOLDEN, "esc_*.npz")))
+GATE = {"force": 0, "trainer": 1, "escort": 2, "allocator": 3}
+
+
+def _scored_setup(path):
+    """(case, kind name, kind id, MT, MA, interval, gate, kwargs of allocate_scored, oracle flags) of a reference-driven trace"""
+    g = np.load(path)
+    base = os.path.basename(path)
+    if base.startswith("rl_"):
+        raw = bool(int(g["raw"]))
+        return g, base[3:-4], "pair_raw" if raw else "pair", 1 if raw else 0, 32, 16, 20, "trainer", dict(edge_valid_only=True), 1
+    if base.startswith("rah_"):
+        return g, base[4:-4], "pair", 0, 32, 16, 15, "trainer", dict(full_task_list=True), 2
+    return g, base[4:-4], "escort", 2, int(g["max_tasks"]), int(g["max_agents"]), int(g["interval"]), "escort", dict(edge_valid_only=False, commit=True), 4
+
+
+@pytest.mark.parametrize("path", SCORED_FILES, ids=[os.path.basename(p)[:-4] for p in SCORED_FILES])
+def test_scored_allocator_reference_traces_and_oracle(path):
+    """env 0 replays the reference's own episode (PairCostHybrid / AttentionRAH / AttentionEscort planner with seeded network
+    outputs: tools/gen_golden.py --rl) — actions, _selected_mask, gate, S_WPS per step, final metrics; the other envs run
+    other seeds with random scores / priorities / reserved sets against the oracle, every field of the state after every step."""
+    g, case, kname, kind, mt, ma, interval, gate, kw, oflags = _scored_setup(path)
+    n, seed0 = 4, int(g["seed"])
+    # (a random-score policy churns escorts harder than any allocator of the registry: the reference episode of the 24-UAV escort
+    # case holds more than the 24-agent tile's 88 pending reveals at t = 60, so it runs on the 64-agent tile)
+    env = _env(case, n, **(dict(tile_agents=64, tile_tasks=128, tile_threats=48) if os.path.basename(path) == "esc_WPS_escort24.npz" else {}))
+    A = env.n_agents
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    env.reset(np.arange(seed0, seed0 + n, dtype=np.uint64))
+    for i, o in enumerate(oracles):
+        o.reset(seed0 + i)
+    rng = np.random.default_rng(5)
+    steps, k = g["step"].tolist(), 0
+    has_sc, has_pri = "scores" in g.files, "pri" in g.files
+    for t in range(len(g["replanned"])):
+        planned = bool(g["replanned"][t])
+        sc = (rng.uniform(-1, 1, (n, ma, mt)) * (0.35 if kind != 2 else 1.0)).astype(np.float32) if has_sc else None
+        pri = rng.uniform(0, 1, (n, mt)) if has_pri else None
+        res = (rng.integers(0, 1 << A, n, dtype=np.uint64) & rng.integers(0, 1 << A, n, dtype=np.uint64)) if has_pri else None
+        if planned:
+            if has_sc:
+                sc[0] = g["scores"][k]
+            if has_pri:
+                pri[0] = g["pri"][k]; res[0] = g["reserved"][k]
+        elif has_pri:
+            res[0] = 0
+        out = env.allocate_scored(kname, mt, ma, edge_scores=sc, task_pri=pri, reserved=res, gate=gate, replan_interval=interval, **kw)
+        aa, ai = out["act_agent"], out["act_index"]
+        assert bool(out["replanned"][0]) == planned, f"{case} t={t}: gate"
+        if planned:
+            assert t == steps[k]
+            if "selected" in g.files:
+                assert np.array_equal(out["selected"][0], g["selected"][k]), f"{case} t={t}: selected mask vs reference"
+            k += 1
+        want = g["actions"][g["actions"][:, 0] == t][:, 1:]
+        want = want[np.argsort(want[:, 0], kind="stable")]
+        n0 = int((aa[0] >= 0).sum())
+        order = np.argsort(aa[0][:n0], kind="stable")
+        assert np.array_equal(np.stack([aa[0][:n0][order], ai[0][:n0][order]], axis=1).reshape(-1, 2), want.reshape(-1, 2)), f"{case} t={t}: actions vs reference"
+        for i, o in enumerate(oracles):
+            oa, oi, osel = o.allocate_scored(interval, 1, GATE[gate], kind, mt, ma, oflags, scores=None if sc is None else sc[i],
+                                            pri=None if pri is None else pri[i], reserved=0 if res is None else int(res[i]))
+            kk = len(oa)
+            assert np.array_equal(aa[i][:kk], oa) and np.all(aa[i][kk:] == -1) and np.array_equal(ai[i][:kk], oi), f"{case} seed {seed0 + i} t={t}: {aa[i]} vs {oa}"
+            assert np.array_equal(out["selected"][i], osel), f"{case} seed {seed0 + i} t={t}: selected mask"
+            assert bool(out["replanned"][i]) == (o.scalars_last_plan() == t)
+            o.step(oa, oi)
+        env.step_staged()
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"scored {case} seed {seed0 + i} t={t + 1}")
+        if "s_wps" in g.files:
+            assert env.metrics()[0][4] == g["s_wps"][t + 1]
+    assert k == len(steps) and np.array_equal(env.metrics()[0], g["metrics"])
+
+
+def test_scored_allocator_device_tensors_equal_the_host_path():
+    import torch
+
+    case, n, mt, ma = "WPS_hard_x2", 64, 32, 16
+    a, b = _env(case, n), _env(case, n)
+    seeds = np.arange(n, dtype=np.uint64)
+    a.reset(seeds); b.reset(seeds)
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    sel = torch.empty((n, ma, mt), dtype=torch.float32, device=dev)
+    rep = torch.empty((n,), dtype=torch.int32, device=dev)
+    for t in range(60):
+        sc = (rng.uniform(-1, 1, (n, ma, mt)) * 0.35).astype(np.float32)
+        pri = rng.uniform(0, 1, (n, mt))
+        res = rng.integers(0, 1 << 16, n, dtype=np.uint64) & rng.integers(0, 1 << 16, n, dtype=np.uint64) & rng.integers(0, 1 << 16, n, dtype=np.uint64)
+        ha = a.allocate_scored("pair", mt, ma, edge_scores=sc, task_pri=pri, reserved=res, gate="trainer", replan_interval=10)
+        b.allocate_scored("pair", mt, ma, edge_scores=torch.from_numpy(sc).to(dev), task_pri=torch.from_numpy(pri).to(dev),
+                          reserved=torch.from_numpy(res.view(np.int64)).to(dev), gate="trainer", replan_interval=10, out={"selected": sel, "replanned": rep})
+        b.sync()
+        assert np.array_equal(sel.cpu().numpy(), ha["selected"]) and np.array_equal(rep.cpu().numpy(), ha["replanned"])
+        assert np.array_equal(a.get("STAGED_ACTIONS"), b.get("STAGED_ACTIONS"))
+        a.step_staged(); b.step_staged()
+    assert np.array_equal(a.metrics(), b.metrics())
+
+
+@pytest.mark.parametrize("gate,flags_kw,kname,kind,oflags", [("allocator", dict(edge_valid_only=True, full_task_list=True), "pair", 0, 3),
+                                                             ("force", dict(edge_valid_only=False, commit=True), "escort", 2, 4),
+                                                             ("escort", dict(edge_valid_only=True), "pair_raw", 1, 1)])
+def test_scored_allocator_on_fuzzed_configs_vs_oracle(gate, flags_kw, kname, kind, oflags):
+    """flag / gate / kind combinations no reference planner uses, on the fuzzed env configurations, with token pads SMALLER
+    than the fleet and the open list (rows and columns beyond the pads carry no score / priority): device vs oracle"""
+    import json
+    from muavta_amd.params import params_from_config
+    from cases import params_of
+
+    cfgs = json.load(open(os.path.join(GOLDEN, "fuzz_configs.json")))
+    rng = np.random.default_rng(23)
+    for name in list(cfgs)[:8]:
+        P = params_of(name)
+        n, mt, ma = 3, 6, 3
+        from muavta_amd.batched import BatchedMultiUAVEnv
+        env = BatchedMultiUAVEnv(P, n)
+        A = env.n_agents
+        oracles = [orc.OracleEnv(P) for _ in range(n)]
+        env.reset(np.arange(n, dtype=np.uint64))
+        for i, o in enumerate(oracles):
+            o.reset(i)
+        for t in range(P.max_time_steps):
+            sc = rng.uniform(-1, 1, (n, ma, mt)).astype(np.float32)
+            pri = rng.uniform(-0.5, 1, (n, mt))
+            res = rng.integers(0, 1 << A, n, dtype=np.uint64) & rng.integers(0, 1 << A, n, dtype=np.uint64)
+            out = env.allocate_scored(kname, mt, ma, edge_scores=sc, task_pri=pri, reserved=res, gate=gate, replan_interval=7, use_visibility=bool(t % 2), **flags_kw)
+            for i, o in enumerate(oracles):
+                oa, oi, osel = o.allocate_scored(7, t % 2, GATE[gate], kind, mt, ma, oflags, scores=sc[i], pri=pri[i], reserved=int(res[i]))
+                kk = len(oa)
+                assert np.array_equal(out["act_agent"][i][:kk], oa) and np.all(out["act_agent"][i][kk:] == -1) and np.array_equal(out["act_index"][i][:kk], oi), f"{name} seed {i} t={t}"
+                assert np.array_equal(out["selected"][i], osel), f"{name} seed {i} t={t}: selected"
+                o.step(oa, oi)
+            env.step_staged()
+            snap = Snapshot(env)
+            for i, o in enumerate(oracles):
+                compare(snap, i, o, f"scored-fuzz {name} seed {i} t={t + 1}")
+            if snap.term[0] or snap.trunc[0]:
+                break
