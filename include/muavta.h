@@ -332,6 +332,26 @@ typedef struct MuavtaScored {
 int muavta_allocate_scored(MuavtaEnv* env, const MuavtaScored* spec, int32_t* act_agent, int32_t* act_index);
 int muavta_allocate_scored_device(MuavtaEnv* env, const MuavtaScored* spec);
 
+/* One iteration of the RL trainer's loop body for every env in ONE launch (experiments/train_pair_cost.py:139-153, run_rl_episode):
+ *   result, tok, ... = policy.plan(env, hung, events, force=True)   <- muavta_allocate_scored_device(plan) with the caller's scores
+ *   actions = _apply_assign(env, result); env.step(actions)         <- muavta_step_staged
+ *   s_now = env.compute_s_wps(); step_r = (s_now - s_prev) / 20     <- s_wps f64 [2][N]: before / after the step (may be NULL)
+ *   next_tok = policy.build_tokens(env)                             <- muavta_tokens_device's outputs (kind and pads of `plan`;
+ *                                                                      all seven or none, n_urgent optional)
+ *   ep_done                                                         <- done u8 [N] (bit 0 terminated, bit 1 truncated; may be NULL)
+ * The caller's network turns the token tensors of call t into the edge scores of call t + 1 on the same GPU: nothing crosses PCIe.
+ * write_obs != 0 also refreshes the handle's observation buffers as env.step does.  An env whose episode has ended is left
+ * alone (no plan, no step: replanned 0, selected 0, s_wps before == after, tokens of its final state), as the reference's loop
+ * ends with the episode.  All pointers are DEVICE pointers; runs on the handle's stream without synchronising. */
+typedef struct MuavtaRlStep {
+  MuavtaScored plan;
+  float* task_feats; uint8_t* task_mask; int32_t* task_ids; float* agent_feats; uint8_t* agent_mask; int32_t* agent_ids;
+  float* edge_valid; int32_t* n_urgent;
+  double* s_wps; uint8_t* done;
+  int32_t write_obs, reserved1;
+} MuavtaRlStep;
+int muavta_rl_step_device(MuavtaEnv* env, const MuavtaRlStep* step);
+
 /* The measured path: reset(seeds) followed by n_steps x (allocate -> step) fused in ONE kernel
  * launch, state resident in LDS (run_wps_episode / run_escort_episode with Local-/Coalition-
  * Hungarian, experiments/wps_eval.py:76-291, experiments/escort_eval.py:86-226).  seeds == NULL

@@ -162,6 +162,49 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_allocate_scored(self.h, C.byref(spec), _vp(aa), _vp(ai)))
         return res
 
+    def token_shapes(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16):
+        """name -> (shape, numpy dtype) of the token tensors `tokens(out=...)` / `rl_step(next_tok=...)` fill."""
+        _, dt, da = self.TOKEN_KINDS[kind]
+        mt = int(max_tasks if max_tasks is not None else (48 if kind == "escort" else 32))
+        N, ma = self.n_envs, int(max_agents)
+        return {"task_feats": ((N, mt, dt), np.float32), "task_mask": ((N, mt), np.uint8), "task_ids": ((N, mt), np.int32),
+                "agent_feats": ((N, ma, da), np.float32), "agent_mask": ((N, ma), np.uint8), "agent_ids": ((N, ma), np.int32),
+                "edge_valid": ((N, ma, mt), np.float32), "n_urgent": ((N,), np.int32)}
+
+    def rl_step(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16, *, edge_scores=None, task_pri=None, reserved=None,
+                gate: str = "trainer", replan_interval: int = 20, use_visibility: bool = True, edge_valid_only: Optional[bool] = None,
+                full_task_list: bool = False, commit: bool = False, selected=None, replanned=None, next_tok: Optional[dict] = None,
+                s_wps=None, done=None, write_obs: bool = False):
+        """muavta_rl_step_device: one iteration of run_rl_episode's loop body (experiments/train_pair_cost.py:139-153) for every
+        env in ONE launch — plan with the caller's scores -> step -> S_WPS before / after -> next tokens.  Every tensor is a
+        contiguous CUDA torch tensor on the env's GPU: inputs as in `allocate_scored`; outputs `selected` f32 [N, MA, MT],
+        `replanned` i32 [N], `next_tok` (dict with the shapes of `token_shapes`), `s_wps` f64 [2, N], `done` u8 [N] (any may be
+        None).  Asynchronous on the handle's stream."""
+        k = self.TOKEN_KINDS[kind][0]
+        mt = int(max_tasks if max_tasks is not None else (48 if kind == "escort" else 32))
+        ma, N = int(max_agents), self.n_envs
+        if edge_valid_only is None:
+            edge_valid_only = kind != "escort"
+        flags = (self.SC_EDGE_VALID_ONLY if edge_valid_only else 0) | (self.SC_FULL_TASK_LIST if full_task_list else 0) | (self.SC_COMMIT if commit else 0)
+        rs = native.MuavtaRlStep()
+        rs.plan = native.MuavtaScored(k, mt, ma, self.GATES[gate], flags, int(replan_interval), int(bool(use_visibility)), 0)
+        rs.write_obs = int(bool(write_obs))
+
+        def put(obj, name, t, shape, size):
+            if t is None:
+                return
+            if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != size or t.device.index != self.device_index:
+                raise ValueError(f"rl_step: {name} must be a contiguous tensor of shape {shape} with {size}-byte elements on cuda:{self.device_index}")
+            setattr(obj, name, t.data_ptr())
+
+        put(rs.plan, "edge_scores", edge_scores, (N, ma, mt), 4); put(rs.plan, "task_pri", task_pri, (N, mt), 8); put(rs.plan, "reserved", reserved, (N,), 8)
+        put(rs.plan, "selected", selected, (N, ma, mt), 4); put(rs.plan, "replanned", replanned, (N,), 4)
+        put(rs, "s_wps", s_wps, (2, N), 8); put(rs, "done", done, (N,), 1)
+        if next_tok is not None:
+            for name, (shape, dtype) in self.token_shapes(kind, mt, ma).items():
+                put(rs, name, next_tok[name], shape, np.dtype(dtype).itemsize)
+        self._ck(self.L.muavta_rl_step_device(self.h, C.byref(rs)))
+
     TOKEN_KINDS = {"pair": (0, 13, 12), "pair_raw": (1, 9, 11), "escort": (2, 22, 16)}
 
     def tokens(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16, out=None):
@@ -182,7 +225,10 @@ class BatchedMultiUAVEnv:
         if out is not None:
             ptrs = []
             for name, (shape, dtype) in shapes.items():
-                t = out[name]
+                t = out.get(name) if name in ("n_urgent", "expert_mask", "replanned") else out[name]  # (the three optional outputs)
+                if t is None:
+                    ptrs.append(None)
+                    continue
                 if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != np.dtype(dtype).itemsize:
                     raise ValueError(f"tokens(out=...): {name} must be a contiguous CUDA tensor of shape {shape}, {np.dtype(dtype).name}")
                 ptrs.append(C.c_void_p(t.data_ptr()))

@@ -309,6 +309,15 @@ __global__ __launch_bounds__(WG) void k_allocate(const DevCtx* __restrict__ ctxp
   copy16(blob, L.S, sizeof(EnvState<TL>));
 }
 
+template <class TL>
+__device__ __forceinline__ typename Sim<TL>::TokPtrs global_tok_ptrs(typename Sim<TL>::TokPtrs K) {  // kernel-argument pointers as global (not FLAT) accesses
+  K.task_feats = as_global(K.task_feats); K.task_mask = as_global(K.task_mask); K.task_ids = as_global(K.task_ids);
+  K.agent_feats = as_global(K.agent_feats); K.agent_mask = as_global(K.agent_mask); K.agent_ids = as_global(K.agent_ids);
+  K.edge_valid = as_global(K.edge_valid); K.n_urgent = as_global(K.n_urgent); K.expert_mask = as_global(K.expert_mask);
+  K.replanned = as_global(K.replanned);
+  return K;
+}
+
 // muavta_allocate_scored: k_allocate with the caller's edge scores / priorities / reserved agents (Sim::allocate<true>).  The
 // task list handed to the allocator sits in T bytes of LDS behind the tile.
 enum { SCORED_EXTRA_LDS = 128 };
@@ -337,6 +346,48 @@ __global__ __launch_bounds__(WG) void k_allocate_scored(const DevCtx* __restrict
   copy16(blob, L.S, sizeof(EnvState<TL>));
 }
 
+// muavta_rl_step_device: one iteration of run_rl_episode's loop body (experiments/train_pair_cost.py:139-153) per env and launch —
+// policy.plan with the caller's scores (allocate<true>) -> _apply_assign -> env.step -> compute_s_wps -> build_tokens (next_tok) —
+// with ONE load and ONE store of the env record instead of four (k_tokens, k_allocate_scored, k_step, k_metrics).
+template <class TL>
+__global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rl_step(const DevCtx* __restrict__ ctxp, ScoredDev sc, typename Sim<TL>::TokPtrs K, int interval, int use_vis,
+                                                                    int write_obs, double* s_wps, uint8_t* done, int n_envs, int env_base) {
+  const DevCtx& ctx = ctx_ref(ctxp);
+  const DevParams& P = ctx.P;
+  const int env = env_base + blockIdx.x;
+  __shared__ __align__(16) unsigned char lds_own[Lds<TL>::bytes() + SCORED_EXTRA_LDS];
+  Lds<TL> L(lds_own + lds_zero());
+  EnvState<TL>* blob = blob_of<TL>(ctx, env);
+  copy16(L.S, blob, sizeof(EnvState<TL>));
+  lds_sync();
+  sc.scores = as_global(sc.scores); sc.pri = as_global(sc.pri); sc.reserved = as_global(sc.reserved);
+  sc.selected = as_global(sc.selected); sc.replanned = as_global(sc.replanned);
+  K = global_tok_ptrs<TL>(K);
+  s_wps = as_global(s_wps); done = as_global(done);
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, P, tape_of(ctx, env));
+  const double before = sim.s_wps();
+  if (!(L.S->terminated || L.S->truncated)) {  // (uniform)  the reference's loop ends with the episode (:139)
+    sim.template allocate<true>(interval, use_vis, 4, &sc, env, lds_own + Lds<TL>::bytes());
+    lds_sync();
+    sim.step(true);
+    if (write_obs) obs_for_env(sim, P, obs_ptrs(ctx), env);
+    lds_sync();
+  } else {
+    if (sc.replanned && threadIdx.x == 0) sc.replanned[env] = 0;
+    if (sc.selected) for (int i = threadIdx.x; i < sc.MA * sc.MT; i += WG) sc.selected[(size_t)env * sc.MA * sc.MT + i] = 0.f;
+  }
+  if (threadIdx.x == 0) {
+    if (s_wps) { s_wps[env] = before; s_wps[(size_t)n_envs + env] = sim.s_wps(); }
+    if (done) done[env] = (uint8_t)((L.S->terminated ? 1 : 0) | (L.S->truncated ? 2 : 0));
+  }
+  if (K.task_feats) {
+    cold_sync();
+    sim.tokens(K, env);  // next_tok (:150): the tokens the policy sees at the next iteration
+  }
+  lds_sync();
+  copy16(blob, L.S, sizeof(EnvState<TL>));
+}
+
 // The body of the fused rollout, OUT OF LINE on purpose.  Inlined into the 150-step loop of k_rollout the compiler hoists
 // loop invariants across the whole body and the kernel needs 255 VGPRs (+188 B/lane of scratch: two waves per SIMD); as a
 // function of its own the body fits the 128 VGPRs of FOUR waves per SIMD — with 10 KiB of LDS per env that is 16 resident
@@ -360,14 +411,6 @@ struct RecordPtrs {
   ObsPtrs O;       // O.tasks == nullptr: no observation rings
   int n_envs;
 };
-template <class TL>
-__device__ __forceinline__ typename Sim<TL>::TokPtrs global_tok_ptrs(typename Sim<TL>::TokPtrs K) {  // kernel-argument pointers as global (not FLAT) accesses
-  K.task_feats = as_global(K.task_feats); K.task_mask = as_global(K.task_mask); K.task_ids = as_global(K.task_ids);
-  K.agent_feats = as_global(K.agent_feats); K.agent_mask = as_global(K.agent_mask); K.agent_ids = as_global(K.agent_ids);
-  K.edge_valid = as_global(K.edge_valid); K.n_urgent = as_global(K.n_urgent); K.expert_mask = as_global(K.expert_mask);
-  K.replanned = as_global(K.replanned);
-  return K;
-}
 template <class TL, bool REC>
 __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned char* lds_own, uint32_t lds_base, int env, int phases, int interval, int use_vis, int mode,
                                                 const RecordPtrs<TL>& rec, int slot, int oslot) {
@@ -832,6 +875,14 @@ static void launch_tokens(MuavtaEnv* e, int kind, int max_tasks, int max_agents,
   typename Sim<TL>::TokPtrs K{task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned,
                               kind, max_tasks, max_agents};
   hipLaunchKernelGGL(k_tokens<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, K);
+}
+
+template <class TL>
+static void launch_rl_step(MuavtaEnv* e, const ScoredDev& sc, const MuavtaRlStep* rs) {
+  typename Sim<TL>::TokPtrs K{rs->task_feats, rs->task_mask, rs->task_ids, rs->agent_feats, rs->agent_mask, rs->agent_ids, rs->edge_valid, rs->n_urgent,
+                              nullptr, nullptr, rs->plan.kind, rs->plan.max_tasks, rs->plan.max_agents};
+  hipLaunchKernelGGL(k_rl_step<TL>, dim3(e->n_envs), dim3(WG), 0, e->stream, (const DevCtx*)e->d_ctx, sc, K, rs->plan.replan_interval, rs->plan.use_visibility,
+                     rs->write_obs, rs->s_wps, rs->done, e->n_envs, 0);
 }
 
 int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
@@ -1505,6 +1556,24 @@ int muavta_allocate_scored(MuavtaEnv* e, const MuavtaScored* sp, int32_t* act_ag
     HIPCHK(e, hipMemcpyAsync(act_index, e->d_act_index, bytes, hipMemcpyDeviceToHost, e->stream));
   }
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+int muavta_rl_step_device(MuavtaEnv* e, const MuavtaRlStep* rs) {
+  if (!e || !rs) return MUAVTA_E_ARG;
+  const MuavtaScored* sp = &rs->plan;
+  if (int rc = scored_check(e, sp)) return rc;
+  const bool tok = rs->task_feats != nullptr;
+  if (tok && (!rs->task_mask || !rs->task_ids || !rs->agent_feats || !rs->agent_mask || !rs->agent_ids || !rs->edge_valid)) {
+    e->err = "muavta_rl_step_device: the next-token outputs come all together or not at all (n_urgent alone is optional)"; return MUAVTA_E_ARG;
+  }
+  DeviceScope scope_(e->device);
+  MAIN_OP(e);
+  ScoredDev sc{sp->edge_scores, sp->task_pri, (const unsigned long long*)sp->reserved, sp->selected, sp->replanned, sp->kind, sp->max_tasks,
+               sp->max_agents, sp->gate, sp->flags};
+  if (e->d_rel) { e->err = "muavta_rl_step_device: the release log must be off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
+  DISPATCH(e, launch_rl_step<TL>(e, sc, rs));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
   return MUAVTA_OK;
 }
 }  // extern "C" (the launcher below is a template)

@@ -6,6 +6,8 @@ state, `_expert_mask` turns the expert's pairs into the label matrix, and the ep
 phase rewards each step with `(S_WPS_now - S_WPS_prev) / 20`.  Here the same loop runs for thousands of envs per
 launch: expert = `muavta_allocate` in MUAVTA_ALLOC_HUNGARIAN_GATED mode without the visibility mask, tokens +
 labels = one `k_tokens` launch (optionally straight into torch tensors), reward from `muavta_metrics`.
+`rl_stream` closes the loop for the RL phase (run_rl_episode, :132-156): the caller's network turns the token tensors into edge
+scores on the same GPU and `muavta_rl_step_device` plans with them (Hungarian + scores), steps and emits the next tokens.
 The learner itself (the torch nets of TaskAllocation/Hybrid) is the caller's; this module is its data path.
 """
 from __future__ import annotations
@@ -71,6 +73,62 @@ def il_record(env: BatchedMultiUAVEnv, seeds, n_steps: int = 150, interval: int 
     diff = rings["s_wps"][1:] - rings["s_wps"][:-1]
     out["step_reward"] = torch.div(diff, torch.full_like(diff, 20.0))  # tensor / tensor: IEEE division (a scalar divisor becomes a multiplication by its reciprocal)
     return out
+
+
+def rl_stream(env: BatchedMultiUAVEnv, seeds, policy, n_steps: int = 150, interval: int = 20, kind: str = "pair", max_tasks: int = 32,
+              max_agents: int = 16, gate: str = "trainer", device=None, fused: bool = True, **plan_kw):
+    """run_rl_episode (experiments/train_pair_cost.py:132-156) for every env of the batch at once, the policy in the loop:
+
+        for t, tr in rl_stream(env, seeds, policy): buffer.push(tr)          # policy.push(tok, scores, ..., step_r, next_tok, done)
+
+    `policy(tok) -> edge_scores`: a callable on the SAME GPU that maps the token tensors (dict of CUDA torch tensors: task_feats,
+    task_mask, agent_feats, agent_mask, edge_valid, ...; the layout of `env.tokens(kind, max_tasks, max_agents)`) to a contiguous
+    float32 CUDA tensor [N, max_agents, max_tasks] — what `PairCostHybrid.act` returns (`tanh(logits) * score_clamp`), batched.
+    Each step: scores -> `muavta_rl_step_device` (Hungarian with the scores under the trainer's gate, env.step, S_WPS before /
+    after, next tokens) — one launch, nothing crosses PCIe.  Yields `(t, transition)` with CUDA tensors: `tok`, `scores`,
+    `selected` (_selected_mask), `replanned` (rows that are RL samples: the reference pushes only when it planned), `step_reward`
+    ((S_WPS_now - S_WPS_prev) / 20), `next_tok`, `done` (u8: bit 0 terminated, bit 1 truncated).  The token dicts alternate
+    between two buffer sets: `tok` of step t is `next_tok` of step t - 1 and is overwritten at step t + 1 — copy what must live
+    longer.  `fused=False` runs the same step as four separate launches (tokens / allocate_scored / step / metrics): the
+    cross-check of the fused kernel.  Envs whose episode has ended idle (replanned 0, reward 0)."""
+    import torch
+
+    dev = torch.device("cuda", env.device_index if device is None else device)
+    tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32, np.float64: torch.float64}
+    shapes = env.token_shapes(kind, max_tasks, max_agents)
+    N = env.n_envs
+    bufs = [{name: torch.empty(shape, dtype=tdt[dtype], device=dev) for name, (shape, dtype) in shapes.items()} for _ in range(2)]
+    selected = torch.empty((N, max_agents, max_tasks), dtype=torch.float32, device=dev)
+    replanned = torch.empty((N,), dtype=torch.int32, device=dev)
+    s_wps = torch.empty((2, N), dtype=torch.float64, device=dev)
+    done = torch.empty((N,), dtype=torch.uint8, device=dev)
+    twenty = torch.full((N,), 20.0, dtype=torch.float64, device=dev)
+    env.reset(np.asarray(seeds, dtype=np.uint64))
+    env.tokens(kind, max_tasks, max_agents, out=bufs[0])   # tok of step 0
+    for t in range(n_steps):
+        tok, nxt = bufs[t & 1], bufs[(t + 1) & 1]
+        env.sync()                                       # the handle's stream wrote `tok`; the policy runs on torch's stream
+        scores = policy(tok)
+        if scores.dtype != torch.float32 or not scores.is_contiguous():
+            scores = scores.to(torch.float32).contiguous()
+        env.wait_stream(torch.cuda.current_stream(dev).cuda_stream)   # ... and the scores must be complete before the plan reads them
+        if fused:
+            env.rl_step(kind, max_tasks, max_agents, edge_scores=scores, gate=gate, replan_interval=interval, selected=selected,
+                        replanned=replanned, next_tok=nxt, s_wps=s_wps, done=done, **plan_kw)
+            env.sync()
+        else:
+            env.allocate_scored(kind, max_tasks, max_agents, edge_scores=scores, gate=gate, replan_interval=interval,
+                                out={"selected": selected, "replanned": replanned}, **plan_kw)
+            before = env.metrics()[:, S_WPS_COL]
+            env.step_staged()
+            after = env.metrics()[:, S_WPS_COL]
+            _, term, trunc = env.step_result()
+            env.tokens(kind, max_tasks, max_agents, out=nxt)
+            env.sync()
+            s_wps.copy_(torch.from_numpy(np.stack([before, after])))
+            done.copy_(torch.from_numpy((term.astype(np.uint8) | (trunc.astype(np.uint8) << 1))))
+        yield t, {"tok": tok, "scores": scores, "selected": selected, "replanned": replanned,
+                  "step_reward": torch.div(s_wps[1] - s_wps[0], twenty), "next_tok": nxt, "done": done}
 
 
 def step_rewards(s_wps_prev: np.ndarray, s_wps_now: np.ndarray) -> np.ndarray:

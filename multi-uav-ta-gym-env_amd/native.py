@@ -33,7 +33,7 @@ EXPORTS = [
     "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
     "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_step_lists",
-    "muavta_allocate_scored", "muavta_allocate_scored_device",
+    "muavta_allocate_scored", "muavta_allocate_scored_device", "muavta_rl_step_device",
 ]
 
 
@@ -71,6 +71,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return SO_PATH
+
+
+class MuavtaRlStep(C.Structure):
+    """include/muavta.h: MuavtaRlStep (muavta_rl_step_device)."""
+    _fields_ = [("plan", MuavtaScored)] + [(n, C.c_void_p) for n in ("task_feats", "task_mask", "task_ids", "agent_feats", "agent_mask", "agent_ids",
+                                                                      "edge_valid", "n_urgent", "s_wps", "done")] + [("write_obs", C.c_int32), ("reserved1", C.c_int32)]
 
 
 _LIB = None
@@ -144,6 +150,7 @@ def lib() -> C.CDLL:
     L.muavta_tokens_device.argtypes = [vp, i32, i32, i32] + [vp] * 10
     L.muavta_allocate_scored.argtypes = [vp, C.POINTER(MuavtaScored), vp, vp]
     L.muavta_allocate_scored_device.argtypes = [vp, C.POINTER(MuavtaScored)]
+    L.muavta_rl_step_device.argtypes = [vp, C.POINTER(MuavtaRlStep)]
     L.muavta_abi_sizes.argtypes = [C.POINTER(i32 * 3)]
     for name in EXPORTS:
         if name != "muavta_last_error":

@@ -1522,3 +1522,76 @@ def test_scored_allocator_on_fuzzed_configs_vs_oracle(gate, flags_kw, kname, kin
                 compare(snap, i, o, f"scored-fuzz {name} seed {i} t={t + 1}")
             if snap.term[0] or snap.trunc[0]:
                 break
+
+
+RL_FILES = sorted(glob.glob(os.path.join(GOLDEN, "rl_*.npz")))
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "four-launches"])
+@pytest.mark.parametrize("path", RL_FILES, ids=[os.path.basename(p)[3:-4] for p in RL_FILES])
+def test_rl_stream_policy_in_the_loop_vs_reference_and_oracle(path, fused):
+    """run_rl_episode batched (muavta_amd.il.rl_stream; muavta_rl_step_device when fused): env 0 replays the reference episode
+    driven by PairCostHybrid.plan(scores=seeded) — tok, selected, replanned, step reward, next_tok, done — the other envs run
+    other seeds against the oracle, with the policy a function of the token tensors on the GPU."""
+    import torch
+    from muavta_amd.il import rl_stream
+
+    g = np.load(path)
+    case = os.path.basename(path)[3:-4]
+    raw = bool(int(g["raw"]))
+    kname, kind = ("pair_raw", 1) if raw else ("pair", 0)
+    n, seed0 = 5, int(g["seed"])
+    env = _env(case, n)
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(seed0 + i)
+    steps = g["step"].tolist()
+    state = {"k": 0, "t": 0}
+    ref_scores = torch.from_numpy(g["scores"]).cuda()
+
+    def policy(tok):
+        # a deterministic function of the tokens (so the loop really closes on the device) ...
+        sc = torch.tanh(tok["agent_feats"][:, :, :1] * 3.0 - tok["task_feats"][:, :, 0].unsqueeze(1) * 2.0 + tok["task_feats"][:, :, 1].unsqueeze(1)) * 0.35
+        sc = sc.contiguous()
+        if state["k"] < len(steps) and steps[state["k"]] == state["t"]:  # ... and for env 0 the matrix the reference was given
+            sc[0] = ref_scores[state["k"]]
+        return sc
+
+    pend = None
+    for t, tr in rl_stream(env, np.arange(seed0, seed0 + n), policy, n_steps=len(g["replanned"]), interval=20, kind=kname, fused=fused):
+        sc = tr["scores"].cpu().numpy()
+        sel, rep, rew, dn = tr["selected"].cpu().numpy(), tr["replanned"].cpu().numpy(), tr["step_reward"].cpu().numpy(), tr["done"].cpu().numpy()
+        tok = {k_: v.cpu().numpy() for k_, v in tr["tok"].items()}
+        nxt = {k_: v.cpu().numpy() for k_, v in tr["next_tok"].items()}
+        k = state["k"]
+        assert int(rep[0]) == int(g["replanned"][t]), f"{case} t={t}: gate"
+        if g["replanned"][t]:
+            assert t == steps[k]
+            assert np.array_equal(tok["task_feats"][0], g["tf"][k]) and np.array_equal(tok["agent_feats"][0], g["af"][k]) and np.array_equal(tok["edge_valid"][0], g["ev"][k])
+            assert np.array_equal(tok["task_ids"][0], g["tid"][k]) and np.array_equal(tok["agent_ids"][0], g["aid"][k])
+            assert np.array_equal(sel[0], g["selected"][k]), f"{case} t={t}: selected"
+            assert rew[0] == g["step_r"][k] and bool(dn[0]) == bool(g["ep_done"][k])
+            assert np.array_equal(nxt["task_feats"][0], g["ntf"][k]) and np.array_equal(nxt["agent_feats"][0], g["naf"][k]) and np.array_equal(nxt["task_ids"][0], g["ntid"][k])
+            state["k"] += 1
+        else:
+            assert not sel[0].any()
+        assert rew[0] == (g["s_wps"][t + 1] - g["s_wps"][t]) / 20.0
+        for i, o in enumerate(oracles):
+            want_tok = o.tokens(kind, 32, 16)
+            for key in ("task_feats", "agent_feats", "edge_valid", "task_ids", "agent_ids", "task_mask", "agent_mask"):
+                assert np.array_equal(tok[key][i], want_tok[key]), f"{case} seed {seed0 + i} t={t}: tok {key}"
+            assert int(tok["n_urgent"][i]) == want_tok["n_urgent"]
+            before = o.metrics()[4]
+            oa, oi, osel = o.allocate_scored(20, 1, 1, kind, 32, 16, 1, scores=sc[i])
+            assert np.array_equal(sel[i], osel) and bool(rep[i]) == (o.scalars_last_plan() == t), f"{case} seed {seed0 + i} t={t}"
+            d = o.step(oa, oi)
+            assert rew[i] == (o.metrics()[4] - before) / 20.0 and bool(dn[i]) == bool(d)
+            want_nxt = o.tokens(kind, 32, 16)
+            for key in ("task_feats", "agent_feats", "edge_valid", "task_ids", "agent_ids", "task_mask", "agent_mask"):
+                assert np.array_equal(nxt[key][i], want_nxt[key]), f"{case} seed {seed0 + i} t={t}: next_tok {key}"
+        state["t"] = t + 1
+    assert state["k"] == len(steps) and np.array_equal(env.metrics()[0], g["metrics"])
+    env.refresh_observation()  # (the fused step ran without the observation write, which is what rebuilds initTime / doneTime)
+    snap = Snapshot(env)
+    for i, o in enumerate(oracles):
+        compare(snap, i, o, f"rl_stream {case} seed {seed0 + i} final", check_obs=False)
