@@ -449,6 +449,45 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     except Exception as exc:  # torch without CUDA tensors etc.: the figure is optional
         out["il_samples_per_s"] = None
         out["il_error"] = repr(exc)
+    # the RL trainers' loop with the policy IN the loop (RL half; experiments/train_pair_cost.py:132-156): per env step
+    # one muavta_rl_step_device launch = Hungarian with the caller's edge scores under the trainer's gate -> env.step -> S_WPS before /
+    # after -> next tokens.  The "policy" here is a fixed seeded score tensor on the GPU, so the figure times the env side of the loop.
+    try:
+        import torch
+
+        dev = torch.device("cuda", env.device_index)
+        e4 = BatchedMultiUAVEnv(params_for_case(args.case), args.envs, device=env.device_index)
+        gen = torch.Generator(device=dev); gen.manual_seed(1234)
+        scores = ((torch.rand((args.envs, 16, 32), generator=gen, device=dev) * 2 - 1) * 0.35).contiguous()
+        tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}
+        bufs = [{k: torch.empty(sh, dtype=tdt[dt], device=dev) for k, (sh, dt) in e4.token_shapes("pair", 32, 16).items()} for _ in range(2)]
+        sel = torch.empty((args.envs, 16, 32), dtype=torch.float32, device=dev)
+        rep = torch.empty((args.envs,), dtype=torch.int32, device=dev)
+        sw = torch.empty((2, args.envs), dtype=torch.float64, device=dev)
+        dn = torch.empty((args.envs,), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for rep_i in range(2):  # (first pass: warm-up)
+            e4.reset(seeds)
+            e4.tokens("pair", 32, 16, out=bufs[0])
+            e4.sync()
+            t1 = time.perf_counter()
+            for t in range(HORIZON):
+                e4.rl_step("pair", 32, 16, edge_scores=scores, gate="trainer", replan_interval=args.interval, selected=sel, replanned=rep,
+                           next_tok=bufs[(t + 1) & 1], s_wps=sw, done=dn)
+            e4.sync()
+            dt_rl = time.perf_counter() - t1
+        out["policy_in_loop_env_steps_per_s"] = args.envs * HORIZON / dt_rl
+        out["policy_in_loop_is"] = (f"muavta_rl_step_device, one launch per env step of all {args.envs} envs: plan (Hungarian - caller's f32 edge scores [N,16,32], "
+                                    "trainer gate) -> step -> S_WPS before/after -> next pair tokens 32x16 + edge_valid, + _selected_mask / replanned / done; "
+                                    "the score tensor is fixed and device-resident (times the env side; the reference's run_rl_episode is this loop for one env)")
+        n_flag = int(np.count_nonzero(e4.get("ERROR")))
+        out["policy_in_loop_capacity_flagged_envs"] = n_flag
+        out["policy_in_loop_mean_S_WPS"] = float(e4.metrics()[:, 4].mean()) if not n_flag else None
+        e4.close()
+        del bufs, sel, scores
+    except Exception as exc:
+        out["policy_in_loop_env_steps_per_s"] = None
+        out["policy_in_loop_error"] = repr(exc)
     if args.case == "WPS_hard_x2":
         tiles = {}
         for case, n, interval in OTHER_TILES:
