@@ -23,7 +23,6 @@ box's host cores over a bounded sample of the same workload (rank 0, N=1 only).
 from __future__ import annotations
 
 import argparse
-import hashlib
 import json
 import os
 import sys
@@ -37,6 +36,7 @@ sys.path.insert(0, ROOT)
 # sub-batch figure (fused_step_api, muavta_set_parts) wants the part streams on queues of their own next to torch's and the handle's
 # main / seeding streams.  A runtime knob of the HIP runtime, read when it initialises; a value the caller exported wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("MUAVTA_EAGER_PART_STREAMS", "4")  # (muavta_create opens the sub-batch streams it will be asked for right behind its main streams: INTEGRATION.md)
 
 HORIZON = 150
 # algorithmic bytes per env-step B(A,T,H) = 2*S_state + S_obs + S_act, by agent count of the tile
@@ -50,10 +50,7 @@ def source_hash() -> str:
     """Hash of the kernel sources: PMC traffic figures under profiles/ are only reused for the build they were taken on."""
     from muavta_amd import native
 
-    h = hashlib.sha256()
-    for p in native.sources():
-        h.update(open(p, "rb").read())
-    return h.hexdigest()[:16]
+    return native.source_hash()
 
 
 def pmc_entry(case: str, envs: int):
@@ -220,6 +217,49 @@ def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
     return elapsed, float(np.mean(kernel_ms)), float(np.mean(seed_ms))
 
 
+def time_rollouts_in_flight(envs, seeds, interval, write_obs, steps, warmup, barrier):
+    """The same timed loop with the launches alternating between several handles (each with its own stream, blobs and seeding slots):
+    batch i+1's workgroups take the wave slots that batch i's early finishers free, instead of waiting for its slowest env.  Every
+    launch is still one whole batch; K launches are timed.  Returns (elapsed, mean per-launch kernel ms — overlapping launches, so
+    longer than an isolated one)."""
+    k = len(envs)
+    for w in range(max(warmup, k)):
+        envs[w % k].rollout(seeds, HORIZON, interval, True, write_obs)
+    for e in envs:
+        e.sync()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        envs[i % k].rollout(seeds, HORIZON, interval, True, write_obs)
+    for e in envs:
+        e.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per = [e.kernel_ms_history(max(1, min(64, steps // k))) for e in envs if steps // k >= 1]
+    return elapsed, float(np.mean(np.concatenate(per))) if per else float("nan")
+
+
+def in_flight_figure(case, n, interval, seeds, write_obs, steps, warmup, barrier, device, want_metrics, k=2):
+    """`k` handles of the same case / seeds in flight; every handle's last batch must be complete (no capacity flags) and bit-equal to
+    `want_metrics` (the single-handle batch the oracle check covers)."""
+    from muavta_amd.batched import BatchedMultiUAVEnv
+    from muavta_amd.params import params_for_case
+
+    hs = [BatchedMultiUAVEnv(params_for_case(case), n, device=device) for _ in range(k)]
+    try:
+        el, kms = time_rollouts_in_flight(hs, seeds, interval, write_obs, steps, warmup, barrier)
+        for h in hs:
+            if int(np.count_nonzero(h.get("ERROR"))):
+                raise SystemExit(f"bench: capacity-flagged envs in an in-flight batch of {case}")
+            if want_metrics is not None and not np.array_equal(h.rollout_metrics(), want_metrics):
+                raise SystemExit(f"bench: an in-flight batch of {case} differs from the single-handle batch")
+        return {"env_steps_per_s": n * HORIZON * steps / el, "handles": k, "ms_per_step": el / steps * 1e3, "overlapped_kernel_ms": kms,
+                "bit_equal_to_single_handle_batch": want_metrics is not None}
+    finally:
+        for h in hs:
+            h.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,6 +274,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API / other-tile / IL figures (profiling runs)")
     ap.add_argument("--abi-collective", action="store_true", help="reduce the metrics through muavta_allreduce_metrics (RCCL behind the C ABI) instead of torch.distributed")
     ap.add_argument("--seed-base", type=int, default=0, help="first global env index (default 0: seeds = global env index)")
+    ap.add_argument("--inflight", type=int, default=1, help="handles per rank whose launches alternate in the TIMED loop (default 1: one handle, launches in order; "
+                                                           "2: batch i+1 fills the wave slots batch i's early finishers free).  The N=1 line reports value_two_in_flight either way")
     args = ap.parse_args()
     if args.interval is None:
         args.interval = 12 if "escort" in args.case else 20
@@ -273,6 +315,13 @@ def main():
         torch.cuda.synchronize()
 
     elapsed, mean_kernel_ms, mean_seed_ms = time_rollouts(env, seeds, args.interval, write_obs, args.steps, args.warmup, barrier)
+    if args.inflight > 1:  # the timed region again, launches alternating between `inflight` handles of this rank (the first one above gave the isolated kernel time)
+        others = [BatchedMultiUAVEnv(params_for_case(args.case), args.envs, device=local_rank) for _ in range(args.inflight - 1)]
+        elapsed, _ = time_rollouts_in_flight([env] + others, seeds, args.interval, write_obs, args.steps, args.warmup, barrier)
+        for h in others:
+            if int(np.count_nonzero(h.get("ERROR"))) or not np.array_equal(h.rollout_metrics(), env.rollout_metrics()):
+                raise SystemExit("bench: an in-flight batch is incomplete or differs from the first handle's batch")
+            h.close()
 
     # metrics of the last batch: per-rank partials -> the one collective of this path (muavta_amd/dist.py).  Every env has
     # to produce a result: a capacity-flagged env (ERROR != 0) fails the run, on every rank alike (the count is reduced
@@ -315,6 +364,7 @@ def main():
             # tail; an isolated batch pays k_seed in front of the rollout kernel:
             "value_unpipelined": total_envs * HORIZON / ((mean_kernel_ms + mean_seed_ms) * 1e-3),
             "value_unpipelined_is": "whole-job env-steps/s of ONE isolated batch: envs x 150 / (k_rollout ms + k_seed ms on an idle GPU)",
+            "inflight": args.inflight,
             "quality": {"mean_S_WPS": summary["mean_S_WPS"], "std_S_WPS": summary["std_S_WPS"], "on_time_rate": summary["on_time_rate"],
                         "n_envs": summary["n_envs"], "capacity_flagged_envs": 0},
         }
@@ -354,7 +404,6 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     # the same per-step path with the batch split into sub-batches on their own streams (muavta_set_parts): one launch per part and
     # env step, all asynchronous — a part's launch still ends on its slowest env, but the other parts' launches fill the device
     # meanwhile (and a host-side planner would decide for one part while the others are being stepped)
-    best = (out["fused_step_api_one_stream_env_steps_per_s"], 1)
     for parts in (2, 3, 4):
         env.set_parts(parts)
         rate = 0.0
@@ -371,10 +420,10 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
             if os.environ.get("MUAVTA_BENCH_DEBUG"):
                 print(f"[debug] parts {parts} rep {rep}: host {t_host * 1e3:.2f} ms total {(time.perf_counter() - t1) * 1e3:.2f} ms", file=sys.stderr)
         out[f"fused_step_api_{parts}_parts_env_steps_per_s"] = rate
-        best = max(best, (rate, parts))
     env.set_parts(0)
-    out["fused_step_api_env_steps_per_s"], out["fused_step_api_parts"] = best
-    out["fused_step_api_is"] = (f"one k_rollout(1 step) launch per sub-batch and env step, {best[1]} sub-batch(es) on their own streams "
+    # (no best-of pick: the figure is the TWO-part one — the smallest split that lets the host decide for one part while the device steps the other)
+    out["fused_step_api_env_steps_per_s"], out["fused_step_api_parts"] = out["fused_step_api_2_parts_env_steps_per_s"], 2
+    out["fused_step_api_is"] = ("one k_rollout(1 step) launch per sub-batch and env step, 2 sub-batches on their own streams "
                                 "(muavta_rollout_part); 150 env steps of the whole batch, host-timed")
     # the same one-launch-per-step path with 8x the envs per launch (BASELINE config 3's 32768 on one GPU): a launch ends on its
     # slowest env (one that replans: ~80 us against a 24 us mean step), so a wider batch amortises that tail
@@ -488,6 +537,18 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     except Exception as exc:
         out["policy_in_loop_env_steps_per_s"] = None
         out["policy_in_loop_error"] = repr(exc)
+    # two handles in flight (each its own stream and blobs, same seeds): launches alternate A, B, A, B, so batch i+1's workgroups start in
+    # the wave slots batch i's early finishers free; both handles' batches are checked bit-equal to the headline batch
+    try:
+        env.rollout(seeds, HORIZON, args.interval, True, write_obs)
+        env.sync()
+        tf = in_flight_figure(args.case, args.envs, args.interval, seeds, write_obs, max(args.steps, 8), 4, barrier, env.device_index, env.rollout_metrics())
+        out["value_two_in_flight"] = tf["env_steps_per_s"]
+        out["value_two_in_flight_is"] = (f"the headline loop with launches alternating between 2 handles (own streams): {tf['ms_per_step']:.3f} ms per launch of "
+                                         f"{args.envs} envs x {HORIZON} steps; each overlapped launch lasts {tf['overlapped_kernel_ms']:.3f} ms; both handles' batches bit-equal to the headline batch")
+    except Exception as exc:
+        out["value_two_in_flight"] = None
+        out["value_two_in_flight_error"] = repr(exc)
     if args.case == "WPS_hard_x2":
         tiles = {}
         for case, n, interval in OTHER_TILES:
@@ -499,6 +560,10 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
                            "interval": interval, "ms_per_step": el / 5 * 1e3, "lds_bytes_per_env": int(e2.dims.lds_bytes),
                            "capacity_flagged_envs": flagged, "seed_kernel_ms": sms,
                            "roofline": roofline(case, n, e2.dims.tile_agents, kms)}
+            try:
+                tiles[case]["two_in_flight"] = in_flight_figure(case, n, interval, s2, True, 8, 4, barrier, env.device_index, e2.rollout_metrics())
+            except Exception as exc:
+                tiles[case]["two_in_flight"] = {"env_steps_per_s": None, "error": repr(exc)}
             e2.close()
         out["other_tiles"] = tiles
     return out

@@ -94,7 +94,10 @@ typedef struct MuavtaParams {
   double mutual_support_radius;
   /* Tile (capacity) of one env instance in device memory; 0 = derive a default. */
   int32_t tile_agents;   /* >= n_agents; 16 / 24 / 64 in BASELINE configs */
-  int32_t tile_tasks;    /* live task slots (open + retired-but-referenced); 40 / 48 / 128 */
+  int32_t tile_tasks;    /* live task slots (open + retired-but-referenced); 40 / 48 / 128.  The library picks the smallest built tile
+                            that holds (tile_agents, tile_tasks, tile_threats); a tile_tasks below 40 (the smallest tile's slot count) caps the
+                            slots an env may use at that number (field widths stay the tile's: MuavtaDims.tile_tasks) — an env that needs
+                            more sets MUAVTA_F_ERROR, which is how the capacity path (BatchedMultiUAVEnv.rollout(escalate=True)) is tested */
   int32_t tile_threats;  /* >= sum(threat_count) */
   int32_t random_init_pos; /* config.random_init_pos (DroneEnv.py:607) */
 } MuavtaParams;
@@ -409,7 +412,11 @@ int muavta_domain_math(int32_t device, const double* x, const double* y, int32_t
 int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double* movement, int32_t n,
                            const double* obstacles, int32_t n_obstacles, double* out);
 
-/* Device pointers for zero-copy consumers in the same process (torch.from_blob etc.). */
+/* Device pointers for zero-copy consumers in the same process (torch.from_blob etc.).  The observation buffers are READ-ONLY for
+ * the caller: the observation writer leaves rows alone that it knows to hold pad rows already, so a consumer that changes them in
+ * place (in-place normalisation, clearing the view) must call muavta_refresh_observation afterwards, which rewrites every row.
+ * Read-after-write: `*stream` orders the whole-batch entry points only; with sub-batches active (muavta_set_parts) use muavta_sync /
+ * muavta_wait_part before reading. */
 int muavta_device_ptrs(MuavtaEnv* env, void** state, void** obs_tasks, void** obs_legal, void** obs_agents,
                        void** metrics, void** stream);
 
@@ -449,7 +456,9 @@ int muavta_rollout_record(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps
 /* Sub-batches.  The reference's loop is "observe -> decide -> env.step" for ONE env (experiments/wps_eval.py:112-133,273); a batch
  * stepped by one launch per env step ends every launch on its slowest env (one that replans) while the host can do nothing.
  * muavta_set_parts splits the handle's env range into n_parts contiguous parts (0 or 1: off; at most 8), each with its own
- * stream: the *_part calls below are the per-step entry points for ONE part — asynchronous on that part's stream, so the host can
+ * stream (created on first use; MUAVTA_EAGER_PART_STREAMS=n in the environment makes muavta_create create n of them up front —
+ * HIP binds a stream to one of its GPU_MAX_HW_QUEUES hardware queues, 4 by default, when it first gets work, and two part streams
+ * that land on one queue execute in order: see INTEGRATION.md): the *_part calls below are the per-step entry points for ONE part — asynchronous on that part's stream, so the host can
  * decide for part A while the device steps part B, and the parts' launches overlap on the device.  Results are identical to the
  * whole-batch calls (env instances are independent).  The whole-batch entry points stay valid at any time: they are ordered
  * after everything the parts have queued, and a later *_part call is ordered after them (event waits on the device).
@@ -470,7 +479,8 @@ int muavta_observe_part(MuavtaEnv* env, int32_t part, float* tasks, uint64_t* le
 int muavta_wait_part(MuavtaEnv* env, int32_t part);
 
 /* Duration of the last muavta_rollout launch, measured with HIP events recorded on the handle's own
- * stream around the kernel (ms).  Blocks until that launch has finished. */
+ * stream around the kernel (ms).  Blocks until that launch has finished.  muavta_rollout_part launches record no event pair:
+ * after one, this call and muavta_kernel_ms_history return MUAVTA_E_STATE until the next whole-batch rollout. */
 int muavta_last_kernel_ms(MuavtaEnv* env, float* ms);
 /* The same for the last n rollout launches (1 <= n <= 64, oldest first): the handle keeps a ring of event pairs, so a
  * caller can queue launches back to back — the seeding of launch i+1 then overlaps launch i — and read the per-launch
@@ -486,12 +496,14 @@ int muavta_sync(MuavtaEnv* env);
  * starts only after the work `other_stream` (a hipStream_t; NULL = the legacy default stream) holds at the time of the call.
  * For callers that hand the library device buffers another stream may still be using — e.g. ring tensors a caching allocator
  * recycled while earlier kernels that read them are queued on the framework's stream (torch.cuda.current_stream().cuda_stream)
- * — before muavta_rollout_record / muavta_tokens_device overwrite them.  The other direction is muavta_sync or an event on the
- * stream muavta_device_ptrs returns.  The reference has no counterpart: it is single-threaded host code. */
+ * — before muavta_rollout_record / muavta_tokens_device overwrite them.  The wait also covers the sub-batch streams (their next
+ * launch is ordered after the handle's stream).  The other direction is muavta_sync (or, without sub-batches, an event on the
+ * stream muavta_device_ptrs returns).  The reference has no counterpart: it is single-threaded host code. */
 int muavta_wait_stream(MuavtaEnv* env, void* other_stream);
 /* Metrics written by the last muavta_rollout itself (f64 [N, 30]); no extra launch. */
 int muavta_rollout_metrics(MuavtaEnv* env, double* out);
-/* Rebuild the observation tensors from the current state (after muavta_set / muavta_set_state). */
+/* Rebuild the observation tensors from the current state (after muavta_set / muavta_set_state, or after a consumer wrote into the
+ * zero-copy observation views): a FULL rewrite, pad rows included. */
 int muavta_refresh_observation(MuavtaEnv* env);
 /* Raw MT19937 tapes of the env's random.Random streams (checkpoint/resume next to get/set_state):
  * u32 [N, 4 streams (agent, obs, tgt, mission), 2 blocks, 624]. */

@@ -45,6 +45,9 @@ class BatchedMultiUAVEnv:
         self.T, self.H, self.Q, self.E, self.A_tile = d.tile_tasks, d.n_threats, d.queue_cap, d.event_cap, d.tile_agents
         self.max_tasks = d.max_tasks
         self.possible_agents = self.params.possible_agents
+        self._alloc_mode = 0
+        self.escalated = {}     # rollout(escalate=True): env index -> (handle of the larger tile, row)
+        self._esc_rows = None
 
     # ------------------------------------------------------------------ plumbing
     def _ck(self, rc: int):
@@ -52,6 +55,9 @@ class BatchedMultiUAVEnv:
             raise MuavtaError(f"muavta error {rc}: {self.L.muavta_last_error(self.h).decode()}")
 
     def close(self):
+        for h in getattr(self, "_esc_handles", {}).values():
+            h.close()
+        self._esc_handles = {}
         if getattr(self, "h", None) and self.h.value:
             self.L.muavta_destroy(self.h)
             self.h = C.c_void_p()
@@ -104,7 +110,8 @@ class BatchedMultiUAVEnv:
         """'hungarian' (Local-/Coalition-Hungarian), 'urgency_pair' (UrgencyPair.plan under the WPS harness gate) or
         'urgency_coalition' (UrgencyCoalition.plan under the escort harness gate, with commit locks) or 'hungarian_gated'
         (the trainers' expert: allocate_tasks(force=True) under _should_replan(env, events, interval), train_pair_cost.py:33-43)."""
-        self._ck(self.L.muavta_set_allocator(self.h, {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2, "hungarian_gated": 3}[name]))
+        self._alloc_mode = {"hungarian": 0, "urgency_pair": 1, "urgency_coalition": 2, "hungarian_gated": 3}[name]
+        self._ck(self.L.muavta_set_allocator(self.h, self._alloc_mode))
 
     GATES = {"force": 0, "trainer": 1, "escort": 2, "allocator": 3}
     SC_EDGE_VALID_ONLY, SC_FULL_TASK_LIST, SC_COMMIT = 1, 2, 4
@@ -282,13 +289,61 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_step_staged(self.h))
 
     def rollout(self, seeds: Optional[Sequence[int]], n_steps: int = 150, replan_interval: int = 20,
-                use_visibility: bool = True, write_obs: bool = True):
+                use_visibility: bool = True, write_obs: bool = True, escalate: bool = False):
+        """muavta_rollout.  `escalate=True` (needs seeds): an env that overflowed its tile (`ERROR != 0` — the reference's task list,
+        queues and event lists are unbounded Python lists, DroneEnv.py:325-328,1894-1895; the device's tiles are not) is re-run
+        from its seed in a handle of the next larger tile (16x40 -> 24x48 -> 64x128, same configuration) on the same GPU, and
+        `rollout_metrics()` returns its row from there; `escalated` maps env index -> (handle, row in that handle) for callers
+        that want the final state of such an env (`handle.get(...)`: the task-slot axis has the larger tile's width).  The
+        capacity flag of the small tile stays readable through `get("ERROR")`.  Blocks until the batch is complete."""
         s = None
         if seeds is not None:
             s = np.ascontiguousarray(np.asarray(seeds, dtype=np.uint64))
             if s.shape != (self.n_envs,):
                 raise ValueError(f"seeds must have shape ({self.n_envs},)")
+        self.escalated = {}
+        self._esc_rows = None
         self._ck(self.L.muavta_rollout(self.h, _vp(s), int(n_steps), int(replan_interval), int(use_visibility), int(write_obs)))
+        if escalate:
+            if s is None:
+                raise ValueError("rollout(escalate=True) re-runs flagged envs from their seeds: pass seeds")
+            self._escalate(s, int(n_steps), int(replan_interval), bool(use_visibility), bool(write_obs))
+
+    TILE_LADDER = ((16, 40, 16), (24, 48, 24), (64, 128, 48))
+
+    def _escalate(self, seeds, n_steps, interval, use_vis, write_obs):
+        idx = np.nonzero(self.get("ERROR"))[0]
+        if not len(idx):
+            return
+        rows = {}
+        rung = next((i for i, (a, t, h) in enumerate(self.TILE_LADDER) if self.A_tile <= a and self.T <= t), len(self.TILE_LADDER))
+        if not hasattr(self, "_esc_handles"):
+            self._esc_handles = {}
+        while len(idx):
+            rung += 1
+            if rung >= len(self.TILE_LADDER):
+                raise MuavtaError(f"envs {idx[:8].tolist()} overflow the largest tile (64 agents x 128 task slots): no tile left to escalate to")
+            a, t, hh = self.TILE_LADDER[rung]
+            h = self._esc_handles.get(rung)
+            if h is None or h.n_envs < len(idx):
+                if h is not None:
+                    h.close()
+                p = MuavtaParams.from_buffer_copy(self.params)
+                p.tile_agents, p.tile_tasks, p.tile_threats = a, t, max(hh, self.H)
+                h = BatchedMultiUAVEnv(p, max(len(idx), 64), device=self.device_index)
+                self._esc_handles[rung] = h
+            h._ck(h.L.muavta_set_allocator(h.h, self._alloc_mode))
+            s2 = np.full(h.n_envs, seeds[idx[0]], dtype=np.uint64)
+            s2[:len(idx)] = seeds[idx]
+            h.rollout(s2, n_steps, interval, use_vis, write_obs)
+            m = h.rollout_metrics()
+            bad = h.get("ERROR")[:len(idx)] != 0
+            for k, i in enumerate(idx):
+                if not bad[k]:
+                    rows[int(i)] = m[k].copy()
+                    self.escalated[int(i)] = (h, k)
+            idx = idx[bad]
+        self._esc_rows = rows
 
     def record_shapes(self, kind: str, n_steps: int, max_tasks: int, max_agents: int):
         """name -> (shape, numpy dtype) of the rings `rollout_record` fills."""
@@ -456,6 +511,9 @@ class BatchedMultiUAVEnv:
     def rollout_metrics(self) -> np.ndarray:
         m = np.empty((self.n_envs, N_METRICS), dtype=np.float64)
         self._ck(self.L.muavta_rollout_metrics(self.h, _vp(m)))
+        if self._esc_rows:  # rollout(escalate=True): rows of the envs that were re-run on a larger tile
+            for i, row in self._esc_rows.items():
+                m[i] = row
         return m
 
     def metrics_dicts(self):

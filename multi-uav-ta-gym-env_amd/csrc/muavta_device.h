@@ -1321,7 +1321,8 @@ struct Sim {
     S.next_task_id = 1;
     S.last_plan_step = -1000000000;
     for (int k = 0; k < T; k++) S.t_id[k] = -1;
-    for (int w = 0; w < KW; w++) S.free_slots[w] = (w == KW - 1 && (T & 31)) ? ((1u << (T & 31)) - 1u) : 0xffffffffu;
+    const int cap = P.slot_cap > 0 && P.slot_cap < T ? P.slot_cap : T;  // (a requested tile_tasks below the tile's slot count caps the live slots)
+    for (int w = 0; w < KW; w++) S.free_slots[w] = cap >= 32 * (w + 1) ? 0xffffffffu : cap > 32 * w ? ((1u << (cap - 32 * w)) - 1u) : 0u;
     for (int h = 0; h < H; h++) { S.h_status[h] = -9; S.h_target[h] = -1; S.h_mission[h] = -1; S.h_intercept[h] = -1; S.h_task_id[h] = -1; S.h_task_slot[h] = -1; }
     for (int a = 0; a < A; a++) { S.a_state[a] = -1; S.a_last_id[a] = -1; S.a_last_slot[a] = -1; S.a_fail[a] = -1; S.a_task_start[a] = -1; S.a_name[a] = -1; S.a_type[a] = 0; }
     // obstacles (:579-583)

@@ -588,6 +588,10 @@ __global__ __launch_bounds__(WG) void k_observe(const DevCtx* __restrict__ ctxp)
   Lds<TL> L(smem);
   copy16(L.S, blob_of<TL>(ctx, env), sizeof(EnvState<TL>));
   lds_sync();
+  // muavta_refresh_observation is the FULL rewrite of the handle's observation buffers: pad rows included, whatever the record
+  // believes they hold (a caller may have touched the zero-copy views of muavta_device_ptrs in place)
+  if (threadIdx.x == 0) L.S->obs_rows = -1;
+  lds_sync();
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, nullptr);
   obs_for_env(sim, ctx.P, obs_ptrs(ctx), env);
   lds_sync();
@@ -836,6 +840,7 @@ struct MuavtaEnv {
   enum { EV_RING = 64 };
   hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};  // ev0[i] .. ev1[i]: the k_rollout launch number i (mod EV_RING)
   unsigned long long n_rollouts = 0;
+  bool timing_stale = false;  // a *_part rollout ran since the last whole-batch one: the event ring describes an older launch
   float last_ms = 0.f;
   bool last_seeded = false;
   bool did_reset = false;
@@ -1278,6 +1283,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   else if (ta <= Tile64::A && tt <= Tile64::T && th <= Tile64::H) e->tile = TK64;
   else { g_create_error = "muavta_create: requested tile exceeds 64 agents x 128 task slots x 48 threats"; delete e; return MUAVTA_E_ARG; }
   size_t scratch_bytes = 0;
+  e->P.slot_cap = (tt > 0 && tt < Tile16::T) ? tt : 0;  // a request below the smallest tile's slot count caps the live slots (0: no cap)
   DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->Q = TL::Q; e->state_bytes = sizeof(EnvState<TL>);
                 e->cold_bytes = sizeof(EnvCold<TL>); scratch_bytes = sizeof(Scratch<TL>); });
   (void)scratch_bytes;
@@ -1294,10 +1300,17 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   // taking the least-loaded queue, and two streams on one queue execute in order.  Created lazily in the middle of a process'
   // life (after the framework's own streams, copy engines ...) two part streams could land on ONE queue: measured r3, two
   // sub-batches ran at 46 M env-steps/s inside bench.py against 70 M in a fresh process, with identical kernels.
-  for (int p = 0; p < MuavtaEnv::MAX_PARTS; p++) {
-    CK(hipStreamCreateWithFlags(&e->part_stream[p], hipStreamNonBlocking));
-    CK(hipEventCreateWithFlags(&e->part_ev[p], hipEventDisableTiming));
-    CK(hipEventRecord(e->part_ev[p], e->part_stream[p]));
+  // (r4) Opt-in: MUAVTA_EAGER_PART_STREAMS=n (0..8, default 0) creates n of them here; the rest are created by muavta_set_parts when
+  // they are first asked for.  A handle that never uses sub-batches owns two streams, not ten.
+  {
+    const char* ev = getenv("MUAVTA_EAGER_PART_STREAMS");
+    int eager = ev ? atoi(ev) : 0;
+    eager = eager < 0 ? 0 : eager > MuavtaEnv::MAX_PARTS ? MuavtaEnv::MAX_PARTS : eager;
+    for (int p = 0; p < eager; p++) {
+      CK(hipStreamCreateWithFlags(&e->part_stream[p], hipStreamNonBlocking));
+      CK(hipEventCreateWithFlags(&e->part_ev[p], hipEventDisableTiming));
+      CK(hipEventRecord(e->part_ev[p], e->part_stream[p]));
+    }
   }
   CK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   const size_t N = (size_t)n_envs, mt = (size_t)e->P.max_tasks, nA = (size_t)e->P.n_agents;
@@ -1619,6 +1632,7 @@ static int rollout_impl(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, in
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1[evi], e->stream));
   e->n_rollouts++;
+  e->timing_stale = false;
   if (slot >= 0) { int rc = seeding_consumed(e, slot); if (rc) return rc; }
   e->did_reset = true;
   e->host_valid = false;
@@ -1654,7 +1668,14 @@ int muavta_set_parts(MuavtaEnv* e, int32_t n_parts) {
   DeviceScope scope_(e->device);
   MAIN_OP(e);  // whatever the old parts hold is ordered in front of the main stream
   if (n_parts == 1) n_parts = 0;
-  for (int p = 0; p < n_parts; p++) { e->part_busy[p] = false; e->part_fork_needed[p] = true; }  // (streams and events exist since muavta_create)
+  for (int p = 0; p < n_parts; p++) {
+    if (!e->part_stream[p]) {  // (not among the MUAVTA_EAGER_PART_STREAMS created by muavta_create)
+      HIPCHK(e, hipStreamCreateWithFlags(&e->part_stream[p], hipStreamNonBlocking));
+      HIPCHK(e, hipEventCreateWithFlags(&e->part_ev[p], hipEventDisableTiming));
+      HIPCHK(e, hipEventRecord(e->part_ev[p], e->part_stream[p]));
+    }
+    e->part_busy[p] = false; e->part_fork_needed[p] = true;
+  }
   if (n_parts && !e->d_part_agent) {
     HIPCHK(e, hipMalloc((void**)&e->d_part_agent, (size_t)e->n_envs * e->A * sizeof(int32_t)));
     HIPCHK(e, hipMalloc((void**)&e->d_part_index, (size_t)e->n_envs * e->A * sizeof(int32_t)));
@@ -1678,6 +1699,7 @@ int muavta_rollout_part(MuavtaEnv* e, int32_t part, int32_t n_steps, int32_t int
   part_range(e, part, &first, &count);
   DISPATCH(e, launch_rollout<TL>(e, nullptr, n_steps, interval, use_vis, write_obs, nullptr, 0, nullptr, e->part_stream[part], first, count));
   HIPCHK(e, hipGetLastError());
+  e->timing_stale = true;  // (part launches carry no event pair: muavta_last_kernel_ms / _history refuse until the next whole-batch rollout)
   e->host_valid = false;
   return MUAVTA_OK;
 }
@@ -1793,6 +1815,8 @@ int muavta_wait_stream(MuavtaEnv* e, void* other_stream) {  // work queued on th
   HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   hipError_t r = hipEventRecord(ev, (hipStream_t)other_stream);
   if (r == hipSuccess) r = hipStreamWaitEvent(e->stream, ev, 0);
+  // sub-batches: a part's stream is ordered after the main stream's work at its next launch (fork_part), so the wait carries over
+  for (int p = 0; p < e->n_parts; p++) e->part_fork_needed[p] = true;
   hipEventDestroy(ev);  // (destruction is deferred by the runtime until the event has completed)
   if (r != hipSuccess) { e->err = std::string("muavta_wait_stream: ") + hipGetErrorString(r); return MUAVTA_E_HIP; }
   return MUAVTA_OK;
@@ -1802,6 +1826,7 @@ int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
   if (!e || !ms) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
   if (!e->n_rollouts) { e->err = "no rollout launched yet"; return MUAVTA_E_STATE; }
+  if (e->timing_stale) { e->err = "muavta_last_kernel_ms: the last rollout was a muavta_rollout_part launch, which records no event pair"; return MUAVTA_E_STATE; }
   const int evi = (int)((e->n_rollouts - 1) % MuavtaEnv::EV_RING);
   HIPCHK(e, hipEventSynchronize(e->ev1[evi]));
   HIPCHK(e, hipEventElapsedTime(ms, e->ev0[evi], e->ev1[evi]));
@@ -1812,6 +1837,7 @@ int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
 int muavta_kernel_ms_history(MuavtaEnv* e, float* ms, int32_t n) {  // durations of the last n rollout launches, oldest first
   if (!e || !ms || n < 1 || n > MuavtaEnv::EV_RING) { if (e) e->err = "muavta_kernel_ms_history: 1 <= n <= 64"; return MUAVTA_E_ARG; }
   if ((unsigned long long)n > e->n_rollouts) { e->err = "fewer rollouts launched than asked for"; return MUAVTA_E_STATE; }
+  if (e->timing_stale) { e->err = "muavta_kernel_ms_history: the last rollout was a muavta_rollout_part launch, which records no event pair"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
   for (int k = 0; k < n; k++) {
     const int evi = (int)((e->n_rollouts - (unsigned long long)n + (unsigned long long)k) % MuavtaEnv::EV_RING);

@@ -54,6 +54,16 @@ def sources():
         os.path.join(os.path.dirname(PKG_DIR), "include", "muavta.h")]
 
 
+def source_hash() -> str:
+    """Hash of the kernel sources: PMC figures under profiles/ are only reused for the build they were taken on (bench.py)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in sources():
+        h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     if not os.path.exists(SO_PATH):
         return True

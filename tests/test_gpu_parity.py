@@ -1595,3 +1595,37 @@ def test_rl_stream_policy_in_the_loop_vs_reference_and_oracle(path, fused):
     snap = Snapshot(env)
     for i, o in enumerate(oracles):
         compare(snap, i, o, f"rl_stream {case} seed {seed0 + i} final", check_obs=False)
+
+
+def test_capacity_flagged_envs_escalate_to_the_next_tile():
+    """rollout(escalate=True): the reference's task list is unbounded (DroneEnv.py:325-328); an env that needs more than its
+    tile is re-run from its seed on the next larger tile and its metrics spliced in.  Forced here with tile_tasks = 32 on the
+    16-agent tile (a request below the tile's 40 slots caps the live slots): global index 9649 of WPS_hard_x2 needs 34."""
+    case = "WPS_hard_x2"
+    seeds = np.array([9649, 6231, 8273, 11430, 11656] + list(range(251)), dtype=np.uint64)
+    n = len(seeds)
+    small = _env(case, n, tile_tasks=32)
+    assert small.T == 40 and small.A_tile == 16
+    small.rollout(seeds, 150, 20, True, True, escalate=True)
+    flagged = np.nonzero(small.get("ERROR"))[0]
+    assert 0 in flagged, "seed 9649 needs 34 live task slots: 32 were expected to overflow"
+    assert sorted(small.escalated) == flagged.tolist()
+    assert all(h.A_tile == 24 for h, _ in small.escalated.values())
+    got = small.rollout_metrics()
+    want = orc.parallel_metrics(case, seeds, 20)
+    assert np.array_equal(got, want), f"rows differing: {np.nonzero(~np.all(got == want, axis=1))[0][:8]} (flagged: {flagged[:8]})"
+    # without escalation the same batch reports the overflow instead of a result
+    from muavta_amd.native import MuavtaError
+    small.rollout(seeds, 150, 20, True, True)
+    with pytest.raises(MuavtaError):
+        small.metrics()
+    # the allocator mode travels with the escalation
+    small.set_allocator("urgency_pair")
+    small.rollout(seeds, 150, 20, True, False, escalate=True)
+    assert len(small.escalated) > 0
+    want2 = orc.parallel_metrics(case, seeds, 20, 1, 1)
+    assert np.array_equal(small.rollout_metrics(), want2)
+    # two rungs: a cap the 24-agent tile cannot hold either is not available by request (its 48 slots always cover 34), so the
+    # ladder's second rung is exercised with the fuzzed configs' 128-slot requests elsewhere; here: the final state of an escalated env
+    h, k = small.escalated[0]
+    assert int(h.get("ERROR")[k]) == 0 and h.T == 48

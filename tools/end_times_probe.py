@@ -23,7 +23,7 @@ assert env.L.muavta_diag_times(env.h, out.ctypes.data_as(C.c_void_p), n) == 0
 t0 = out[0].min()
 start, end, hw = (out[0] - t0) * 1e-5, (out[1] - t0) * 1e-5, out[2]   # ms
 simd = (hw >> 4) & 0xFFF | ((hw >> 16) << 12)
-print(f"{case} {n} envs: kernel {env.last_kernel_ms():.3f} ms; steps run per env: mean {env.rollout_metrics()[:, 8].mean():.1f}")
+print(f"{case} {n} envs: kernel {env.last_kernel_ms():.3f} ms; mean makespan metric (conclusion_time: max_time_steps + 1 when the mission never concluded; every env ran all 150 steps) {env.rollout_metrics()[:, 8].mean():.1f}")
 print("wave start  ms: min %.3f  median %.3f  max %.3f" % (start.min(), np.median(start), start.max()))
 q = np.percentile(end, [0, 5, 25, 50, 75, 95, 99, 100])
 print("wave end    ms: min %.3f  p5 %.3f  p25 %.3f  median %.3f  p75 %.3f  p95 %.3f  p99 %.3f  max %.3f" % tuple(q))

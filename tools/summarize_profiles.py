@@ -8,10 +8,10 @@ per-env HBM record and single-lane tape words — stated as uncalibrated in DESI
 import csv, glob, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
-from bench import source_hash
+from muavta_amd.native import source_hash  # (not from bench: importing bench sets process-wide HIP runtime knobs)
 for src in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*"))):
     case = os.path.basename(src)
     ks = sorted(glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # (gpurun merges: newest collection first)
@@ -34,13 +34,14 @@ for src in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", "*")
             if "k_rollout" not in r["Kernel_Name"]:
                 continue
             own.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            if not meta:  # launch geometry / register figures of a k_rollout row (NOT of whatever kernel the CSV happens to end with)
+                meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count") if k in r}
             if sub == "sq4" and r["Counter_Name"] in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU"):
                 continue  # (already collected in sq1 / sq2; here only as the same-pass denominators of the lane figure below)
             pmc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         if sub == "sq4" and "SQ_THREAD_CYCLES_VALU" in own and "SQ_ACTIVE_INST_VALU" in own:
             # rocprofv3's VALUUtilization: thread-cycles / (instruction cycles x 64) — mean share of the 64 lanes a VALU instruction has enabled
             lanes = 64.0 * sum(own["SQ_THREAD_CYCLES_VALU"]) / (sum(own["SQ_ACTIVE_INST_VALU"]) * 64.0)
-            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     json.dump(bench, open(os.path.join(dst, f"{tag}_{case}_bench.json"), "w"), indent=1)
     envs = bench["config"]["envs_per_gpu"]
