@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 # sub-batch figure (fused_step_api, muavta_set_parts) wants the part streams on queues of their own next to torch's and the handle's
 # main / seeding streams.  A runtime knob of the HIP runtime, read when it initialises; a value the caller exported wins.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("MUAVTA_EAGER_PART_STREAMS", "4")  # (muavta_create opens the sub-batch streams it will be asked for right behind its main streams: INTEGRATION.md)
+os.environ.setdefault("MUAVTA_EAGER_PART_STREAMS", "8")  # (muavta_create opens the sub-batch streams it will be asked for right behind its main streams: INTEGRATION.md)
 
 HORIZON = 150
 # algorithmic bytes per env-step B(A,T,H) = 2*S_state + S_obs + S_act, by agent count of the tile
@@ -210,10 +210,12 @@ def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
     env.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    gaps = env.launch_gaps_ms(min(pending, 64)).tolist() if pending >= 2 else []
     if pending:
         kernel_ms.extend(env.kernel_ms_history(pending).tolist())
     if not seed_ms:
         seed_ms.append(env.last_seed_ms())
+    time_rollouts.last_gap_ms = float(np.mean(gaps)) if gaps else None   # start(i + 1) - end(i) on the handle's stream, from the same event ring
     return elapsed, float(np.mean(kernel_ms)), float(np.mean(seed_ms))
 
 
@@ -315,6 +317,7 @@ def main():
         torch.cuda.synchronize()
 
     elapsed, mean_kernel_ms, mean_seed_ms = time_rollouts(env, seeds, args.interval, write_obs, args.steps, args.warmup, barrier)
+    launch_gap_ms = getattr(time_rollouts, "last_gap_ms", None)
     if args.inflight > 1:  # the timed region again, launches alternating between `inflight` handles of this rank (the first one above gave the isolated kernel time)
         others = [BatchedMultiUAVEnv(params_for_case(args.case), args.envs, device=local_rank) for _ in range(args.inflight - 1)]
         elapsed, _ = time_rollouts_in_flight([env] + others, seeds, args.interval, write_obs, args.steps, args.warmup, barrier)
@@ -360,6 +363,11 @@ def main():
                                       + (" (muavta_allreduce_metrics)" if args.abi_collective else " (torch.distributed nccl backend)" if dist is not None else "")},
             "roofline": roofline(args.case, args.envs, env.dims.tile_agents, mean_kernel_ms),
             "seed_kernel_ms": mean_seed_ms,
+            # where ms_per_step goes: the k_rollout launch itself (roofline.kernel_ms), the gap to the next launch on the handle's stream
+            # (command processing + waiting for the next batch's seeding, from the same HIP event ring), and what is left: the host's
+            # closing synchronisation and barrier, amortised over `steps` launches
+            "launch_gap_ms": launch_gap_ms,
+            "ms_per_step_unaccounted": (elapsed / args.steps * 1e3 - mean_kernel_ms - launch_gap_ms) if (launch_gap_ms is not None and args.inflight == 1) else None,
             # launches are queued back to back, so launch i+1's seeding (upload + k_seed on a second stream) runs under launch i's
             # tail; an isolated batch pays k_seed in front of the rollout kernel:
             "value_unpipelined": total_envs * HORIZON / ((mean_kernel_ms + mean_seed_ms) * 1e-3),
@@ -384,6 +392,11 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     from muavta_amd.params import params_for_case
 
     out = {}
+
+    def mark(what):
+        print(f"[bench] {what}", file=sys.stderr, flush=True)
+
+    mark("step_api")
     # step_api: one k_allocate + one k_step launch per env step (a caller that looks at the plan);
     # fused_step_api: muavta_rollout(h, NULL, 1, ...) = allocate + step + observe in ONE launch per env step.
     env.reset(seeds)
@@ -405,6 +418,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     # env step, all asynchronous — a part's launch still ends on its slowest env, but the other parts' launches fill the device
     # meanwhile (and a host-side planner would decide for one part while the others are being stepped)
     for parts in (2, 3, 4):
+        mark(f"fused step api, {parts} parts")
         env.set_parts(parts)
         rate = 0.0
         for rep in range(2):  # (the first pass also creates the part streams and takes their first launches)
@@ -427,6 +441,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
                                 "(muavta_rollout_part); 150 env steps of the whole batch, host-timed")
     # the same one-launch-per-step path with 8x the envs per launch (BASELINE config 3's 32768 on one GPU): a launch ends on its
     # slowest env (one that replans: ~80 us against a 24 us mean step), so a wider batch amortises that tail
+    mark("fused step api, wide batch")
     try:
         n_wide = 8 * args.envs
         ew = BatchedMultiUAVEnv(params_for_case(args.case), n_wide, device=env.device_index)
@@ -448,6 +463,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     # obs_ring: the fused rollout in launches of K steps whose per-step observations (+ reward, done) land in slot t of device
     # rings [K][N][...] (muavta_rollout_record) instead of overwriting one buffer — every step's observation stays readable by
     # a consumer on the device, at K steps per launch instead of one
+    mark("observation rings")
     try:
         import torch
 
@@ -476,6 +492,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     env.rollout(seeds, HORIZON, args.interval, True, write_obs)  # restore the headline batch's final state
     env.sync()
     # the trainers' data loop: samples = (env, step) pairs with token tensors + expert labels + step reward
+    mark("il rings / il stream")
     try:
         from muavta_amd.il import il_record, il_stream
 
@@ -501,6 +518,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     # the RL trainers' loop with the policy IN the loop (RL half; experiments/train_pair_cost.py:132-156): per env step
     # one muavta_rl_step_device launch = Hungarian with the caller's edge scores under the trainer's gate -> env.step -> S_WPS before /
     # after -> next tokens.  The "policy" here is a fixed seeded score tensor on the GPU, so the figure times the env side of the loop.
+    mark("policy in the loop")
     try:
         import torch
 
@@ -539,6 +557,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
         out["policy_in_loop_error"] = repr(exc)
     # two handles in flight (each its own stream and blobs, same seeds): launches alternate A, B, A, B, so batch i+1's workgroups start in
     # the wave slots batch i's early finishers free; both handles' batches are checked bit-equal to the headline batch
+    mark("two handles in flight")
     try:
         env.rollout(seeds, HORIZON, args.interval, True, write_obs)
         env.sync()
@@ -552,6 +571,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     if args.case == "WPS_hard_x2":
         tiles = {}
         for case, n, interval in OTHER_TILES:
+            mark(f"other tile {case}")
             e2 = BatchedMultiUAVEnv(params_for_case(case), n, device=env.device_index)
             s2 = np.arange(n, dtype=np.uint64)
             el, kms, sms = time_rollouts(e2, s2, interval, True, 5, 2, barrier)

@@ -486,6 +486,9 @@ int muavta_last_kernel_ms(MuavtaEnv* env, float* ms);
  * caller can queue launches back to back — the seeding of launch i+1 then overlaps launch i — and read the per-launch
  * durations afterwards.  Blocks until the newest of them has finished. */
 int muavta_kernel_ms_history(MuavtaEnv* env, float* ms, int32_t n);
+/* The gaps BETWEEN the last n rollout launches (2 <= n <= 64): ms[k] = start of launch k + 1 minus end of launch k on the handle's
+ * stream, n - 1 values, oldest first — what a queue of back-to-back launches loses to command processing / seeding waits. */
+int muavta_launch_gaps_ms(MuavtaEnv* env, float* ms, int32_t n);
 /* Same for the RNG seeding kernel (CPython init_by_array of the four random.Random streams per env,
  * DroneEnv.py:531-538) that ran in front of that rollout; 0 when the rollout continued without seeds. */
 int muavta_last_seed_ms(MuavtaEnv* env, float* ms);  /* (seed upload + k_seed run on a second stream of the handle: when launches

@@ -479,6 +479,12 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_kernel_ms_history(self.h, _vp(out), int(n)))
         return out
 
+    def launch_gaps_ms(self, n: int) -> np.ndarray:
+        """Idle time (ms) of the handle's stream between the last n rollout launches: n - 1 gaps, oldest first."""
+        out = np.empty(int(n) - 1, dtype=np.float32)
+        self._ck(self.L.muavta_launch_gaps_ms(self.h, _vp(out), int(n)))
+        return out
+
     def last_seed_ms(self) -> float:
         ms = C.c_float()
         self._ck(self.L.muavta_last_seed_ms(self.h, C.byref(ms)))

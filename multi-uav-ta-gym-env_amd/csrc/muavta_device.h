@@ -3417,7 +3417,8 @@ struct Sim {
         }
       }
       // no pair under the acceptance threshold -> the round accepts nothing whatever the assignment is
-      if (__ballot(feasible) == 0ull) break;
+      PROF_COUNT(62, 1000 * Rr);
+      if (__ballot(feasible) == 0ull) { PROF_COUNT(63, 1000 * Rr); break; }
       lds_sync();
       PROF(12);
       if (reg_cols) lsap_reg_solve(Rr, Cc, [&](int i) -> double { return col.get(i); });

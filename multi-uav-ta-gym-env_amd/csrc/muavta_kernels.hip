@@ -219,7 +219,7 @@ DEV uint32_t seed_output(const uint32_t* mt, int i) {
 // stream seeds (Random.randint(0, 2^63-1) == _randbelow(2^63): getrandbits(64) until < 2^63, in the order obs, tgt, mission,
 // DroneEnv.py:535-538); phase 2: the obs / tgt / mission lanes run theirs, the seeds handed over by a lane shuffle.  No LDS and
 // ~40 VGPRs: the waves find room next to a running rollout, so the seeding of the NEXT launch overlaps all of this one.
-__global__ __launch_bounds__(WG) void k_seed(const uint64_t* seeds, int n, int with_obs, uint32_t* seedbuf, uint32_t* seedtmp) {
+__global__ __launch_bounds__(WG, 8) void k_seed(const uint64_t* seeds, int n, int with_obs, uint32_t* seedbuf, uint32_t* seedtmp) {
   const int lane = threadIdx.x, el = lane >> 2, st = lane & 3;
   const int e = blockIdx.x * 16 + el;
   uint32_t* mt = seedbuf + ((size_t)blockIdx.x * WG + lane) * 624;  // [N][4][624]: this lane's stream
@@ -411,6 +411,9 @@ struct RecordPtrs {
   ObsPtrs O;       // O.tasks == nullptr: no observation rings
   int n_envs;
 };
+struct RecBlob { uint32_t w[64]; };  // 256 B: a RecordPtrs<TL> by value
+__global__ void k_store_rec(RecBlob b, uint32_t* dst) { dst[threadIdx.x] = b.w[threadIdx.x]; }
+
 template <class TL, bool REC>
 __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned char* lds_own, uint32_t lds_base, int env, int phases, int interval, int use_vis, int mode,
                                                 const RecordPtrs<TL>& rec, int slot, int oslot) {
@@ -452,8 +455,15 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned cha
 
 template <class TL, bool REC>
 __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx* __restrict__ ctxp, const uint64_t* seeds, int n_steps, int interval, int use_vis,
-                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf, RecordPtrs<TL> rec, int epoch, int env_base) {
+                                                int mode, int write_obs, double* metrics, const uint32_t* seedbuf, const RecordPtrs<TL>* __restrict__ recp, int epoch, int env_base) {
   const DevCtx& ctx = ctx_ref(ctxp);
+  // The ring pointers of muavta_rollout_record sit in device memory (one slot per handle, written on the launch's stream just ahead of
+  // it) and are read through the scalar cache where they are used, like the context: as by-value kernel arguments they were ~40
+  // SGPRs that the recording variants kept alive across the whole step loop (r3: 176-181 SGPR spills, 8 spilled VGPRs + 48 B of
+  // scratch on the 24-agent tile).  The plain rollout gets the handle's all-zero slot and never reads it.
+  const uint32_t rec_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)recp), rec_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)recp >> 32));
+  // (unsigned halves: v_readfirstlane returns int, and a low word with bit 31 set would sign-extend into the high word)
+  const RecordPtrs<TL>& rec = *(const RecordPtrs<TL>*)(const AS4 RecordPtrs<TL>*)(((uint64_t)rec_hi << 32) | (uint64_t)rec_lo);
   const int env = env_base + blockIdx.x;
   KERNEL_LDS(TL);
   Lds<TL> L(lds_own);
@@ -817,6 +827,8 @@ struct MuavtaEnv {
   DevCtx* d_ctx = nullptr;  // device copy of {P, O, tapes}
   uint32_t* d_pace = nullptr;
   uint32_t pace_epoch = 0;
+  enum { REC_SLOT = 256 };
+  void* d_rec = nullptr;  // [2][REC_SLOT]: slot 0 all zero (plain rollouts), slot 1 the RecordPtrs of the muavta_rollout_record launch in flight
   uint64_t* d_seeds[2] = {nullptr, nullptr};
   int32_t *d_act_agent = nullptr, *d_act_index = nullptr, *d_call_out = nullptr;
   int32_t *d_list_agent = nullptr, *d_list_index = nullptr;  // muavta_step_lists rows [N][list_cap] (grown on demand)
@@ -1339,6 +1351,8 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
     CK(hipMalloc((void**)&e->d_pace, (size_t)PACE_KEYS * 16 * sizeof(uint32_t)));
     CK(hipMemsetAsync(e->d_pace, 0, (size_t)PACE_KEYS * 16 * sizeof(uint32_t), e->stream));  // epoch 0 is never issued
     h.P = e->P; h.O = e->O; h.tapes = e->tapes; h.blobs = e->blobs; h.cold = e->cold; h.pace = e->d_pace;
+    CK(hipMalloc(&e->d_rec, 2 * MuavtaEnv::REC_SLOT));
+    CK(hipMemsetAsync(e->d_rec, 0, 2 * MuavtaEnv::REC_SLOT, e->stream));
     CK(hipMalloc((void**)&e->d_ctx, sizeof(DevCtx)));
     CK(hipMemcpyAsync(e->d_ctx, &h, sizeof(DevCtx), hipMemcpyHostToDevice, e->stream));
     CK(hipStreamSynchronize(e->stream));  // `h` is a stack object
@@ -1363,7 +1377,7 @@ int muavta_destroy(MuavtaEnv* e) {
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
   hipFree(e->d_part_agent); hipFree(e->d_part_index);
   if (e->stream) hipStreamSynchronize(e->stream);
-  if (e->d_seedtmp) hipFree(e->d_seedtmp); hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); if (e->d_list_agent) hipFree(e->d_list_agent); if (e->d_list_index) hipFree(e->d_list_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
+  if (e->d_seedtmp) hipFree(e->d_seedtmp); hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); if (e->d_rec) hipFree(e->d_rec); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); if (e->d_list_agent) hipFree(e->d_list_agent); if (e->d_list_index) hipFree(e->d_list_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
   for (int i = 0; i < MuavtaEnv::EV_RING; i++) { if (e->ev0[i]) hipEventDestroy(e->ev0[i]); if (e->ev1[i]) hipEventDestroy(e->ev1[i]); }
   for (int b = 0; b < 2; b++) {
@@ -1607,11 +1621,19 @@ static void launch_rollout(MuavtaEnv* e, const uint64_t* ds, int n_steps, int in
       R.O.flags = rec->obs_flags; R.O.reward = rec->obs_reward; R.O.done = rec->obs_done;
     }
     R.n_envs = e->n_envs;
+    static_assert(sizeof(RecordPtrs<TL>) <= MuavtaEnv::REC_SLOT, "record-pointer slot too small");
+    // The slot is filled by a one-lane kernel that takes the struct BY VALUE (kernel arguments are captured when the launch is queued)
+    // — stream-ordered behind the previous launch that read the slot.  NOT hipMemcpyAsync from this stack frame: for pageable memory the
+    // runtime may pin the pages and copy after the call has returned, by when the frame is gone (first r4 build: wild ring pointers).
+    RecBlob blob;
+    memset(&blob, 0, sizeof(blob));
+    memcpy(&blob, &R, sizeof(R));
+    hipLaunchKernelGGL(k_store_rec, dim3(1), dim3(64), 0, stream, blob, (uint32_t*)((char*)e->d_rec + MuavtaEnv::REC_SLOT));
     hipLaunchKernelGGL((k_rollout<TL, true>), dim3(n_launch), dim3(WG), extra_lds, stream, (const DevCtx*)e->d_ctx, ds,
-                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch, env_base);
+                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, (const RecordPtrs<TL>*)((char*)e->d_rec + MuavtaEnv::REC_SLOT), epoch, env_base);
   } else {
     hipLaunchKernelGGL((k_rollout<TL, false>), dim3(n_launch), dim3(WG), extra_lds, stream, (const DevCtx*)e->d_ctx, ds,
-                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, R, epoch, env_base);
+                       n_steps, interval, use_vis, e->alloc_mode, write_obs, e->d_metrics, sb, (const RecordPtrs<TL>*)e->d_rec, epoch, env_base);
   }
 }
 extern "C" {
@@ -1845,6 +1867,19 @@ int muavta_kernel_ms_history(MuavtaEnv* e, float* ms, int32_t n) {  // durations
     HIPCHK(e, hipEventElapsedTime(&ms[k], e->ev0[evi], e->ev1[evi]));
   }
   e->last_ms = ms[n - 1];
+  return MUAVTA_OK;
+}
+
+int muavta_launch_gaps_ms(MuavtaEnv* e, float* ms, int32_t n) {  // idle time of the handle's stream between the last n rollout launches: n - 1 gaps, oldest first
+  if (!e || !ms || n < 2 || n > MuavtaEnv::EV_RING) { if (e) e->err = "muavta_launch_gaps_ms: 2 <= n <= 64"; return MUAVTA_E_ARG; }
+  if ((unsigned long long)n > e->n_rollouts) { e->err = "fewer rollouts launched than asked for"; return MUAVTA_E_STATE; }
+  if (e->timing_stale) { e->err = "muavta_launch_gaps_ms: the last rollout was a muavta_rollout_part launch, which records no event pair"; return MUAVTA_E_STATE; }
+  DeviceScope scope_(e->device);
+  for (int k = 0; k + 1 < n; k++) {
+    const int a = (int)((e->n_rollouts - (unsigned long long)n + (unsigned long long)k) % MuavtaEnv::EV_RING), b = (a + 1) % MuavtaEnv::EV_RING;
+    HIPCHK(e, hipEventSynchronize(e->ev0[b]));
+    HIPCHK(e, hipEventElapsedTime(&ms[k], e->ev1[a], e->ev0[b]));  // end of launch i .. start of launch i + 1
+  }
   return MUAVTA_OK;
 }
 

@@ -59,7 +59,7 @@ for i in range(48):
     if v[i] == 0: continue
     print(f"  {str(names.get(i, i)):40s} {100 * v[i] / tot:6.2f} %   {v[i] / n / 150:9.0f} cyc/step")
 cnames = ["LSAP solves", "LSAP scan steps (inner iterations)", "LSAP rows (sum)", "LSAP columns (sum)", "replans (allocate ran)", "releaseAllTasks calls",
-          "threat passes", "threat events (serial replays)", "escort syncs with entries", "escort map entries (sum)", "escort sync loop iterations", "", "", "", "", "",
+          "threat passes", "threat events (serial replays)", "escort syncs with entries", "escort map entries (sum)", "escort sync loop iterations", "", "", "", "cost-build rows (sum over rounds)", "... of rounds that turned out infeasible (no solve)",
           "end-of-step slow path entered", "... with retired slots present", "movement passes", "movement events"]
 for i, nm in extra.items():
     if counts[i - 48]: print(f"  {nm:40s} {100 * counts[i - 48] / tot:6.2f} %   {counts[i - 48] / n / 150:9.0f} cyc/step   (cycles; part of the slot named in brackets)"); counts[i - 48] = 0
