@@ -1629,3 +1629,57 @@ def test_capacity_flagged_envs_escalate_to_the_next_tile():
     # ladder's second rung is exercised with the fuzzed configs' 128-slot requests elsewhere; here: the final state of an escalated env
     h, k = small.escalated[0]
     assert int(h.get("ERROR")[k]) == 0 and h.T == 48
+
+
+def _scored_soak_worker(args):
+    """oracle side of test_scored_allocator_soak: the same per-(seed, step) pseudo-random planner inputs, one env at a time"""
+    case, seeds, n_steps, kind, mt, ma, gate, oflags, interval = args
+    import numpy as _np
+    o = orc.OracleEnv(params_for_case(case))
+    out = _np.zeros((len(seeds), 30))
+    for i, sd in enumerate(seeds):
+        o.reset(int(sd))
+        for t in range(n_steps):
+            sc, pri, res = _scored_soak_inputs(int(sd), t, mt, ma, o.A)
+            oa, oi, _ = o.allocate_scored(interval, 1, gate, kind, mt, ma, oflags, scores=sc, pri=pri, reserved=res)
+            if o.step(oa, oi):
+                break
+        out[i] = o.metrics()
+    return out
+
+
+def _scored_soak_inputs(seed, t, mt, ma, n_agents):
+    rng = np.random.default_rng([seed, t, 77])
+    sc = (rng.uniform(-1, 1, (ma, mt)) * 0.35).astype(np.float32)
+    pri = rng.uniform(0, 1, mt)
+    bits = rng.integers(0, 8, n_agents) == 0  # each agent reserved with probability 1/8
+    res = int(sum(1 << int(a) for a in np.nonzero(bits)[0]))
+    return sc, pri, res
+
+
+@pytest.mark.parametrize("case,kname,kind,mt,ma,gate,kw,oflags,interval,n", [
+    ("WPS_hard_x2", "pair", 0, 32, 16, "trainer", dict(edge_valid_only=True), 1, 20, 384),
+    ("WPS_burst64", "pair", 0, 32, 16, "allocator", dict(edge_valid_only=True, full_task_list=True), 3, 20, 96),
+    ("WPS_escort", "escort", 2, 32, 16, "escort", dict(edge_valid_only=False, commit=True), 4, 12, 128)])
+def test_scored_allocator_soak(case, kname, kind, mt, ma, gate, kw, oflags, interval, n):
+    """whole episodes of many seeds with per-step pseudo-random scores + priorities + reserved agents: final metrics vs the oracle"""
+    import multiprocessing as mp
+
+    env = _env(case, n)
+    seeds = np.arange(5000, 5000 + n, dtype=np.uint64)
+    env.reset(seeds)
+    A = env.n_agents
+    for t in range(150):
+        ins = [_scored_soak_inputs(int(sd), t, mt, ma, A) for sd in seeds]
+        sc = np.stack([x[0] for x in ins]); pri = np.stack([x[1] for x in ins]); res = np.array([x[2] for x in ins], dtype=np.uint64)
+        env.allocate_scored(kname, mt, ma, edge_scores=sc, task_pri=pri, reserved=res, gate=gate, replan_interval=interval, want_selected=False, fetch=False, **kw)
+        env.step_staged()
+    assert not env.get("ERROR").any()
+    got = env.metrics()
+    orc.lib()
+    procs = 8
+    chunk = (n + procs - 1) // procs
+    jobs = [(case, seeds[i:i + chunk].tolist(), 150, kind, mt, ma, GATE[gate], oflags, interval) for i in range(0, n, chunk)]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        want = np.concatenate(pool.map(_scored_soak_worker, jobs), axis=0)
+    assert np.array_equal(got, want), f"{case}: rows differing {np.nonzero(~np.all(got == want, axis=1))[0][:8]}"
