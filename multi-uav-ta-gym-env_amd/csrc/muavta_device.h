@@ -301,6 +301,13 @@ struct Sim {
   }  // after the blob was (re)loaded or reset behind this object's back
 
   DEV void fail(int code) { if (S.error == 0) S.error = code; }
+  // S.obs_rows = (rows of the handle's task tensor from which on pad rows are known to be there) | OBS_STATIC, or -1 (unknown).
+  // OBS_STATIC: the columns of rows [0, n_open) that only change with a task's requirement / allocation vectors or with the open list
+  // itself (id, current_reqs, alloc_reqs, type, unmet) are up to date in the handle's buffer; the observation writer then only
+  // rewrites the columns that move every step (position, status, init / end time, age).  Cleared by everything that changes
+  // allocatedReqs (the times_dirty sites), currentReqs, orgReqs, or the open list.  Any lane may clear it (same value).
+  enum { OBS_STATIC = 1 << 16 };
+  DEV void obs_static_clear() { const int v = S.obs_rows; if (v > 0) S.obs_rows = v & (OBS_STATIC - 1); }
   DEV double speed_of(int t) const {  // P.speed[t] without a memory access for a per-lane t
     return t == 0 ? P.speed[0] : t == 1 ? P.speed[1] : t == 2 ? P.speed[2] : t == 3 ? P.speed[3] : t == 4 ? P.speed[4]
          : t == 5 ? P.speed[5] : P.speed[6];
@@ -480,7 +487,7 @@ struct Sim {
     if (S.t_status[s] == 2) return;
     for (int c = 0; c < 6; c++) C.t_alloc[c][s] -= S.a_caps[c][a];
     S.t_ndet[s] -= 1;
-    S.times_dirty = 1;
+    S.times_dirty = 1; obs_static_clear();
   }
   // UAV.desAllocate (DroneEnvComponents.py:97-113) for a task id that IS in the queue at position k.
   DEV void des_allocate_at(int a, int k) {
@@ -558,7 +565,7 @@ struct Sim {
     qs().a_nfy[a] = S.t_py[s];
     // Task.addAgentCap (DroneEnvComponents.py:306-326); status != 2 checked above
     S.t_ndet[s] += 1;
-    S.times_dirty = 1;
+    S.times_dirty = 1; obs_static_clear();
     for (int c = 0; c < 6; c++) C.t_alloc[c][s] += S.a_caps[c][a];
     S.t_status[s] = 1;
     return true;
@@ -687,6 +694,7 @@ struct Sim {
     S.t_px[s] = x; S.t_py[s] = y;
     for (int c = 0; c < 6; c++) { C.t_cur[c][s] = 0; C.t_alloc[c][s] = 0; }
     C.t_cur[type][s] = req;
+    obs_static_clear();
     qs().t_org[s] = req; qs().t_done[s] = 0;
     C.t_init[s] = -1; C.t_dtime[s] = -1;
     S.t_status[s] = 0; S.t_type[s] = type; S.t_created[s] = 0; S.t_deadline[s] = -1; S.t_required[s] = 0;
@@ -824,7 +832,7 @@ struct Sim {
 #pragma unroll
       for (int c = 0; c < 6; c++) C.t_alloc[c][s] = al[c];
       S.t_ndet[s] -= nd;
-      S.times_dirty = 1;
+      S.times_dirty = 1; obs_static_clear();
     }
     S.t_status[s] = 2;
     int recon = S.t_prot_agent[s];
@@ -888,7 +896,7 @@ struct Sim {
 #pragma unroll
         for (int c = 0; c < 6; c++) C.t_alloc[c][s] = al[c];
         S.t_ndet[s] -= __popcll(cm);
-        S.times_dirty = 1;
+        S.times_dirty = 1; obs_static_clear();
       }
       S.t_status[s] = 2;
       S.esc_mask &= ~(1ull << recon);  // (== S.t_prot_agent[s]: the map is keyed by the protected UAV)
@@ -1100,7 +1108,7 @@ struct Sim {
 #pragma unroll
           for (int c = 0; c < 6; c++) C.t_alloc[c][sl] = al[c];
           S.t_ndet[sl] -= nd;
-          S.times_dirty = 1;
+          S.times_dirty = 1; obs_static_clear();
         }
       }
     } else if (lane == 0) {
@@ -1867,7 +1875,7 @@ struct Sim {
           S.t_status[s] = 1;
         }
       }
-      if (lane == 0) S.times_dirty = 1;
+      if (lane == 0) S.times_dirty = 1; obs_static_clear();
     }
     const int n_re = __popcll(__ballot(realloc));
     if (lane == 0 && n_re) { S.n_reallocations += n_re; S.n_task_switches += n_re; }
@@ -2068,11 +2076,12 @@ struct Sim {
               qs().t_done[cs] = done_cs;
 #pragma unroll
               for (int c = 0; c < 6; c++) C.t_cur[c][cs] = cur6[c] - S.a_caps[c][a];
+              obs_static_clear();
               if (was_head && S.t_status[cs] != 2) {  // remove_agent_cap(cs, a)
 #pragma unroll
                 for (int c = 0; c < 6; c++) C.t_alloc[c][cs] = al6[c] - S.a_caps[c][a];
                 S.t_ndet[cs] -= 1;
-                S.times_dirty = 1;
+                S.times_dirty = 1; obs_static_clear();
               }
               if (done_cs >= org_cs) {
                 const bool esc = S.t_flags[cs] & TF_ESCORT;
@@ -2199,6 +2208,7 @@ struct Sim {
             if (s >= 0) {
               C.t_cur[MUAVTA_ATT][s] = defence * 2;
               C.t_cur[MUAVTA_DEF][s] = attack * 2;
+              obs_static_clear();
               S.t_threat[s] = h;
               S.t_created[s] = tnow;
               if (ty == MUAVTA_T1) { S.t_required[s] = 2; S.t_flags[s] |= TF_ELIGIBLE; S.t_elig[s] = P.escort_mask; }
@@ -2732,8 +2742,9 @@ struct Sim {
       PROF(35);
     }
     {  // compact t_order (drop freed slots) and rebuild last_tasks_info (:492) with ballot + popcount
-      const int n = S.n_order;
+      const int n = S.n_order, no_old = S.n_open;
       int w = 0, no = 0;
+      bool moved = false;  // some row of last_tasks_info holds another task than before (the observation rows' static columns follow the list)
       for (int base = 0; base < n; base += WG) {
         const int k = base + lane;
         int s = -1;
@@ -2747,11 +2758,16 @@ struct Sim {
         const unsigned long long below = (1ull << lane) - 1ull;
         lds_sync();  // every lane has read its t_order entry before any is overwritten
         if (alive) S.t_order[w + prefix_count(am)] = s;
-        if (open) { const int row = no + prefix_count(om); S.open_slot[row] = s; S.t_row[s] = (uint8_t)row; }
+        if (open) {
+          const int row = no + prefix_count(om);
+          moved |= row >= no_old || (int)S.open_slot[row] != s;  // (a row is only ever rewritten by the lane that holds its new content: rows ascend with k)
+          S.open_slot[row] = s; S.t_row[s] = (uint8_t)row;
+        }
         w += __popcll(am);
         no += __popcll(om);
       }
-      if (lane == 0) { S.n_order = w; S.n_open = no; S.n_act = 0; }
+      const bool list_changed = __ballot(moved) != 0ull || no != no_old;
+      if (lane == 0) { S.n_order = w; S.n_open = no; S.n_act = 0; if (list_changed) obs_static_clear(); }
     }
     lds_sync();
   }
@@ -2866,13 +2882,19 @@ struct Sim {
     cold_sync();  // the rows below read the requirement vectors the serial phases of this step may have changed
     const int MT = P.max_tasks, nA = P.n_agents;
     const int n = __builtin_amdgcn_readfirstlane(S.n_open);
-    const int pad_known = handle_buffer ? __builtin_amdgcn_readfirstlane(S.obs_rows) : -1;
+    const int obs_state = handle_buffer ? __builtin_amdgcn_readfirstlane(S.obs_rows) : -1;
+    const int pad_known = obs_state < 0 ? -1 : (obs_state & (OBS_STATIC - 1));
     const int pad_until = pad_known < 0 ? MT : pad_known;  // pad rows below this index have to be (re)written
+    // (r4) LIGHT pass: the handle's buffer already holds the static columns of every open row (OBS_STATIC: no requirement /
+    // allocation vector and no open-list change since the last write) — only the columns that move every step are rewritten:
+    // position (Int and escort tasks follow their threat / UAV), status, init / end time (relative to t), age.  6 stores and 2
+    // HBM operands per row instead of 21 and 16.
+    const bool light = o_tasks != nullptr && obs_state > 0 && (obs_state & OBS_STATIC) != 0;
     // The HBM rows of the first 64 observation rows are requested NOW, so that their latency runs under the rebuild of the
     // task times below (LDS work); (initTime, doneTime) then come from the scratch tile when they were rebuilt.
     double pc[6], pa[6], pti = 0, ptd = 0;
     const bool dirty = __builtin_amdgcn_readfirstlane(S.times_dirty) != 0;  // (uniform: a scalar branch picks LDS or HBM below, not a per-lane pointer select)
-    if (MUAVTA_OBS_PREFETCH) {
+    if (MUAVTA_OBS_PREFETCH && !light) {
       const int s0 = lane < n ? (int)S.open_slot[lane] : 0;
 #pragma unroll
       for (int c = 0; c < 6; c++) { pc[c] = lane < n ? C.t_cur[c][s0] : 0.0; pa[c] = lane < n ? C.t_alloc[c][s0] : 0.0; }
@@ -2898,6 +2920,20 @@ struct Sim {
         const int tid = S.t_id[s];
         ty = S.t_type[s];
         typemask = (S.t_flags[s] & TF_ELIGIBLE) ? S.t_elig[s] : 0xffffffffu;
+        if (light) {  // (uniform)
+          const double ti = C.t_init[s], td = C.t_dtime[s];  // (OBS_STATIC implies the task times are not dirty)
+          if (P.saturate_mask && C.t_alloc[ty][s] >= qs().t_org[s]) typemask = 0;
+          uint32_t off = ju * 4u;
+          const uint32_t cstride = (uint32_t)MT * 4u;
+          at_lane(o_tasks, off + cstride) = (float)div_small(S.t_px[s], MAX_COORD, INV_COORD);
+          at_lane(o_tasks, off + 2u * cstride) = (float)div_small(S.t_py[s], MAX_COORD, INV_COORD);
+          at_lane(o_tasks, off + 3u * cstride) = (float)S.t_status[s];
+          if (P.include_time_windows) {
+            at_lane(o_tasks, off + 16u * cstride) = (float)div_small_any(ti - (double)tnow, mts, inv_mts);
+            at_lane(o_tasks, off + 17u * cstride) = (float)div_small_any(td - (double)tnow, mts, inv_mts);
+          }
+          at_lane(o_tasks, off + 20u * cstride) = (float)fmin(div_small((double)tnow - (double)S.t_created[s], mts, inv_mts), 1.0);
+        } else {
         float r[21];
         r[0] = (float)tid;
         r[1] = (float)div_small(S.t_px[s], MAX_COORD, INV_COORD);
@@ -2936,6 +2972,7 @@ struct Sim {
           const uint32_t cstride = (uint32_t)MT * 4u;
 #pragma unroll
           for (int c = 0; c < 21; c++) { at_lane(o_tasks, off) = r[c]; off += cstride; }
+        }
         }
       } else if (o_tasks && in_mt && (j < pad_until || j == 0)) {
         // pad rows are {"status": -1}; with no open task row 0 is task_idle (all zeros).  Rows the buffer already holds as pad rows
@@ -3011,7 +3048,7 @@ struct Sim {
       o_flags[3] = (float)div_small((double)tnow, mts, inv_mts);
       o_flags[4] = (float)div_small((double)n, (double)(P.max_tasks > 1 ? P.max_tasks : 1), P.inv_max_tasks);
     }
-    if (handle_buffer && o_tasks && lane == 0) S.obs_rows = n > 0 ? n : 1;  // rows from here on hold pad rows now
+    if (handle_buffer && o_tasks && lane == 0) S.obs_rows = (n > 0 ? n : 1) | OBS_STATIC;  // rows from here on hold pad rows now; the open rows' static columns are current
   }
 
   // ====================================================================================================

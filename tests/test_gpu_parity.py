@@ -1197,7 +1197,7 @@ def test_comm_abi_single_rank():
     env.close()
 
 
-@pytest.mark.parametrize("extra", [[], ["--abi-collective"]], ids=["torch-nccl", "abi-rccl"])
+@pytest.mark.parametrize("extra", [[], ["--abi-collective"], ["--inflight", "2"]], ids=["torch-nccl", "abi-rccl", "two-handles-in-flight"])
 def test_bench_under_torchrun_world_size_1(extra):
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, nccl backend = RCCL), at world size 1:
     sharding, barrier-bracketed timing, metric reduction and the single JSON line."""
@@ -1217,6 +1217,7 @@ def test_bench_under_torchrun_world_size_1(extra):
     line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["total_envs"] == 512 and out["quality"]["n_envs"] == 512
+    assert out["inflight"] == (2 if "--inflight" in extra else 1)
     want = orc.parallel_metrics("WPS_hard_x2", np.arange(512), 20)
     assert out["quality"]["mean_S_WPS"] == float(want[:, 4].sum()) / 512
 
@@ -1683,3 +1684,35 @@ def test_scored_allocator_soak(case, kname, kind, mt, ma, gate, kw, oflags, inte
     with mp.get_context("spawn").Pool(procs) as pool:
         want = np.concatenate(pool.map(_scored_soak_worker, jobs), axis=0)
     assert np.array_equal(got, want), f"{case}: rows differing {np.nonzero(~np.all(got == want, axis=1))[0][:8]}"
+
+
+@pytest.mark.parametrize("case,interval,n,mode", [("WPS_hard_x2", 20, 256, "hungarian"), ("WPS_escort24", 12, 128, "hungarian"), ("WPS_burst64", 20, 64, "hungarian"),
+                                                  ("WPS_escort", 12, 128, "urgency_coalition"), ("FUZZ03", 20, 64, "hungarian"), ("FUZZ07", 20, 64, "hungarian"),
+                                                  ("FUZZ11", 12, 64, "hungarian")])
+def test_incremental_observation_rows_equal_a_full_rewrite(case, interval, n, mode):
+    """(r4) The observation writer only rewrites the per-step columns of rows whose static columns the handle's buffer already
+    holds (OBS_STATIC).  Two identical batches stepped in lockstep: A reads the incrementally maintained buffer, B has it rewritten
+    in full before every read (muavta_refresh_observation) — every tensor must be equal after every step."""
+    from cases import params_of
+    from muavta_amd.batched import BatchedMultiUAVEnv
+
+    P = params_of(case)
+    a, b = BatchedMultiUAVEnv(P, n), BatchedMultiUAVEnv(P, n)
+    a.set_allocator(mode); b.set_allocator(mode)
+    seeds = np.arange(300, 300 + n, dtype=np.uint64)
+    a.reset(seeds); b.reset(seeds)
+    n_light = 0
+    for t in range(P.max_time_steps):
+        for e in (a, b):
+            e.allocate(interval, True, fetch=False)
+            e.step_staged()
+        n_light += int(np.count_nonzero(a.get("SCALARS")[:, 0] >= 0))  # (keeps the host mirror honest: a get between steps must not disturb the flag)
+        b.refresh_observation()
+        oa, ob = a.observe(), b.observe()
+        for name in oa:
+            x, y = np.ascontiguousarray(oa[name]), np.ascontiguousarray(ob[name])
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), f"{case} t={t + 1}: {name} differs in envs {np.nonzero((x != y).reshape(n, -1).any(axis=1))[0][:6]}"
+        _, term, trunc = a.step_result()
+        if (term | trunc).all():
+            break
+    assert np.array_equal(a.metrics(), b.metrics())
