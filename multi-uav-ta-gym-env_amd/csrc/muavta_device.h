@@ -2879,6 +2879,13 @@ struct Sim {
   // handle_buffer: the tensors are the handle's single observation buffer (overwritten in place every step), not a ring slot —
   // its pad rows are only rewritten where live rows have just disappeared (S.obs_rows)
   DEV void write_obs(float* o_tasks, unsigned long long* o_legal, uint8_t* o_pad, float* o_agents, float* o_flags, bool handle_buffer = false) {
+#ifdef MUAVTA_OBS_SKIP  // timing experiments only (results are wrong): bit 0 task rows, 1 legal mask, 2 agent rows + flags, 3 pad flags, 4 everything
+    if (MUAVTA_OBS_SKIP & 16) return;
+    if (MUAVTA_OBS_SKIP & 1) o_tasks = nullptr;
+    if (MUAVTA_OBS_SKIP & 2) o_legal = nullptr;
+    if (MUAVTA_OBS_SKIP & 4) { o_agents = nullptr; o_flags = nullptr; }
+    if (MUAVTA_OBS_SKIP & 8) o_pad = nullptr;
+#endif
     cold_sync();  // the rows below read the requirement vectors the serial phases of this step may have changed
     const int MT = P.max_tasks, nA = P.n_agents;
     const int n = __builtin_amdgcn_readfirstlane(S.n_open);
@@ -2925,8 +2932,10 @@ struct Sim {
           if (P.saturate_mask && C.t_alloc[ty][s] >= qs().t_org[s]) typemask = 0;
           uint32_t off = ju * 4u;
           const uint32_t cstride = (uint32_t)MT * 4u;
-          at_lane(o_tasks, off + cstride) = (float)div_small(S.t_px[s], MAX_COORD, INV_COORD);
-          at_lane(o_tasks, off + 2u * cstride) = (float)div_small(S.t_py[s], MAX_COORD, INV_COORD);
+          if (ty == MUAVTA_INT || (S.t_flags[s] & TF_ESCORT)) {  // the tasks that move: an Int task follows its threat, an escort its UAV
+            at_lane(o_tasks, off + cstride) = (float)div_small(S.t_px[s], MAX_COORD, INV_COORD);
+            at_lane(o_tasks, off + 2u * cstride) = (float)div_small(S.t_py[s], MAX_COORD, INV_COORD);
+          }
           at_lane(o_tasks, off + 3u * cstride) = (float)S.t_status[s];
           if (P.include_time_windows) {
             at_lane(o_tasks, off + 16u * cstride) = (float)div_small_any(ti - (double)tnow, mts, inv_mts);
@@ -2983,7 +2992,7 @@ struct Sim {
 #pragma unroll
         for (int c = 0; c < 21; c++) { at_lane(o_tasks, off) = c == 3 ? st : 0.f; off += cstride; }
       }
-      if (o_pad && in_mt) o_pad[ju] = j < (n == 0 ? 1 : n);
+      if (o_pad && in_mt && !light) o_pad[ju] = j < (n == 0 ? 1 : n);  // (light: the open list, and with it the pad mask, is what the buffer holds)
       PROF(16);
       if (o_legal) {
         // legal_mask without a per-agent loop: one ballot per agent TYPE gives the rows that type may take
