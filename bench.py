@@ -18,7 +18,12 @@ kernel keeps the env state in LDS, so this is an algorithmic-equivalent rate, NO
 `roofline.traffic` / `roofline.measured_hbm_GBs` are the PMC-measured bytes (see `roofline.note`).
 `cpu_baseline` = the CPU oracle (oracle/, a restatement of the reference: kind "port") timed on ALL of this
 box's host cores over a bounded sample of the same workload (rank 0, N=1 only).
-`other_tiles` (N=1 only) = the same measurement for BASELINE configs 4 and 5 (24x48 escort, 64x128 burst).
+`other_tiles` (N=1 only) = the same measurement for BASELINE configs 4 and 5 (24x48 escort, 64x128 burst), each also with two handles
+in flight.  Further N=1 figures (r4): `value_two_in_flight` (the headline loop with launches alternating between two handles),
+`launch_gap_ms` / `ms_per_step_unaccounted` (where ms_per_step goes beyond the kernel), `policy_in_loop_env_steps_per_s`
+(muavta_rl_step_device: the RL trainers' loop with caller-supplied edge scores, one launch per env step).
+`--inflight 2` makes the TIMED loop itself alternate between two handles per rank (composes with --gpus N: each rank owns its handles,
+the metric reduction still runs once).  Progress lines go to stderr.
 """
 from __future__ import annotations
 

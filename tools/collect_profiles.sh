@@ -3,7 +3,7 @@
 # guide prescribes (FETCH_SIZE and WRITE_SIZE cannot share a pass), each with --kernel-trace only and the program directly
 # after `--`.  Output under gpurun_out/prof_<tag>/<case>/; tools/summarize_profiles.py turns it into profiles/<tag>_*.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 CASES=${2:-"WPS_hard_x2:4096 WPS_escort24:4096 WPS_burst64:1024"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for ce in $CASES; do

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): the round's closing evidence — parity suite, full bench line, phase shares with event
 # counts, the seeding / sub-batch probes.  Output under gpurun_out/<tag>/ (copied into profiles/ by the builder).
 set -u
-TAG=${1:-r03final}
+TAG=${1:-r04final}
 OUT=gpurun_out/$TAG
 cd "$GRAFT_REPO_ROOT" && mkdir -p "$OUT"
 export TMPDIR=/tmp
