@@ -1716,3 +1716,19 @@ def test_incremental_observation_rows_equal_a_full_rewrite(case, interval, n, mo
         if (term | trunc).all():
             break
     assert np.array_equal(a.metrics(), b.metrics())
+
+
+def test_in_flight_rollouts_equal_one_handle_at_a_time():
+    """muavta_amd.pipeline.InFlightRollouts: batches alternating between two handles give the batches a single handle gives"""
+    from muavta_amd.pipeline import InFlightRollouts
+
+    case, n = "WPS_escort24", 256
+    batches = [np.arange(b * n, (b + 1) * n, dtype=np.uint64) for b in range(5)]
+    pipe = InFlightRollouts(params_for_case(case), n, handles=2)
+    got = pipe.run(batches, 150, 12)
+    pipe.close()
+    one = _env(case, n)
+    for b, seeds in enumerate(batches):
+        one.rollout(seeds, 150, 12, True, True)
+        assert np.array_equal(got[b], one.rollout_metrics()), f"batch {b}"
+    assert np.array_equal(got[0], orc.parallel_metrics(case, batches[0], 12))
