@@ -549,6 +549,22 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
             e4.sync()
             dt_rl = time.perf_counter() - t1
         out["policy_in_loop_env_steps_per_s"] = args.envs * HORIZON / dt_rl
+        # the same loop with the batch in two sub-batches on their own streams (MuavtaRlStep.part): what a trainer that runs its network on
+        # part A's tokens while the device steps part B gets from the env side
+        e4.set_parts(2)
+        for rep_i in range(2):
+            e4.reset(seeds)
+            e4.tokens("pair", 32, 16, out=bufs[0])
+            e4.sync()
+            t1 = time.perf_counter()
+            for t in range(HORIZON):
+                for p_ in range(2):
+                    e4.rl_step("pair", 32, 16, edge_scores=scores, gate="trainer", replan_interval=args.interval, selected=sel, replanned=rep,
+                               next_tok=bufs[(t + 1) & 1], s_wps=sw, done=dn, part=p_)
+            e4.sync()
+            dt_rl2 = time.perf_counter() - t1
+        e4.set_parts(0)
+        out["policy_in_loop_2_parts_env_steps_per_s"] = args.envs * HORIZON / dt_rl2
         out["policy_in_loop_is"] = (f"muavta_rl_step_device, one launch per env step of all {args.envs} envs: plan (Hungarian - caller's f32 edge scores [N,16,32], "
                                     "trainer gate) -> step -> S_WPS before/after -> next pair tokens 32x16 + edge_valid, + _selected_mask / replanned / done; "
                                     "the score tensor is fixed and device-resident (times the env side; the reference's run_rl_episode is this loop for one env)")

@@ -351,7 +351,10 @@ typedef struct MuavtaRlStep {
   float* task_feats; uint8_t* task_mask; int32_t* task_ids; float* agent_feats; uint8_t* agent_mask; int32_t* agent_ids;
   float* edge_valid; int32_t* n_urgent;
   double* s_wps; uint8_t* done;
-  int32_t write_obs, reserved1;
+  int32_t write_obs;
+  int32_t part;   /* 0 = the whole batch on the handle's stream; p + 1 = sub-batch p (muavta_set_parts) on its own stream: the tensors stay
+                     the whole batch's [N, ...] and the launch reads / writes the part's rows — the network runs on part A's tokens
+                     while the device steps part B (muavta_wait_part before reading a part's outputs) */
 } MuavtaRlStep;
 int muavta_rl_step_device(MuavtaEnv* env, const MuavtaRlStep* step);
 

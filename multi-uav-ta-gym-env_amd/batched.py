@@ -181,12 +181,13 @@ class BatchedMultiUAVEnv:
     def rl_step(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16, *, edge_scores=None, task_pri=None, reserved=None,
                 gate: str = "trainer", replan_interval: int = 20, use_visibility: bool = True, edge_valid_only: Optional[bool] = None,
                 full_task_list: bool = False, commit: bool = False, selected=None, replanned=None, next_tok: Optional[dict] = None,
-                s_wps=None, done=None, write_obs: bool = False):
+                s_wps=None, done=None, write_obs: bool = False, part: Optional[int] = None):
         """muavta_rl_step_device: one iteration of run_rl_episode's loop body (experiments/train_pair_cost.py:139-153) for every
         env in ONE launch — plan with the caller's scores -> step -> S_WPS before / after -> next tokens.  Every tensor is a
         contiguous CUDA torch tensor on the env's GPU: inputs as in `allocate_scored`; outputs `selected` f32 [N, MA, MT],
         `replanned` i32 [N], `next_tok` (dict with the shapes of `token_shapes`), `s_wps` f64 [2, N], `done` u8 [N] (any may be
-        None).  Asynchronous on the handle's stream."""
+        None).  Asynchronous on the handle's stream — or, with `part=p` after `set_parts(k)`, on sub-batch p's stream for its rows only
+        (`wait_part(p)` before reading them): the network can work on one part's tokens while the device steps the other."""
         k = self.TOKEN_KINDS[kind][0]
         mt = int(max_tasks if max_tasks is not None else (48 if kind == "escort" else 32))
         ma, N = int(max_agents), self.n_envs
@@ -196,6 +197,7 @@ class BatchedMultiUAVEnv:
         rs = native.MuavtaRlStep()
         rs.plan = native.MuavtaScored(k, mt, ma, self.GATES[gate], flags, int(replan_interval), int(bool(use_visibility)), 0)
         rs.write_obs = int(bool(write_obs))
+        rs.part = 0 if part is None else int(part) + 1   # a sub-batch of set_parts() on its own stream; tensors stay whole-batch
 
         def put(obj, name, t, shape, size):
             if t is None:

@@ -895,11 +895,11 @@ static void launch_tokens(MuavtaEnv* e, int kind, int max_tasks, int max_agents,
 }
 
 template <class TL>
-static void launch_rl_step(MuavtaEnv* e, const ScoredDev& sc, const MuavtaRlStep* rs) {
+static void launch_rl_step(MuavtaEnv* e, const ScoredDev& sc, const MuavtaRlStep* rs, hipStream_t stream, int first, int count) {
   typename Sim<TL>::TokPtrs K{rs->task_feats, rs->task_mask, rs->task_ids, rs->agent_feats, rs->agent_mask, rs->agent_ids, rs->edge_valid, rs->n_urgent,
                               nullptr, nullptr, rs->plan.kind, rs->plan.max_tasks, rs->plan.max_agents};
-  hipLaunchKernelGGL(k_rl_step<TL>, dim3(e->n_envs), dim3(WG), 0, e->stream, (const DevCtx*)e->d_ctx, sc, K, rs->plan.replan_interval, rs->plan.use_visibility,
-                     rs->write_obs, rs->s_wps, rs->done, e->n_envs, 0);
+  hipLaunchKernelGGL(k_rl_step<TL>, dim3(count), dim3(WG), 0, stream, (const DevCtx*)e->d_ctx, sc, K, rs->plan.replan_interval, rs->plan.use_visibility,
+                     rs->write_obs, rs->s_wps, rs->done, e->n_envs, first);
 }
 
 int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
@@ -1594,11 +1594,21 @@ int muavta_rl_step_device(MuavtaEnv* e, const MuavtaRlStep* rs) {
     e->err = "muavta_rl_step_device: the next-token outputs come all together or not at all (n_urgent alone is optional)"; return MUAVTA_E_ARG;
   }
   DeviceScope scope_(e->device);
-  MAIN_OP(e);
+  if (e->d_rel) { e->err = "muavta_rl_step_device: the release log must be off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
   ScoredDev sc{sp->edge_scores, sp->task_pri, (const unsigned long long*)sp->reserved, sp->selected, sp->replanned, sp->kind, sp->max_tasks,
                sp->max_agents, sp->gate, sp->flags};
-  if (e->d_rel) { e->err = "muavta_rl_step_device: the release log must be off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
-  DISPATCH(e, launch_rl_step<TL>(e, sc, rs));
+  hipStream_t stream = e->stream;
+  int first = 0, count = e->n_envs;
+  if (rs->part > 0) {  // one sub-batch on its own stream (muavta_set_parts): the tensors are the whole batch's, the launch touches the part's rows
+    const int part = rs->part - 1;
+    { int rc = check_part(e, part, "muavta_rl_step_device"); if (rc) return rc; }
+    { int rc = fork_part(e, part); if (rc) return rc; }
+    part_range(e, part, &first, &count);
+    stream = e->part_stream[part];
+  } else {
+    MAIN_OP(e);
+  }
+  DISPATCH(e, launch_rl_step<TL>(e, sc, rs, stream, first, count));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   return MUAVTA_OK;

@@ -86,7 +86,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 class MuavtaRlStep(C.Structure):
     """include/muavta.h: MuavtaRlStep (muavta_rl_step_device)."""
     _fields_ = [("plan", MuavtaScored)] + [(n, C.c_void_p) for n in ("task_feats", "task_mask", "task_ids", "agent_feats", "agent_mask", "agent_ids",
-                                                                      "edge_valid", "n_urgent", "s_wps", "done")] + [("write_obs", C.c_int32), ("reserved1", C.c_int32)]
+                                                                      "edge_valid", "n_urgent", "s_wps", "done")] + [("write_obs", C.c_int32), ("part", C.c_int32)]
 
 
 _LIB = None

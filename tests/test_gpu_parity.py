@@ -1732,3 +1732,40 @@ def test_in_flight_rollouts_equal_one_handle_at_a_time():
         one.rollout(seeds, 150, 12, True, True)
         assert np.array_equal(got[b], one.rollout_metrics()), f"batch {b}"
     assert np.array_equal(got[0], orc.parallel_metrics(case, batches[0], 12))
+
+
+def test_rl_step_by_sub_batches_equals_the_whole_batch_launch():
+    """MuavtaRlStep.part: the fused RL step launched per sub-batch on the parts' own streams (whole-batch tensors, the part's rows)
+    leaves the same tensors and the same env state as one launch over the whole batch."""
+    import torch
+
+    case, n, mt, ma = "WPS_hard_x2", 96, 32, 16
+    a, b = _env(case, n), _env(case, n)
+    seeds = np.arange(40, 40 + n, dtype=np.uint64)
+    a.reset(seeds); b.reset(seeds)
+    b.set_parts(3)
+    dev = torch.device("cuda", 0)
+    tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32}
+
+    def outs(env):
+        o = {"next_tok": {k: torch.zeros(sh, dtype=tdt[dt], device=dev) for k, (sh, dt) in env.token_shapes("pair", mt, ma).items()},
+             "selected": torch.zeros((n, ma, mt), dtype=torch.float32, device=dev), "replanned": torch.zeros((n,), dtype=torch.int32, device=dev),
+             "s_wps": torch.zeros((2, n), dtype=torch.float64, device=dev), "done": torch.zeros((n,), dtype=torch.uint8, device=dev)}
+        return o
+
+    oa, ob = outs(a), outs(b)
+    gen = torch.Generator(device=dev); gen.manual_seed(3)
+    for t in range(60):
+        sc = ((torch.rand((n, ma, mt), generator=gen, device=dev) * 2 - 1) * 0.35).contiguous()
+        torch.cuda.synchronize()
+        a.rl_step("pair", mt, ma, edge_scores=sc, gate="trainer", replan_interval=10, **oa)
+        for p in range(3):
+            b.rl_step("pair", mt, ma, edge_scores=sc, gate="trainer", replan_interval=10, part=p, **ob)
+        a.sync(); b.wait_part(-1)
+        for k in ("selected", "replanned", "s_wps", "done"):
+            assert torch.equal(oa[k], ob[k]), f"t={t}: {k}"
+        for k in oa["next_tok"]:
+            assert torch.equal(oa["next_tok"][k], ob["next_tok"][k]), f"t={t}: next_tok {k}"
+    b.set_parts(0)
+    assert np.array_equal(a.metrics(), b.metrics())
+    assert np.array_equal(a.get("AGENT_POS"), b.get("AGENT_POS"))
