@@ -32,7 +32,7 @@ if "get" in PRE:
 if "torchops" in PRE:
     import torch
     torch.cuda.synchronize(); t = torch.tensor([1.0, 2.0], dtype=torch.float64, device="cuda"); print(float(t[0]))
-for parts in (0, 2, 4):
+for parts in (0, 2, 3, 4):
     env.set_parts(parts)
     for rep in range(2):
         env.reset(seeds); env.sync()
