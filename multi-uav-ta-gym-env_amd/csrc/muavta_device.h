@@ -132,6 +132,13 @@ DEV double norm2(double x, double y) { return fsqrt(fma(y, y, x * x)); }  // np.
 DEV bool is_recon(int t) { return t == MUAVTA_R1 || t == MUAVTA_R2; }
 DEV bool is_fighter(int t) { return t == MUAVTA_F1 || t == MUAVTA_F2; }
 
+// Timing experiments only (diagnostic builds; results are wrong unless the ablated phase has nothing to do, as in tools/quiet_probe.py's
+// quiet workload): -DMUAVTA_ABLATE=<bit mask> compiles a phase of the step out, so that the launch time without it is its true cost.
+#ifndef MUAVTA_ABLATE
+#define MUAVTA_ABLATE 0
+#endif
+#define ABL(bit) ((MUAVTA_ABLATE >> (bit)) & 1)
+
 template <class TL>
 struct alignas(16) Scratch {
   enum { A = TL::A, T = TL::T,
@@ -1462,8 +1469,8 @@ struct Sim {
 
   DEV void step(bool write_obs_flag) {
     PROF(0);
-    rng_refill();
-    const uint32_t rng_words = rng_prefetch_issue();
+    uint32_t rng_words = 0;
+    if (!ABL(0)) { rng_refill(); rng_words = rng_prefetch_issue(); }
     PROF(1);
     // previous positions stay in registers of the lane that owns the agent
     double prev_x = 0, prev_y = 0;
@@ -1479,6 +1486,7 @@ struct Sim {
       lds_sync();
       int last_arg = -1000;
       bool last_changed = true;
+      if (!ABL(1))
       for (int k = 0; k < nev; k++)
         if (S.dev_tag[k] == MUAVTA_EV_RESET_ALLOCATION) {
           const int arg = S.dev_arg[k];
@@ -1488,6 +1496,7 @@ struct Sim {
         }
     }
     PROF(2);
+    if (!ABL(2))
     for (;;) {
       if (S.n_act > 0 && !apply_actions_parallel(r_action, r_distance, r_squality)) {
         precompute_actions();
@@ -1503,7 +1512,7 @@ struct Sim {
     PROF(3);
     // movement (:965-1129): lanes commit every agent up to the first "event" agent, lane 0 plays that one
     // agent exactly as the reference does, and the wave resumes behind it
-    for (int start = 0; start < P.n_agents;) {
+    for (int start = ABL(3) ? P.n_agents : 0; start < P.n_agents;) {
       const int first = move_parallel(start);
       cold_sync();  // (lanes that dropped a retired head shifted their EnvCold queue-time row)
       PROF(26);
@@ -1517,8 +1526,8 @@ struct Sim {
       start = first + 1;
     }
     // distances (:1131-1138): np.linalg.norm(axis=1) == sqrt(x*x + y*y), no fma
-    double dist_sum;
-    {
+    double dist_sum = 0.0;
+    if (!ABL(4)) {
       double d = 0.0;
       if (lane < P.n_agents) {
         double dx = S.a_px[lane] - prev_x, dy = S.a_py[lane] - prev_y;
@@ -1529,11 +1538,14 @@ struct Sim {
       if constexpr (A <= 16) dist_sum = np_sum_lanes16(d, P.n_agents);  // np.sum(dists) (:1138)
       else { lds_sync(); dist_sum = np_sum_wave(X.u, P.n_agents); }
     }
-    rng_prefetch_commit(rng_words);
+    if (!ABL(0)) rng_prefetch_commit(rng_words);
     PROF(5);
+    if (!ABL(5)) {
     precompute_threat_targets();
     if (lane == 0) step_serial_b(dist_sum);
     lds_sync();
+    }
+    if (!ABL(5))
     {  // update_threats (:1725-1744): lanes advance every threat up to the first one that engages or leaves the area,
        // lane 0 plays that one as the reference does, and the wave resumes behind it
       unsigned long long livemask = 0ull;
@@ -1571,11 +1583,14 @@ struct Sim {
       if (lane == 0) step_serial_b2();
     }
     lds_sync();
+    if (!ABL(6)) {
     if (P.escort_enabled) sync_escorts_coop();
     PROF(6);
     sense_parallel();  // _wps_update_sensing (:1506-1523)
     lds_sync();
+    }
     PROF(7);
+    if (!ABL(7))
     {
       // wave-wide pre-checks so that lane 0 only walks the lists when something is due this step.  ONE pass over the live
       // slots gives both "a window expired" and "a task still blocks mission completion"; the agents' idle / responding
@@ -1609,7 +1624,7 @@ struct Sim {
     }
     lds_sync();
     PROF(8);
-    finish_step_parallel(true);
+    if (!ABL(8)) finish_step_parallel(true);
     PROF(9);
   }
 

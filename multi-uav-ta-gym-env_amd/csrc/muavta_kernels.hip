@@ -440,7 +440,7 @@ __device__ MUAVTA_PHASE_ATTR void rollout_phase(const DevCtx* ctxp, unsigned cha
     obs_for_env(sim, ctx.P, O, at, handle_buffer);
   }
   lds_sync();
-  if ((phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) {
+  if (!ABL(9) && (phases & PH_ALLOC) && !(L.S->terminated || L.S->truncated)) {
     sim.allocate(interval, use_vis, mode);
     if (REC && rec.K.task_feats) {  // the sample of step `slot`: tokens + labels of the plan just staged, S_WPS before the step
       const typename Sim<TL>::TokPtrs K = global_tok_ptrs<TL>(rec.K);
@@ -469,8 +469,19 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
   Lds<TL> L(lds_own);
   EnvState<TL>* blob = blob_of<TL>(ctx, env);
   Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
+// (r4) The pacing row is read and written with WORKGROUP-scope (plain) accesses: the waves that share a row share a SIMD, hence a CU
+// and its vector L1, which is coherent for them; a slightly stale counter only delays a priority change by a step.  With AGENT scope
+// (r2, r3) every step's 16-lane read went to the memory side of the fabric (~2 us on this eight-XCD part) and — VMEM loads return in
+// order — the step's first `s_waitcnt vmcnt(0)` waited for it: tools/ablate_probe.py measured the whole pacing block at 0.35 ms of a
+// 1.19 ms quiet launch.  Headline 240 -> 248 M on one box (profiles/r04_ab_pacing.txt); publishing every 2nd / 4th step changes nothing.
+#ifndef MUAVTA_PACE_SCOPE
+#define MUAVTA_PACE_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
+#ifndef MUAVTA_PACE_EVERY
+#define MUAVTA_PACE_EVERY 1  // publish / read / re-rank every n-th step (a power of two)
+#endif
 #if MUAVTA_PACE_PRIO
-  constexpr bool PACED = TL::A <= 32;  // the 64-agent tile has one or two waves per SIMD: nothing to pace
+  constexpr bool PACED = TL::A <= 32 && !ABL(10);  // the 64-agent tile has one or two waves per SIMD: nothing to pace
   // Pacing: the envs whose waves share a SIMD advance at different speeds (replans, episode length), and the launch ends on
   // the SIMD whose last env runs alone, at a quarter of the SIMD's multi-wave throughput.  Each wave publishes its step
   // counter in a row of the SIMD it runs on (hardware ids), reads its neighbours' and asks for issue priority while nobody
@@ -522,15 +533,15 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
     } else ph = (write_obs && !(REC && rec.O.tasks)) ? 0 : PH_OBS;  // with observation rings the handle's buffer gets the final one
 #if MUAVTA_PACE_PRIO
     uint32_t seen = 0;
-    if (PACED && k >= 1 && k <= n_steps) {
-      if (threadIdx.x == 0) __hip_atomic_store(pace_row + (hw_id & 15u), pace_tag | (uint32_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (threadIdx.x < 16) seen = __hip_atomic_load(pace_row + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PACED && k >= 1 && k <= n_steps && (k & (MUAVTA_PACE_EVERY - 1)) == 0) {
+      if (threadIdx.x == 0) __hip_atomic_store(pace_row + (hw_id & 15u), pace_tag | (uint32_t)k, __ATOMIC_RELAXED, MUAVTA_PACE_SCOPE);
+      if (threadIdx.x < 16) seen = __hip_atomic_load(pace_row + threadIdx.x, __ATOMIC_RELAXED, MUAVTA_PACE_SCOPE);
     }
 #endif
     if (ph) rollout_phase<TL, REC>(ctxp, lds_own, lds_base, env, ph, interval, use_vis, mode, rec, k < n_steps ? k : n_steps,
                                    (REC && rec.O.tasks && k >= 1 && k <= n_steps) ? k - 1 : -1);
 #if MUAVTA_PACE_PRIO
-    if (PACED && k >= 1 && k <= n_steps) {  // consumed a step later: the load's latency stays off the env's dependent chain
+    if (PACED && k >= 1 && k <= n_steps && (k & (MUAVTA_PACE_EVERY - 1)) == 0) {  // consumed a step later: the load's latency stays off the env's dependent chain
       const bool behind_me = threadIdx.x < 16 && (seen >> 16) == (uint32_t)epoch && (seen & 0xFFFFu) < (uint32_t)k;
 #if MUAVTA_PACE_PRIO == 4  // ranked: 3 for the last env of the SIMD, one less per neighbour that is further behind
       const int n_behind = __popcll(__ballot(behind_me));
@@ -552,14 +563,14 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
                               st + MUAVTA_PACE_HOLD_WINDOW >= (uint32_t)k;
         if (__ballot(wait_for) == 0ull) break;
         __builtin_amdgcn_s_sleep(MUAVTA_PACE_HOLD_SLEEP);
-        if (threadIdx.x < 16) seen = __hip_atomic_load(pace_row + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x < 16) seen = __hip_atomic_load(pace_row + threadIdx.x, __ATOMIC_RELAXED, MUAVTA_PACE_SCOPE);
       }
 #endif
     }
 #endif
   }
 #if MUAVTA_PACE_PRIO
-  if (PACED && threadIdx.x == 0) __hip_atomic_store(pace_row + (hw_id & 15u), pace_tag | 0xFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (PACED && threadIdx.x == 0) __hip_atomic_store(pace_row + (hw_id & 15u), pace_tag | 0xFFFFu, __ATOMIC_RELAXED, MUAVTA_PACE_SCOPE);
   __builtin_amdgcn_s_setprio(0);
 #endif
   if (REC && rec.K.task_feats) {  // S_WPS after the last step closes the reward series
