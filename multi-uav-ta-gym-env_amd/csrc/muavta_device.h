@@ -1596,7 +1596,7 @@ struct Sim {
       // slots gives both "a window expired" and "a task still blocks mission completion"; the agents' idle / responding
       // flags are read alongside.  Only a window expiry (status changes, agents freed) invalidates them: evaluated again then.
       bool due = false, expiring = false, idle = false, resp = false, blocking = false;
-      for (int k = lane; k < S.n_pending; k += WG) due |= tnow >= S.pend_time[k];
+      if (!ABL(12)) for (int k = lane; k < S.n_pending; k += WG) due |= tnow >= S.pend_time[k];
       auto scan_slots = [&]() {
         expiring = false; blocking = false;
         for (int k = lane; k < S.n_order; k += WG) {
@@ -1608,7 +1608,7 @@ struct Sim {
         idle = false; resp = false;
         if (lane < P.n_agents && S.a_state[lane] != -1) { idle = S.a_qlen[lane] == 0; resp = !idle; }
       };
-      scan_slots();
+      if (!ABL(12)) scan_slots();
       const bool any_due = __ballot(due) != 0ull;
       const bool any_exp = P.hard_windows && __ballot(expiring) != 0ull;
       PROF(28);
@@ -1620,7 +1620,7 @@ struct Sim {
       const bool responding = __ballot(resp) != 0ull;
       const bool all_done_tasks = __ballot(blocking) == 0ull;
       PROF(32);
-      if (lane == 0) step_serial_c(r_action, r_distance, r_quality, r_squality, n_idle, responding, all_done_tasks);
+      if (!ABL(11) && lane == 0) step_serial_c(r_action, r_distance, r_quality, r_squality, n_idle, responding, all_done_tasks);
     }
     lds_sync();
     PROF(8);
@@ -2686,7 +2686,12 @@ struct Sim {
     double total = P.rw[0] * action_reward + P.rw[1] * distance_reward + P.rw[2] * quality_reward + P.rw[3] * S_quality_reward +
                    P.rw[4] * (double)P.n_tasks * 0.0 + P.rw[5] * alloc_reward + P.rw[6] * time_penaulty + P.rw[7] * step_reward;
     PROF(37);
-    const double shared = total / P.reward_norm_factor / (double)P.max_time_steps;
+    // two divisions on lane 0's chain in EVERY step: the range-restricted sequence (8 VALU each, bit-identical to IEEE inside its
+    // domain: `total` is 0 or a sum of reward terms of ordinary magnitude, the divisors are a positive constant >= 0.002 and a step
+    // count) instead of the compiler's ~35-instruction expansion.  A configuration without static tasks has reward_norm_factor == 0
+    // (the reference raises ZeroDivisionError in its first step): that one keeps the plain division.
+    const double shared = P.reward_norm_factor != 0 ? fdiv(fdiv(total, P.reward_norm_factor), (double)P.max_time_steps)
+                                                    : total / P.reward_norm_factor / (double)P.max_time_steps;
     PROF(38);
     const bool all_done = (ntid > 1) && all_done_tasks;
     const bool timed_out = (tnow >= P.max_time_steps) && (P.max_time_steps > 0);
