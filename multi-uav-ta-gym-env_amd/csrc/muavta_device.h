@@ -1513,8 +1513,12 @@ struct Sim {
     // movement (:965-1129): lanes commit every agent up to the first "event" agent, lane 0 plays that one
     // agent exactly as the reference does, and the wave resumes behind it
     for (int start = ABL(3) ? P.n_agents : 0; start < P.n_agents;) {
-      const int first = move_parallel(start);
-      cold_sync();  // (lanes that dropped a retired head shifted their EnvCold queue-time row)
+      bool popped = false;
+      const int first = move_parallel(start, popped);
+      // (lanes that dropped a retired head shifted their EnvCold queue-time row: only then do the HBM stores have to be drained.  An
+      // unconditional vmcnt(0) here — half a microsecond after the step issued its RNG-window loads and a few after the previous step's
+      // observation stores — waited for all of those in every step)
+      if (popped) cold_sync(); else lds_sync();
       PROF(26);
 #ifdef MUAVTA_PROF
       PROF_COUNT(40, 1000); if (first < P.n_agents) PROF_COUNT(41, 1000);
@@ -1641,7 +1645,7 @@ struct Sim {
   // loop and commit their lane's result.  An agent either heads for its current task or (idle) for the
   // base, never both, so each lane runs ONE distance / unit-vector / displacement pipeline.
   // Returns the index of the first event agent >= start (n_agents if none).
-  DEV int move_parallel(int start) {
+  DEV int move_parallel(int start, bool& popped) {
     const int a = lane;
     const bool in_fleet = a >= start && a < P.n_agents;
     const int ai = in_fleet ? a : 0;  // (lanes outside the fleet read agent 0's fields and discard them)
@@ -1717,6 +1721,7 @@ struct Sim {
     const unsigned long long em = __ballot(evt);
     const int first = em ? __ffsll((long long)em) - 1 : P.n_agents;
     PROF(34);
+    popped = __ballot(live && a < first && pop_head) != 0ull;  // (uniform)
     if (live && a < first) {  // commit: own fields only
       if (pop_head) {
         des_allocate(a, cid);
@@ -2683,15 +2688,26 @@ struct Sim {
     const int irs = S.idle_reserve_steps, pr = S.pending_reset, ntid = S.next_task_id, ct = S.conclusion_time;
     const double time_penaulty = S.r_time_penalty, alloc_reward = S.r_alloc, step_reward = S.step_reward, FR = S.F_Reward;
     PROF(36);
-    double total = P.rw[0] * action_reward + P.rw[1] * distance_reward + P.rw[2] * quality_reward + P.rw[3] * S_quality_reward +
+    // Most steps add nothing to any reward term (no action applied, no task concluded): with finite weights >= 0 every product is then
+    // +0.0, their sum is +0.0 and so is the quotient — the 15 dependent multiply-adds and two divisions on lane 0's chain are skipped.
+    // (bit patterns, not values: a -0.0 term would make the reference's sum depend on the order of the signed zeros)
+    const unsigned long long any_bits = (unsigned long long)__double_as_longlong(action_reward) | (unsigned long long)__double_as_longlong(distance_reward) |
+                                        (unsigned long long)__double_as_longlong(quality_reward) | (unsigned long long)__double_as_longlong(S_quality_reward) |
+                                        (unsigned long long)__double_as_longlong(alloc_reward) | (unsigned long long)__double_as_longlong(time_penaulty) |
+                                        (unsigned long long)__double_as_longlong(step_reward);
+    const bool quiet_reward = P.rw_plain && any_bits == 0ull;
+    double total = 0.0;
+    if (!quiet_reward)
+    total = P.rw[0] * action_reward + P.rw[1] * distance_reward + P.rw[2] * quality_reward + P.rw[3] * S_quality_reward +
                    P.rw[4] * (double)P.n_tasks * 0.0 + P.rw[5] * alloc_reward + P.rw[6] * time_penaulty + P.rw[7] * step_reward;
     PROF(37);
     // two divisions on lane 0's chain in EVERY step: the range-restricted sequence (8 VALU each, bit-identical to IEEE inside its
     // domain: `total` is 0 or a sum of reward terms of ordinary magnitude, the divisors are a positive constant >= 0.002 and a step
     // count) instead of the compiler's ~35-instruction expansion.  A configuration without static tasks has reward_norm_factor == 0
     // (the reference raises ZeroDivisionError in its first step): that one keeps the plain division.
-    const double shared = P.reward_norm_factor != 0 ? fdiv(fdiv(total, P.reward_norm_factor), (double)P.max_time_steps)
-                                                    : total / P.reward_norm_factor / (double)P.max_time_steps;
+    const double shared = quiet_reward ? 0.0
+                          : P.reward_norm_factor != 0 ? fdiv(fdiv(total, P.reward_norm_factor), (double)P.max_time_steps)
+                                                      : total / P.reward_norm_factor / (double)P.max_time_steps;
     PROF(38);
     const bool all_done = (ntid > 1) && all_done_tasks;
     const bool timed_out = (tnow >= P.max_time_steps) && (P.max_time_steps > 0);

@@ -976,6 +976,8 @@ int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
   d->reassign_penalty = p->reassign_penalty; d->escort_radius = p->escort_radius; d->escort_requirement = p->escort_requirement;
   d->escort_intercept_radius = p->escort_intercept_radius; d->mutual_support_radius = p->mutual_support_radius;
   for (int i = 0; i < 8; i++) d->rw[i] = p->reward_weights[i];
+  d->rw_plain = d->reward_norm_factor > 0 ? 1 : 0;
+  for (int i = 0; i < 8; i++) if (!(p->reward_weights[i] >= 0 && std::isfinite(p->reward_weights[i]))) d->rw_plain = 0;
   d->inv_mts = 1.0 / (double)(d->max_time_steps > 1 ? d->max_time_steps : 1);
   d->inv_max_tasks = 1.0 / (double)(d->max_tasks > 1 ? d->max_tasks : 1);
   return MUAVTA_OK;

@@ -52,7 +52,8 @@ struct DevParams {
   double rw[8];
   double escort_sq_bound;   // the same threshold for escort_radius (coverage test of _sync_escorts)
   double inv_mts, inv_max_tasks;  // RN(1 / max(max_time_steps, 1)), RN(1 / max(max_tasks, 1)): Sim::div_small
-  int32_t slot_cap, pad0_;        // live task slots an env may use: MuavtaParams.tile_tasks when it is below the tile's slot count, else the tile's
+  int32_t slot_cap;               // live task slots an env may use: MuavtaParams.tile_tasks when it is below the tile's slot count, else the tile's
+  int32_t rw_plain;               // every reward weight is finite and >= 0 and reward_norm_factor > 0: a step whose reward terms are all +0.0 has reward +0.0
 };
 
 template <int A_, int T_, int H_, int R_, int E_, int Q_, bool REGC_ = false, bool OTFC_ = false, bool SLIM_ = false>
