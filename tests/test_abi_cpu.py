@@ -72,3 +72,29 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in text and "import orc" not in text and "oracle_backend" not in text, f
                 assert not re.search(r'#include\s+"[^"]*oracle', text), f
+
+
+def test_binding_structs_match_the_header_field_by_field(tmp_path):
+    """MuavtaParams / MuavtaDims / MuavtaRecord / MuavtaScored / MuavtaRlStep: sizeof and the offset of every field of the ctypes
+    binding against a C program that includes include/muavta.h (gcc: the header is plain C)."""
+    import subprocess
+
+    from muavta_amd.native import MuavtaRlStep, MuavtaScored
+    from muavta_amd.params import MuavtaRecord
+
+    structs = {"MuavtaParams": MuavtaParams, "MuavtaDims": MuavtaDims, "MuavtaRecord": MuavtaRecord, "MuavtaScored": MuavtaScored, "MuavtaRlStep": MuavtaRlStep}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "muavta.h"', 'int main(void) {']
+    for name, st in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for field, *_ in st._fields_:
+            lines.append(f'  printf("{name}.{field} %zu\\n", offsetof({name}, {field}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for name, st in structs.items():
+        assert int(got[name]) == C.sizeof(st), f"sizeof({name}): header {got[name]}, binding {C.sizeof(st)}"
+        for field, *_ in st._fields_:
+            assert int(got[f"{name}.{field}"]) == getattr(st, field).offset, f"{name}.{field}: header offset {got[f'{name}.{field}']}, binding {getattr(st, field).offset}"
