@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Wide configuration fuzz on the GPU (not part of the test suite): the random configurations of tests/fuzz_reference.py::wide_config
+— the ones the CPU oracle is checked against the REFERENCE on in the container — run through the HIP library on all three tiles
+and are compared with the oracle:
+
+  fused     muavta_rollout over N seeds per (config, tile), the allocator mode rotating with the config number: all 30 metrics
+            of every env that did not overflow its tile, bit for bit;
+  stepwise  reset + max_time_steps x (allocate -> step) on one tile per config, every field of every env and the observation
+            after every step (test_gpu_parity.compare).
+
+    python tests/fuzz_device.py [first_k [n_configs [seeds_per_config]]]
+
+Lives under tests/ because it uses the oracle as its checker."""
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import orc  # noqa: E402
+from fuzz_reference import wide_config  # noqa: E402
+from muavta_amd.batched import BatchedMultiUAVEnv  # noqa: E402
+from muavta_amd.params import params_from_config  # noqa: E402
+from test_gpu_parity import Snapshot, compare  # noqa: E402
+
+TILES = ((16, 40, 16), (24, 48, 24), (64, 128, 48))
+MODES = ((0, "hungarian"), (1, "urgency_pair"), (2, "urgency_coalition"), (3, "hungarian_gated"))
+
+
+def params(cfg, tile):
+    c = dict(cfg)
+    c["threats_list"] = [tuple(x) for x in c["threats_list"]]
+    c["escort_agent_types"] = tuple(c["escort_agent_types"])
+    return params_from_config(c, None, tile_agents=tile[0], tile_tasks=tile[1], tile_threats=tile[2])
+
+
+def fused(k, w, n_seeds, log):
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+    mode, name = MODES[k % 4]
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n_seeds)], dtype=np.uint64)
+    p0 = params(cfg, TILES[2])
+    steps = p0.max_time_steps
+    o = orc.OracleEnv(p0)
+    want = []
+    for s in seeds:
+        o.rollout_mode(int(s), steps, interval, 1, mode)
+        want.append(o.metrics().copy())
+    bad = flagged = checked = 0
+    for tile in TILES:
+        env = BatchedMultiUAVEnv(params(cfg, tile), n_seeds)
+        env.set_allocator(name)
+        env.rollout(seeds, steps, interval, True, True)
+        got, err = env.rollout_metrics(), env.get("ERROR")
+        for i in range(n_seeds):
+            if err[i]:
+                flagged += 1
+                continue
+            checked += 1
+            if not np.array_equal(got[i], want[i]):
+                bad += 1
+                d = np.nonzero(got[i] != want[i])[0]
+                log(f"k={k} FUSED MISMATCH tile {tile} mode {name} seed {int(seeds[i])} interval {interval}: metric columns {d.tolist()} got {got[i][d].tolist()} want {want[i][d].tolist()}")
+        if tile == TILES[2] and err.any():
+            log(f"k={k} note: {int((err != 0).sum())} envs overflow the 64 x 128 tile, codes {np.unique(err[err != 0]).tolist()}")
+        env.close()
+    return bad, flagged, checked
+
+
+def stepwise(k, w, log):
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+    mode, name = MODES[(k // 3) % 4]
+    tile = TILES[k % 3]
+    p = params(cfg, tile)
+    n = 2
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    env = BatchedMultiUAVEnv(p, n)
+    env.set_allocator(name)
+    oracles = [orc.OracleEnv(p) for _ in range(n)]
+    env.reset(seeds)
+    for i, o in enumerate(oracles):
+        o.reset(int(seeds[i]))
+    tag = f"k={k} tile {tile} mode {name} interval {interval}"
+    try:
+        snap = Snapshot(env)
+        if snap.ERROR.any():
+            return "overflow"
+        for i, o in enumerate(oracles):
+            compare(snap, i, o, f"{tag} seed {seeds[i]} after reset")
+        for t in range(p.max_time_steps):
+            done = [bool(o.dims()["terminated"] or o.dims()["truncated"]) for o in oracles]
+            if any(done):
+                break
+            aa, ai = env.allocate(interval, True)
+            for i, o in enumerate(oracles):
+                oa, oi = o.allocate_mode(interval, 1, mode)
+                kk = len(oa)
+                assert np.array_equal(aa[i][:kk], oa) and np.all(aa[i][kk:] == -1) and np.array_equal(ai[i][:kk], oi), \
+                    f"{tag} seed {seeds[i]} t={t}: plan {aa[i][:kk + 2]} / {ai[i][:kk + 2]} vs {oa} / {oi}"
+                o.step(oa, oi)
+            env.step(aa, ai)
+            snap = Snapshot(env)
+            if snap.ERROR.any():
+                return "overflow"
+            for i, o in enumerate(oracles):
+                compare(snap, i, o, f"{tag} seed {seeds[i]} t={t + 1}")
+        m = env.metrics()
+        for i, o in enumerate(oracles):
+            assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: final metrics"
+    except AssertionError as exc:
+        log(f"STEPWISE MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
+if __name__ == "__main__":
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+    n_cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 50
+    n_seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+
+    def log(msg):
+        print(msg, flush=True)
+
+    t0 = time.time()
+    tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "errors": 0}
+    for k in range(first, first + n_cfg):
+        w = wide_config(k)
+        try:
+            b, f, c = fused(k, w, n_seeds, log)
+            tot["fused_bad"] += b; tot["fused_flagged"] += f; tot["fused_checked"] += c
+            tot["step_" + stepwise(k, w, log)] += 1
+        except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
+            tot["errors"] += 1
+            log(f"k={k} ERROR {type(exc).__name__}: {str(exc)[:300]}")
+        if (k - first) % 10 == 9:
+            log(f"... {k - first + 1} configs, {time.time() - t0:.0f} s: {tot}")
+    log(f"configs {first}..{first + n_cfg - 1}, {n_seeds} seeds each on 3 tiles: {tot}  ({time.time() - t0:.0f} s)")

@@ -1,0 +1,125 @@
+#!/usr/bin/env python3
+"""Wide differential fuzz, THIS container only (not part of the test suite): random configurations are run through the REFERENCE
+(imported from /root/reference by tools/refshim.py, driven by tools/gen_golden.py::run_episode) and the resulting full trace is
+checked step by step against the CPU oracle with the same comparison the committed traces go through
+(test_oracle_golden.check_trace): plans, every LSAP call, drained events, state, observation, final metrics — all bit for bit.
+
+    python tests/fuzz_reference.py [first_k [n_configs [procs]]]      # e.g. 1000 400 6
+
+Lives under tests/ because it uses the oracle as its checker.  A configuration the reference itself cannot run is skipped; a
+configuration the oracle disagrees on is printed with its key and can be pinned with --save (written as trace_WIDE<k>_s<seed>.npz
++ an entry in tests/golden/wide_configs.json by hand)."""
+import json
+import os
+import random
+import sys
+import time
+import traceback
+from multiprocessing import Pool
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def wide_config(k: int) -> dict:
+    """A wider net than tools/gen_golden.py::fuzz_config: fleets up to 16 UAVs, every knob agentEnvOptions has on this path, odd
+    radii / windows / horizons; the replan interval and the episode seed are part of the draw."""
+    r = random.Random(0x5EED0000 + k)
+    pick = r.choice
+    big = r.random() < 0.35
+    hi = 4 if big else 2
+    agents = {t: r.randint(0, hi) for t in ("F1", "F2", "R1", "R2")}
+    if agents["F1"] + agents["F2"] == 0:
+        agents[pick(["F1", "F2"])] = 1
+    if agents["R1"] + agents["R2"] == 0:
+        agents[pick(["R1", "R2"])] = 1
+    if r.random() < 0.3:  # group order is semantic (ids, names, shuffles): permute it
+        keys = list(agents)
+        r.shuffle(keys)
+        agents = {t: agents[t] for t in keys}
+    agents = {t: n for t, n in agents.items() if n > 0 or r.random() < 0.5}
+    threats = []
+    if r.random() < 0.85:
+        threats.append(("T1", r.randint(1, 6)))
+    if r.random() < 0.7:
+        threats.append(("T2", r.randint(1, 5)))
+    if len(threats) == 2 and r.random() < 0.3:
+        threats.reverse()
+    cfg = {
+        "agents": agents, "tasks": {"Att": r.randint(0, 5), "Rec": r.randint(1, 6), "Hold": pick([0, 0, 0, 1, 2])},
+        "threats_list": threats, "max_time_steps": pick([40, 60, 97, 150, 150, 200, 260]),
+        "simulation_frame_rate": pick([0.01, 0.01, 0.02, 0.015, 0.008]),
+        "multiple_tasks_per_agent": pick([True, True, True, False]), "random_init_pos": pick([False, False, True]),
+        "num_obstacles": pick([0, 0, 0, 0, 2, 3]), "fail_rate": pick([0.0, 0.0, 0.05, 0.2, 0.5]),
+        "early_terminate": pick([False, False, True]), "capability_mask": pick([False, True]), "saturate_mask": pick([False, True]),
+        "reward_weights": pick([None, None, {"action": 0.5, "distance": 1.0, "quality": 0.7, "s_quality": 1.0, "time": 0.1, "alloc": 0.2,
+                                             "time_penaulty": 0.25, "step": 0.3},
+                                {"action": 1.0, "distance": 0.0, "quality": 1.0, "s_quality": 0.0, "time": 1.0, "alloc": 1.0,
+                                 "time_penaulty": 0.0, "step": 1.0}]),
+        "arrival_rate": pick([0.0, 0.03, 0.08, 0.2, 0.45]), "include_time_windows": pick([False, True]),
+        "dynamic_idle_penalty": pick([0.0, 0.05, 0.5]), "sense_radius": pick([0.0, 40.0, 90.0, 250.0, 2000.0]),
+        "threat_delay": pick([0, 1, 6, 20, 45]), "hard_windows": pick([False, True, True]), "window_length": pick([3, 12, 25, 40, 90]),
+        "burst_mode": pick([False, True]), "burst_size": pick([1, 2, 3, 4]), "miss_penalty": pick([0.0, 25.0, 30.0]),
+        "on_time_bonus": pick([0.0, 10.0, 12.0]), "dual_region_bursts": pick([False, True]),
+        "share_knowledge": pick([True, True, False]), "commit_horizon": pick([0, 0, 10, 25]), "reassign_penalty": pick([0.0, 2.0, 0.5]),
+        "escort_enabled": pick([False, True]), "escort_radius": pick([40.0, 70.0, 120.0]), "escort_requirement": pick([1.2, 2.5, 0.8, 3.1]),
+        "escort_intercept_radius": pick([100.0, 60.0, 200.0]), "mutual_support_radius": pick([80.0, 150.0, 20.0]),
+        "escort_agent_types": pick([("F1", "F2"), ("F2",), ("F1", "F2", "R2"), ("F1",)]),
+    }
+    if cfg["reward_weights"] is None:
+        del cfg["reward_weights"]
+    interval = pick([1, 5, 12, 12, 20, 20, 33])
+    seed = pick([0, 1, 2, 3, 4, 7, 123456789, 2 ** 32 + 5, 2 ** 63 - 1])
+    return {"cfg": cfg, "interval": interval, "seed": seed}
+
+
+def run_one(k: int):
+    import numpy as np  # noqa: F401
+    import gen_golden as G
+    from mUAV_TA.MultiDroneEnvUtils import agentEnvOptions
+    from muavta_amd.params import params_from_config
+    import test_oracle_golden as TOG
+
+    w = wide_config(k)
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+
+    def make_env(case, _cfg=cfg):
+        return G.MultiUAVEnv(agentEnvOptions(render_speed=-1, action_mode="TaskAssign", multiple_agents_per_task=True, fixed_seed=-1, **_cfg))
+
+    G.make_env = make_env
+    t0 = time.time()
+    try:
+        tr = G.run_episode(f"WIDE{k}", seed, interval, True)
+    except Exception as exc:  # a combination the reference itself cannot run
+        return k, "skip", f"{type(exc).__name__}: {exc}", 0.0
+    t_ref = time.time() - t0
+    try:
+        P = params_from_config(dict(cfg), None, tile_agents=16, tile_tasks=128, tile_threats=16)
+        TOG.check_trace(tr, f"WIDE{k}", P, seed)
+    except AssertionError as exc:
+        if "--save" in sys.argv:
+            np.savez_compressed(os.path.join(HERE, "golden", f"trace_WIDE{k}_s{seed}.npz"), **tr)
+        return k, "MISMATCH", str(exc)[:400], t_ref
+    except Exception as exc:
+        return k, "ERROR", "".join(traceback.format_exception_only(type(exc), exc))[:400], t_ref
+    return k, "ok", f"steps {tr['pos'].shape[0] - 1} tasks {int(tr['n_task_ids'])} S_WPS {tr['metrics'][4]:.3f}", t_ref
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    first = int(args[0]) if len(args) > 0 else 0
+    n = int(args[1]) if len(args) > 1 else 100
+    procs = int(args[2]) if len(args) > 2 else 4
+    counts = {}
+    t0 = time.time()
+    with Pool(procs) as pool:
+        for k, status, msg, t_ref in pool.imap_unordered(run_one, range(first, first + n)):
+            counts[status] = counts.get(status, 0) + 1
+            if status != "ok" or "--verbose" in sys.argv:
+                print(f"k={k} {status}: {msg}", flush=True)
+                if status in ("MISMATCH", "ERROR"):
+                    print("   ", json.dumps(wide_config(k)), flush=True)
+    print(f"configs {first}..{first + n - 1}: {counts}  ({time.time() - t0:.0f} s)", flush=True)

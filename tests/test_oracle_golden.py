@@ -83,14 +83,11 @@ def check_state(e, g, s, tag):
     assert np.array_equal(fl, g["obs_flags"][s]), f"{tag} step {s}: event_flags"
 
 
-@pytest.mark.parametrize("path", TRACES, ids=[os.path.basename(p)[6:-4] for p in TRACES])
-def test_trace_bit_exact(path):
-    g = np.load(path)
-    name = os.path.basename(path)[6:-4]
-    case, seed = name.rsplit("_s", 1)
-    seed = int(seed)
+def check_trace(g, name, params, seed):
+    """One reference episode (the arrays tools/gen_golden.py::run_episode(full=True) returns) against the oracle: every step's
+    plan, LSAP calls, drained events, state and observation, then the final metrics."""
     interval = int(g["interval"])
-    e = orc.OracleEnv(params_of(case))
+    e = orc.OracleEnv(params)
     e.reset(seed)
     rows, _, _ = e.agents()
     assert np.array_equal(rows[:, 12].astype(int), g["agent_type"])
@@ -126,6 +123,14 @@ def test_trace_bit_exact(path):
     assert lsap_i == len(g["lsap_step"])
     assert np.array_equal(e.metrics(), g["metrics"]), f"{name}: final metrics"
     assert e.dims()["n_replans"] == int(g["n_replans"])
+
+
+@pytest.mark.parametrize("path", TRACES, ids=[os.path.basename(p)[6:-4] for p in TRACES])
+def test_trace_bit_exact(path):
+    g = np.load(path)
+    name = os.path.basename(path)[6:-4]
+    case, seed = name.rsplit("_s", 1)
+    check_trace(g, name, params_of(case), int(seed))
 
 
 LIST_TRACES = sorted(glob.glob(os.path.join(GOLDEN, "lists_*.npz")))

@@ -192,11 +192,13 @@ def snapshot(env):
 
 
 def snapshot_obs(env):
-    """Numeric view of the observation dicts (DroneEnv.py:365-415,468-492)."""
+    """Numeric view of the observation dicts (DroneEnv.py:365-415,468-492).  The reference's lists are max_tasks long unless MORE
+    than max_tasks tasks are open (its pad count goes negative and pads nothing: :410-413); the fixed-width tensors of the
+    batched API keep the first max_tasks rows, which is what is captured then."""
     T = env.max_tasks
     first = env.observations[env.agents_obj[0].name]
     ti = np.zeros((T, 21), dtype=np.float32)
-    for j, info in enumerate(first["tasks_info"]):
+    for j, info in enumerate(first["tasks_info"][:T]):
         if info.get("status", -1) == -1 and "id" not in info:
             ti[j, 3] = -1.0
             continue
@@ -214,7 +216,7 @@ def snapshot_obs(env):
     ag = np.zeros((env.n_agents, 9), dtype=np.float32)
     for i, a in enumerate(env.agents_obj):
         o = env.observations[a.name]
-        legal[i] = o["legal_mask"]
+        legal[i] = o["legal_mask"][:T]
         ag[i, 0:2] = o["agent_position"]
         ag[i, 2:8] = o["agent_caps"]
         ag[i, 8] = o["alloc_task"]
