@@ -1946,6 +1946,12 @@ void orc_get_tasks(void* h, double* rows, double* reqs) {
     for (int c = 0; c < 6; c++) { reqs[k * 18 + c] = t.currentReqs[c]; reqs[k * 18 + 6 + c] = t.allocatedReqs[c]; reqs[k * 18 + 12 + c] = t.doneReqs[c]; }
   }
 }
+// orgReqs[typeIdx] by task id (the requirement a task was created with: DroneEnvComponents.py:232; Det keeps its initial count
+// while currentReqs[5] is decremented per spawn, DroneEnv.py:1637)
+void orc_get_task_org(void* h, double* out) {
+  Env* e = (Env*)h;
+  for (size_t k = 0; k < e->tasks.size(); k++) out[k] = e->tasks[k].orgReqs[e->tasks[k].type];
+}
 void orc_get_known(void* h, uint8_t* out) {  // [A, NT]
   Env* e = (Env*)h;
   size_t nt = e->tasks.size();

@@ -6,7 +6,10 @@ and are compared with the oracle:
   fused     muavta_rollout over N seeds per (config, tile), the allocator mode rotating with the config number: all 30 metrics
             of every env that did not overflow its tile, bit for bit;
   stepwise  reset + max_time_steps x (allocate -> step) on one tile per config, every field of every env and the observation
-            after every step (test_gpu_parity.compare).
+            after every step (test_gpu_parity.compare);
+  scored    the allocator with caller-supplied edge scores / task priorities / reserved agents (muavta_allocate_scored), a gate /
+            flag / token-kind / pad combination per config, pseudo-random inputs per step, visibility toggling: plan, _selected_mask
+            and the full state after every step.
 
     python tests/fuzz_device.py [first_k [n_configs [seeds_per_config]]]
 
@@ -28,7 +31,13 @@ from muavta_amd.batched import BatchedMultiUAVEnv  # noqa: E402
 from muavta_amd.params import params_from_config  # noqa: E402
 from test_gpu_parity import Snapshot, compare  # noqa: E402
 
+from test_gpu_parity import GATE  # noqa: E402
+
 TILES = ((16, 40, 16), (24, 48, 24), (64, 128, 48))
+SCORED = (("allocator", dict(edge_valid_only=True, full_task_list=True), "pair", 0, 3), ("force", dict(edge_valid_only=False, commit=True), "escort", 2, 4),
+          ("escort", dict(edge_valid_only=True), "pair_raw", 1, 1), ("trainer", dict(edge_valid_only=True), "pair", 0, 1),
+          ("trainer", dict(full_task_list=True), "pair", 0, 2), ("escort", dict(edge_valid_only=False, commit=True), "escort", 2, 4))
+PADS = ((32, 16), (6, 3), (48, 16), (12, 8))
 MODES = ((0, "hungarian"), (1, "urgency_pair"), (2, "urgency_coalition"), (3, "hungarian_gated"))
 
 
@@ -119,6 +128,55 @@ def stepwise(k, w, log):
     return "ok"
 
 
+def scored(k, w, log):
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+    gate, kw, kname, kind, oflags = SCORED[k % len(SCORED)]
+    mt, ma = PADS[(k // len(SCORED)) % len(PADS)]
+    tile = TILES[(k // 2) % 3]
+    p = params(cfg, tile)
+    n = 2
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    env = BatchedMultiUAVEnv(p, n)
+    A = env.n_agents
+    oracles = [orc.OracleEnv(p) for _ in range(n)]
+    env.reset(seeds)
+    for i, o in enumerate(oracles):
+        o.reset(int(seeds[i]))
+    rng = np.random.default_rng(1000 + k)
+    tag = f"k={k} scored tile {tile} gate {gate} kind {kname} pads {mt}x{ma} flags {kw} interval {interval}"
+    try:
+        if env.get("ERROR").any():
+            return "overflow"
+        for t in range(p.max_time_steps):
+            if any(bool(o.dims()["terminated"] or o.dims()["truncated"]) for o in oracles):
+                break
+            sc = (rng.uniform(-1, 1, (n, ma, mt)) * (0.35 if kind != 2 else 1.0)).astype(np.float32)
+            pri = rng.uniform(-0.5, 1, (n, mt))
+            res = rng.integers(0, 1 << A, n, dtype=np.uint64) & rng.integers(0, 1 << A, n, dtype=np.uint64)
+            vis = bool((t // 3) % 2)
+            out = env.allocate_scored(kname, mt, ma, edge_scores=sc, task_pri=pri, reserved=res, gate=gate, replan_interval=interval, use_visibility=vis, **kw)
+            for i, o in enumerate(oracles):
+                oa, oi, osel = o.allocate_scored(interval, int(vis), GATE[gate], kind, mt, ma, oflags, scores=sc[i], pri=pri[i], reserved=int(res[i]))
+                kk = len(oa)
+                assert np.array_equal(out["act_agent"][i][:kk], oa) and np.all(out["act_agent"][i][kk:] == -1) and np.array_equal(out["act_index"][i][:kk], oi), \
+                    f"{tag} seed {seeds[i]} t={t}: plan {out['act_agent'][i][:kk + 2]} / {out['act_index'][i][:kk + 2]} vs {oa} / {oi}"
+                assert np.array_equal(out["selected"][i], osel), f"{tag} seed {seeds[i]} t={t}: selected mask"
+                assert bool(out["replanned"][i]) == (o.scalars_last_plan() == t), f"{tag} seed {seeds[i]} t={t}: gate"
+                o.step(oa, oi)
+            env.step_staged()
+            snap = Snapshot(env)
+            if snap.ERROR.any():
+                return "overflow"
+            for i, o in enumerate(oracles):
+                compare(snap, i, o, f"{tag} seed {seeds[i]} t={t + 1}")
+    except AssertionError as exc:
+        log(f"SCORED MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     n_cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 50
@@ -128,13 +186,15 @@ if __name__ == "__main__":
         print(msg, flush=True)
 
     t0 = time.time()
-    tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "errors": 0}
+    tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "scored_ok": 0, "scored_bad": 0,
+           "scored_overflow": 0, "errors": 0}
     for k in range(first, first + n_cfg):
         w = wide_config(k)
         try:
             b, f, c = fused(k, w, n_seeds, log)
             tot["fused_bad"] += b; tot["fused_flagged"] += f; tot["fused_checked"] += c
             tot["step_" + stepwise(k, w, log)] += 1
+            tot["scored_" + scored(k, w, log)] += 1
         except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
             tot["errors"] += 1
             log(f"k={k} ERROR {type(exc).__name__}: {str(exc)[:300]}")

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Wide differential fuzz of the policy-in-the-loop path, THIS container only (not part of the test suite): random configurations
+(fuzz_reference.wide_config; fleets of at most 16 UAVs, the trainers' token pad) are run through the REFERENCE's run_rl_episode loop
+with PairCostHybrid.plan(scores=<seeded matrix>) (tools/gen_golden.py::rl_episode) and checked against the oracle's scored allocator
+with the comparison the committed rl_*.npz traces go through (test_oracle_golden.check_rl): tokens, edge_valid, every scored LSAP
+cost matrix and assignment, _selected_mask, pairs, actions, step rewards, next tokens, done flags, final metrics — bit for bit.
+
+    python tests/fuzz_reference_rl.py [first_k [n_configs [procs]]]
+
+Lives under tests/ because it uses the oracle as its checker."""
+import os
+import sys
+import time
+import traceback
+from multiprocessing import Pool
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from fuzz_reference import wide_config  # noqa: E402
+
+
+def run_one(k: int):
+    import gen_golden as G
+    from mUAV_TA.MultiDroneEnvUtils import agentEnvOptions
+    from muavta_amd.params import params_from_config
+    import test_oracle_golden as TOG
+
+    w = wide_config(k)
+    cfg, seed = w["cfg"], w["seed"]
+    raw = bool(k & 1)
+    try:
+        env = G.MultiUAVEnv(agentEnvOptions(render_speed=-1, action_mode="TaskAssign", multiple_agents_per_task=True, fixed_seed=-1, **cfg))
+        tr = G.rl_episode(env, seed, raw)
+    except Exception as exc:  # a combination the reference itself cannot run
+        return k, "skip", f"{type(exc).__name__}: {str(exc)[:200]}"
+    try:
+        P = params_from_config(dict(cfg), None, tile_agents=16, tile_tasks=128, tile_threats=16)
+        TOG.check_rl(tr, f"WIDE{k}", P)
+    except AssertionError as exc:
+        return k, "MISMATCH", str(exc)[:400]
+    except Exception as exc:
+        return k, "ERROR", "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))[-700:]
+    return k, "ok", f"plans {len(tr['step'])} S_WPS {tr['metrics'][4]:.3f}"
+
+
+if __name__ == "__main__":
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    first = int(args[0]) if len(args) > 0 else 0
+    n = int(args[1]) if len(args) > 1 else 100
+    procs = int(args[2]) if len(args) > 2 else 4
+    counts = {}
+    t0 = time.time()
+    with Pool(procs) as pool:
+        for k, status, msg in pool.imap_unordered(run_one, range(first, first + n)):
+            counts[status] = counts.get(status, 0) + 1
+            if status != "ok" or "--verbose" in sys.argv:
+                print(f"k={k} {status}: {msg}", flush=True)
+    print(f"configs {first}..{first + n - 1}: {counts}  ({time.time() - t0:.0f} s)", flush=True)

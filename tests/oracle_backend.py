@@ -118,8 +118,7 @@ class OracleBackend:
         if name == "TASK_ORG_DONE":
             ty = trow[:, 6].astype(int)
             done = reqs[np.arange(nt), 2, ty]
-            org = np.where(trow[:, 6] >= 0, 0.0, 0.0)
-            return np.stack([self._org(trow, reqs), done], axis=1)[None]
+            return np.stack([self.o.task_org(), done], axis=1)[None]
         if name == "TASK_TIMES":
             return trow[:, 3:5][None].copy()
         if name == "TASK_META":
@@ -178,10 +177,3 @@ class OracleBackend:
             return out[None]
         raise KeyError(name)
 
-    @staticmethod
-    def _org(trow, reqs):
-        # orgReqs[typeIdx]: static tasks 1.0, Det = its initial count, Int 2.0, escort = requirement; the oracle
-        # does not export orgReqs, so recover it as doneReqs + currentReqs at the type index when possible
-        ty = trow[:, 6].astype(int)
-        n = trow.shape[0]
-        return reqs[np.arange(n), 0, ty] + reqs[np.arange(n), 2, ty]

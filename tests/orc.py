@@ -139,6 +139,12 @@ class OracleEnv:
         self.L.orc_get_tasks(self.h, _p(rows), _p(reqs))
         return rows, reqs
 
+    def task_org(self):
+        """orgReqs[typeIdx] by task id."""
+        out = np.zeros(self.dims()["n_task_ids"])
+        self.L.orc_get_task_org(self.h, _p(out))
+        return out
+
     def known(self):
         nt = self.dims()["n_task_ids"]
         k = np.zeros((self.A, nt), dtype=np.uint8)

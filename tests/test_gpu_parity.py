@@ -63,6 +63,7 @@ def compare(snap, i, o, tag, check_obs=True):
     open_oracle = {k for k in range(1, trow.shape[0]) if int(trow[k, 0]) != 2}
     assert open_oracle <= set(ids[live].tolist()), f"{tag}: open task missing on device"
     known = o.known()
+    org = o.task_org()
     for s in live:
         k = int(ids[s])
         assert snap.TASK_STATUS[i, s] == int(trow[k, 0]), f"{tag}: task {k} status"
@@ -71,6 +72,7 @@ def compare(snap, i, o, tag, check_obs=True):
         assert np.array_equal(snap.TASK_ALLOC[i, s], reqs[k, 1]), f"{tag}: task {k} allocatedReqs"
         ty = int(trow[k, 6])
         assert snap.TASK_ORG_DONE[i, s, 1] == reqs[k, 2, ty], f"{tag}: task {k} doneReqs"
+        assert snap.TASK_ORG_DONE[i, s, 0] == org[k], f"{tag}: task {k} orgReqs"
         meta = snap.TASK_META[i, s]
         assert list(meta[0:5]) == [int(x) for x in trow[k, 6:11]], f"{tag}: task {k} meta {meta} vs {trow[k, 6:11]}"
         assert meta[6] == int(trow[k, 11]) and meta[7] == int(trow[k, 12]), f"{tag}: task {k} escort meta"

@@ -395,14 +395,12 @@ def _acts_at(g, t):
     return a[np.argsort(a[:, 0], kind="stable")]
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rl_*.npz"))))
-def test_rl_loop_scored_plans_vs_reference(path):
+def check_rl(g, case, params):
     """run_rl_episode (experiments/train_pair_cost.py:132-156) with PairCostHybrid.plan(scores=seeded): scored cost matrices,
     assignments, _selected_mask, actions, tokens / next tokens, step rewards, done, final metrics"""
-    g = np.load(path)
-    case = os.path.basename(path)[3:-4]
     kind = 1 if int(g["raw"]) else 0
-    e = orc.OracleEnv(params_for_case(case))
+    interval = int(g["interval"]) if "interval" in g else 20
+    e = orc.OracleEnv(params)
     e.reset(int(g["seed"]))
     steps, k = g["step"].tolist(), 0
     assert e.metrics()[4] == g["s_wps"][0]
@@ -410,17 +408,17 @@ def test_rl_loop_scored_plans_vs_reference(path):
     for t in range(len(g["replanned"])):
         tok = e.tokens(kind, 32, 16)
         if pending is not None:  # next_tok of the previous transition = tokens after its step
-            assert np.array_equal(tok["task_feats"], g["ntf"][pending]) and np.array_equal(tok["agent_feats"], g["naf"][pending])
-            assert np.array_equal(tok["task_ids"], g["ntid"][pending])
+            assert np.array_equal(tok["task_feats"], g["ntf"][pending]) and np.array_equal(tok["agent_feats"], g["naf"][pending]), f"{case} t={t}: next tokens"
+            assert np.array_equal(tok["task_ids"], g["ntid"][pending]), f"{case} t={t}: next token ids"
             pending = None
         planned = bool(g["replanned"][t])
         sc = g["scores"][k] if planned else np.zeros((16, 32), np.float32)
-        aa, ai, sel = e.allocate_scored(20, 1, GATE_TRAINER, kind, 32, 16, SC_EDGE_VALID_ONLY, scores=sc)
+        aa, ai, sel = e.allocate_scored(interval, 1, GATE_TRAINER, kind, 32, 16, SC_EDGE_VALID_ONLY, scores=sc)
         assert (e.scalars_last_plan() == t) == planned, f"{case} t={t}: gate"
         if planned:
             assert t == steps[k]
-            assert np.array_equal(tok["task_feats"], g["tf"][k]) and np.array_equal(tok["agent_feats"], g["af"][k])
-            assert np.array_equal(tok["edge_valid"], g["ev"][k]) and np.array_equal(tok["task_ids"], g["tid"][k]) and np.array_equal(tok["agent_ids"], g["aid"][k])
+            assert np.array_equal(tok["task_feats"], g["tf"][k]) and np.array_equal(tok["agent_feats"], g["af"][k]), f"{case} t={t}: token features"
+            assert np.array_equal(tok["edge_valid"], g["ev"][k]) and np.array_equal(tok["task_ids"], g["tid"][k]) and np.array_equal(tok["agent_ids"], g["aid"][k]), f"{case} t={t}: edge_valid / ids"
             _check_lsap(e, g, t, case)
             assert np.array_equal(sel, g["selected"][k]), f"{case} t={t}: selected mask"
             want = g["pairs"][g["pairs"][:, 0] == t][:, 1:]
@@ -432,12 +430,18 @@ def test_rl_loop_scored_plans_vs_reference(path):
         order = np.argsort(aa, kind="stable")
         assert np.array_equal(np.stack([aa[order], ai[order]], axis=1).reshape(-1, 2), want_a.reshape(-1, 2)), f"{case} t={t}: actions"
         done = e.step(aa, ai)
-        assert e.metrics()[4] == g["s_wps"][t + 1]
+        assert e.metrics()[4] == g["s_wps"][t + 1], f"{case} t={t}: S_WPS"
         if planned:
-            assert (e.metrics()[4] - g["s_wps"][t]) / 20.0 == g["step_r"][k] and bool(done) == bool(g["ep_done"][k])
+            assert (e.metrics()[4] - g["s_wps"][t]) / 20.0 == g["step_r"][k] and bool(done) == bool(g["ep_done"][k]), f"{case} t={t}: step reward / done"
             k += 1
-    assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"])
+    assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"]), f"{case}: final metrics"
     assert e.dims()["n_replans"] == int(g["n_replans"])
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rl_*.npz"))))
+def test_rl_loop_scored_plans_vs_reference(path):
+    case = os.path.basename(path)[3:-4]
+    check_rl(np.load(path), case, params_for_case(case))
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rah_*.npz"))))

@@ -792,65 +792,73 @@ def _pack_lsap(tap):
                 lsap_col=np.concatenate([c[3] for c in tap.calls]) if tap.calls else np.zeros(0, dtype=np.int64))
 
 
-def gen_rl():
+def rl_episode(env, seed, raw, interval=20):
+    """run_rl_episode (experiments/train_pair_cost.py:132-156) with the net's output replaced by a seeded score matrix
+    (PairCostHybrid.plan(scores=...), PairCostHybrid.py:312-327): every plan's tokens, scores, LSAP calls, _selected_mask, pairs and
+    actions, the step rewards, next tokens and done flags."""
     import experiments.train_pair_cost as T
     from TaskAllocation.Hybrid.PairCostHybrid import PairCostHybrid
 
+    policy = PairCostHybrid(use_attention=False, max_tasks=32, max_agents=16, d_model=16, raw_features=raw, device="cpu")
+    tap = LsapTap()
+    HA.linear_sum_assignment = tap
+    try:
+        rng = np.random.default_rng(4200 + seed % 1000003)
+        obs, info = env.reset(seed=seed)
+        hung = HA.HungarianAllocator(replan_interval=interval, max_coord=env.max_coord)
+        done = {a: False for a in env.agents}
+        trunc = {a: False for a in env.agents}
+        rec = {k: [] for k in ("step", "scores", "selected", "tid", "aid", "tf", "af", "ev", "ntf", "naf", "ntid", "step_r", "ep_done")}
+        pairs, acts, replanned, s_wps = [], [], [], [float(env.compute_s_wps())]
+        s_prev = s_wps[0]
+        while not all(done.values()) and not all(trunc.values()):
+            events = _events(info)
+            actions = {}
+            tok = None
+            rp = T._should_replan(env, events)
+            replanned.append(int(rp))
+            tap.step = env.time_steps
+            if rp:
+                # the net's output stand-in: tanh-range scores, NOT masked by edge_valid (edge_score_dict must do that)
+                scores = (rng.uniform(-1.0, 1.0, (16, 32)) * 0.35).astype(np.float32)
+                result, tok, scores, noise, logits, selected = policy.plan(env, hung, events=events, explore=False, force=True, scores=scores)
+                actions = T._apply_assign(env, result)
+                t_plan = env.time_steps
+                for name, task in result:
+                    pairs.append((t_plan, env.agent_by_name[name].id, task.id))
+                for name, idx in actions.items():
+                    acts.append((t_plan, env.agent_by_name[name].id, idx))
+            obs, reward, done, trunc, info = env.step(actions)
+            s_now = float(env.compute_s_wps())
+            step_r = (s_now - s_prev) / 20.0
+            s_prev = s_now
+            s_wps.append(s_now)
+            ep_done = all(done.values()) or all(trunc.values())
+            if tok is not None:
+                next_tok = policy.build_tokens(env)
+                tid, aid = _ids(tok, 32, 16)
+                ntid, _ = _ids(next_tok, 32, 16)
+                rec["step"].append(t_plan); rec["scores"].append(scores); rec["selected"].append(selected)
+                rec["tid"].append(tid); rec["aid"].append(aid); rec["tf"].append(tok["task_feats"]); rec["af"].append(tok["agent_feats"])
+                rec["ev"].append(tok["edge_valid"]); rec["ntf"].append(next_tok["task_feats"]); rec["naf"].append(next_tok["agent_feats"])
+                rec["ntid"].append(ntid); rec["step_r"].append(step_r); rec["ep_done"].append(int(ep_done))
+    finally:
+        HA.linear_sum_assignment = linear_sum_assignment
+    out = {k: np.stack([np.asarray(x) for x in v]) if v else np.zeros(0) for k, v in rec.items()}
+    out.update(_pack_lsap(tap))
+    out.update(pairs=np.array(pairs, dtype=np.int64).reshape(-1, 3), actions=np.array(acts, dtype=np.int64).reshape(-1, 3),
+               replanned=np.array(replanned, dtype=np.int64), s_wps=np.array(s_wps), seed=np.int64(seed), raw=np.int64(raw),
+               n_replans=np.int64(hung.n_replans), interval=np.int64(interval),
+               metrics=np.array([float(info["metrics"][k]) for k in METRIC_KEYS]))
+    return out
+
+
+def gen_rl():
     for case, seed, raw in (("WPS_hard", 0, False), ("WPS_hard_x2", 1, False), ("WPS_attn", 2, True), ("WPS_burst64", 0, False)):
-        env = make_env(case)
-        policy = PairCostHybrid(use_attention=False, max_tasks=32, max_agents=16, d_model=16, raw_features=raw, device="cpu")
-        tap = LsapTap()
-        HA.linear_sum_assignment = tap
-        try:
-            rng = np.random.default_rng(4200 + seed)
-            obs, info = env.reset(seed=seed)
-            hung = HA.HungarianAllocator(replan_interval=20, max_coord=env.max_coord)
-            done = {a: False for a in env.agents}
-            trunc = {a: False for a in env.agents}
-            rec = {k: [] for k in ("step", "scores", "selected", "tid", "aid", "tf", "af", "ev", "ntf", "naf", "ntid", "step_r", "ep_done")}
-            pairs, acts, replanned, s_wps = [], [], [], [float(env.compute_s_wps())]
-            s_prev = s_wps[0]
-            while not all(done.values()) and not all(trunc.values()):
-                events = _events(info)
-                actions = {}
-                tok = None
-                rp = T._should_replan(env, events)
-                replanned.append(int(rp))
-                tap.step = env.time_steps
-                if rp:
-                    # the net's output stand-in: tanh-range scores, NOT masked by edge_valid (edge_score_dict must do that)
-                    scores = (rng.uniform(-1.0, 1.0, (16, 32)) * 0.35).astype(np.float32)
-                    result, tok, scores, noise, logits, selected = policy.plan(env, hung, events=events, explore=False, force=True, scores=scores)
-                    actions = T._apply_assign(env, result)
-                    t_plan = env.time_steps
-                    for name, task in result:
-                        pairs.append((t_plan, env.agent_by_name[name].id, task.id))
-                    for name, idx in actions.items():
-                        acts.append((t_plan, env.agent_by_name[name].id, idx))
-                obs, reward, done, trunc, info = env.step(actions)
-                s_now = float(env.compute_s_wps())
-                step_r = (s_now - s_prev) / 20.0
-                s_prev = s_now
-                s_wps.append(s_now)
-                ep_done = all(done.values()) or all(trunc.values())
-                if tok is not None:
-                    next_tok = policy.build_tokens(env)
-                    tid, aid = _ids(tok, 32, 16)
-                    ntid, _ = _ids(next_tok, 32, 16)
-                    rec["step"].append(t_plan); rec["scores"].append(scores); rec["selected"].append(selected)
-                    rec["tid"].append(tid); rec["aid"].append(aid); rec["tf"].append(tok["task_feats"]); rec["af"].append(tok["agent_feats"])
-                    rec["ev"].append(tok["edge_valid"]); rec["ntf"].append(next_tok["task_feats"]); rec["naf"].append(next_tok["agent_feats"])
-                    rec["ntid"].append(ntid); rec["step_r"].append(step_r); rec["ep_done"].append(int(ep_done))
-        finally:
-            HA.linear_sum_assignment = linear_sum_assignment
-        out = {k: np.stack([np.asarray(x) for x in v]) for k, v in rec.items()}
-        out.update(_pack_lsap(tap))
-        out.update(pairs=np.array(pairs, dtype=np.int64).reshape(-1, 3), actions=np.array(acts, dtype=np.int64).reshape(-1, 3),
-                   replanned=np.array(replanned, dtype=np.int64), s_wps=np.array(s_wps), seed=np.int64(seed), raw=np.int64(raw),
-                   n_replans=np.int64(hung.n_replans),
-                   metrics=np.array([float(info["metrics"][k]) for k in METRIC_KEYS]))
+        out = rl_episode(make_env(case), seed, raw)
+        del out["interval"]
         np.savez_compressed(os.path.join(OUT, f"rl_{case}.npz"), **out)
-        print("rl", case, out["scores"].shape, "selected", int(out["selected"].sum()), "pairs", len(pairs), "S_WPS", out["metrics"][4],
+        print("rl", case, out["scores"].shape, "selected", int(out["selected"].sum()), "pairs", len(out["pairs"]), "S_WPS", out["metrics"][4],
               "max token tasks", int((out["tid"] >= 0).sum(axis=1).max()))
 
 
