@@ -374,7 +374,11 @@ int muavta_rollout(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps, int32
  *   pad     u8  [N, max_tasks]      mask
  *   agents  f32 [N, A, 9]           agent_position(2), agent_caps(6), alloc_task
  *   flags   f32 [N, 5]              event_flags
- * Any pointer may be NULL. */
+ * Any pointer may be NULL.
+ * More than max_tasks open tasks (possible: threat / escort tasks are created past the arrival cap of DroneEnv.py:1646-1689): the
+ * reference's lists then simply grow (its pad count goes negative, :410-413); the fixed-width tensors hold the FIRST max_tasks rows.
+ * The open list itself (MUAVTA_F_OPEN_IDS, what action indices refer to) is never truncated, and an index >= max_tasks is applied
+ * as the reference applies it.  Pinned on reference episodes in that regime by tests/fuzz_reference.py. */
 int muavta_observe(MuavtaEnv* env, float* tasks, uint64_t* legal, uint8_t* pad, float* agents, float* flags);
 
 /* rewards / terminations / truncations of the last step: reward f64 [N] (shared by all agents of an

@@ -2514,7 +2514,7 @@ struct Sim {
     const int n = S.n_escorts;
     if (n == 0) return;
     int recon = -1, es = -1, eid = -1;
-    bool retire = false, dead = false, esc_live = false;
+    bool retire = false, dead = false, esc_live = false, esc_here = false;
     if (lane < n) {
       recon = S.esc_agent[lane]; es = S.esc_slot[lane]; eid = S.esc_id[lane];
       const int rid = S.esc_pid[lane], rs = S.esc_pslot[lane];
@@ -2523,7 +2523,8 @@ struct Sim {
       const bool rec_done = ref_retired(rid, rs);
       const bool wrong_task = S.a_qlen[recon] > 0 && S.a_qid[recon][0] != rid;
       retire = dead || idle || rec_done || wrong_task;
-      esc_live = !ref_retired(eid, es);
+      esc_here = ref_valid(eid, es);  // an escort that expired by its hard window keeps its map entry (status 2, never popped) ...
+      esc_live = esc_here && S.t_status[es] != 2;
     }
     const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     unsigned long long rm = __ballot(retire), todo = all;
@@ -2560,7 +2561,7 @@ struct Sim {
             if (__builtin_amdgcn_ballot_w64(neark == k) != 0ull) cov |= 1ull << k;
           }
         if ((seg >> lane) & 1ull) {
-          if (esc_live) { S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon]; }  // follow the protected UAV
+          if (esc_here) { S.t_px[es] = S.a_px[recon]; S.t_py[es] = S.a_py[recon]; }  // ... and follows the protected UAV (:1995); only coverage asks for status != 2 (:1751)
         }
         if (lane == 0) { S.escort_required_steps += __popcll(seg); S.escort_covered_steps += __popcll(cov); }
         todo &= ~seg;
@@ -2952,7 +2953,10 @@ struct Sim {
     int my_st = 0, my_hid = 0, my_ty = 0;
     if (lane < nA) { my_st = S.a_state[lane]; my_hid = head_id(lane); my_ty = S.a_type[lane]; }
     const bool capm = P.capability_mask != 0;
-    for (int base = 0; base < MT; base += WG) {
+    // (the reference's lists are max_tasks long unless MORE tasks are open — then they grow, DroneEnv.py:410-413 — and its "no legal
+    // action" fallback looks at all of them: the loop covers every open row, the stores the first max_tasks)
+    const int row_lim = n > MT ? n : MT;
+    for (int base = 0; base < row_lim; base += WG) {
       const int j = base + lane;
       const uint32_t ju = (uint32_t)j;  // unsigned lane offset + uniform column pointer: stores take the (SGPR base, VGPR offset) form
       const bool in_n = j < n, in_mt = j < MT;
@@ -2968,6 +2972,8 @@ struct Sim {
           if (P.saturate_mask && C.t_alloc[ty][s] >= qs().t_org[s]) typemask = 0;
           uint32_t off = ju * 4u;
           const uint32_t cstride = (uint32_t)MT * 4u;
+          // (more open tasks than max_tasks: the tensor holds the first max_tasks rows; rows beyond it only feed the legal-mask ballots)
+          if (in_mt) {
           if (ty == MUAVTA_INT || (S.t_flags[s] & TF_ESCORT)) {  // the tasks that move: an Int task follows its threat, an escort its UAV
             at_lane(o_tasks, off + cstride) = (float)div_small(S.t_px[s], MAX_COORD, INV_COORD);
             at_lane(o_tasks, off + 2u * cstride) = (float)div_small(S.t_py[s], MAX_COORD, INV_COORD);
@@ -2978,6 +2984,7 @@ struct Sim {
             at_lane(o_tasks, off + 17u * cstride) = (float)div_small_any(td - (double)tnow, mts, inv_mts);
           }
           at_lane(o_tasks, off + 20u * cstride) = (float)fmin(div_small((double)tnow - (double)S.t_created[s], mts, inv_mts), 1.0);
+          }
         } else {
         float r[21];
         r[0] = (float)tid;
@@ -3069,6 +3076,10 @@ struct Sim {
       else if (n > 0) { leg0 |= cur0; leg1 |= cur1; }
       // "no legal action" fallback (:401-408): the current task if it is open, else row 0
       if ((leg0 | leg1) == 0ull && n > 0 && my_st != 2) leg0 = 1ull;
+      if (n > MT) {  // rows beyond the tensor's width took part in the fallback above and are dropped here
+        if (MT < 64) { leg0 &= (1ull << MT) - 1ull; leg1 = 0ull; }
+        else if (MT < 128) leg1 &= (1ull << (MT - 64)) - 1ull;
+      }
       const int KM = (MT + 63) >> 6;
       o_legal[lane * KM] = leg0;
       if (KM > 1) o_legal[lane * KM + 1] = leg1;

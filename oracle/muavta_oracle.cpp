@@ -2079,12 +2079,13 @@ void orc_observe(void* h, float* tinfo, uint8_t* legal, uint8_t* pad, float* ag,
       } else if (n == 0) {
         L[0] = 1;
       } else {
+        // (more than max_tasks open tasks: the reference's list has them all, :396-408 look at all of them; the tensor keeps the first T)
         bool any = false;
-        for (int j = 0; j < n && j < T; j++) { L[j] = e->is_task_action_valid(a, e->tasks[open[j]]); any |= L[j]; }
+        for (int j = 0; j < n; j++) { bool v = e->is_task_action_valid(a, e->tasks[open[j]]); if (j < T) L[j] = v; any |= v; }
         if (!any) {
           int cur = a.tasks.empty() ? -1 : a.tasks[0];
           bool found = false;
-          for (int j = 0; j < n && j < T; j++) if (e->tasks[open[j]].id == cur) { L[j] = 1; found = true; break; }
+          for (int j = 0; j < n; j++) if (e->tasks[open[j]].id == cur) { if (j < T) L[j] = 1; found = true; break; }
           if (!found) L[0] = 1;
         }
       }

@@ -1,5 +1,6 @@
 """Case name -> MuavtaParams for the parity tests: registry cases (muavta_amd.scenarios) and the fuzzed configurations
-whose reference traces are committed as tests/golden/trace_FUZZ*.npz (configs: tests/golden/fuzz_configs.json)."""
+whose reference traces are committed as tests/golden/trace_FUZZ*.npz (configs: tests/golden/fuzz_configs.json) and
+tests/golden/trace_WIDE*.npz (configs the wide fuzz found device bugs on: tests/golden/wide_configs.json, tests/fuzz_reference.py --pin)."""
 import json
 import os
 
@@ -11,13 +12,17 @@ _FUZZ = None
 def fuzz_configs():
     global _FUZZ
     if _FUZZ is None:
-        with open(os.path.join(os.path.dirname(__file__), "golden", "fuzz_configs.json")) as f:
-            _FUZZ = json.load(f)
+        _FUZZ = {}
+        for name in ("fuzz_configs.json", "wide_configs.json"):
+            path = os.path.join(os.path.dirname(__file__), "golden", name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    _FUZZ.update(json.load(f))
     return _FUZZ
 
 
 def params_of(case: str, **tiles):
-    if case.startswith("FUZZ"):
+    if case.startswith("FUZZ") or case.startswith("WIDE"):
         cfg = dict(fuzz_configs()[case])
         cfg["threats_list"] = [tuple(x) for x in cfg["threats_list"]]
         cfg["escort_agent_types"] = tuple(cfg["escort_agent_types"])

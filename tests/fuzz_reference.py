@@ -6,9 +6,12 @@ checked step by step against the CPU oracle with the same comparison the committ
 
     python tests/fuzz_reference.py [first_k [n_configs [procs]]]      # e.g. 1000 400 6
 
+    python tests/fuzz_reference.py --pin k [k ...]                    # commit those configs as fixtures
+
 Lives under tests/ because it uses the oracle as its checker.  A configuration the reference itself cannot run is skipped; a
-configuration the oracle disagrees on is printed with its key and can be pinned with --save (written as trace_WIDE<k>_s<seed>.npz
-+ an entry in tests/golden/wide_configs.json by hand)."""
+configuration the oracle disagrees on is printed with its key.  --pin writes the reference's full trace of the named configurations
+as tests/golden/trace_WIDE<k>_s<seed>.npz and their configs into tests/golden/wide_configs.json: from then on they are part of
+the test suite (test_oracle_golden.test_trace_bit_exact; on the GPU test_fuzzed_config_stepwise_vs_oracle_and_reference_metrics)."""
 import json
 import os
 import random
@@ -107,6 +110,30 @@ def run_one(k: int):
         return k, "ERROR", "".join(traceback.format_exception_only(type(exc), exc))[:400], t_ref
     return k, "ok", f"steps {tr['pos'].shape[0] - 1} tasks {int(tr['n_task_ids'])} S_WPS {tr['metrics'][4]:.3f}", t_ref
 
+
+def pin(ks):
+    import numpy as np
+    import gen_golden as G
+    from mUAV_TA.MultiDroneEnvUtils import agentEnvOptions
+
+    path = os.path.join(HERE, "golden", "wide_configs.json")
+    configs = json.load(open(path)) if os.path.exists(path) else {}
+    for k in ks:
+        w = wide_config(k)
+        G.make_env = lambda case, _cfg=w["cfg"]: G.MultiUAVEnv(agentEnvOptions(render_speed=-1, action_mode="TaskAssign", multiple_agents_per_task=True,
+                                                                                 fixed_seed=-1, **_cfg))
+        tr = G.run_episode(f"WIDE{k}", w["seed"], w["interval"], True)
+        out = os.path.join(HERE, "golden", f"trace_WIDE{k}_s{w['seed']}.npz")
+        np.savez_compressed(out, **tr)
+        configs[f"WIDE{k}"] = w["cfg"]
+        print(out, os.path.getsize(out) // 1024, "KiB", "steps", tr["pos"].shape[0] - 1, "tasks", int(tr["n_task_ids"]), "S_WPS", tr["metrics"][4])
+    with open(path, "w") as f:
+        json.dump(configs, f, indent=1)  # key order is semantic: groups are created in dict order
+
+
+if __name__ == "__main__" and "--pin" in sys.argv:
+    pin([int(a) for a in sys.argv[1:] if not a.startswith("--")])
+    sys.exit(0)
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]

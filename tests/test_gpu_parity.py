@@ -1041,6 +1041,58 @@ def test_fuzzed_config_stepwise_vs_oracle_and_reference_metrics(path):
         assert np.all(env.get("ERROR") == 0)
 
 
+WIDE_TRACES = sorted(glob.glob(os.path.join(GOLDEN, "trace_WIDE*.npz")))
+
+
+@pytest.mark.parametrize("path", WIDE_TRACES, ids=[os.path.basename(p)[6:-4] for p in WIDE_TRACES])
+def test_wide_fuzz_regressions_stepwise_vs_oracle_and_reference_metrics(path):
+    """Configurations on which the wide fuzz (tests/fuzz_device.py) found device bugs, pinned as reference traces: MORE open tasks
+    than max_tasks (the observation tensor keeps the first max_tasks rows; r4's incremental row writer stored the rows beyond
+    them into the next feature columns), and an escort task that expired by its hard window while its map entry lives on (it
+    keeps following its UAV, DroneEnv.py:1995).  Every tile that holds the episode, stepwise against the oracle; env 0 is the
+    reference's own episode (final metrics)."""
+    from cases import params_of
+    from muavta_amd.batched import BatchedMultiUAVEnv
+
+    g = np.load(path)
+    case, seed0 = os.path.basename(path)[6:-4].rsplit("_s", 1)
+    seed0, interval, n = int(seed0), int(g["interval"]), 2
+    ran = 0
+    for tiles in (dict(tile_agents=16, tile_tasks=40, tile_threats=16), dict(tile_agents=24, tile_tasks=48, tile_threats=24),
+                  dict(tile_agents=64, tile_tasks=128, tile_threats=48)):
+        p = params_of(case, **tiles)
+        env = BatchedMultiUAVEnv(p, n)
+        seeds = np.array([seed0, seed0 - 1 if seed0 > 2 ** 62 else seed0 + 1], dtype=np.uint64)
+        oracles = [orc.OracleEnv(p) for _ in range(n)]
+        env.reset(seeds)
+        for i, o in enumerate(oracles):
+            o.reset(int(seeds[i]))
+        overflow = False
+        for t in range(p.max_time_steps):
+            if any(o.dims()["terminated"] or o.dims()["truncated"] for o in oracles):
+                break
+            aa, ai = env.allocate(interval, True)
+            for i, o in enumerate(oracles):
+                oa, oi = o.allocate(interval, 1)
+                k = len(oa)
+                assert np.array_equal(aa[i][:k], oa) and np.all(aa[i][k:] == -1) and np.array_equal(ai[i][:k], oi), f"{case} {tiles} seed {seeds[i]} t={t}"
+                o.step(oa, oi)
+            env.step(aa, ai)
+            snap = Snapshot(env)
+            if snap.ERROR.any():  # the episode needs more than this tile (only the largest one must hold it)
+                overflow = True
+                break
+            for i, o in enumerate(oracles):
+                compare(snap, i, o, f"{case} {tiles} seed {seeds[i]} t={t + 1}")
+        if overflow:
+            assert tiles["tile_agents"] < 64, f"{case}: overflows the largest tile"
+            continue
+        ran += 1
+        if oracles[0].dims()["terminated"] or oracles[0].dims()["truncated"]:
+            assert np.array_equal(env.metrics()[0], g["metrics"]), f"{case} {tiles}: reference metrics"
+    assert ran >= 1
+
+
 def test_seeds_beyond_32_bits():
     """init_by_array with a two-word key (seed >= 2^32): the batched seeding kernel against the oracle's CPython restatement."""
     case = "WPS_hard"
