@@ -414,6 +414,12 @@ int muavta_lsap_impl(int32_t device, const double* cost, int32_t n_problems, int
  * domain the results equal the IEEE-754 correctly rounded ones bit for bit; the parity tests pin that against numpy. */
 int muavta_domain_math(int32_t device, const double* x, const double* y, int32_t n, double* out_sqrt, double* out_div, double* out_div_neg);
 
+/* Diagnostic: the natural logarithm of the obstacle repulsion (core_sim/src/sim_core.rs:44, f64::ln = the host libm's log),
+ * evaluated on the device for n positive, finite, normal arguments: libm_log in csrc/muavta_device.h restates the published
+ * algorithm of that function (Arm optimized-routines log.c as shipped in glibc) so that device and host agree bit for bit; the
+ * parity tests pin that against the host's log. */
+int muavta_domain_log(int32_t device, const double* x, int32_t n, double* out);
+
 /* core_sim.SimCore.avoid_obstacles (core_sim/src/sim_core.rs:25-59) for n (position, movement)
  * pairs against one obstacle list, evaluated on the device. */
 int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double* movement, int32_t n,

@@ -617,6 +617,17 @@ def avoid_obstacles(agent_pos, obstacles, movement, device: int = 0):
     return out
 
 
+def domain_log(x, device: int = 0):
+    """The obstacle path's natural logarithm as the device computes it (diagnostic, `muavta_domain_log`)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    out = np.empty_like(x)
+    L = native.lib()
+    rc = L.muavta_domain_log(int(device), _vp(x), x.shape[0], _vp(out))
+    if rc != 0:
+        raise MuavtaError(f"muavta_domain_log failed ({rc}): {L.muavta_last_error(None).decode()}")
+    return out
+
+
 def domain_math(x, y, device: int = 0):
     """The kernels' range-restricted sqrt / division on the device (diagnostic, `muavta_domain_math`):
     returns (sqrt(x), x / y, -x / y) as the device computes them."""

@@ -756,6 +756,11 @@ __global__ void k_domain_math(const double* x, const double* y, int n, double* o
   out_div2[i] = fdiv_r(-x[i], y[i], r);
 }
 
+__global__ void k_libm_log(const double* x, int n, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = libm_log(x[i]);
+}
+
 __global__ void k_avoid(const double* pos, const double* mov, int n, const double* obst, int n_obs, double* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -768,7 +773,7 @@ __global__ void k_avoid(const double* pos, const double* mov, int n, const doubl
     double d_zone = sqrt(dx * dx + dy * dy) - obst[3 * o + 2];
     if (d_zone < 40.0) {
       double nx = dx / d_zone, ny = dy / d_zone;
-      double force = log(fmax(1.05, d_zone));
+      double force = libm_log(fmax(1.05, d_zone));
       force = 0.5 / (1.0 - force);
       double ang = atan2(my, mx) - atan2(dy, dx);
       ang = fmod(ang + PI, 2.0 * PI) - PI;
@@ -2317,6 +2322,24 @@ int muavta_domain_math(int32_t device, const double* x, const double* y, int32_t
   CK(hipMemcpy(out_sqrt, d[2], bytes, hipMemcpyDeviceToHost));
   CK(hipMemcpy(out_div, d[3], bytes, hipMemcpyDeviceToHost));
   CK(hipMemcpy(out_div_neg, d[4], bytes, hipMemcpyDeviceToHost));
+#undef CK
+  for (double* q : d) hipFree(q);
+  return MUAVTA_OK;
+}
+
+int muavta_domain_log(int32_t device, const double* x, int32_t n, double* out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "muavta_domain_log: no HIP device"; return MUAVTA_E_NO_DEVICE; }
+  if (!x || !out || n < 1) return MUAVTA_E_ARG;
+  double* d[2] = {nullptr, nullptr};
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); for (double* q : d) hipFree(q); return MUAVTA_E_HIP; } } while (0)
+  DeviceScope scope_(device);
+  const size_t bytes = (size_t)n * sizeof(double);
+  for (double*& q : d) CK(hipMalloc(&q, bytes));
+  CK(hipMemcpy(d[0], x, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_libm_log, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], n, d[1]);
+  CK(hipGetLastError());
+  CK(hipMemcpy(out, d[1], bytes, hipMemcpyDeviceToHost));
 #undef CK
   for (double* q : d) hipFree(q);
   return MUAVTA_OK;

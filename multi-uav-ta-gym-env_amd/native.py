@@ -32,7 +32,7 @@ EXPORTS = [
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
     "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
-    "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_step_lists",
+    "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_domain_log", "muavta_step_lists",
     "muavta_allocate_scored", "muavta_allocate_scored_device", "muavta_rl_step_device", "muavta_launch_gaps_ms",
 ]
 
@@ -134,6 +134,7 @@ def lib() -> C.CDLL:
     L.muavta_lsap_impl.argtypes = [i32, vp, i32, i32, i32, vp, vp, i32]
     L.muavta_avoid_obstacles.argtypes = [i32, vp, vp, i32, vp, i32, vp]
     L.muavta_domain_math.argtypes = [i32, vp, vp, i32, vp, vp, vp]
+    L.muavta_domain_log.argtypes = [i32, vp, i32, vp]
     L.muavta_device_ptrs.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.muavta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.muavta_kernel_ms_history.argtypes = [vp, vp, C.c_int32]

@@ -6,7 +6,7 @@ and are compared with the oracle:
   fused     muavta_rollout over N seeds per (config, tile), the allocator mode rotating with the config number: all 30 metrics
             of every env that did not overflow its tile, bit for bit;
   stepwise  reset + max_time_steps x (allocate -> step) on one tile per config, every field of every env and the observation
-            after every step (test_gpu_parity.compare);
+            after every step (test_gpu_parity.compare), the token builders every fourth step;
   scored    the allocator with caller-supplied edge scores / task priorities / reserved agents (muavta_allocate_scored), a gate /
             flag / token-kind / pad combination per config, pseudo-random inputs per step, visibility toggling: plan, _selected_mask
             and the full state after every step.
@@ -36,7 +36,7 @@ from test_gpu_parity import GATE  # noqa: E402
 TILES = ((16, 40, 16), (24, 48, 24), (64, 128, 48))
 SCORED = (("allocator", dict(edge_valid_only=True, full_task_list=True), "pair", 0, 3), ("force", dict(edge_valid_only=False, commit=True), "escort", 2, 4),
           ("escort", dict(edge_valid_only=True), "pair_raw", 1, 1), ("trainer", dict(edge_valid_only=True), "pair", 0, 1),
-          ("trainer", dict(full_task_list=True), "pair", 0, 2), ("escort", dict(edge_valid_only=False, commit=True), "escort", 2, 4))
+          ("trainer", dict(full_task_list=True, edge_valid_only=False), "pair", 0, 2), ("escort", dict(edge_valid_only=False, commit=True), "escort", 2, 4))
 PADS = ((32, 16), (6, 3), (48, 16), (12, 8))
 MODES = ((0, "hungarian"), (1, "urgency_pair"), (2, "urgency_coalition"), (3, "hungarian_gated"))
 
@@ -117,6 +117,14 @@ def stepwise(k, w, log):
                 return "overflow"
             for i, o in enumerate(oracles):
                 compare(snap, i, o, f"{tag} seed {seeds[i]} t={t + 1}")
+            if t % 4 == 3:  # the token builders (muavta_tokens) on the same state: kind and pads rotate
+                kind, (mt, ma) = (t // 4 + k) % 3, PADS[(t // 4 + k // 3) % len(PADS)]
+                got = env.tokens(("pair", "pair_raw", "escort")[kind], mt, ma)
+                for i, o in enumerate(oracles):
+                    want = o.tokens(kind, mt, ma)
+                    for key in want:
+                        gv = int(got[key][i]) if key == "n_urgent" else got[key][i]
+                        assert np.array_equal(np.asarray(gv), np.asarray(want[key])), f"{tag} seed {seeds[i]} t={t + 1}: tokens kind {kind} pads {mt}x{ma}: {key}"
         m = env.metrics()
         for i, o in enumerate(oracles):
             assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: final metrics"

@@ -335,14 +335,30 @@ def test_lsap_known_answers_and_ties():
             assert np.array_equal(r[k], orow) and np.array_equal(c[k], ocol), shape
 
 
+def test_libm_log_bit_exact():
+    """(r4) The obstacle repulsion's logarithm (sim_core.rs:44, f64::ln = the host libm's log): the device's restatement of that
+    function's published algorithm against the HOST's log, bit for bit — the argument range of the path (1.05 .. 40), the
+    near-1 branch, and positive normal numbers at large."""
+    import math
+    from muavta_amd.batched import domain_log
+    rng = np.random.default_rng(17)
+    x = np.concatenate([rng.uniform(1.05, 40.0, 1_200_000), rng.uniform(0.93, 1.07, 400_000), np.array([1.0, 1.05, 40.0, 0.9375, 1.0646, 1.0648]),
+                        np.ldexp(rng.uniform(1.0, 2.0, 400_000), rng.integers(-1000, 1000, 400_000))])
+    got = domain_log(x)
+    want = np.fromiter(map(math.log, x.tolist()), dtype=np.float64, count=len(x))  # (math.log is libm's log; numpy may use its own SIMD kernels)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"{len(bad)} of {len(x)} differ, e.g. x={x[bad[0]].hex()} device {got[bad[0]].hex()} host {want[bad[0]].hex()}"
+
+
 def test_avoid_obstacles_vs_oracle():
-    """K > 0 obstacles: no reference test pins this (parity unpinned); device vs the CPU restatement of
-    core_sim/src/sim_core.rs:25-59, tolerance 1e-9 because log/atan2 are library calls."""
+    """K > 0 obstacles: no reference test pins this (parity unpinned: sim_core.rs cannot be compiled here); device vs the CPU
+    restatement of core_sim/src/sim_core.rs:25-59.  (r4) Bit for bit: the logarithm is the host libm's on both sides
+    (test_libm_log_bit_exact), sqrt / division are IEEE, and of atan2 only the sign of the wrapped angle difference is used."""
     import ctypes as C
     from muavta_amd.batched import avoid_obstacles
     rng = np.random.default_rng(3)
     obst = np.array([[300.0, 300.0, 50.0], [700.0, 200.0, 80.0], [500.0, 500.0, 30.0]])
-    pos = rng.uniform(100, 900, (256, 2)); mov = rng.uniform(-1, 1, (256, 2))
+    pos = rng.uniform(100, 900, (20000, 2)); mov = rng.uniform(-1, 1, (20000, 2))
     got = avoid_obstacles(pos, obst, mov)
     L = orc.lib()
     want = np.zeros_like(got)
@@ -351,12 +367,12 @@ def test_avoid_obstacles_vs_oracle():
         L.orc_avoid_obstacles(obst.ctypes.data_as(C.c_void_p), 3, pos[i].ctypes.data_as(C.c_void_p),
                               mov[i].ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
         want[i] = out
-    assert np.allclose(got, want, rtol=1e-9, atol=1e-9)
+    assert np.array_equal(got, want), f"{int((got != want).any(axis=1).sum())} of {len(pos)} differ"
     assert np.array_equal(avoid_obstacles(pos, np.zeros((0, 3)), mov), np.zeros_like(pos))  # K=0: the live configs
     from muavta_amd.core_sim import SimCore  # the reference's call shape: lists in, [dx, dy] out (DroneEnv.py:1033)
     sc = SimCore()
     one = sc.avoid_obstacles(list(pos[5]), [list(o) for o in obst], list(mov[5]))
-    assert isinstance(one, list) and len(one) == 2 and np.allclose(one, want[5], rtol=1e-9, atol=1e-9)
+    assert isinstance(one, list) and len(one) == 2 and np.array_equal(one, want[5])
     assert sc.avoid_obstacles([1.0, 2.0], [], [0.5, 0.5]) == [0.0, 0.0]
 
 
