@@ -2631,19 +2631,28 @@ struct Sim {
     PROF(59);
     const int n = S.n_escorts;
     if (n == 0) return;
-    int recon = -1, es = -1, eid = -1;
+    int recon = -1, es = -1, eid = -1, rid = -1, rs = -1;
     bool retire = false, dead = false, esc_live = false, esc_here = false;
+    auto decide = [&]() {  // :1978-1990 for the lane's entry, on the state as it is now
+      if (lane < n) {
+        dead = S.a_state[recon] == -1;
+        const bool idle = S.a_qlen[recon] == 0 || S.a_state[recon] == 0 || S.a_state[recon] == 3;
+        const bool rec_done = ref_retired(rid, rs);
+        const bool wrong_task = S.a_qlen[recon] > 0 && S.a_qid[recon][0] != rid;
+        retire = dead || idle || rec_done || wrong_task;
+      }
+    };
     if (lane < n) {
       recon = S.esc_agent[lane]; es = S.esc_slot[lane]; eid = S.esc_id[lane];
-      const int rid = S.esc_pid[lane], rs = S.esc_pslot[lane];
-      dead = S.a_state[recon] == -1;
-      const bool idle = S.a_qlen[recon] == 0 || S.a_state[recon] == 0 || S.a_state[recon] == 3;
-      const bool rec_done = ref_retired(rid, rs);
-      const bool wrong_task = S.a_qlen[recon] > 0 && S.a_qid[recon][0] != rid;
-      retire = dead || idle || rec_done || wrong_task;
+      rid = S.esc_pid[lane]; rs = S.esc_pslot[lane];
       esc_here = ref_valid(eid, es);  // an escort that expired by its hard window keeps its map entry (status 2, never popped) ...
       esc_live = esc_here && S.t_status[es] != 2;
     }
+    decide();
+    // With a RECON type among escort_agent_types a protected UAV can itself hold another UAV's escort task: retiring that escort
+    // rewrites its queue (head, idle state), i.e. the verdict of ITS OWN entry further down the map.  Then the entries behind a
+    // retirement are decided again on the new state, as the reference's loop sees them (found by tests/fuzz_device.py, config 7178).
+    const bool recon_escorts = (P.escort_mask & ((1u << MUAVTA_R1) | (1u << MUAVTA_R2))) != 0u;
     const unsigned long long all = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
     unsigned long long rm = __ballot(retire), todo = all;
     PROF_COUNT(56, 1000); PROF_COUNT(57, 1000 * n);
@@ -2692,6 +2701,11 @@ struct Sim {
         retire_escort_coop(rk, dk);
         (void)ek;
         todo &= ~low;
+        if (recon_escorts && todo) {
+          lds_sync();
+          decide();
+          rm = __ballot(retire);
+        }
         PROF(61);
       }
     }

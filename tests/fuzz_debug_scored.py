@@ -37,6 +37,8 @@ for t in range(p.max_time_steps):
         if not (np.array_equal(out["act_agent"][i][:kk], oa) and np.all(out["act_agent"][i][kk:] == -1) and np.array_equal(out["act_index"][i][:kk], oi)):
             print("PLAN MISMATCH t", t, "env", i, out["act_agent"][i], out["act_index"][i], oa, oi); sys.exit(0)
         o.step(oa, oi)
+    pre_esc = env.get("ESCORTS").copy(); pre_q = env.get("AGENT_QUEUE").copy(); pre_state = env.get("AGENT_STATE").copy()
+    staged = env.get("STAGED_ACTIONS").copy()
     env.step_staged()
     snap = Snapshot(env)
     for i, o in enumerate(oracles):
@@ -52,6 +54,9 @@ for t in range(p.max_time_steps):
             print(" queues dev", snap.AGENT_QUEUE[i][:, :5].tolist()); print(" queues orc", q[:, :5].tolist())
             print(" states", snap.AGENT_STATE[i], rows[:, 2].astype(int))
             print(" events", o.events().tolist(), "dev events", snap.EVENTS[i][:8].tolist())
+            print(" staged actions (agent, task id...)", staged[i][:10].tolist())
+            print(" before the step: escorts", pre_esc[i][:6].tolist(), "queues", pre_q[i][:, :4].tolist(), "states", pre_state[i].tolist())
+            print(" after: escorts", env.get("ESCORTS")[i][:6].tolist(), "types", snap.AGENT_TYPE[i].tolist())
             print(" scalars dev", snap.SCALARS[i].tolist()); print(" scalars orc", o.scalars().tolist(), o.dims())
             sys.exit(0)
 print("no mismatch")

@@ -131,6 +131,59 @@ def pin(ks):
         json.dump(configs, f, indent=1)  # key order is semantic: groups are created in dict order
 
 
+def pin_scored(ks):
+    """The scored-allocator leg of tests/fuzz_device.py for config k (pseudo-random scores / priorities / reserved agents through the
+    ORACLE's scored allocator) gives an action sequence; the REFERENCE is driven with exactly those actions and its trace is
+    committed as tests/golden/lists_WIDE<k>_s<seed>.npz (the format of the list-valued action traces: oracle and device replay
+    it in test_list_valued_actions_trace_bit_exact / test_reference_list_valued_action_traces_on_the_device)."""
+    import numpy as np
+    import gen_golden as G
+    import orc
+    from mUAV_TA.MultiDroneEnvUtils import agentEnvOptions
+    from muavta_amd.params import params_from_config
+
+    SCORED = (("allocator", 0, 3), ("force", 2, 4), ("escort", 1, 1), ("trainer", 0, 1), ("trainer", 0, 2), ("escort", 2, 4))  # (gate, token kind, oracle flags): fuzz_device.SCORED
+    PADS = ((32, 16), (6, 3), (48, 16), (12, 8))
+    GATE = {"force": 0, "trainer": 1, "escort": 2, "allocator": 3}
+    path = os.path.join(HERE, "golden", "wide_configs.json")
+    configs = json.load(open(path)) if os.path.exists(path) else {}
+    for k in ks:
+        w = wide_config(k)
+        cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+        gate, kind, oflags = SCORED[k % len(SCORED)]
+        mt, ma = PADS[(k // len(SCORED)) % len(PADS)]
+        o = orc.OracleEnv(params_from_config(dict(cfg), None, tile_agents=16, tile_tasks=128, tile_threats=16))
+        o.reset(seed)
+        rng = np.random.default_rng(1000 + k)
+        n, A = 2, o.A
+
+        def next_actions(env, t):
+            sc = (rng.uniform(-1, 1, (n, ma, mt)) * (0.35 if kind != 2 else 1.0)).astype(np.float32)
+            pri = rng.uniform(-0.5, 1, (n, mt))
+            res = rng.integers(0, 1 << A, n, dtype=np.uint64) & rng.integers(0, 1 << A, n, dtype=np.uint64)
+            oa, oi, _ = o.allocate_scored(interval, int(bool((t // 3) % 2)), GATE[gate], kind, mt, ma, oflags, scores=sc[0], pri=pri[0], reserved=int(res[0]))
+            o.step(oa, oi)
+            actions, items = {}, []
+            for a, i in zip(oa, oi):
+                actions.setdefault(env.agents_obj[int(a)].name, []).append(int(i))
+                items.append((int(a), int(i)))
+            return {name: (v if len(v) > 1 else v[0]) for name, v in actions.items()}, items
+
+        env = G.MultiUAVEnv(agentEnvOptions(render_speed=-1, action_mode="TaskAssign", multiple_agents_per_task=True, fixed_seed=-1, **cfg))
+        tr = G.drive_with_actions(env, seed, cfg["max_time_steps"], next_actions)
+        tr["multi"] = np.int64(bool(cfg["multiple_tasks_per_agent"]))
+        out = os.path.join(HERE, "golden", f"lists_WIDE{k}_s{seed}.npz")
+        np.savez_compressed(out, **tr)
+        configs[f"WIDE{k}"] = cfg
+        print(out, os.path.getsize(out) // 1024, "KiB", "steps", tr["pos"].shape[0] - 1, "items", len(tr["actions"]))
+    with open(path, "w") as f:
+        json.dump(configs, f, indent=1)
+
+
+if __name__ == "__main__" and "--pin-scored" in sys.argv:
+    pin_scored([int(a) for a in sys.argv[1:] if not a.startswith("--")])
+    sys.exit(0)
+
 if __name__ == "__main__" and "--pin" in sys.argv:
     pin([int(a) for a in sys.argv[1:] if not a.startswith("--")])
     sys.exit(0)

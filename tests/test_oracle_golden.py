@@ -143,6 +143,8 @@ def lists_params(path, **tiles):
     from muavta_amd.scenarios import CASE_SPECS, TILES, WPS_ENV_FLAGS
     g = np.load(path)
     case = os.path.basename(path)[6:-4].rsplit("_s", 1)[0]
+    if case.startswith("WIDE"):  # an action-driven episode of a wide-fuzz configuration (tests/fuzz_reference.py --pin-scored)
+        return g, params_of(case, **tiles)
     flags = dict(WPS_ENV_FLAGS)
     flags["multiple_tasks_per_agent"] = bool(int(g["multi"]))
     ta, tt, th = TILES[case]
@@ -161,7 +163,7 @@ def test_list_valued_actions_trace_bit_exact(path):
     e.reset(int(g["seed"]))
     check_state(e, g, 0, name)
     acts, evs = g["actions"], g["events"]
-    assert np.bincount(acts[:, 0]).max() > 32
+    assert "WIDE" in name or np.bincount(acts[:, 0]).max() > 32  # (the random-list traces go past every tile's action_cap)
     for s in range(g["pos"].shape[0] - 1):
         ga = acts[acts[:, 0] == s]
         e.step(ga[:, 1].astype(np.int32), ga[:, 2].astype(np.int32))

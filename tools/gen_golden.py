@@ -710,25 +710,17 @@ if __name__ == "__main__" and "--fuzz" in sys.argv:
 # other (DroneEnv.py:822-838).  No allocator here: random lists (repeated tasks, indices beyond the open list, dead agents,
 # more items per step than any tile's action_cap) drive the env; the trace holds the flattened (t, agent id, index) items.
 # ------------------------------------------------------------------------------------------------
-def run_episode_lists(case, seed, steps, multi):
-    spec = CASE_SPECS[case]
-    cfg = make_config(spec, dict(WPS_ENV_FLAGS))
-    cfg.multiple_tasks_per_agent = multi
-    env = MultiUAVEnv(cfg)
+def drive_with_actions(env, seed, steps, next_actions):
+    """reset + `steps` x env.step(next_actions(env, t)) with everything snapshotted; next_actions returns the reference's own
+    actions dict {agent name: index | [indices]} and the flattened (agent id, index) items it stands for."""
     obs, info = env.reset(seed=seed)
-    rng = np.random.default_rng(1000 + seed)
     recs, obs_rows, act_rows, ev_rows, rewards = [snapshot(env)], [snapshot_obs(env)], [], [], [0.0]
     open_ids = [t.id for t in env.last_tasks_info]
     open_ptr = [0, len(open_ids)]
     for t in range(steps):
-        actions = {}
-        names = [a.name for a in env.agents_obj]
-        for k in rng.permutation(len(names))[:int(rng.integers(1, len(names) + 1))]:
-            n_items = int(rng.integers(1, 8))
-            idxs = [int(rng.integers(0, 4)) if rng.random() < 0.9 else 37 for _ in range(n_items)]
-            actions[names[k]] = idxs if (n_items > 1 or rng.random() < 0.5) else idxs[0]  # a bare int is a one-item list (:822-823)
-            for i in idxs:
-                act_rows.append((env.time_steps, env.agent_by_name[names[k]].id, i))
+        actions, items = next_actions(env, t)
+        for aid, i in items:
+            act_rows.append((env.time_steps, aid, i))
         obs, reward, done, trunc, info = env.step(actions)
         for ev in info["events"]:
             ev_rows.append((env.time_steps, EVENT_CODE[ev[0]], int(ev[1])))
@@ -748,8 +740,29 @@ def run_episode_lists(case, seed, steps, multi):
     out["open_ptr"] = np.array(open_ptr, dtype=np.int64)
     out["open_ids"] = np.array(open_ids, dtype=np.int64)
     out["max_tasks"] = np.int64(env.max_tasks)
-    out["multi"] = np.int64(multi)
     out["seed"] = np.int64(seed)
+    return out
+
+
+def run_episode_lists(case, seed, steps, multi):
+    spec = CASE_SPECS[case]
+    cfg = make_config(spec, dict(WPS_ENV_FLAGS))
+    cfg.multiple_tasks_per_agent = multi
+    env = MultiUAVEnv(cfg)
+    rng = np.random.default_rng(1000 + seed)
+
+    def next_actions(env, t):
+        actions, items = {}, []
+        names = [a.name for a in env.agents_obj]
+        for k in rng.permutation(len(names))[:int(rng.integers(1, len(names) + 1))]:
+            n_items = int(rng.integers(1, 8))
+            idxs = [int(rng.integers(0, 4)) if rng.random() < 0.9 else 37 for _ in range(n_items)]
+            actions[names[k]] = idxs if (n_items > 1 or rng.random() < 0.5) else idxs[0]  # a bare int is a one-item list (:822-823)
+            items += [(env.agent_by_name[names[k]].id, i) for i in idxs]
+        return actions, items
+
+    out = drive_with_actions(env, seed, steps, next_actions)
+    out["multi"] = np.int64(multi)
     return out
 
 
