@@ -9,7 +9,12 @@ and are compared with the oracle:
             after every step (test_gpu_parity.compare), the token builders every fourth step;
   scored    the allocator with caller-supplied edge scores / task priorities / reserved agents (muavta_allocate_scored), a gate /
             flag / token-kind / pad combination per config, pseudo-random inputs per step, visibility toggling: plan, _selected_mask
-            and the full state after every step.
+            and the full state after every step;
+  lists     list-valued actions (env.step({agent: [index, ...]}), DroneEnv.py:813-838): random lists — repeated tasks, indices beyond
+            the open list, dead agents, more items than the tile's action capacity — through muavta_step_lists, state after every step;
+  rl        the fused policy-in-the-loop step (muavta_rl_step_device through il.rl_stream: scored Hungarian -> step -> S_WPS ->
+            next tokens in one launch) with a seeded score tensor per step: selected mask, gate, step reward, next tokens, done flags
+            and the final metrics.
 
     python tests/fuzz_device.py [first_k [n_configs [seeds_per_config]]]
 
@@ -105,26 +110,29 @@ def stepwise(k, w, log):
             if any(done):
                 break
             aa, ai = env.allocate(interval, True)
+            plans = []
             for i, o in enumerate(oracles):
                 oa, oi = o.allocate_mode(interval, 1, mode)
                 kk = len(oa)
                 assert np.array_equal(aa[i][:kk], oa) and np.all(aa[i][kk:] == -1) and np.array_equal(ai[i][:kk], oi), \
                     f"{tag} seed {seeds[i]} t={t}: plan {aa[i][:kk + 2]} / {ai[i][:kk + 2]} vs {oa} / {oi}"
-                o.step(oa, oi)
-            env.step(aa, ai)
-            snap = Snapshot(env)
-            if snap.ERROR.any():
-                return "overflow"
-            for i, o in enumerate(oracles):
-                compare(snap, i, o, f"{tag} seed {seeds[i]} t={t + 1}")
-            if t % 4 == 3:  # the token builders (muavta_tokens) on the same state: kind and pads rotate
+                plans.append((oa, oi))
+            if t % 4 == 3:  # the token builders (muavta_tokens) between the plan and the step (the expert mask is the staged plan's): kind and pads rotate
                 kind, (mt, ma) = (t // 4 + k) % 3, PADS[(t // 4 + k // 3) % len(PADS)]
                 got = env.tokens(("pair", "pair_raw", "escort")[kind], mt, ma)
                 for i, o in enumerate(oracles):
                     want = o.tokens(kind, mt, ma)
                     for key in want:
                         gv = int(got[key][i]) if key == "n_urgent" else got[key][i]
-                        assert np.array_equal(np.asarray(gv), np.asarray(want[key])), f"{tag} seed {seeds[i]} t={t + 1}: tokens kind {kind} pads {mt}x{ma}: {key}"
+                        assert np.array_equal(np.asarray(gv), np.asarray(want[key])), f"{tag} seed {seeds[i]} t={t}: tokens kind {kind} pads {mt}x{ma}: {key}"
+            for i, o in enumerate(oracles):
+                o.step(*plans[i])
+            env.step(aa, ai)
+            snap = Snapshot(env)
+            if snap.ERROR.any():
+                return "overflow"
+            for i, o in enumerate(oracles):
+                compare(snap, i, o, f"{tag} seed {seeds[i]} t={t + 1}")
         m = env.metrics()
         for i, o in enumerate(oracles):
             assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: final metrics"
@@ -185,17 +193,125 @@ def scored(k, w, log):
     return "ok"
 
 
+def lists(k, w, log):
+    cfg, seed = w["cfg"], w["seed"]
+    tile = TILES[(k // 5) % 3]
+    p = params(cfg, tile)
+    n = 2
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    env = BatchedMultiUAVEnv(p, n)
+    A = env.n_agents
+    oracles = [orc.OracleEnv(p) for _ in range(n)]
+    env.reset(seeds)
+    for i, o in enumerate(oracles):
+        o.reset(int(seeds[i]))
+    rng = np.random.default_rng(2000 + k)
+    tag = f"k={k} lists tile {tile}"
+    try:
+        if env.get("ERROR").any():
+            return "overflow"
+        for t in range(min(p.max_time_steps, 80)):
+            if any(bool(o.dims()["terminated"] or o.dims()["truncated"]) for o in oracles):
+                break
+            rows = []
+            for i in range(n):
+                items = []
+                for a in rng.permutation(A)[:int(rng.integers(0, A + 1))]:
+                    for _ in range(int(rng.integers(1, 7))):
+                        items.append((int(a), int(rng.integers(0, 5)) if rng.random() < 0.9 else int(rng.integers(20, 140))))
+                rows.append(items)
+            aa, ai = env.pack_actions(rows)
+            env.step(aa, ai)
+            for i, o in enumerate(oracles):
+                o.step(np.array([x[0] for x in rows[i]], dtype=np.int32), np.array([x[1] for x in rows[i]], dtype=np.int32))
+            snap = Snapshot(env)
+            if snap.ERROR.any():
+                return "overflow"
+            for i, o in enumerate(oracles):
+                compare(snap, i, o, f"{tag} seed {seeds[i]} t={t + 1}")
+    except AssertionError as exc:
+        log(f"LISTS MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
+def rl(k, w, log):
+    import torch
+    from muavta_amd import il
+
+    cfg, seed = w["cfg"], w["seed"]
+    kind = (0, 1)[k % 2]
+    kname = ("pair", "pair_raw")[kind]
+    mt, ma = ((32, 16), (12, 8), (48, 16))[(k // 2) % 3]
+    tile = TILES[(k // 7) % 3]
+    p = params(cfg, tile)
+    n = 3
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    env = BatchedMultiUAVEnv(p, n)
+    oracles = [orc.OracleEnv(p) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(int(seeds[i]))
+    rng = np.random.default_rng(3000 + k)
+    dev = torch.device("cuda", 0)
+    cur = {}
+
+    def policy(tok):
+        cur["sc"] = (rng.uniform(-1, 1, (n, ma, mt)) * 0.35).astype(np.float32)
+        return torch.from_numpy(cur["sc"]).to(dev)
+
+    tag = f"k={k} rl tile {tile} kind {kname} pads {mt}x{ma}"
+    done_o = [False] * n
+    try:
+        for t, tr in il.rl_stream(env, seeds, policy, n_steps=p.max_time_steps, interval=20, kind=kname, max_tasks=mt, max_agents=ma, gate="trainer", fused=True):
+            if env.get("ERROR").any():
+                return "overflow"
+            sel, rep = tr["selected"].cpu().numpy(), tr["replanned"].cpu().numpy()
+            rew, dn = tr["step_reward"].cpu().numpy(), tr["done"].cpu().numpy()
+            nxt = {key: v.cpu().numpy() for key, v in tr["next_tok"].items()}
+            for i, o in enumerate(oracles):
+                if done_o[i]:
+                    continue
+                s0 = o.metrics()[4]
+                oa, oi, osel = o.allocate_scored(20, 1, GATE["trainer"], kind, mt, ma, 1, scores=cur["sc"][i])
+                assert np.array_equal(sel[i], osel), f"{tag} seed {seeds[i]} t={t}: selected mask"
+                assert bool(rep[i]) == (o.scalars_last_plan() == t), f"{tag} seed {seeds[i]} t={t}: gate"
+                d = o.step(oa, oi)
+                assert rew[i] == (o.metrics()[4] - s0) / 20.0, f"{tag} seed {seeds[i]} t={t}: step reward {rew[i]} vs {(o.metrics()[4] - s0) / 20.0}"
+                dd = o.dims()
+                assert int(dn[i]) == (int(bool(dd["terminated"])) | (int(bool(dd["truncated"])) << 1)), f"{tag} seed {seeds[i]} t={t}: done"
+                want = o.tokens(kind, mt, ma)
+                for key in want:
+                    if key in nxt:
+                        gv = int(nxt[key][i]) if key == "n_urgent" else nxt[key][i]
+                        assert np.array_equal(np.asarray(gv), np.asarray(want[key])), f"{tag} seed {seeds[i]} t={t}: next tokens: {key}"
+                done_o[i] = bool(d)
+            if all(done_o):
+                break
+        m = env.metrics()
+        for i, o in enumerate(oracles):
+            assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: final metrics"
+    except AssertionError as exc:
+        log(f"RL MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
 if __name__ == "__main__":
-    first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
-    n_cfg = int(sys.argv[2]) if len(sys.argv) > 2 else 50
-    n_seeds = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    first = int(args[0]) if len(args) > 0 else 0
+    n_cfg = int(args[1]) if len(args) > 1 else 50
+    n_seeds = int(args[2]) if len(args) > 2 else 16
 
     def log(msg):
         print(msg, flush=True)
 
     t0 = time.time()
     tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "scored_ok": 0, "scored_bad": 0,
-           "scored_overflow": 0, "errors": 0}
+           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "errors": 0}
     for k in range(first, first + n_cfg):
         w = wide_config(k)
         try:
@@ -203,6 +319,9 @@ if __name__ == "__main__":
             tot["fused_bad"] += b; tot["fused_flagged"] += f; tot["fused_checked"] += c
             tot["step_" + stepwise(k, w, log)] += 1
             tot["scored_" + scored(k, w, log)] += 1
+            if "--more" in sys.argv:
+                tot["lists_" + lists(k, w, log)] += 1
+                tot["rl_" + rl(k, w, log)] += 1
         except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
             tot["errors"] += 1
             log(f"k={k} ERROR {type(exc).__name__}: {str(exc)[:300]}")
