@@ -46,6 +46,20 @@ PADS = ((32, 16), (6, 3), (48, 16), (12, 8))
 MODES = ((0, "hungarian"), (1, "urgency_pair"), (2, "urgency_coalition"), (3, "hungarian_gated"))
 
 
+def tiles_for(cfg):
+    """the tiles that hold the configuration's fleet and threat list (the large family of wide_config needs the bigger ones)"""
+    na, nh = sum(cfg["agents"].values()), sum(n for _, n in cfg["threats_list"])
+    return tuple(t for t in TILES if na <= t[0] and nh <= t[2])
+
+
+def reserved_bits(rng, n, A):
+    """n random reserved-agent masks over A agents, each agent reserved with probability 1/4"""
+    if A < 63:
+        return rng.integers(0, 1 << A, n, dtype=np.uint64) & rng.integers(0, 1 << A, n, dtype=np.uint64)
+    bits = rng.integers(0, 4, (n, A)) == 0
+    return np.array([sum(1 << int(a) for a in np.nonzero(row)[0]) for row in bits], dtype=np.uint64)
+
+
 def params(cfg, tile):
     c = dict(cfg)
     c["threats_list"] = [tuple(x) for x in c["threats_list"]]
@@ -65,7 +79,7 @@ def fused(k, w, n_seeds, log):
         o.rollout_mode(int(s), steps, interval, 1, mode)
         want.append(o.metrics().copy())
     bad = flagged = checked = 0
-    for tile in TILES:
+    for tile in tiles_for(cfg):
         env = BatchedMultiUAVEnv(params(cfg, tile), n_seeds)
         env.set_allocator(name)
         env.rollout(seeds, steps, interval, True, True)
@@ -88,7 +102,7 @@ def fused(k, w, n_seeds, log):
 def stepwise(k, w, log):
     cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
     mode, name = MODES[(k // 3) % 4]
-    tile = TILES[k % 3]
+    tile = tiles_for(cfg)[k % len(tiles_for(cfg))]
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
@@ -148,7 +162,7 @@ def scored(k, w, log):
     cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
     gate, kw, kname, kind, oflags = SCORED[k % len(SCORED)]
     mt, ma = PADS[(k // len(SCORED)) % len(PADS)]
-    tile = TILES[(k // 2) % 3]
+    tile = tiles_for(cfg)[(k // 2) % len(tiles_for(cfg))]
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
@@ -168,7 +182,7 @@ def scored(k, w, log):
                 break
             sc = (rng.uniform(-1, 1, (n, ma, mt)) * (0.35 if kind != 2 else 1.0)).astype(np.float32)
             pri = rng.uniform(-0.5, 1, (n, mt))
-            res = rng.integers(0, 1 << A, n, dtype=np.uint64) & rng.integers(0, 1 << A, n, dtype=np.uint64)
+            res = reserved_bits(rng, n, A)
             vis = bool((t // 3) % 2)
             out = env.allocate_scored(kname, mt, ma, edge_scores=sc, task_pri=pri, reserved=res, gate=gate, replan_interval=interval, use_visibility=vis, **kw)
             for i, o in enumerate(oracles):
@@ -195,7 +209,7 @@ def scored(k, w, log):
 
 def lists(k, w, log):
     cfg, seed = w["cfg"], w["seed"]
-    tile = TILES[(k // 5) % 3]
+    tile = tiles_for(cfg)[(k // 5) % len(tiles_for(cfg))]
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
@@ -245,7 +259,7 @@ def rl(k, w, log):
     kind = (0, 1)[k % 2]
     kname = ("pair", "pair_raw")[kind]
     mt, ma = ((32, 16), (12, 8), (48, 16))[(k // 2) % 3]
-    tile = TILES[(k // 7) % 3]
+    tile = tiles_for(cfg)[(k // 7) % len(tiles_for(cfg))]
     p = params(cfg, tile)
     n = 3
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)

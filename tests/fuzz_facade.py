@@ -123,8 +123,8 @@ def run_one(k: int):
     except Exception as exc:
         return k, "skip", f"{type(exc).__name__}: {exc}"
     try:
-        p = params_from_config(opts, None, tile_agents=16, tile_tasks=128, tile_threats=16)
-        F = Facade(opts, backend=OracleBackend(p), tile_agents=16, tile_tasks=128, tile_threats=16)
+        p = params_from_config(opts, None, tile_agents=64, tile_tasks=128, tile_threats=48)
+        F = Facade(opts, backend=OracleBackend(p), tile_agents=64, tile_tasks=128, tile_threats=48)
         fobs, finfo = F.reset(seed=seed)
         T = R.max_tasks
         assert F.max_tasks == T and F.possible_agents == R.possible_agents and F.max_agents == R.max_agents

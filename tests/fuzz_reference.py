@@ -27,13 +27,20 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
+BIG = 1_000_000  # keys from here on draw the LARGE family: fleets of up to 64 UAVs, up to 48 static tasks, up to 40 threats
+
+
 def wide_config(k: int) -> dict:
-    """A wider net than tools/gen_golden.py::fuzz_config: fleets up to 16 UAVs, every knob agentEnvOptions has on this path, odd
-    radii / windows / horizons; the replan interval and the episode seed are part of the draw."""
+    """A wider net than tools/gen_golden.py::fuzz_config: fleets up to 16 UAVs (k >= BIG: up to 64 — the 24- and 64-agent tiles),
+    every knob agentEnvOptions has on this path, odd radii / windows / horizons; the replan interval and the episode seed are part
+    of the draw."""
     r = random.Random(0x5EED0000 + k)
     pick = r.choice
     big = r.random() < 0.35
     hi = 4 if big else 2
+    large = k >= BIG
+    if large:
+        hi = pick([5, 6, 8, 12, 16])
     agents = {t: r.randint(0, hi) for t in ("F1", "F2", "R1", "R2")}
     if agents["F1"] + agents["F2"] == 0:
         agents[pick(["F1", "F2"])] = 1
@@ -46,13 +53,13 @@ def wide_config(k: int) -> dict:
     agents = {t: n for t, n in agents.items() if n > 0 or r.random() < 0.5}
     threats = []
     if r.random() < 0.85:
-        threats.append(("T1", r.randint(1, 6)))
+        threats.append(("T1", r.randint(1, 24 if large else 6)))
     if r.random() < 0.7:
-        threats.append(("T2", r.randint(1, 5)))
+        threats.append(("T2", r.randint(1, 16 if large else 5)))
     if len(threats) == 2 and r.random() < 0.3:
         threats.reverse()
     cfg = {
-        "agents": agents, "tasks": {"Att": r.randint(0, 5), "Rec": r.randint(1, 6), "Hold": pick([0, 0, 0, 1, 2])},
+        "agents": agents, "tasks": {"Att": r.randint(0, 16 if large else 5), "Rec": r.randint(1, 32 if large else 6), "Hold": pick([0, 0, 0, 1, 2])},
         "threats_list": threats, "max_time_steps": pick([40, 60, 97, 150, 150, 200, 260]),
         "simulation_frame_rate": pick([0.01, 0.01, 0.02, 0.015, 0.008]),
         "multiple_tasks_per_agent": pick([True, True, True, False]), "random_init_pos": pick([False, False, True]),
@@ -100,7 +107,7 @@ def run_one(k: int):
         return k, "skip", f"{type(exc).__name__}: {exc}", 0.0
     t_ref = time.time() - t0
     try:
-        P = params_from_config(dict(cfg), None, tile_agents=16, tile_tasks=128, tile_threats=16)
+        P = params_from_config(dict(cfg), None, tile_agents=64, tile_tasks=128, tile_threats=48)
         TOG.check_trace(tr, f"WIDE{k}", P, seed)
     except AssertionError as exc:
         if "--save" in sys.argv:
@@ -152,7 +159,7 @@ def pin_scored(ks):
         cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
         gate, kind, oflags = SCORED[k % len(SCORED)]
         mt, ma = PADS[(k // len(SCORED)) % len(PADS)]
-        o = orc.OracleEnv(params_from_config(dict(cfg), None, tile_agents=16, tile_tasks=128, tile_threats=16))
+        o = orc.OracleEnv(params_from_config(dict(cfg), None, tile_agents=64, tile_tasks=128, tile_threats=48))
         o.reset(seed)
         rng = np.random.default_rng(1000 + k)
         n, A = 2, o.A

@@ -38,7 +38,7 @@ def run_one(k: int):
     except Exception as exc:  # a combination the reference itself cannot run
         return k, "skip", f"{type(exc).__name__}: {str(exc)[:200]}"
     try:
-        P = params_from_config(dict(cfg), None, tile_agents=16, tile_tasks=128, tile_threats=16)
+        P = params_from_config(dict(cfg), None, tile_agents=64, tile_tasks=128, tile_threats=48)
         TOG.check_rl(tr, f"WIDE{k}", P)
     except AssertionError as exc:
         return k, "MISMATCH", str(exc)[:400]
