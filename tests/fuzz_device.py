@@ -12,6 +12,12 @@ and are compared with the oracle:
             and the full state after every step;
   lists     list-valued actions (env.step({agent: [index, ...]}), DroneEnv.py:813-838): random lists — repeated tasks, indices beyond
             the open list, dead agents, more items than the tile's action capacity — through muavta_step_lists, state after every step;
+  rings     the RECORDING rollout (muavta_rollout_record with per-step observation rings): slot t = what DroneEnv.step returned at step
+            t (observation dict, reward, done), the slots behind an env's last step untouched, final state and metrics;
+  mutators  the out-of-step calls of the reference's own tests and planners (muavta_call behind the facade: UAV.allocate,
+            UAV.tasks = [task_idle], state / position / required_agents writes, _create_escort_for, _sync_escorts, _retire_escort,
+            _escort_fighters_near, _is_task_action_valid) at random points of an episode, the facade on the HIP backend next to the
+            facade on the oracle backend: every field after every call and every step;
   rl        the fused policy-in-the-loop step (muavta_rl_step_device through il.rl_stream: scored Hungarian -> step -> S_WPS ->
             next tokens in one launch) with a seeded score tensor per step: selected mask, gate, step reward, next tokens, done flags
             and the final metrics.
@@ -75,14 +81,21 @@ def fused(k, w, n_seeds, log):
     steps = p0.max_time_steps
     o = orc.OracleEnv(p0)
     want = []
+    use_vis = k % 5 != 0    # every fifth config plans without the visibility map (Global-Hungarian)
+    write_obs = k % 3 != 0  # every third skips the per-step observation write (a different instantiation of the step loop)
+    split = (k % 7 == 0) and steps > 20  # ... and some run the episode as two launches, the second continuing without a reset
     for s in seeds:
-        o.rollout_mode(int(s), steps, interval, 1, mode)
+        o.rollout_mode(int(s), steps, interval, int(use_vis), mode)
         want.append(o.metrics().copy())
     bad = flagged = checked = 0
     for tile in tiles_for(cfg):
         env = BatchedMultiUAVEnv(params(cfg, tile), n_seeds)
         env.set_allocator(name)
-        env.rollout(seeds, steps, interval, True, True)
+        if split:
+            env.rollout(seeds, steps // 3, interval, use_vis, write_obs)
+            env.rollout(None, steps - steps // 3, interval, use_vis, write_obs)
+        else:
+            env.rollout(seeds, steps, interval, use_vis, write_obs)
         got, err = env.rollout_metrics(), env.get("ERROR")
         for i in range(n_seeds):
             if err[i]:
@@ -92,7 +105,7 @@ def fused(k, w, n_seeds, log):
             if not np.array_equal(got[i], want[i]):
                 bad += 1
                 d = np.nonzero(got[i] != want[i])[0]
-                log(f"k={k} FUSED MISMATCH tile {tile} mode {name} seed {int(seeds[i])} interval {interval}: metric columns {d.tolist()} got {got[i][d].tolist()} want {want[i][d].tolist()}")
+                log(f"k={k} FUSED MISMATCH tile {tile} mode {name} seed {int(seeds[i])} interval {interval} vis {use_vis} obs {write_obs} split {split}: metric columns {d.tolist()} got {got[i][d].tolist()} want {want[i][d].tolist()}")
         if tile == TILES[2] and err.any():
             log(f"k={k} note: {int((err != 0).sum())} envs overflow the 64 x 128 tile, codes {np.unique(err[err != 0]).tolist()}")
         env.close()
@@ -251,6 +264,145 @@ def lists(k, w, log):
     return "ok"
 
 
+def rings(k, w, log):
+    import torch
+
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+    tile = tiles_for(cfg)[(k // 11) % len(tiles_for(cfg))]
+    p = params(cfg, tile)
+    n, steps = 3, p.max_time_steps
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    env = BatchedMultiUAVEnv(p, n)
+    tag = f"k={k} rings tile {tile} interval {interval}"
+    try:
+        dev = torch.device("cuda", env.device_index)
+        R = {key: torch.zeros(shape, dtype=getattr(torch, np.dtype(dt).name), device=dev) for key, (shape, dt) in env.obs_ring_shapes(steps).items()}
+        env.rollout_record(seeds, steps, interval, True, obs_rings=R)
+        env.sync()
+        snap = Snapshot(env)
+        R = {key: v.cpu().numpy() for key, v in R.items()}
+        MT = env.max_tasks
+        m = env.rollout_metrics()
+        for i in range(n):
+            if snap.ERROR[i]:
+                continue
+            o = orc.OracleEnv(p)
+            o.reset(int(seeds[i]))
+            t_end = steps
+            for t in range(steps):
+                a, ix = o.allocate_mode(interval, 1, 0)
+                o.step(a, ix)
+                ti, legal, pad, ag, fl = o.observe()
+                st = f"{tag} seed {seeds[i]} slot {t}"
+                assert np.array_equal(R["obs_tasks"][t, i].T, ti), f"{st}: tasks_info"
+                bits = ((R["obs_legal"][t, i][:, :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)).reshape(legal.shape[0], -1)[:, :MT]
+                assert np.array_equal(bits.astype(bool), legal), f"{st}: legal_mask"
+                assert np.array_equal(R["obs_pad"][t, i].astype(bool), pad), f"{st}: pad mask"
+                assert np.array_equal(R["obs_agents"][t, i], ag), f"{st}: agent rows"
+                assert np.array_equal(R["obs_flags"][t, i], fl), f"{st}: event flags"
+                d = o.dims()
+                assert R["obs_reward"][t, i] == o.scalars()[1], f"{st}: reward"
+                assert R["obs_done"][t, i] == (1 if d["terminated"] else 0) | (2 if d["truncated"] else 0), f"{st}: done flags"
+                if d["terminated"] or d["truncated"]:
+                    t_end = t + 1
+                    break
+            assert np.all(R["obs_done"][t_end:, i] == env.OBS_UNWRITTEN), f"{tag} seed {seeds[i]}: slots after the last step"
+            compare(snap, i, o, f"{tag} seed {seeds[i]} after the recorded rollout")
+            assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: metrics"
+    except AssertionError as exc:
+        log(f"RINGS MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
+def mutators(k, w, log):
+    from oracle_backend import OracleBackend
+    from muavta_amd.env import MultiUAVEnv
+
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+    tile = tiles_for(cfg)[(k // 13) % len(tiles_for(cfg))]
+    c = dict(cfg)
+    c["threats_list"] = [tuple(x) for x in c["threats_list"]]
+    c["escort_agent_types"] = tuple(c["escort_agent_types"])
+    p = params(cfg, tile)
+    tiles = dict(tile_agents=tile[0], tile_tasks=tile[1], tile_threats=tile[2])
+    hip = MultiUAVEnv(dict(c), **tiles)
+    ref = MultiUAVEnv(dict(c), backend=OracleBackend(p), **tiles)
+    envs = (hip, ref)
+    rng = np.random.default_rng(4000 + k)
+    tag = f"k={k} mutators tile {tile}"
+    try:
+        for e in envs:
+            e.reset(seed=seed)
+        for t in range(min(p.max_time_steps, 60)):
+            if hip._b.get("ERROR").any():
+                return "overflow"
+            for _ in range(int(rng.integers(0, 3))):
+                op = int(rng.integers(0, 8))
+                ai_, ti_ = int(rng.integers(0, 64)), int(rng.integers(0, 64))
+                vec = rng.uniform(50.0, 650.0, 2)
+                val = int(rng.integers(0, 4))
+                outs = []
+                for e in envs:
+                    live = e.get_live_agents()
+                    if not live:
+                        outs.append(None)
+                        continue
+                    a = live[ai_ % len(live)]
+                    open_ = list(e.last_tasks_info)
+                    task = open_[ti_ % len(open_)] if open_ else None
+                    r = None
+                    if op == 0 and task is not None:
+                        r = (bool(e._is_task_action_valid(a, task)),)
+                        if r[0]:
+                            r += (bool(a.allocate(task, e.time_steps)),)
+                    elif op == 1:
+                        a.tasks = [e.task_idle]
+                        a.state = 0
+                    elif op == 2:
+                        a.position = vec
+                    elif op == 3 and task is not None:
+                        task.required_agents = val
+                    elif op == 4 and e.escort_enabled and task is not None and a.type in ("R1", "R2") and task.type == "Rec":
+                        esc = e._create_escort_for(a, task)
+                        r = None if esc is None else (esc.id, esc.required_agents)
+                    elif op == 5 and e.escort_enabled:
+                        e._sync_escorts()
+                    elif op == 6 and e.escort_enabled and e._escort_by_recon:
+                        names = sorted(e._escort_by_recon)
+                        e._retire_escort(e._escort_by_recon[names[ti_ % len(names)]], failed=bool(val & 1))
+                        r = (e.escort_completed, e.escort_failed)
+                    elif op == 7 and e.escort_enabled:
+                        r = [x.id for x in e._escort_fighters_near(a, float(vec[0]))]
+                    outs.append(r)
+                assert outs[0] == outs[1], f"{tag} t={t} op {op}: returned {outs[0]} vs {outs[1]}"
+                if hip._b.get("ERROR").any():
+                    return "overflow"
+                compare(Snapshot(hip._b), 0, ref._b.o, f"{tag} t={t} after op {op}", check_obs=False)
+            acts = []
+            for e in envs:
+                aa, ai = e._b.allocate(interval, True)
+                acts.append({e.agents_obj[int(a)].name: int(i) for a, i in zip(aa[0], ai[0]) if a >= 0})
+            assert acts[0] == acts[1], f"{tag} t={t}: plans {acts[0]} vs {acts[1]}"
+            done = False
+            for e, ac in zip(envs, acts):
+                _, _, term, trunc, _ = e.step(ac)
+                done = all(term.values()) or all(trunc.values())
+            if hip._b.get("ERROR").any():
+                return "overflow"
+            compare(Snapshot(hip._b), 0, ref._b.o, f"{tag} step {t + 1}")
+            if done:
+                break
+    except AssertionError as exc:
+        log(f"MUTATORS MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        hip._b.close()
+    return "ok"
+
+
 def rl(k, w, log):
     import torch
     from muavta_amd import il
@@ -325,7 +477,7 @@ if __name__ == "__main__":
 
     t0 = time.time()
     tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "scored_ok": 0, "scored_bad": 0,
-           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "errors": 0}
+           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "errors": 0}
     for k in range(first, first + n_cfg):
         w = wide_config(k)
         try:
@@ -336,6 +488,8 @@ if __name__ == "__main__":
             if "--more" in sys.argv:
                 tot["lists_" + lists(k, w, log)] += 1
                 tot["rl_" + rl(k, w, log)] += 1
+                tot["rings_" + rings(k, w, log)] += 1
+                tot["mutators_" + mutators(k, w, log)] += 1
         except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
             tot["errors"] += 1
             log(f"k={k} ERROR {type(exc).__name__}: {str(exc)[:300]}")
