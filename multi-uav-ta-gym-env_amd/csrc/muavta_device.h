@@ -3352,7 +3352,9 @@ struct Sim {
             if (k < S.n_open) {
               s = S.open_slot[k];
               const int ty = S.t_type[s];
-              under = C.t_alloc[ty][s] < C.t_cur[ty][s];
+              // (status: the open list is the one of the last observation — an out-of-step _retire_escort (muavta_call) concludes a task
+              // behind it, and the harness lists are built from env.tasks with `status != 2` at call time)
+              under = S.t_status[s] != 2 && C.t_alloc[ty][s] < C.t_cur[ty][s];
             }
             const unsigned long long um = __ballot(under);
             if (k < S.n_open) {
@@ -3379,8 +3381,10 @@ struct Sim {
         if (k < S.n_open) {
           s = S.open_slot[k];
           const int ty = S.t_type[s];
-          // Urgency-Pair only plans over build_att_tokens' open_tasks: underfilled at the type index (AttentionRAH.py:69-73)
-          under = mode != 1 || C.t_alloc[ty][s] < C.t_cur[ty][s];
+          // Urgency-Pair only plans over build_att_tokens' open_tasks: underfilled at the type index (AttentionRAH.py:69-73).
+          // _open_tasks (paper_eval.py:96-101) reads env.tasks when it is called: a task an out-of-step _retire_escort (muavta_call)
+          // concluded since the last observation is still in `open_slot` and not in that list
+          under = S.t_status[s] != 2 && (mode != 1 || C.t_alloc[ty][s] < C.t_cur[ty][s]);
         }
         const unsigned long long um = mode == 1 ? __ballot(under) : 0ull;
         if (k < S.n_open) {

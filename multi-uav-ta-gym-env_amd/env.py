@@ -474,6 +474,10 @@ class MultiUAVEnv:
                 if tid == 0 or tid in self._revealed:
                     continue
                 born = self._born.setdefault(tid, t._last.get("meta2", now))  # never resident: created (and gone) this step
+                if t._slot() >= 0:
+                    continue  # still resident: the device's known bits carry its reveal when the step that processes it has run
+                              # (a task created BETWEEN steps — _create_escort_for / _sync_escorts called by a planner — is revealed by
+                              # the next step's _wps_process_reveals, not at creation)
                 if now >= born + delay:
                     self._revealed.add(tid)
                     for s in self._known.values():

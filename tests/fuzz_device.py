@@ -317,7 +317,7 @@ def rings(k, w, log):
     return "ok"
 
 
-def mutators(k, w, log):
+def mutators(k, w, log, verbose=False):
     from oracle_backend import OracleBackend
     from muavta_amd.env import MultiUAVEnv
 
@@ -359,8 +359,12 @@ def mutators(k, w, log):
                         if r[0]:
                             r += (bool(a.allocate(task, e.time_steps)),)
                     elif op == 1:
-                        a.tasks = [e.task_idle]
-                        a.state = 0
+                        # (`agent.tasks = [...]` is a plain list assignment in the reference — the tasks' allocationDetails keep the agent.  Its
+                        # own tests only scaffold IDLE agents that way (test_escort.py:95), and that is the supported contract: the device
+                        # keeps allocationDetails in the queues)
+                        if len(a.tasks) == 1 and a.tasks[0].id == 0:
+                            a.tasks = [e.task_idle]
+                            a.state = 0
                     elif op == 2:
                         a.position = vec
                     elif op == 3 and task is not None:
@@ -377,6 +381,8 @@ def mutators(k, w, log):
                     elif op == 7 and e.escort_enabled:
                         r = [x.id for x in e._escort_fighters_near(a, float(vec[0]))]
                     outs.append(r)
+                    if verbose and e is hip:
+                        log(f"   t={t} op {op} agent {a.name} (queue {[x.id for x in a.tasks]}, state {a.state}) task {None if task is None else (task.id, task.type)} vec {vec.tolist()} val {val} -> {r}")
                 assert outs[0] == outs[1], f"{tag} t={t} op {op}: returned {outs[0]} vs {outs[1]}"
                 if hip._b.get("ERROR").any():
                     return "overflow"
@@ -385,6 +391,17 @@ def mutators(k, w, log):
             for e in envs:
                 aa, ai = e._b.allocate(interval, True)
                 acts.append({e.agents_obj[int(a)].name: int(i) for a, i in zip(aa[0], ai[0]) if a >= 0})
+            if verbose and acts[0] != acts[1]:
+                o = ref._b.o
+                shapes, costs, rws, cls = o.lsap_calls()
+                log(f"   oracle LSAP shapes {shapes.tolist()} first costs {costs[:40].tolist()} rows {rws.tolist()} cols {cls.tolist()}")
+                trow, reqs = o.tasks()
+                log(f"   open {o.open_ids().tolist()}")
+                for kk in o.open_ids().tolist():
+                    log(f"   task {kk}: type {int(trow[kk, 6])} required {int(trow[kk, 9])} ndet {int(trow[kk, 5])} cur {reqs[kk, 0].tolist()} alloc {reqs[kk, 1].tolist()} pos {trow[kk, 1:3].tolist()}")
+                log(f"   device staged {hip._b.get('STAGED_ACTIONS')[0][:8].tolist()}  oracle last_actions {o.last_actions().tolist()}")
+                sn = Snapshot(hip._b)
+                log(f"   device task ids {sn.TASK_ID[0][:16].tolist()} meta required {[int(m[3]) for m in sn.TASK_META[0][:16]]} ndet {[int(m[5]) for m in sn.TASK_META[0][:16]]}")
             assert acts[0] == acts[1], f"{tag} t={t}: plans {acts[0]} vs {acts[1]}"
             done = False
             for e, ac in zip(envs, acts):

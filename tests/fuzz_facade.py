@@ -130,12 +130,57 @@ def run_one(k: int):
         assert F.max_tasks == T and F.possible_agents == R.possible_agents and F.max_agents == R.max_agents
         same_obs(robs, fobs, T, f"{tag} reset")
         same_world(R, F, f"{tag} reset")
+        mut = "--mutators" in sys.argv
+        rng = np.random.default_rng(4000 + k)
         hr = HungarianAllocator(replan_interval=interval, max_coord=R.max_coord)
         hf = HungarianAllocator(replan_interval=interval, max_coord=F.max_coord)
         rdone = {a: False for a in R.agents}
         rtrunc = dict(rdone)
         t = 0
         while not all(rdone.values()) and not all(rtrunc.values()):
+            for _ in range(int(rng.integers(0, 3)) if mut else 0):
+                # the out-of-step calls of the reference's own tests and planners (the op set of tests/fuzz_device.py::mutators), the same
+                # call on the reference env and on the facade
+                op = int(rng.integers(0, 8))
+                ai_, ti_ = int(rng.integers(0, 64)), int(rng.integers(0, 64))
+                vec = rng.uniform(50.0, 650.0, 2)
+                val = int(rng.integers(0, 4))
+                outs = []
+                for e in (R, F):
+                    live = e.get_live_agents()
+                    if not live:
+                        outs.append(None)
+                        continue
+                    a = live[ai_ % len(live)]
+                    open_ = list(e.last_tasks_info)
+                    task = open_[ti_ % len(open_)] if open_ else None
+                    r = None
+                    if op == 0 and task is not None:
+                        r = (bool(e._is_task_action_valid(a, task)),)
+                        if r[0]:
+                            r += (bool(a.allocate(task, e.time_steps)),)
+                    elif op == 1:
+                        if len(a.tasks) == 1 and a.tasks[0].id == 0:
+                            a.tasks = [e.task_idle]
+                            a.state = 0
+                    elif op == 2:
+                        a.position = np.array(vec)
+                    elif op == 3 and task is not None:
+                        task.required_agents = val
+                    elif op == 4 and e.escort_enabled and task is not None and a.type in ("R1", "R2") and task.type == "Rec":
+                        esc = e._create_escort_for(a, task)
+                        r = None if esc is None else (esc.id, esc.required_agents)
+                    elif op == 5 and e.escort_enabled:
+                        e._sync_escorts()
+                    elif op == 6 and e.escort_enabled and e._escort_by_recon:
+                        names = sorted(e._escort_by_recon)
+                        e._retire_escort(e._escort_by_recon[names[ti_ % len(names)]], failed=bool(val & 1))
+                        r = (e.escort_completed, e.escort_failed)
+                    elif op == 7 and e.escort_enabled:
+                        r = [x.id for x in e._escort_fighters_near(a, float(vec[0]))]
+                    outs.append(r)
+                assert outs[0] == outs[1], f"{tag} t={t} op {op}: returned {outs[0]} vs {outs[1]}"
+                same_world(R, F, f"{tag} t={t} after op {op}")
             try:
                 ra = _apply_assign(R, hr.allocate_tasks(R.get_live_agents(), _open_tasks(R), time_step=R.time_steps, events=_events(rinfo),
                                                          agent_known_ids=R.agent_visibility_map()))
