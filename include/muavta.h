@@ -259,7 +259,11 @@ int muavta_set_allocator(MuavtaEnv* env, int32_t mode);
  *   MUAVTA_OP_SET_QUEUE           `agent.tasks = [t0, t1, ...]` (plain list assignment, e.g. test_escort.py:95: no Task bookkeeping):
  *                                 iargs = {agent, n <= 6, id0 .. id5}; [task_idle] (id 0) is the empty queue.  iargs[7] = 1 with
  *                                 n = 0 is UAV.allocate(task_idle) (DroneEnvComponents.py:59-60,85-92): besides `tasks = [idle]` it
- *                                 resets next_free_time = 0, next_free_position = position, re_eval = False, last_task = None
+ *                                 resets next_free_time = 0, next_free_position = position, re_eval = False, last_task = None.
+ *                                 CONTRACT: the reference's assignment leaves Task.allocationDetails alone (an agent stays in the
+ *                                 details of a task it no longer queues); the device keeps allocationDetails IN the queues, so the
+ *                                 call is exact for what the reference's own callers do with it — scaffolding agents whose queue is
+ *                                 [task_idle] (test_escort.py:95) — and drops the old queue's detail entries otherwise
  * Runs on the handle's stream and synchronises.  Returns MUAVTA_E_ARG for ids outside the env. */
 typedef enum MuavtaOp {
   MUAVTA_OP_UAV_ALLOCATE = 0, MUAVTA_OP_CREATE_ESCORT, MUAVTA_OP_SYNC_ESCORTS, MUAVTA_OP_RETIRE_ESCORT,

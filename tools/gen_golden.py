@@ -55,7 +55,7 @@ SCALARS = [
     "protection_breaches", "threats_intercepted", "recon_losses", "escort_losses",
     "mutual_support_engagements", "protected_rec_completed",
 ]
-QCAP = 12
+QCAP = 16  # (queue columns of a snapshot; the oracle exports 16: deeper queues are skipped by the fuzz drivers)
 
 
 def make_env(case):
