@@ -2936,7 +2936,7 @@ struct Sim {
         no += __popcll(om);
       }
       const bool list_changed = __ballot(moved) != 0ull || no != no_old;
-      if (lane == 0) { S.n_order = w; S.n_open = no; S.n_act = 0; if (list_changed) obs_static_clear(); }
+      if (lane == 0) { S.n_order = w; S.n_open = no; S.n_act = 0; S.list_stale = 0; if (list_changed) obs_static_clear(); }
     }
     lds_sync();
   }
@@ -3303,6 +3303,23 @@ struct Sim {
     if (go && lane == 0) S.gate_step = tnow + 1;
     const bool vis = use_visibility && envvis;  // agent_visibility_map() is None
     int nr = 0, n_live = 1;
+    // The allocator's task list is env.tasks filtered at CALL time (_open_tasks, paper_eval.py:96-101): last_tasks_info as the last
+    // observation left it, MINUS what was concluded since (the status tests below) PLUS what an out-of-step call created since — ids
+    // are monotone, so those follow it in env.tasks order.  They become rows [n_open, n_plan) of open_slot for this plan only (beyond
+    // n_open nobody else looks); a pair with such a task consumes its agent and the task's residual like any other and is then dropped,
+    // as _apply_assign drops a task that is not in env.last_tasks_info (wps_eval.py:55-61).
+    int n_plan = S.n_open;
+    if (go && S.list_stale) {  // (uniform; only ever set by muavta_call)
+      const int n0 = S.n_open;
+      lds_sync();
+      const int n_new = compact_to(S.open_slot + n0, S.n_order,
+                                   [&](int k) { const int s = S.t_order[k]; const int r = S.t_row[s]; return S.t_status[s] != 2 && !(r < n0 && (int)S.open_slot[r] == s); },
+                                   [&](int k) { return (int)S.t_order[k]; });
+      lds_sync();
+      for (int k = lane; k < n_new; k += WG) S.t_row[S.open_slot[n0 + k]] = (uint8_t)(n0 + k);
+      n_plan = n0 + n_new;
+      lds_sync();
+    }
     if (go) {
       cold_sync();  // residual demand reads currentReqs / allocatedReqs
       if constexpr (SC) {
@@ -3315,7 +3332,7 @@ struct Sim {
           const int n_list = escort_sorted_list(envvis, n_live_raw, n_all);
           const int n_cols = n_list < sc.MT ? n_list : sc.MT;  // columns = the first MT entries = the list handed over
           n_sc = n_cols;
-          for (int k = lane; k < S.n_open; k += WG) { const int s = S.open_slot[k]; pair_info()[s] = 255; X.resid[s] = 0.0; }  // (after the helper: pair_info may alias X.remaining)
+          for (int k = lane; k < n_plan; k += WG) { const int s = S.open_slot[k]; pair_info()[s] = 255; X.resid[s] = 0.0; }  // (after the helper: pair_info may alias X.remaining)
           lds_sync();
           for (int j = lane; j < n_cols; j += WG) {
             const int s = X.path[j];
@@ -3345,11 +3362,11 @@ struct Sim {
         }
         if (sc.kind != 2) {  // build_att_tokens' open_tasks (AttentionRAH.py:69-73): underfilled at the type index, env.tasks order
           const bool full = (sc.flags & MUAVTA_SC_FULL_TASK_LIST) != 0;
-          for (int base = 0; base < S.n_open; base += WG) {
+          for (int base = 0; base < n_plan; base += WG) {
             const int k = base + lane;
             bool under = false, inl = false;
             int s = 0, rank = 0;
-            if (k < S.n_open) {
+            if (k < n_plan) {
               s = S.open_slot[k];
               const int ty = S.t_type[s];
               // (status: the open list is the one of the last observation — an out-of-step _retire_escort (muavta_call) concludes a task
@@ -3357,7 +3374,7 @@ struct Sim {
               under = S.t_status[s] != 2 && C.t_alloc[ty][s] < C.t_cur[ty][s];
             }
             const unsigned long long um = __ballot(under);
-            if (k < S.n_open) {
+            if (k < n_plan) {
               rank = n_under + prefix_count(um);
               inl = under && (full || rank < sc.MT);
               pair_info()[s] = (int16_t)(!under ? 255 : rank < sc.MT ? rank : 254);  // token column; 254: in the list, no column
@@ -3374,11 +3391,11 @@ struct Sim {
           any_open = n_sc > 0;  // every entry of the sorted list has residual demand
         }
       } else
-      for (int base = 0; base < S.n_open; base += WG) {
+      for (int base = 0; base < n_plan; base += WG) {
         const int k = base + lane;
         bool under = false;
         int s = 0;
-        if (k < S.n_open) {
+        if (k < n_plan) {
           s = S.open_slot[k];
           const int ty = S.t_type[s];
           // Urgency-Pair only plans over build_att_tokens' open_tasks: underfilled at the type index (AttentionRAH.py:69-73).
@@ -3387,7 +3404,7 @@ struct Sim {
           under = S.t_status[s] != 2 && (mode != 1 || C.t_alloc[ty][s] < C.t_cur[ty][s]);
         }
         const unsigned long long um = mode == 1 ? __ballot(under) : 0ull;
-        if (k < S.n_open) {
+        if (k < n_plan) {
           // (Urgency-Pair hands the allocator the 32 token rows only: tok["open_tasks"] = kept, PairCostHybrid.py:36,62)
           const double r = (under && !(mode == 1 && n_under + prefix_count(um) >= 32)) ? residual_demand(s) : 0.0;
           X.resid[s] = r;
@@ -3399,7 +3416,7 @@ struct Sim {
             int n_know = 0;
             if (vis) for (int b = 0; b < P.n_agents; b++) n_know += (S.known[b][s >> 5] >> (s & 31)) & 1u;
             pair_info()[s] = (rank < 32 ? rank : 255) | (n_know << 8);
-          } else if (k < S.n_open) pair_info()[s] = 255;
+          } else if (k < n_plan) pair_info()[s] = 255;
           n_under += __popcll(um);
         }
       }
@@ -3420,7 +3437,7 @@ struct Sim {
       // round_tasks: open tasks (that had residual > 0 initially) with residual > 1e-9, in last_tasks_info order
       int nc;
       if constexpr (SC) nc = compact_to(X.roundT, n_sc, [&](int i) { return X.resid[S.open_slot[sc_list[i]]] > 1e-9; }, [&](int i) { return (int)sc_list[i]; });
-      else nc = compact_to(X.roundT, S.n_open, [&](int k) { return X.resid[S.open_slot[k]] > 1e-9; }, [&](int k) { return k; });
+      else nc = compact_to(X.roundT, n_plan, [&](int k) { return X.resid[S.open_slot[k]] > 1e-9; }, [&](int k) { return k; });
       lds_sync();
       if (nr == 0 || nc == 0) break;
       const bool tr = nc < nr;              // scipy transposes so that rows <= cols
@@ -3658,7 +3675,7 @@ struct Sim {
       PROF(13);
       // accept (:182-204): one free agent per lane, actions appended in ascending agent order (scipy returns
       // rows sorted); each task appears at most once per round, so the residual updates are independent
-      int n_acc = 0, n_left = 0;
+      int n_acc = 0, n_left = 0, n_staged = 0;
       for (int base = 0; base < nr; base += WG) {
         const int i = base + lane;
         bool acc = false, keep = false;
@@ -3680,20 +3697,26 @@ struct Sim {
             }
           }
         }
-        const unsigned long long am = __ballot(acc), km = __ballot(keep);
+        // (a task beyond last_tasks_info — created by an out-of-step call since the last observation — takes its agent out of the round and
+        // has its residual reduced like any other, but the pair is not an action: _apply_assign only keeps tasks of env.last_tasks_info)
+        const bool stage = acc && oi < S.n_open;
+        const unsigned long long am = __ballot(acc), km = __ballot(keep), sm = __ballot(stage);
         const unsigned long long below = (1ull << lane) - 1ull;
         lds_sync();  // freeA fully read before it is compacted in place
         if (acc) {
-          const int n = n_act + n_acc + prefix_count(am);
-          S.act_agent[n] = a; S.act_slot[n] = s; S.act_index[n] = oi;
+          if (stage) {
+            const int n = n_act + n_staged + prefix_count(sm);
+            S.act_agent[n] = a; S.act_slot[n] = s; S.act_index[n] = oi;
+          }
           const double delivered = is_escort_task(s) ? 1.0 : S.a_caps[S.t_type[s]][a];
           X.resid[s] = fmax(X.resid[s] - delivered, 0.0);
         }
         if (keep) X.freeA[n_left + prefix_count(km)] = a;
         n_acc += __popcll(am);
+        n_staged += __popcll(sm);
         n_left += __popcll(km);
       }
-      n_act += n_acc;
+      n_act += n_staged;
       nr = n_acc ? n_left : 0;  // no accept -> stop
       lds_sync();
       PROF(14);

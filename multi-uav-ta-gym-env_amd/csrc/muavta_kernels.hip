@@ -667,12 +667,15 @@ __global__ __launch_bounds__(WG) void k_call(const DevCtx* __restrict__ ctxp, Ca
     case MUAVTA_OP_CREATE_ESCORT: {
       const int s = slot_of(a.i[1]);
       if (lane == 0) {
+        S.list_stale = 1;  // (a task may be born behind last_tasks_info: Sim::allocate extends its list)
         if (ctx.P.escort_enabled && (s >= 0 || a.i[1] == 0)) sim.create_escort_for(ag, s);  // rec_task None (id 0): protected_task = None
         const int k = sim.escort_lookup(ag);
         out[0] = (ctx.P.escort_enabled && k >= 0) ? (int)S.esc_id[k] : -1;
       }
     } break;
     case MUAVTA_OP_SYNC_ESCORTS:
+      if (lane == 0) S.list_stale = 1;
+      lds_sync();
       if (ctx.P.escort_enabled) sim.sync_escorts_coop();
       break;
     case MUAVTA_OP_RETIRE_ESCORT:

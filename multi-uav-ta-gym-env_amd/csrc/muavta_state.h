@@ -182,6 +182,9 @@ struct alignas(16) EnvState : QueueSide<TL::A, TL::T, !TL::SLIM> {
   int32_t times_dirty;                // some allocationDetails changed since initTime/doneTime were rebuilt
   int32_t obs_rows;                   // rows [obs_rows, max_tasks) of the HANDLE's observation task tensor are known to hold pad rows
                                       // ({"status": -1}); -1: unknown (after a reset, or when the host rewrote the state)
+  int32_t list_stale;                 // an out-of-step call (muavta_call) created tasks since `open_slot` (last_tasks_info) was built: the
+                                      // allocator's list — the harness reads env.tasks when it plans — is that list plus the newer tasks
+                                      // (fits the tail padding of every tile: the record does not grow)
 };
 
 // Standard tiles (BASELINE.json configs).  The 16-agent tile has 40 task slots — the bound at which the reference stops
