@@ -1109,6 +1109,21 @@ def test_wide_fuzz_regressions_stepwise_vs_oracle_and_reference_metrics(path):
     assert ran >= 1
 
 
+@pytest.mark.parametrize("leg,k", [("mutators", 12794), ("mutators", 12782), ("mutators", 14016), ("mutators", 14068), ("mutators", 14173),
+                                   ("scored", 7178), ("stepwise", 992), ("stepwise", 40), ("rl", 12041), ("lists", 12042), ("rings", 12043)])
+def test_wide_fuzz_legs_on_the_configurations_that_found_bugs(leg, k):
+    """One episode of a leg of tests/fuzz_device.py on the configurations that exposed device bugs (the allocator's list after an
+    out-of-step _retire_escort / _create_escort_for, the recon-as-escort retire verdicts, rows beyond max_tasks, the expired escort
+    that follows its UAV) plus one plain configuration per remaining leg, so that the fuzz driver itself stays runnable."""
+    import fuzz_device as FD
+    from fuzz_reference import wide_config
+
+    msgs = []
+    w = wide_config(k)
+    out = getattr(FD, leg)(k, w, msgs.append)
+    assert out in ("ok", "overflow") and not msgs, msgs
+
+
 def test_seeds_beyond_32_bits():
     """init_by_array with a two-word key (seed >= 2^32): the batched seeding kernel against the oracle's CPython restatement."""
     case = "WPS_hard"
