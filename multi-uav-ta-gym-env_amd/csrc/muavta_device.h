@@ -2860,11 +2860,18 @@ struct Sim {
     if (gc) {
       // fast path: no live slot is retired and every live slot is already listed as open (no task was created
       // or retired since the lists were built) -> t_order / last_tasks_info are unchanged
-      const int n = S.n_order;
-      bool ret = false;
-      for (int k = lane; k < n; k += WG) ret |= S.t_status[S.t_order[k]] == 2;
+      // (... and the two lists really are the same list: with the tile FULL, a task concluded in this step can have had its slot
+      // recycled on demand for a task created in the same step — no retired slot is left and the counts agree, but that slot now
+      // sits at the END of t_order and still at its old row of last_tasks_info.  Found by tests/fuzz_device.py, config 1000488.)
+      const int n = S.n_order, no = S.n_open;
+      bool ret = false, diff = false;
+      for (int k = lane; k < n; k += WG) {
+        const int s = S.t_order[k];
+        ret |= S.t_status[s] == 2;
+        diff |= k >= no || (int)S.open_slot[k] != s;
+      }
       const bool any_ret = __ballot(ret) != 0ull;
-      if (!any_ret && S.n_open == n) {
+      if (!any_ret && no == n && __ballot(diff) == 0ull) {
         if (lane == 0) S.n_act = 0;
         lds_sync();
         return;
@@ -3100,7 +3107,9 @@ struct Sim {
         ty = S.t_type[s];
         typemask = (S.t_flags[s] & TF_ELIGIBLE) ? S.t_elig[s] : 0xffffffffu;
         if (light) {  // (uniform)
-          const double ti = C.t_init[s], td = C.t_dtime[s];  // (OBS_STATIC implies the task times are not dirty)
+          // (OBS_STATIC implies the task times are not dirty.  These two HBM operands sit on the step's chain: a build without them ran
+          // 1.2 % faster, requesting them at the start of step() instead won back 0.3 % — within noise, not adopted: profiles/r04_ab_obs_light_prefetch.txt)
+          const double ti = C.t_init[s], td = C.t_dtime[s];
           if (P.saturate_mask && C.t_alloc[ty][s] >= qs().t_org[s]) typemask = 0;
           uint32_t off = ju * 4u;
           const uint32_t cstride = (uint32_t)MT * 4u;

@@ -48,6 +48,8 @@ for t in range(p.max_time_steps):
             print("MISMATCH", exc, "ERROR", snap.ERROR)
             trow, reqs = o.tasks(); ids = snap.TASK_ID[i]
             print(" device slots (id,status):", [(int(x), int(snap.TASK_STATUS[i, s])) for s, x in enumerate(ids) if x >= 0])
+            print(" device OPEN_IDS:", snap.OPEN_IDS[i].tolist())
+            print(" oracle open_ids:", o.open_ids().tolist())
             print(" oracle open:", [kk for kk in range(1, trow.shape[0]) if int(trow[kk, 0]) != 2], "n tasks", trow.shape[0])
             print(" oracle rows of missing:", [(kk, trow[kk, :13].tolist()) for kk in range(1, trow.shape[0]) if int(trow[kk, 0]) != 2 and kk not in set(ids.tolist())])
             rows, caps, q = o.agents()

@@ -155,8 +155,10 @@ def pin_scored(ks):
     path = os.path.join(HERE, "golden", "wide_configs.json")
     configs = json.load(open(path)) if os.path.exists(path) else {}
     for k in ks:
+        k, env_i = (int(x) for x in (str(k).split(":") + ["0"])[:2])  # "k:i" = env i of the fuzz leg's batch (seed + i, the i-th rows of its inputs)
         w = wide_config(k)
         cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+        seed = seed - env_i if seed > 2 ** 62 else seed + env_i
         gate, kind, oflags = SCORED[k % len(SCORED)]
         mt, ma = PADS[(k // len(SCORED)) % len(PADS)]
         o = orc.OracleEnv(params_from_config(dict(cfg), None, tile_agents=64, tile_tasks=128, tile_threats=48))
@@ -168,7 +170,7 @@ def pin_scored(ks):
             sc = (rng.uniform(-1, 1, (n, ma, mt)) * (0.35 if kind != 2 else 1.0)).astype(np.float32)
             pri = rng.uniform(-0.5, 1, (n, mt))
             res = rng.integers(0, 1 << A, n, dtype=np.uint64) & rng.integers(0, 1 << A, n, dtype=np.uint64)
-            oa, oi, _ = o.allocate_scored(interval, int(bool((t // 3) % 2)), GATE[gate], kind, mt, ma, oflags, scores=sc[0], pri=pri[0], reserved=int(res[0]))
+            oa, oi, _ = o.allocate_scored(interval, int(bool((t // 3) % 2)), GATE[gate], kind, mt, ma, oflags, scores=sc[env_i], pri=pri[env_i], reserved=int(res[env_i]))
             o.step(oa, oi)
             actions, items = {}, []
             for a, i in zip(oa, oi):
@@ -188,7 +190,7 @@ def pin_scored(ks):
 
 
 if __name__ == "__main__" and "--pin-scored" in sys.argv:
-    pin_scored([int(a) for a in sys.argv[1:] if not a.startswith("--")])
+    pin_scored([a for a in sys.argv[1:] if not a.startswith("--")])
     sys.exit(0)
 
 if __name__ == "__main__" and "--pin" in sys.argv:

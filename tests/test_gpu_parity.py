@@ -497,26 +497,41 @@ def test_reference_list_valued_action_traces_on_the_device(path):
     and the reference's positions / rewards directly."""
     from test_oracle_golden import lists_params
     from muavta_amd.batched import BatchedMultiUAVEnv
-    g, p = lists_params(path)
     name = os.path.basename(path)[:-4]
-    env = BatchedMultiUAVEnv(p, 2)  # two copies of the episode: the rows are per env
-    seed = int(g["seed"])
-    env.reset(np.array([seed, seed], dtype=np.uint64))
-    o = orc.OracleEnv(p)
-    o.reset(seed)
-    acts = g["actions"]
-    for t in range(g["pos"].shape[0] - 1):
-        ga = acts[acts[:, 0] == t]
-        items = [(int(a), int(i)) for a, i in ga[:, 1:3]]
-        aa, ai = env.pack_actions([items, items])
-        env.step(aa, ai)
-        o.step(ga[:, 1].astype(np.int32), ga[:, 2].astype(np.int32))
-        snap = Snapshot(env)
-        for i in range(2):
-            compare(snap, i, o, f"{name} t={t + 1}")
-        assert np.array_equal(env.get("AGENT_POS")[0][:p.n_agents], g["pos"][t + 1]), f"{name} t={t + 1}: positions vs the reference"
-        assert env.step_result()[0][0] == g["reward"][t + 1], f"{name} t={t + 1}: reward vs the reference"
-    assert np.all(env.get("ERROR") == 0)
+    # (the action-driven traces of wide-fuzz configurations — tests/fuzz_reference.py --pin-scored — run on every tile that holds the
+    # fleet: WIDE1000488 needs the 40-slot tile exactly full, WIDE7178 fails on all of them without its fix)
+    tile_sets = [{}] if "WIDE" not in name else [dict(tile_agents=16, tile_tasks=40, tile_threats=16), dict(tile_agents=24, tile_tasks=48, tile_threats=24),
+                                                 dict(tile_agents=64, tile_tasks=128, tile_threats=48)]
+    ran = 0
+    for tiles in tile_sets:
+        g, p = lists_params(path, **tiles)
+        env = BatchedMultiUAVEnv(p, 2)  # two copies of the episode: the rows are per env
+        seed = int(g["seed"])
+        env.reset(np.array([seed, seed], dtype=np.uint64))
+        o = orc.OracleEnv(p)
+        o.reset(seed)
+        acts = g["actions"]
+        overflow = False
+        for t in range(g["pos"].shape[0] - 1):
+            ga = acts[acts[:, 0] == t]
+            items = [(int(a), int(i)) for a, i in ga[:, 1:3]]
+            aa, ai = env.pack_actions([items, items])
+            env.step(aa, ai)
+            o.step(ga[:, 1].astype(np.int32), ga[:, 2].astype(np.int32))
+            snap = Snapshot(env)
+            if tiles and snap.ERROR.any():  # (a smaller tile than the episode needs: only the largest must hold it)
+                overflow = True
+                break
+            for i in range(2):
+                compare(snap, i, o, f"{name} {tiles} t={t + 1}")
+            assert np.array_equal(env.get("AGENT_POS")[0][:p.n_agents], g["pos"][t + 1]), f"{name} t={t + 1}: positions vs the reference"
+            assert env.step_result()[0][0] == g["reward"][t + 1], f"{name} t={t + 1}: reward vs the reference"
+        if overflow:
+            assert tiles["tile_agents"] < 64
+            continue
+        ran += 1
+        assert np.all(env.get("ERROR") == 0)
+    assert ran >= 1
 
 
 def test_agent_ids_outside_the_fleet_are_rejected():
