@@ -52,10 +52,16 @@ PADS = ((32, 16), (6, 3), (48, 16), (12, 8))
 MODES = ((0, "hungarian"), (1, "urgency_pair"), (2, "urgency_coalition"), (3, "hungarian_gated"))
 
 
-def tiles_for(cfg):
-    """the tiles that hold the configuration's fleet and threat list (the large family of wide_config needs the bigger ones)"""
+def tiles_for(cfg, k=None):
+    """the tiles that hold the configuration's fleet and threat list (the large family of wide_config needs the bigger ones); with k
+    also a CAPPED 16-agent tile (tile_tasks below 40 caps the live slots): the episodes that fit it run with the tile full or nearly
+    full most of the time — on-demand slot recycling, the capacity edges — and the ones that do not are flagged and skipped"""
     na, nh = sum(cfg["agents"].values()), sum(n for _, n in cfg["threats_list"])
-    return tuple(t for t in TILES if na <= t[0] and nh <= t[2])
+    out = tuple(t for t in TILES if na <= t[0] and nh <= t[2])
+    if k is not None and na <= 16 and nh <= 16:
+        n_static = sum(cfg["tasks"].values()) + len(cfg["threats_list"])
+        out += ((16, min(39, n_static + 2 + (k * 7) % 12), 16),)
+    return out
 
 
 def reserved_bits(rng, n, A):
@@ -88,7 +94,7 @@ def fused(k, w, n_seeds, log):
         o.rollout_mode(int(s), steps, interval, int(use_vis), mode)
         want.append(o.metrics().copy())
     bad = flagged = checked = 0
-    for tile in tiles_for(cfg):
+    for tile in tiles_for(cfg, k):
         env = BatchedMultiUAVEnv(params(cfg, tile), n_seeds)
         env.set_allocator(name)
         if split:
@@ -115,7 +121,7 @@ def fused(k, w, n_seeds, log):
 def stepwise(k, w, log):
     cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
     mode, name = MODES[(k // 3) % 4]
-    tile = tiles_for(cfg)[k % len(tiles_for(cfg))]
+    tile = tiles_for(cfg, k)[k % len(tiles_for(cfg, k))]
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
@@ -175,7 +181,7 @@ def scored(k, w, log):
     cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
     gate, kw, kname, kind, oflags = SCORED[k % len(SCORED)]
     mt, ma = PADS[(k // len(SCORED)) % len(PADS)]
-    tile = tiles_for(cfg)[(k // 2) % len(tiles_for(cfg))]
+    tile = tiles_for(cfg, k)[(k // 2) % len(tiles_for(cfg, k))]
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
@@ -222,7 +228,7 @@ def scored(k, w, log):
 
 def lists(k, w, log):
     cfg, seed = w["cfg"], w["seed"]
-    tile = tiles_for(cfg)[(k // 5) % len(tiles_for(cfg))]
+    tile = tiles_for(cfg, k)[(k // 5) % len(tiles_for(cfg, k))]
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)

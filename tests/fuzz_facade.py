@@ -28,6 +28,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 from fuzz_reference import wide_config  # noqa: E402
 
 
+class QueueTooDeep(Exception):
+    pass
+
+
 def f32(x):
     return np.asarray(x, dtype=np.float64).astype(np.float32)
 
@@ -69,6 +73,8 @@ def same_world(R, F, tag):
         assert ra.name == fa.name and ra.type == fa.type and ra.typeIdx == fa.typeIdx and ra.id == fa.id, f"{tag}: agent identity"
         assert np.array_equal(np.asarray(ra.position, dtype=np.float64), fa.position), f"{tag} {ra.name}: position"
         assert ra.state == fa.state, f"{tag} {ra.name}: state"
+        if len(ra.tasks) > 16:
+            raise QueueTooDeep(f"{ra.name} queues {len(ra.tasks)} tasks")  # (the test backend exports 16 queue columns; the device tiles hold 10-12)
         assert [t.id for t in ra.tasks] == [t.id for t in fa.tasks], f"{tag} {ra.name}: queue"
         assert np.array_equal(np.asarray(ra.next_free_position, dtype=np.float64), fa.next_free_position), f"{tag} {ra.name}: next_free_position"
         assert float(ra.next_free_time) == fa.next_free_time, f"{tag} {ra.name}: next_free_time"
@@ -207,6 +213,8 @@ def run_one(k: int):
         for key in METRIC_KEYS:
             assert float(rinfo["metrics"][key]) == float(finfo["metrics"][key]), f"{tag}: metric {key}"
         assert R.compute_s_wps() == F.compute_s_wps() and R.compute_s_esc() == F.compute_s_esc()
+    except QueueTooDeep as exc:
+        return k, "skip", str(exc)
     except AssertionError as exc:
         return k, "MISMATCH", str(exc)[:500]
     except Exception as exc:
