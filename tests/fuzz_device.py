@@ -18,6 +18,9 @@ and are compared with the oracle:
             UAV.tasks = [task_idle], state / position / required_agents writes, _create_escort_for, _sync_escorts, _retire_escort,
             _escort_fighters_near, _is_task_action_valid) at random points of an episode, the facade on the HIP backend next to the
             facade on the oracle backend: every field after every call and every step;
+  resume    checkpoint / resume and the sub-batch entry points: a fused rollout up to a random step, muavta_get_state + muavta_get_rng,
+            a FRESH handle restored from them (muavta_set_state + muavta_set_rng), the rest of the episode there as sub-batch launches
+            (muavta_set_parts + muavta_rollout_part): metrics and final state of the uninterrupted oracle episode;
   rl        the fused policy-in-the-loop step (muavta_rl_step_device through il.rl_stream: scored Hungarian -> step -> S_WPS ->
             next tokens in one launch) with a seeded score tensor per step: selected mask, gate, step reward, next tokens, done flags
             and the final metrics.
@@ -426,6 +429,49 @@ def mutators(k, w, log, verbose=False):
     return "ok"
 
 
+def resume(k, w, log):
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+    tile = tiles_for(cfg)[(k // 3) % len(tiles_for(cfg))]
+    p = params(cfg, tile)
+    n, steps = 6, p.max_time_steps
+    cut = 1 + (k * 13) % max(steps - 1, 1)
+    mode, name = MODES[(k // 5) % 4]
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    a = BatchedMultiUAVEnv(p, n)
+    b = BatchedMultiUAVEnv(p, n)
+    tag = f"k={k} resume tile {tile} mode {name} cut {cut}/{steps}"
+    try:
+        a.set_allocator(name)
+        a.rollout(seeds, cut, interval, True, True)
+        a.sync()
+        st, rg = a.get_state(), a.get_rng()
+        b.set_allocator(name)
+        b.set_state(st)
+        b.set_rng(rg)
+        parts = 2 + k % 2
+        b.set_parts(parts)
+        for part in range(parts):
+            b.rollout_part(part, steps - cut, interval, True, True)
+        b.wait_part(-1)
+        b.sync()
+        b.refresh_observation()  # (an env whose episode ended before the cut takes no step in b: its observation is b's to rebuild from the restored state)
+        snap = Snapshot(b)
+        m = b.metrics()
+        for i in range(n):
+            if snap.ERROR[i]:
+                continue
+            o = orc.OracleEnv(p)
+            o.rollout_mode(int(seeds[i]), steps, interval, 1, mode)
+            assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: metrics columns {np.nonzero(m[i] != o.metrics())[0].tolist()}"
+            compare(snap, i, o, f"{tag} seed {seeds[i]} final state")
+    except AssertionError as exc:
+        log(f"RESUME MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        a.close(); b.close()
+    return "ok"
+
+
 def rl(k, w, log):
     import torch
     from muavta_amd import il
@@ -500,7 +546,7 @@ if __name__ == "__main__":
 
     t0 = time.time()
     tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "scored_ok": 0, "scored_bad": 0,
-           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "errors": 0}
+           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "errors": 0}
     for k in range(first, first + n_cfg):
         w = wide_config(k)
         try:
@@ -513,6 +559,7 @@ if __name__ == "__main__":
                 tot["rl_" + rl(k, w, log)] += 1
                 tot["rings_" + rings(k, w, log)] += 1
                 tot["mutators_" + mutators(k, w, log)] += 1
+                tot["resume_" + resume(k, w, log)] += 1
         except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
             tot["errors"] += 1
             log(f"k={k} ERROR {type(exc).__name__}: {str(exc)[:300]}")

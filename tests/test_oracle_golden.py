@@ -159,11 +159,16 @@ def test_list_valued_actions_trace_bit_exact(path):
     items reproduces every step's state, reward, events and observation."""
     g, p = lists_params(path)
     name = os.path.basename(path)[:-4]
+    assert "WIDE" in name or np.bincount(g["actions"][:, 0]).max() > 32  # (the random-list traces go past every tile's action_cap)
+    check_lists(g, name, p)
+
+
+def check_lists(g, name, p):
+    """an action-driven reference episode (tools/gen_golden.py::drive_with_actions) against the oracle fed the same flattened items"""
     e = orc.OracleEnv(p)
     e.reset(int(g["seed"]))
     check_state(e, g, 0, name)
     acts, evs = g["actions"], g["events"]
-    assert "WIDE" in name or np.bincount(acts[:, 0]).max() > 32  # (the random-list traces go past every tile's action_cap)
     for s in range(g["pos"].shape[0] - 1):
         ga = acts[acts[:, 0] == s]
         e.step(ga[:, 1].astype(np.int32), ga[:, 2].astype(np.int32))
