@@ -456,7 +456,7 @@ def resume(k, w, log):
         b.sync()
         b.refresh_observation()  # (an env whose episode ended before the cut takes no step in b: its observation is b's to rebuild from the restored state)
         snap = Snapshot(b)
-        m = b.metrics()
+        m = b.rollout_metrics()  # (the rows of the last launches; muavta_metrics refuses a batch with a capacity-flagged env)
         for i in range(n):
             if snap.ERROR[i]:
                 continue
@@ -546,7 +546,7 @@ if __name__ == "__main__":
 
     t0 = time.time()
     tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "scored_ok": 0, "scored_bad": 0,
-           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "errors": 0}
+           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "resume_overflow": 0, "errors": 0}
     for k in range(first, first + n_cfg):
         w = wide_config(k)
         try:
