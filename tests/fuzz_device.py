@@ -18,6 +18,8 @@ and are compared with the oracle:
             UAV.tasks = [task_idle], state / position / required_agents writes, _create_escort_for, _sync_escorts, _retire_escort,
             _escort_fighters_near, _is_task_action_valid) at random points of an episode, the facade on the HIP backend next to the
             facade on the oracle backend: every field after every call and every step;
+  ilrings   the trainers' data rings (muavta_rollout_record through il.il_record: per-step token tensors, edge_valid, the expert's plan
+            as a mask, the gate bit, the S_WPS series) against the oracle stepping the same seeds under the trainers' gate;
   resume    checkpoint / resume and the sub-batch entry points: a fused rollout up to a random step, muavta_get_state + muavta_get_rng,
             a FRESH handle restored from them (muavta_set_state + muavta_set_rng), the rest of the episode there as sub-batch launches
             (muavta_set_parts + muavta_rollout_part): metrics and final state of the uninterrupted oracle episode;
@@ -429,6 +431,49 @@ def mutators(k, w, log, verbose=False):
     return "ok"
 
 
+def ilrings(k, w, log):
+    from muavta_amd.il import il_record
+
+    cfg, seed = w["cfg"], w["seed"]
+    tile = tiles_for(cfg)[(k // 17) % len(tiles_for(cfg))]
+    p = params(cfg, tile)
+    kind = k % 3
+    kname = ("pair", "pair_raw", "escort")[kind]
+    mt, ma = ((32, 16), (12, 8), (48, 16))[(k // 3) % 3]
+    n, steps, interval = 3, p.max_time_steps, 20
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    env = BatchedMultiUAVEnv(p, n)
+    tag = f"k={k} ilrings tile {tile} kind {kname} pads {mt}x{ma}"
+    try:
+        rec = {key: v.cpu().numpy() for key, v in il_record(env, seeds, steps, interval, kname, mt, ma).items()}
+        err = env.get("ERROR")
+        m = env.rollout_metrics()
+        for i in range(n):
+            if err[i]:
+                continue
+            o = orc.OracleEnv(p)
+            o.reset(int(seeds[i]))
+            assert rec["s_wps"][0, i] == o.metrics()[4], f"{tag} seed {seeds[i]}: S_WPS[0]"
+            for t in range(steps):
+                oa, oi = o.allocate_mode(interval, 1, 3)  # the trainers' expert under _should_replan(env, events, interval)
+                want = o.tokens(kind, mt, ma)
+                for key in want:
+                    gv = int(rec[key][t, i]) if key == "n_urgent" else rec[key][t, i]
+                    assert np.array_equal(np.asarray(gv), np.asarray(want[key])), f"{tag} seed {seeds[i]} t={t}: {key}"
+                assert bool(rec["replanned"][t, i]) == (o.scalars_last_plan() == t), f"{tag} seed {seeds[i]} t={t}: gate"
+                done = o.step(oa, oi)
+                assert rec["s_wps"][t + 1, i] == o.metrics()[4], f"{tag} seed {seeds[i]} t={t}: S_WPS series"
+                if done:
+                    break
+            assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: metrics"
+    except AssertionError as exc:
+        log(f"ILRINGS MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
 def resume(k, w, log):
     cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
     tile = tiles_for(cfg)[(k // 3) % len(tiles_for(cfg))]
@@ -546,7 +591,7 @@ if __name__ == "__main__":
 
     t0 = time.time()
     tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "scored_ok": 0, "scored_bad": 0,
-           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "resume_overflow": 0, "errors": 0}
+           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "resume_overflow": 0, "ilrings_ok": 0, "ilrings_bad": 0, "errors": 0}
     for k in range(first, first + n_cfg):
         w = wide_config(k)
         try:
@@ -560,6 +605,7 @@ if __name__ == "__main__":
                 tot["rings_" + rings(k, w, log)] += 1
                 tot["mutators_" + mutators(k, w, log)] += 1
                 tot["resume_" + resume(k, w, log)] += 1
+                tot["ilrings_" + ilrings(k, w, log)] += 1
         except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
             tot["errors"] += 1
             log(f"k={k} ERROR {type(exc).__name__}: {str(exc)[:300]}")
