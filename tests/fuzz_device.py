@@ -455,7 +455,7 @@ def ilrings(k, w, log):
             o.reset(int(seeds[i]))
             assert rec["s_wps"][0, i] == o.metrics()[4], f"{tag} seed {seeds[i]}: S_WPS[0]"
             for t in range(steps):
-                oa, oi = o.allocate_mode(interval, 1, 3)  # the trainers' expert under _should_replan(env, events, interval)
+                oa, oi = o.allocate_mode(interval, 0, 3)  # the trainers' expert: Global-Hungarian (no visibility map, train_pair_cost.py:111) under _should_replan(env, events, interval)
                 want = o.tokens(kind, mt, ma)
                 for key in want:
                     gv = int(rec[key][t, i]) if key == "n_urgent" else rec[key][t, i]
