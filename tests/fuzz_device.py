@@ -84,6 +84,9 @@ def params(cfg, tile):
     return params_from_config(c, None, tile_agents=tile[0], tile_tasks=tile[1], tile_threats=tile[2])
 
 
+ESCALATED = [0]  # envs whose metric row came from rollout(escalate=True)
+
+
 def fused(k, w, n_seeds, log):
     cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
     mode, name = MODES[k % 4]
@@ -99,15 +102,26 @@ def fused(k, w, n_seeds, log):
         o.rollout_mode(int(s), steps, interval, int(use_vis), mode)
         want.append(o.metrics().copy())
     bad = flagged = checked = 0
+    n_esc = [0]
     for tile in tiles_for(cfg, k):
         env = BatchedMultiUAVEnv(params(cfg, tile), n_seeds)
         env.set_allocator(name)
+        escalate = (not split) and k % 2 == 0 and tile[0] < 64  # every other config: flagged envs re-run on the next larger tile and spliced in
         if split:
             env.rollout(seeds, steps // 3, interval, use_vis, write_obs)
             env.rollout(None, steps - steps // 3, interval, use_vis, write_obs)
         else:
-            env.rollout(seeds, steps, interval, use_vis, write_obs)
+            try:
+                env.rollout(seeds, steps, interval, use_vis, write_obs, escalate=escalate)
+            except Exception as exc:  # (an env that overflows the LARGEST tile: rollout(escalate=True) says so)
+                if "no tile left" not in str(exc):
+                    raise
+                escalate = False
         got, err = env.rollout_metrics(), env.get("ERROR")
+        if escalate:  # rows of escalated envs come from the larger tile: every env is comparable
+            esc = set(env.escalated)
+            err = np.array([0 if i in esc else e for i, e in enumerate(err)])
+            n_esc[0] += len(esc)
         for i in range(n_seeds):
             if err[i]:
                 flagged += 1
@@ -120,6 +134,7 @@ def fused(k, w, n_seeds, log):
         if tile == TILES[2] and err.any():
             log(f"k={k} note: {int((err != 0).sum())} envs overflow the 64 x 128 tile, codes {np.unique(err[err != 0]).tolist()}")
         env.close()
+    ESCALATED[0] += n_esc[0]
     return bad, flagged, checked
 
 
@@ -611,4 +626,4 @@ if __name__ == "__main__":
             log(f"k={k} ERROR {type(exc).__name__}: {str(exc)[:300]}")
         if (k - first) % 10 == 9:
             log(f"... {k - first + 1} configs, {time.time() - t0:.0f} s: {tot}")
-    log(f"configs {first}..{first + n_cfg - 1}, {n_seeds} seeds each on 3 tiles: {tot}  ({time.time() - t0:.0f} s)")
+    log(f"configs {first}..{first + n_cfg - 1}, {n_seeds} seeds each on 3 tiles: {tot}  escalated envs compared: {ESCALATED[0]}  ({time.time() - t0:.0f} s)")
