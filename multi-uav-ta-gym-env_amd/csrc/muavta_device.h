@@ -408,6 +408,7 @@ struct Sim {
   // blob; reset() points it at a 192-word-per-stream copy in the scratch tile (a reset draws ~100 words)
   const uint32_t* win_ptr;
   uint32_t win_len, win_stride;
+  bool in_step = false;  // step() is running in this object (reclaim_slot_serial: which slots may be recycled on demand)
 
   __device__ Sim(State& s, Cold& c, Scratch<TL>& x, const DevParams& p, uint32_t* t)
       : S(s), C(c), X(x), P(p), tape(t), lane(opaque_lane()), win_ptr(&s.rng_win[0][0]), win_len(8), win_stride(8), tnow(s.time_steps) {}
@@ -795,6 +796,10 @@ struct Sim {
     for (int k = 0; k < S.n_order; k++) {
       int s = S.t_order[k];
       if (S.t_status[s] != 2 || !slot_unreferenced(S.t_id[s])) continue;
+      // Outside a step (muavta_call: _create_escort_for / _sync_escorts on a full tile) a slot that last_tasks_info still lists is not
+      // recycled: nothing rebuilds that list before the next step applies action indices through it, and its row would name the new
+      // tenant.  Inside a step the list is only read before the first creation and rebuilt at the end.  No slot left: capacity flag.
+      if (!in_step) { const int r = S.t_row[s]; if (r < S.n_open && (int)S.open_slot[r] == s) continue; }
       bool staged = false;  // actions still to be applied this step may name it (-> invalid-action penalty)
       for (int j = 0; j < S.n_act; j++) staged |= (S.act_slot[j] == s);
       if (staged || pending_item_names_slot(s)) continue;
@@ -1587,6 +1592,7 @@ struct Sim {
 
   DEV void step(bool write_obs_flag) {
     PROF(0);
+    in_step = true;
     uint32_t rng_words = 0;
     if (!ABL(0)) { rng_refill(); rng_words = rng_prefetch_issue(); }
     PROF(1);

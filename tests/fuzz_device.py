@@ -409,9 +409,9 @@ def mutators(k, w, log, verbose=False):
                     outs.append(r)
                     if verbose and e is hip:
                         log(f"   t={t} op {op} agent {a.name} (queue {[x.id for x in a.tasks]}, state {a.state}) task {None if task is None else (task.id, task.type)} vec {vec.tolist()} val {val} -> {r}")
-                assert outs[0] == outs[1], f"{tag} t={t} op {op}: returned {outs[0]} vs {outs[1]}"
-                if hip._b.get("ERROR").any():
+                if hip._b.get("ERROR").any():  # (e.g. UAV.allocate beyond the tile's queue depth returns False AND raises the capacity flag)
                     return "overflow"
+                assert outs[0] == outs[1], f"{tag} t={t} op {op}: returned {outs[0]} vs {outs[1]}"
                 compare(Snapshot(hip._b), 0, ref._b.o, f"{tag} t={t} after op {op}", check_obs=False)
             acts = []
             for e in envs:

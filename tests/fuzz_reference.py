@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 BIG = 1_000_000  # keys from here on draw the LARGE family: fleets of up to 64 UAVs, up to 48 static tasks, up to 40 threats
+EDGE = 2_000_000  # ... and from here on the EDGE family: small-family draws with a few knobs at extreme values
 
 
 def wide_config(k: int) -> dict:
@@ -39,7 +40,7 @@ def wide_config(k: int) -> dict:
     pick = r.choice
     big = r.random() < 0.35
     hi = 4 if big else 2
-    large = k >= BIG
+    large = BIG <= k < EDGE
     if large:
         hi = pick([5, 6, 8, 12, 16])
     agents = {t: r.randint(0, hi) for t in ("F1", "F2", "R1", "R2")}
@@ -84,6 +85,18 @@ def wide_config(k: int) -> dict:
         del cfg["reward_weights"]
     interval = pick([1, 5, 12, 12, 20, 20, 33])
     seed = pick([0, 1, 2, 3, 4, 7, 123456789, 2 ** 32 + 5, 2 ** 63 - 1])
+    if k >= EDGE:  # the EDGE family: a handful of knobs pushed to values at the rim of what the options accept
+        for _ in range(r.randint(2, 5)):
+            key, values = pick([("max_time_steps", [1, 2, 3, 5, 11]), ("fail_rate", [0.9, 1.0]), ("arrival_rate", [0.9, 1.0]),
+                                ("simulation_frame_rate", [0.002, 0.05, 0.1]), ("sense_radius", [1.0, 5000.0]), ("threat_delay", [200, 3]),
+                                ("window_length", [1, 2, 300]), ("burst_size", [8, 20]), ("escort_requirement", [0.1, 9.9]),
+                                ("escort_radius", [1.0, 2000.0]), ("escort_intercept_radius", [1.0, 2000.0]), ("mutual_support_radius", [0.5, 3000.0]),
+                                ("miss_penalty", [1000.0]), ("on_time_bonus", [1000.0]), ("reassign_penalty", [50.0]), ("dynamic_idle_penalty", [10.0]),
+                                ("commit_horizon", [1, 500]), ("agents", [{"F1": 1, "R1": 1}, {"F2": 1, "R2": 1}, {"R2": 2, "F1": 1}, {"F1": 8, "R1": 8}]),
+                                ("tasks", [{"Att": 0, "Rec": 1, "Hold": 0}, {"Att": 1, "Rec": 1, "Hold": 3}, {"Att": 12, "Rec": 1, "Hold": 0}]),
+                                ("threats_list", [[], [("T1", 1)], [("T2", 16)], [("T1", 8), ("T2", 8)]])])
+            cfg[key] = pick(values)
+        interval = pick([1, 2, 3, 50, 1000])
     return {"cfg": cfg, "interval": interval, "seed": seed}
 
 
