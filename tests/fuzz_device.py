@@ -622,6 +622,9 @@ if __name__ == "__main__":
                 tot["resume_" + resume(k, w, log)] += 1
                 tot["ilrings_" + ilrings(k, w, log)] += 1
         except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
+            if "overflowed a tile" in str(exc):  # (a capacity flag met by a call that refuses flagged batches, e.g. the facade's metrics)
+                tot["capacity_exceptions"] = tot.get("capacity_exceptions", 0) + 1
+                continue
             tot["errors"] += 1
             log(f"k={k} ERROR {type(exc).__name__}: {str(exc)[:300]}")
         if (k - first) % 10 == 9:
