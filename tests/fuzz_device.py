@@ -20,6 +20,9 @@ and are compared with the oracle:
             facade on the oracle backend: every field after every call and every step;
   ilrings   the trainers' data rings (muavta_rollout_record through il.il_record: per-step token tensors, edge_valid, the expert's plan
             as a mask, the gate bit, the S_WPS series) against the oracle stepping the same seeds under the trainers' gate;
+  inflight  two handles whose launches are queued alternately WITHOUT a synchronisation in between, several seed sets each (the seeding
+            of launch i + 1 runs under launch i through the two seeding slots, batches of the two handles overlap on the device): the
+            metrics of every handle's last batch;
   resume    checkpoint / resume and the sub-batch entry points: a fused rollout up to a random step, muavta_get_state + muavta_get_rng,
             a FRESH handle restored from them (muavta_set_state + muavta_set_rng), the rest of the episode there as sub-batch launches
             (muavta_set_parts + muavta_rollout_part): metrics and final state of the uninterrupted oracle episode;
@@ -489,6 +492,42 @@ def ilrings(k, w, log):
     return "ok"
 
 
+def inflight(k, w, log):
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+    tile = tiles_for(cfg)[(k // 19) % len(tiles_for(cfg))]
+    p = params(cfg, tile)
+    n, steps, rounds = 8, p.max_time_steps, 4
+    mode, name = MODES[(k // 2) % 4]
+    base = min(seed, 2 ** 62)
+    envs = [BatchedMultiUAVEnv(p, n) for _ in range(2)]
+    tag = f"k={k} inflight tile {tile} mode {name}"
+    try:
+        last = [None, None]
+        for e in envs:
+            e.set_allocator(name)
+        for r in range(rounds):
+            for j, e in enumerate(envs):
+                sd = np.arange(base + 100 * (2 * r + j), base + 100 * (2 * r + j) + n, dtype=np.uint64)
+                e.rollout(sd, steps, interval, True, bool((k + r) & 1))  # queued: no sync between launches or handles
+                last[j] = sd
+        for j, e in enumerate(envs):
+            e.sync()
+            got, err = e.rollout_metrics(), e.get("ERROR")
+            o = orc.OracleEnv(p)
+            for i in range(n):
+                if err[i]:
+                    continue
+                o.rollout_mode(int(last[j][i]), steps, interval, 1, mode)
+                assert np.array_equal(got[i], o.metrics()), f"{tag} handle {j} seed {int(last[j][i])}: metric columns {np.nonzero(got[i] != o.metrics())[0].tolist()}"
+    except AssertionError as exc:
+        log(f"INFLIGHT MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        for e in envs:
+            e.close()
+    return "ok"
+
+
 def resume(k, w, log):
     cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
     tile = tiles_for(cfg)[(k // 3) % len(tiles_for(cfg))]
@@ -606,7 +645,7 @@ if __name__ == "__main__":
 
     t0 = time.time()
     tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "scored_ok": 0, "scored_bad": 0,
-           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "resume_overflow": 0, "ilrings_ok": 0, "ilrings_bad": 0, "errors": 0}
+           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "resume_overflow": 0, "ilrings_ok": 0, "ilrings_bad": 0, "inflight_ok": 0, "inflight_bad": 0, "errors": 0}
     for k in range(first, first + n_cfg):
         w = wide_config(k)
         try:
@@ -621,6 +660,7 @@ if __name__ == "__main__":
                 tot["mutators_" + mutators(k, w, log)] += 1
                 tot["resume_" + resume(k, w, log)] += 1
                 tot["ilrings_" + ilrings(k, w, log)] += 1
+                tot["inflight_" + inflight(k, w, log)] += 1
         except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
             if "overflowed a tile" in str(exc):  # (a capacity flag met by a call that refuses flagged batches, e.g. the facade's metrics)
                 tot["capacity_exceptions"] = tot.get("capacity_exceptions", 0) + 1
