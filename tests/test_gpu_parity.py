@@ -1125,7 +1125,8 @@ def test_wide_fuzz_regressions_stepwise_vs_oracle_and_reference_metrics(path):
 
 
 @pytest.mark.parametrize("leg,k", [("mutators", 12794), ("mutators", 12782), ("mutators", 14016), ("mutators", 14068), ("mutators", 14173),
-                                   ("scored", 7178), ("stepwise", 992), ("stepwise", 40), ("rl", 12041), ("lists", 12042), ("rings", 12043)])
+                                   ("scored", 7178), ("mutators", 1001642), ("stepwise", 992), ("stepwise", 40), ("rl", 12041), ("lists", 12042), ("rings", 12043),
+                                   ("resume", 17001), ("ilrings", 18801), ("inflight", 21001)])
 def test_wide_fuzz_legs_on_the_configurations_that_found_bugs(leg, k):
     """One episode of a leg of tests/fuzz_device.py on the configurations that exposed device bugs (the allocator's list after an
     out-of-step _retire_escort / _create_escort_for, the recon-as-escort retire verdicts, rows beyond max_tasks, the expired escort
