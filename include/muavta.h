@@ -362,6 +362,42 @@ typedef struct MuavtaRlStep {
 } MuavtaRlStep;
 int muavta_rl_step_device(MuavtaEnv* env, const MuavtaRlStep* step);
 
+/* Run to the next replan gate.  The reference's trainer and evaluation loops consult the planner only when their gate fires and step
+ * with EMPTY actions otherwise (experiments/train_pair_cost.py:34-43,86-89,139-145; wps_eval.py:64-74,248-254,273):
+ *     actions = {}
+ *     if _should_replan(env, events): result, tok, ... = policy.plan(env, hung, events, force=True); actions = _apply_assign(env, result)
+ *     obs, reward, done, trunc, info = env.step(actions)
+ * muavta_rl_run_device is that loop per env inside ONE launch: the FIRST step is muavta_rl_step_device's (`first`: the plan with the caller's
+ * scores under `first.plan.gate`, S_WPS before / after, next tokens, done — the transition run_rl_episode pushes, :146-152), then the env
+ * keeps stepping with empty actions until ITS OWN gate fires again (the same gate, evaluated on the state after each step: clock +
+ * the events the step drained), its episode ends, or max_steps steps have been taken in this launch (0: no bound).  Where it stops it
+ * writes the tokens the policy sees next (park_*: muavta_tokens_device's outputs for that state; all seven or none) — so the caller's
+ * network runs once per launch on the park tokens and its scores are consumed only by the envs that stopped AT a gate:
+ *     n_stepped i32 [N]  env steps this launch took for the env (0: its episode had ended before)
+ *     park      u8  [N]  bit 0 terminated, bit 1 truncated, bit 2 = stopped at a gate (the next launch plans for it; clear when the
+ *                         episode ended or max_steps cut the quiet run short — the next launch then just continues it, its scores unread)
+ *     reward_sum f64 [N] the rewards env.step returned for this launch's steps, added in step order
+ * Outputs of `first` for an env that did NOT plan (replanned 0: it was not at a gate, or its episode had ended): selected 0, s_wps / done
+ * of its first step, next-token rows untouched.  The launch of a whole batch ends when every env has stopped; envs advance by different
+ * numbers of steps (each has its own clock), which is what lets the policy be called once per GATE instead of once per step.
+ * All pointers are DEVICE pointers; asynchronous on the handle's stream (first.part > 0: on that sub-batch's stream, for its rows). */
+typedef struct MuavtaRlRun {
+  MuavtaRlStep first;
+  float* park_task_feats; uint8_t* park_task_mask; int32_t* park_task_ids; float* park_agent_feats; uint8_t* park_agent_mask; int32_t* park_agent_ids;
+  float* park_edge_valid; int32_t* park_n_urgent;
+  int32_t* n_stepped; uint8_t* park; double* reward_sum;
+  int32_t max_steps, reserved;
+} MuavtaRlRun;
+int muavta_rl_run_device(MuavtaEnv* env, const MuavtaRlRun* run);
+/* The same run-ahead for a HOST-side planner (the loop of experiments/wps_eval.py:112-133,248-254,273 with any allocator of the
+ * reference behind the facade): env.step(actions) — act_agent / act_index as in muavta_step, or both NULL: the plan muavta_allocate staged —
+ * followed by env.step({}) until the env's gate (MUAVTA_GATE_*, replan_interval) fires, its episode ends or max_steps steps were taken
+ * (0: no bound).  write_obs != 0 refreshes the handle's observation buffers ONCE, for the state each env stopped in (muavta_observe /
+ * muavta_step_result then describe that state's last step).  n_stepped / park / reward_sum as above, HOST buffers (any may be NULL;
+ * the call synchronises when one is given). */
+int muavta_step_run(MuavtaEnv* env, const int32_t* act_agent, const int32_t* act_index, int32_t gate, int32_t replan_interval, int32_t max_steps,
+                    int32_t write_obs, int32_t* n_stepped, uint8_t* park, double* reward_sum);
+
 /* The measured path: reset(seeds) followed by n_steps x (allocate -> step) fused in ONE kernel
  * launch, state resident in LDS (run_wps_episode / run_escort_episode with Local-/Coalition-
  * Hungarian, experiments/wps_eval.py:76-291, experiments/escort_eval.py:86-226).  seeds == NULL

@@ -214,6 +214,63 @@ class BatchedMultiUAVEnv:
                 put(rs, name, next_tok[name], shape, np.dtype(dtype).itemsize)
         self._ck(self.L.muavta_rl_step_device(self.h, C.byref(rs)))
 
+    def rl_run(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16, *, edge_scores=None, task_pri=None, reserved=None,
+               gate: str = "trainer", replan_interval: int = 20, use_visibility: bool = True, edge_valid_only: Optional[bool] = None,
+               full_task_list: bool = False, commit: bool = False, selected=None, replanned=None, next_tok: Optional[dict] = None,
+               s_wps=None, done=None, park_tok: Optional[dict] = None, n_stepped=None, park=None, reward_sum=None, max_steps: int = 0,
+               write_obs: bool = False, part: Optional[int] = None):
+        """muavta_rl_run_device: `rl_step` for the first step, then every env keeps stepping with empty actions until ITS gate fires
+        again, its episode ends or `max_steps` steps were taken (0: no bound) — the reference's loops consult the policy only at a gate
+        (experiments/train_pair_cost.py:139-145).  Extra outputs (CUDA tensors, any may be None): `park_tok` (dict like `next_tok`: the tokens
+        of the state each env stopped in — what the policy sees next), `n_stepped` i32 [N], `park` u8 [N] (bit 0 terminated, bit 1
+        truncated, bit 2 stopped at a gate), `reward_sum` f64 [N].  `next_tok` rows are written for envs that planned (replanned 1) only."""
+        k = self.TOKEN_KINDS[kind][0]
+        mt = int(max_tasks if max_tasks is not None else (48 if kind == "escort" else 32))
+        ma, N = int(max_agents), self.n_envs
+        if edge_valid_only is None:
+            edge_valid_only = kind != "escort"
+        flags = (self.SC_EDGE_VALID_ONLY if edge_valid_only else 0) | (self.SC_FULL_TASK_LIST if full_task_list else 0) | (self.SC_COMMIT if commit else 0)
+        rr = native.MuavtaRlRun()
+        rs = rr.first
+        rs.plan = native.MuavtaScored(k, mt, ma, self.GATES[gate], flags, int(replan_interval), int(bool(use_visibility)), 0)
+        rs.write_obs = int(bool(write_obs))
+        rs.part = 0 if part is None else int(part) + 1
+        rr.max_steps = int(max_steps)
+
+        def put(obj, name, t, shape, size):
+            if t is None:
+                return
+            if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != size or t.device.index != self.device_index:
+                raise ValueError(f"rl_run: {name} must be a contiguous tensor of shape {shape} with {size}-byte elements on cuda:{self.device_index}")
+            setattr(obj, name, t.data_ptr())
+
+        put(rs.plan, "edge_scores", edge_scores, (N, ma, mt), 4); put(rs.plan, "task_pri", task_pri, (N, mt), 8); put(rs.plan, "reserved", reserved, (N,), 8)
+        put(rs.plan, "selected", selected, (N, ma, mt), 4); put(rs.plan, "replanned", replanned, (N,), 4)
+        put(rs, "s_wps", s_wps, (2, N), 8); put(rs, "done", done, (N,), 1)
+        put(rr, "n_stepped", n_stepped, (N,), 4); put(rr, "park", park, (N,), 1); put(rr, "reward_sum", reward_sum, (N,), 8)
+        for prefix, obj, toks in (("", rs, next_tok), ("park_", rr, park_tok)):
+            if toks is not None:
+                for name, (shape, dtype) in self.token_shapes(kind, mt, ma).items():
+                    put(obj, prefix + name, toks[name], shape, np.dtype(dtype).itemsize)
+        self._ck(self.L.muavta_rl_run_device(self.h, C.byref(rr)))
+
+    def step_run(self, act_agent: Optional[np.ndarray] = None, act_index: Optional[np.ndarray] = None, gate: str = "trainer", replan_interval: int = 20,
+                 max_steps: int = 0, write_obs: bool = True, fetch: bool = True):
+        """muavta_step_run: `step(act_agent, act_index)` (both None: the plan `allocate(fetch=False)` staged) followed by empty-action
+        steps until each env's gate fires, its episode ends or `max_steps` steps were taken — the run-ahead for a host-side planner
+        (experiments/wps_eval.py:248-254,273).  Returns (n_stepped i32 [N], park u8 [N], reward_sum f64 [N]) unless fetch=False."""
+        aa = ai = None
+        if act_agent is not None:
+            aa = np.ascontiguousarray(act_agent, dtype=np.int32)
+            ai = np.ascontiguousarray(act_index, dtype=np.int32)
+            if aa.shape != (self.n_envs, self.A_tile) or ai.shape != aa.shape:
+                raise ValueError(f"actions must have shape ({self.n_envs}, {self.A_tile})")
+        n = np.empty(self.n_envs, dtype=np.int32) if fetch else None
+        pk = np.empty(self.n_envs, dtype=np.uint8) if fetch else None
+        rs = np.empty(self.n_envs, dtype=np.float64) if fetch else None
+        self._ck(self.L.muavta_step_run(self.h, _vp(aa), _vp(ai), self.GATES[gate], int(replan_interval), int(max_steps), int(bool(write_obs)), _vp(n), _vp(pk), _vp(rs)))
+        return (n, pk, rs) if fetch else None
+
     TOKEN_KINDS = {"pair": (0, 13, 12), "pair_raw": (1, 9, 11), "escort": (2, 22, 16)}
 
     def tokens(self, kind: str = "pair", max_tasks: Optional[int] = None, max_agents: int = 16, out=None):

@@ -3278,6 +3278,18 @@ struct Sim {
   //   (sc.kind, sc.MT, sc.MA) — PairCostHybrid.plan, AttentionRAH.plan, AttentionCommit / AttentionEscort._plan_from_scores
   //   (HungarianAllocator.py:79-92,123-124,170-179).  sc_list: T bytes of LDS behind the scratch tile (the task list handed to
   //   allocate_tasks, as positions in last_tasks_info, in the token builder's order).  Compiled into k_allocate_scored only.
+  // The replan gate of the callers' loops as a function of the env state (uniform): MUAVTA_GATE_* of include/muavta.h.  `events` are the
+  // ones the last step drained (infos['events'], S.dev_*), the clock is the step about to be taken — what the reference's loops look at
+  // between two env.step calls.  allocate<true> evaluates it at its entry; the run-to-the-next-gate kernels (k_run) after every step.
+  DEV bool gate_fires(int gate, int interval) const {
+    interval = interval < 1 ? 1 : interval;
+    bool trig = false;
+    for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;  // Reset_Allocation, New_Threat, Agent_Fail
+    if (gate == MUAVTA_GATE_TRAINER) return tnow == 0 || tnow % interval == 0 || __ballot(trig) != 0ull;   // train_pair_cost.py:33-43
+    if (gate == MUAVTA_GATE_ESCORT) return tnow == 0 || tnow % interval == 0 || S.n_dev > 0;               // escort_eval.py:52-58
+    if (gate == MUAVTA_GATE_ALLOCATOR) return (tnow - S.last_plan_step >= interval) || (S.n_dev > 0);      // should_replan (:27-41)
+    return true;
+  }
   template <bool SC = false>
   DEV void allocate(int interval, int use_visibility, int mode = 0, const ScoredDev* scp = nullptr, int env = 0, uint8_t* sc_list = nullptr) {
     PROF(10);
@@ -3288,12 +3300,7 @@ struct Sim {
     int n_sc = 0;  // SC: length of sc_list
     if constexpr (SC) {
       const ScoredDev& sc = *scp;
-      bool trig = false;
-      for (int k = lane; k < S.n_dev; k += WG) trig |= S.dev_tag[k] <= MUAVTA_EV_AGENT_FAIL;
-      if (sc.gate == MUAVTA_GATE_TRAINER) go = tnow == 0 || tnow % interval == 0 || __ballot(trig) != 0ull;   // train_pair_cost.py:33-43
-      else if (sc.gate == MUAVTA_GATE_ESCORT) go = tnow == 0 || tnow % interval == 0 || S.n_dev > 0;           // escort_eval.py:52-58
-      else if (sc.gate == MUAVTA_GATE_ALLOCATOR) go = (tnow - S.last_plan_step >= interval) || (S.n_dev > 0);  // should_replan (:27-41)
-      else go = true;
+      go = gate_fires(sc.gate, interval);
       if ((go || sc.gate == MUAVTA_GATE_ALLOCATOR) && lane == 0) S.n_calls++;
       if (sc.replanned && lane == 0) sc.replanned[env] = go ? 1 : 0;
     } else

@@ -388,6 +388,115 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rl_step(const DevCtx
   copy16(blob, L.S, sizeof(EnvState<TL>));
 }
 
+// muavta_rl_run_device / muavta_step_run: run to the next replan gate.  The reference's trainer and evaluation loops consult the planner
+// only when their gate fires and step with EMPTY actions otherwise (experiments/train_pair_cost.py:86-89,139-145; wps_eval.py:248-254,273):
+//     if _should_replan(env, events): result = policy.plan(...); actions = _apply_assign(env, result)      <- the launch's FIRST step
+//     obs, reward, done, trunc, info = env.step(actions)                                                    <- quiet steps: actions = {}
+// One launch per env takes the first step with its plan — src 0: allocate<true> with the caller's scores under the caller's gate (one
+// iteration of run_rl_episode: S_WPS before / after, next_tok, done); src 1: the actions muavta_allocate staged; src 2: the caller's
+// action rows — and then keeps stepping quietly until the env's own gate fires again, its episode ends, or max_steps steps are taken
+// (0: no bound).  Where it stopped: park tokens (what the policy sees next), park flags, the number of steps taken, the summed reward.
+struct RunOut {
+  double* s_wps;        // [2][N] S_WPS before / after the first step (src 0)
+  uint8_t* done;        // [N] done flags after the first step (src 0: ep_done of the pushed transition)
+  int32_t* n_stepped;   // [N] env steps this launch took
+  uint8_t* park;        // [N] bit 0 terminated, bit 1 truncated, bit 2 stopped at a gate (the next launch plans)
+  double* reward_sum;   // [N] rewards of this launch's steps, added in step order
+};
+enum { RUN_SRC_SCORED = 0, RUN_SRC_STAGED = 1, RUN_SRC_ROWS = 2 };
+// The launch's tensors (~45 pointers) sit in device memory, one slot per stream of the handle, and are read through the scalar cache
+// where they are used — like the ring pointers of the recording rollout: as by-value kernel arguments they stayed live across the whole
+// step loop (first build: 259 SGPR spill stores and 60 spilled VGPRs on the 16-agent tile).
+template <class TL> struct RunArgs { ScoredDev sc; typename Sim<TL>::TokPtrs K, KP; RunOut R; };
+struct RunBlob { uint32_t w[128]; };  // 512 B: a RunArgs<TL> by value
+__global__ void k_store_run(RunBlob b, uint32_t* dst) { dst[threadIdx.x] = b.w[threadIdx.x]; }
+template <class TL>
+__global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_run(const DevCtx* __restrict__ ctxp, const RunArgs<TL>* __restrict__ argp, int src, int gate, int interval, int use_vis,
+                                                                int write_obs, int max_steps, const int32_t* act_agent, const int32_t* act_index, int act_cap, int n_envs,
+                                                                int env_base) {
+  const DevCtx& ctx0 = ctx_ref(ctxp);
+  const int env = env_base + blockIdx.x;
+  __shared__ __align__(16) unsigned char lds_own[Lds<TL>::bytes() + SCORED_EXTRA_LDS];
+  Lds<TL> L(lds_own + lds_zero());
+  EnvState<TL>* blob = blob_of<TL>(ctx0, env);
+  copy16(L.S, blob, sizeof(EnvState<TL>));
+  lds_sync();
+  const uint32_t arg_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)argp), arg_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)argp >> 32));
+  int n = 0;
+  bool at_gate = false;
+  double rsum = 0.0;
+  const bool over0 = L.S->terminated || L.S->truncated;  // (uniform)  the reference's loops end with the episode: such an env is left alone
+  for (;;) {  // ONE call site each for the planner, the step and the token builder; every iteration builds its own Sim (lane-derived values
+              // and launch constants must not be hoisted across the step: see k_rollout)
+    uint32_t lo = arg_lo, hi = arg_hi;
+    asm volatile("" : "+s"(lo), "+s"(hi));
+    const RunArgs<TL>& G = *(const RunArgs<TL>*)(const AS4 RunArgs<TL>*)(((uint64_t)hi << 32) | (uint64_t)lo);
+    const DevCtx& ctx = ctx_ref(ctxp);
+    Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, tape_of(ctx, env));
+    const bool first = n == 0;
+    if (!over0) {
+      if (first) {
+        if (src == RUN_SRC_SCORED) {
+          ScoredDev sc = G.sc;
+          sc.scores = as_global(sc.scores); sc.pri = as_global(sc.pri); sc.reserved = as_global(sc.reserved);
+          sc.selected = as_global(sc.selected); sc.replanned = as_global(sc.replanned);
+          if (threadIdx.x == 0 && G.R.s_wps) as_global(G.R.s_wps)[env] = sim.s_wps();  // before the step
+          sim.template allocate<true>(interval, use_vis, 4, &sc, env, lds_own + Lds<TL>::bytes());
+          lds_sync();
+        } else if (src == RUN_SRC_ROWS) {
+          sim.more_agent = act_agent + (size_t)env * act_cap; sim.more_index = act_index + (size_t)env * act_cap;
+          sim.more_cap = act_cap; sim.more_pos = 0;
+          sim.stage_more();
+          if (act_cap <= TL::A) sim.more_agent = nullptr;  // (uniform: nothing beyond the staged items)
+          lds_sync();
+        }
+      } else {
+        if (threadIdx.x == 0) L.S->n_act = 0;  // env.step({})
+        lds_sync();
+      }
+      sim.step(true);
+      n++;
+      lds_sync();
+      rsum += L.S->last_reward;
+    } else if (src == RUN_SRC_SCORED) {
+      const ScoredDev& sc = G.sc;
+      if (sc.replanned && threadIdx.x == 0) as_global(sc.replanned)[env] = 0;
+      if (sc.selected) for (int i = threadIdx.x; i < sc.MA * sc.MT; i += WG) as_global(sc.selected)[(size_t)env * sc.MA * sc.MT + i] = 0.f;
+      if (threadIdx.x == 0 && G.R.s_wps) as_global(G.R.s_wps)[env] = sim.s_wps();
+    }
+    const bool over = L.S->terminated || L.S->truncated;
+    if (!over) at_gate = sim.gate_fires(gate, interval);
+    const bool stop = over || at_gate || (max_steps > 0 && n >= max_steps);
+    const bool planned = first && src == RUN_SRC_SCORED && !over0 && L.S->gate_step == sim.tnow;  // (uniform) the gate fired at the step just taken: an RL sample
+    if (first && src == RUN_SRC_SCORED && threadIdx.x == 0) {
+      if (G.R.s_wps) as_global(G.R.s_wps)[(size_t)n_envs + env] = sim.s_wps();
+      if (G.R.done) as_global(G.R.done)[env] = (uint8_t)((L.S->terminated ? 1 : 0) | (L.S->truncated ? 2 : 0));
+    }
+    // next_tok of the planned step (train_pair_cost.py:150-151) and / or the tokens of the state the env stops in
+#pragma nounroll
+    for (int w = 0; w < 2; w++) {
+      const typename Sim<TL>::TokPtrs& Kc = w == 0 ? G.K : G.KP;
+      const bool want = Kc.task_feats != nullptr && (w == 0 ? planned : stop);
+      if (!want) continue;
+      const typename Sim<TL>::TokPtrs cur = global_tok_ptrs<TL>(Kc);
+      cold_sync();
+      sim.tokens(cur, env);
+      lds_sync();
+    }
+    if (stop) {
+      if (write_obs && !over0) { obs_for_env(sim, ctx.P, obs_ptrs(ctx), env); lds_sync(); }
+      if (threadIdx.x == 0) {
+        if (G.R.n_stepped) as_global(G.R.n_stepped)[env] = n;
+        if (G.R.park) as_global(G.R.park)[env] = (uint8_t)((L.S->terminated ? 1 : 0) | (L.S->truncated ? 2 : 0) | (at_gate ? 4 : 0));
+        if (G.R.reward_sum) as_global(G.R.reward_sum)[env] = rsum;
+      }
+      break;
+    }
+  }
+  lds_sync();
+  copy16(blob, L.S, sizeof(EnvState<TL>));
+}
+
 // The body of the fused rollout, OUT OF LINE on purpose.  Inlined into the 150-step loop of k_rollout the compiler hoists
 // loop invariants across the whole body and the kernel needs 255 VGPRs (+188 B/lane of scratch: two waves per SIMD); as a
 // function of its own the body fits the 128 VGPRs of FOUR waves per SIMD — with 10 KiB of LDS per env that is 16 resident
@@ -851,6 +960,9 @@ struct MuavtaEnv {
   uint64_t* d_seeds[2] = {nullptr, nullptr};
   int32_t *d_act_agent = nullptr, *d_act_index = nullptr, *d_call_out = nullptr;
   int32_t *d_list_agent = nullptr, *d_list_index = nullptr;  // muavta_step_lists rows [N][list_cap] (grown on demand)
+  void* d_run = nullptr;  // muavta_step_run's outputs: [N] f64 reward sums | [N] i32 steps taken | [N] u8 park flags
+  enum { RUN_SLOT = 512 };
+  void* d_runargs = nullptr;  // [1 + MAX_PARTS][RUN_SLOT]: the RunArgs of the k_run launch in flight on the main stream / on each part stream
   int list_cap = 0;
   ncclComm_t comm = nullptr;  // muavta_comm_init
   int comm_rank = 0, comm_ranks = 0;
@@ -919,6 +1031,33 @@ static void launch_rl_step(MuavtaEnv* e, const ScoredDev& sc, const MuavtaRlStep
                               nullptr, nullptr, rs->plan.kind, rs->plan.max_tasks, rs->plan.max_agents};
   hipLaunchKernelGGL(k_rl_step<TL>, dim3(count), dim3(WG), 0, stream, (const DevCtx*)e->d_ctx, sc, K, rs->plan.replan_interval, rs->plan.use_visibility,
                      rs->write_obs, rs->s_wps, rs->done, e->n_envs, first);
+}
+
+template <class TL>
+static void launch_run(MuavtaEnv* e, int src, const ScoredDev& sc, const MuavtaRlStep* rs, const MuavtaRlRun* rr, const RunOut& R, int gate, int interval, int use_vis,
+                       int write_obs, int max_steps, const int32_t* da, const int32_t* di, int cap, hipStream_t stream, int slot, int first, int count) {
+  RunArgs<TL> G;
+  memset(&G, 0, sizeof(G));
+  G.sc = sc; G.R = R;
+  if (rs) {
+    typename Sim<TL>::TokPtrs k{rs->task_feats, rs->task_mask, rs->task_ids, rs->agent_feats, rs->agent_mask, rs->agent_ids, rs->edge_valid, rs->n_urgent,
+                                nullptr, nullptr, rs->plan.kind, rs->plan.max_tasks, rs->plan.max_agents};
+    G.K = k;
+  }
+  if (rr && rs) {
+    typename Sim<TL>::TokPtrs k{rr->park_task_feats, rr->park_task_mask, rr->park_task_ids, rr->park_agent_feats, rr->park_agent_mask, rr->park_agent_ids, rr->park_edge_valid,
+                                rr->park_n_urgent, nullptr, nullptr, rs->plan.kind, rs->plan.max_tasks, rs->plan.max_agents};
+    G.KP = k;
+  }
+  static_assert(sizeof(RunArgs<TL>) <= MuavtaEnv::RUN_SLOT, "run-argument slot too small");
+  // (filled by a kernel that takes the struct BY VALUE, stream-ordered behind the previous launch that read the slot: see launch_rollout)
+  RunBlob blob;
+  memset(&blob, 0, sizeof(blob));
+  memcpy(&blob, &G, sizeof(G));
+  uint32_t* dst = (uint32_t*)((char*)e->d_runargs + (size_t)slot * MuavtaEnv::RUN_SLOT);
+  hipLaunchKernelGGL(k_store_run, dim3(1), dim3(128), 0, stream, blob, dst);
+  hipLaunchKernelGGL(k_run<TL>, dim3(count), dim3(WG), 0, stream, (const DevCtx*)e->d_ctx, (const RunArgs<TL>*)dst, src, gate, interval, use_vis, write_obs, max_steps, da, di, cap,
+                     e->n_envs, first);
 }
 
 int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
@@ -1396,7 +1535,7 @@ int muavta_destroy(MuavtaEnv* e) {
     if (e->part_ev[p]) hipEventDestroy(e->part_ev[p]);
   }
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
-  hipFree(e->d_part_agent); hipFree(e->d_part_index);
+  hipFree(e->d_part_agent); hipFree(e->d_part_index); if (e->d_run) hipFree(e->d_run); if (e->d_runargs) hipFree(e->d_runargs);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->d_seedtmp) hipFree(e->d_seedtmp); hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); if (e->d_rec) hipFree(e->d_rec); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); if (e->d_list_agent) hipFree(e->d_list_agent); if (e->d_list_index) hipFree(e->d_list_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
@@ -1632,6 +1771,80 @@ int muavta_rl_step_device(MuavtaEnv* e, const MuavtaRlStep* rs) {
   DISPATCH(e, launch_rl_step<TL>(e, sc, rs, stream, first, count));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
+  return MUAVTA_OK;
+}
+// Run to the next replan gate (k_run; include/muavta.h): the policy in the loop, consulted only where an env's gate fired
+int muavta_rl_run_device(MuavtaEnv* e, const MuavtaRlRun* rr) {
+  if (!e || !rr) return MUAVTA_E_ARG;
+  const MuavtaRlStep* rs = &rr->first;
+  const MuavtaScored* sp = &rs->plan;
+  if (int rc = scored_check(e, sp)) return rc;
+  const bool tok = rs->task_feats != nullptr, ptok = rr->park_task_feats != nullptr;
+  if ((tok && (!rs->task_mask || !rs->task_ids || !rs->agent_feats || !rs->agent_mask || !rs->agent_ids || !rs->edge_valid)) ||
+      (ptok && (!rr->park_task_mask || !rr->park_task_ids || !rr->park_agent_feats || !rr->park_agent_mask || !rr->park_agent_ids || !rr->park_edge_valid))) {
+    e->err = "muavta_rl_run_device: the token outputs (next / park) come all together or not at all (n_urgent alone is optional)"; return MUAVTA_E_ARG;
+  }
+  if (rr->max_steps < 0) { e->err = "muavta_rl_run_device: max_steps >= 0 (0: until the gate fires or the episode ends)"; return MUAVTA_E_ARG; }
+  DeviceScope scope_(e->device);
+  if (e->d_rel) { e->err = "muavta_rl_run_device: the release log must be off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
+  ScoredDev sc{sp->edge_scores, sp->task_pri, (const unsigned long long*)sp->reserved, sp->selected, sp->replanned, sp->kind, sp->max_tasks,
+               sp->max_agents, sp->gate, sp->flags};
+  hipStream_t stream = e->stream;
+  int first = 0, count = e->n_envs;
+  if (rs->part > 0) {
+    const int part = rs->part - 1;
+    { int rc = check_part(e, part, "muavta_rl_run_device"); if (rc) return rc; }
+    { int rc = fork_part(e, part); if (rc) return rc; }
+    part_range(e, part, &first, &count);
+    stream = e->part_stream[part];
+  } else {
+    MAIN_OP(e);
+  }
+  RunOut R{rs->s_wps, rs->done, rr->n_stepped, rr->park, rr->reward_sum};
+  if (!e->d_runargs) HIPCHK(e, hipMalloc(&e->d_runargs, (size_t)(1 + MuavtaEnv::MAX_PARTS) * MuavtaEnv::RUN_SLOT));
+  DISPATCH(e, launch_run<TL>(e, RUN_SRC_SCORED, sc, rs, rr, R, sp->gate, sp->replan_interval, sp->use_visibility, rs->write_obs, rr->max_steps, nullptr, nullptr, 0, stream,
+                             rs->part > 0 ? rs->part : 0, first, count));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
+  return MUAVTA_OK;
+}
+int muavta_step_run(MuavtaEnv* e, const int32_t* act_agent, const int32_t* act_index, int32_t gate, int32_t interval, int32_t max_steps, int32_t write_obs,
+                    int32_t* n_stepped, uint8_t* park, double* reward_sum) {
+  if (!e) return MUAVTA_E_ARG;
+  if (!e->did_reset) { e->err = "muavta_step_run before reset"; return MUAVTA_E_STATE; }
+  if ((act_agent == nullptr) != (act_index == nullptr) || gate < MUAVTA_GATE_FORCE || gate > MUAVTA_GATE_ALLOCATOR || max_steps < 0) {
+    e->err = "muavta_step_run: action rows come as a pair (or both NULL: the staged plan), gate 0..3, max_steps >= 0"; return MUAVTA_E_ARG;
+  }
+  if (act_agent)
+    for (int n = 0; n < e->n_envs; n++)
+      for (int k = 0; k < e->A; k++) {
+        const int a = act_agent[(size_t)n * e->A + k];
+        if (a < 0) break;
+        if (a >= e->P.n_agents) { e->err = "muavta_step_run: env " + std::to_string(n) + " names agent id " + std::to_string(a); return MUAVTA_E_ARG; }
+      }
+  DeviceScope scope_(e->device);
+  if (e->d_rel) { e->err = "muavta_step_run: the release log must be off (muavta_set_release_log)"; return MUAVTA_E_STATE; }
+  MAIN_OP(e);
+  const size_t N = (size_t)e->n_envs;
+  if (!e->d_run) HIPCHK(e, hipMalloc(&e->d_run, N * 16));
+  double* d_rsum = (double*)e->d_run; int32_t* d_n = (int32_t*)(d_rsum + N); uint8_t* d_park = (uint8_t*)(d_n + N);
+  const int32_t *da = nullptr, *di = nullptr;
+  if (act_agent) {
+    const size_t bytes = N * e->A * sizeof(int32_t);
+    HIPCHK(e, hipMemcpyAsync(e->d_act_agent, act_agent, bytes, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_act_index, act_index, bytes, hipMemcpyHostToDevice, e->stream));
+    da = e->d_act_agent; di = e->d_act_index;
+  }
+  ScoredDev sc{};
+  RunOut R{nullptr, nullptr, d_n, d_park, d_rsum};
+  if (!e->d_runargs) HIPCHK(e, hipMalloc(&e->d_runargs, (size_t)(1 + MuavtaEnv::MAX_PARTS) * MuavtaEnv::RUN_SLOT));
+  DISPATCH(e, launch_run<TL>(e, act_agent ? RUN_SRC_ROWS : RUN_SRC_STAGED, sc, nullptr, nullptr, R, gate, interval, 0, write_obs, max_steps, da, di, e->A, e->stream, 0, 0, e->n_envs));
+  HIPCHK(e, hipGetLastError());
+  e->host_valid = false;
+  if (n_stepped) HIPCHK(e, hipMemcpyAsync(n_stepped, d_n, N * 4, hipMemcpyDeviceToHost, e->stream));
+  if (park) HIPCHK(e, hipMemcpyAsync(park, d_park, N, hipMemcpyDeviceToHost, e->stream));
+  if (reward_sum) HIPCHK(e, hipMemcpyAsync(reward_sum, d_rsum, N * 8, hipMemcpyDeviceToHost, e->stream));
+  if (n_stepped || park || reward_sum) HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
 }
 }  // extern "C" (the launcher below is a template)

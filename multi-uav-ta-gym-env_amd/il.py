@@ -76,7 +76,7 @@ def il_record(env: BatchedMultiUAVEnv, seeds, n_steps: int = 150, interval: int 
 
 
 def rl_stream(env: BatchedMultiUAVEnv, seeds, policy, n_steps: int = 150, interval: int = 20, kind: str = "pair", max_tasks: int = 32,
-              max_agents: int = 16, gate: str = "trainer", device=None, fused: bool = True, **plan_kw):
+              max_agents: int = 16, gate: str = "trainer", device=None, fused: bool = True, run_ahead: bool = False, max_steps: int = 0, **plan_kw):
     """run_rl_episode (experiments/train_pair_cost.py:132-156) for every env of the batch at once, the policy in the loop:
 
         for t, tr in rl_stream(env, seeds, policy): buffer.push(tr)          # policy.push(tok, scores, ..., step_r, next_tok, done)
@@ -90,9 +90,16 @@ def rl_stream(env: BatchedMultiUAVEnv, seeds, policy, n_steps: int = 150, interv
     ((S_WPS_now - S_WPS_prev) / 20), `next_tok`, `done` (u8: bit 0 terminated, bit 1 truncated).  The token dicts alternate
     between two buffer sets: `tok` of step t is `next_tok` of step t - 1 and is overwritten at step t + 1 — copy what must live
     longer.  `fused=False` runs the same step as four separate launches (tokens / allocate_scored / step / metrics): the
-    cross-check of the fused kernel.  Envs whose episode has ended idle (replanned 0, reward 0)."""
+    cross-check of the fused kernel.  Envs whose episode has ended idle (replanned 0, reward 0); `selected`, `replanned`, `done` and the
+    reward tensors are the SAME tensors at every yield, overwritten by the next step — clone what must live longer (like the token dicts).
+    `run_ahead=True`: the policy is consulted once per GATE instead of once per step (`rl_run_stream` below; `n_steps` then bounds the
+    number of launches)."""
     import torch
 
+    if run_ahead:
+        yield from rl_run_stream(env, seeds, policy, interval=interval, kind=kind, max_tasks=max_tasks, max_agents=max_agents, gate=gate, device=device,
+                                 max_steps=max_steps, max_launches=n_steps, **plan_kw)
+        return
     dev = torch.device("cuda", env.device_index if device is None else device)
     tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32, np.float64: torch.float64}
     shapes = env.token_shapes(kind, max_tasks, max_agents)
@@ -129,6 +136,56 @@ def rl_stream(env: BatchedMultiUAVEnv, seeds, policy, n_steps: int = 150, interv
             done.copy_(torch.from_numpy((term.astype(np.uint8) | (trunc.astype(np.uint8) << 1))))
         yield t, {"tok": tok, "scores": scores, "selected": selected, "replanned": replanned,
                   "step_reward": torch.div(s_wps[1] - s_wps[0], twenty), "next_tok": nxt, "done": done}
+
+
+def rl_run_stream(env: BatchedMultiUAVEnv, seeds, policy, interval: int = 20, kind: str = "pair", max_tasks: int = 32, max_agents: int = 16,
+                  gate: str = "trainer", device=None, max_steps: int = 0, max_launches: Optional[int] = None, **plan_kw):
+    """run_rl_episode with the policy consulted only where the reference consults it — when `_should_replan` fires
+    (experiments/train_pair_cost.py:139-145) — for every env of the batch at once (muavta_rl_run_device):
+
+        for k, tr in rl_run_stream(env, seeds, policy): buffer.push(rows of tr where tr["replanned"] == 1)
+
+    Every launch plans for the envs that are parked at a gate (scores = `policy(tok)` on the tokens of their parked state), takes that
+    step, records the transition run_rl_episode pushes (`tok`, `scores`, `selected`, `step_reward`, `next_tok`, `done`: rows with
+    `replanned` == 1; `next_tok` rows of the others are stale) and then steps each env with empty actions up to ITS next gate (at most
+    `max_steps` steps per launch when > 0: an env cut short is not at a gate, `replanned` 0 at the next launch, and simply continues).
+    Envs advance by different numbers of steps per launch (`n_stepped`); the stream ends when every episode has ended.  Also yielded:
+    `park` (u8: bit 0 terminated, bit 1 truncated, bit 2 at a gate) and `reward_sum` (env rewards over the launch's steps).  All tensors
+    are reused between yields (two alternating token buffer sets, as in `rl_stream`)."""
+    import torch
+
+    dev = torch.device("cuda", env.device_index if device is None else device)
+    tdt = {np.float32: torch.float32, np.uint8: torch.uint8, np.int32: torch.int32, np.float64: torch.float64}
+    shapes = env.token_shapes(kind, max_tasks, max_agents)
+    N = env.n_envs
+    mk = lambda: {name: torch.empty(shape, dtype=tdt[dtype], device=dev) for name, (shape, dtype) in shapes.items()}  # noqa: E731
+    bufs, nxt = [mk(), mk()], mk()
+    selected = torch.empty((N, max_agents, max_tasks), dtype=torch.float32, device=dev)
+    replanned = torch.empty((N,), dtype=torch.int32, device=dev)
+    s_wps = torch.empty((2, N), dtype=torch.float64, device=dev)
+    done = torch.empty((N,), dtype=torch.uint8, device=dev)
+    n_stepped = torch.empty((N,), dtype=torch.int32, device=dev)
+    park = torch.empty((N,), dtype=torch.uint8, device=dev)
+    reward_sum = torch.empty((N,), dtype=torch.float64, device=dev)
+    twenty = torch.full((N,), 20.0, dtype=torch.float64, device=dev)
+    env.reset(np.asarray(seeds, dtype=np.uint64))
+    env.tokens(kind, max_tasks, max_agents, out=bufs[0])   # tok of the first gate (t = 0)
+    k = 0
+    while max_launches is None or k < max_launches:
+        tok, prk = bufs[k & 1], bufs[(k + 1) & 1]
+        env.sync()
+        scores = policy(tok)
+        if scores.dtype != torch.float32 or not scores.is_contiguous():
+            scores = scores.to(torch.float32).contiguous()
+        env.wait_stream(torch.cuda.current_stream(dev).cuda_stream)
+        env.rl_run(kind, max_tasks, max_agents, edge_scores=scores, gate=gate, replan_interval=interval, selected=selected, replanned=replanned,
+                   next_tok=nxt, s_wps=s_wps, done=done, park_tok=prk, n_stepped=n_stepped, park=park, reward_sum=reward_sum, max_steps=max_steps, **plan_kw)
+        env.sync()
+        yield k, {"tok": tok, "scores": scores, "selected": selected, "replanned": replanned, "step_reward": torch.div(s_wps[1] - s_wps[0], twenty),
+                  "next_tok": nxt, "done": done, "n_stepped": n_stepped, "park": park, "reward_sum": reward_sum, "park_tok": prk}
+        k += 1
+        if bool(((park & 3) != 0).all()):
+            return
 
 
 def step_rewards(s_wps_prev: np.ndarray, s_wps_now: np.ndarray) -> np.ndarray:

@@ -34,6 +34,7 @@ EXPORTS = [
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
     "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_domain_log", "muavta_step_lists",
     "muavta_allocate_scored", "muavta_allocate_scored_device", "muavta_rl_step_device", "muavta_launch_gaps_ms",
+    "muavta_rl_run_device", "muavta_step_run",
 ]
 
 
@@ -87,6 +88,13 @@ class MuavtaRlStep(C.Structure):
     """include/muavta.h: MuavtaRlStep (muavta_rl_step_device)."""
     _fields_ = [("plan", MuavtaScored)] + [(n, C.c_void_p) for n in ("task_feats", "task_mask", "task_ids", "agent_feats", "agent_mask", "agent_ids",
                                                                       "edge_valid", "n_urgent", "s_wps", "done")] + [("write_obs", C.c_int32), ("part", C.c_int32)]
+
+
+class MuavtaRlRun(C.Structure):
+    """include/muavta.h: MuavtaRlRun (muavta_rl_run_device)."""
+    _fields_ = [("first", MuavtaRlStep)] + [(n, C.c_void_p) for n in ("park_task_feats", "park_task_mask", "park_task_ids", "park_agent_feats", "park_agent_mask",
+                                                                       "park_agent_ids", "park_edge_valid", "park_n_urgent", "n_stepped", "park", "reward_sum")] + [
+        ("max_steps", C.c_int32), ("reserved", C.c_int32)]
 
 
 _LIB = None
@@ -163,6 +171,8 @@ def lib() -> C.CDLL:
     L.muavta_allocate_scored.argtypes = [vp, C.POINTER(MuavtaScored), vp, vp]
     L.muavta_allocate_scored_device.argtypes = [vp, C.POINTER(MuavtaScored)]
     L.muavta_rl_step_device.argtypes = [vp, C.POINTER(MuavtaRlStep)]
+    L.muavta_rl_run_device.argtypes = [vp, C.POINTER(MuavtaRlRun)]
+    L.muavta_step_run.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.muavta_abi_sizes.argtypes = [C.POINTER(i32 * 3)]
     for name in EXPORTS:
         if name != "muavta_last_error":

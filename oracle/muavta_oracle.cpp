@@ -1613,6 +1613,36 @@ struct Env {
     std::stable_sort(out.begin(), out.end(), [&](int x, int y) { return key[x] < key[y]; });
     return out;
   }
+  // The callers' replan gates (MUAVTA_GATE_* of include/muavta.h) on the current state: the clock of the step about to be taken and
+  // the events the last step drained (`events = _events(info)`), as the reference's loops evaluate them between two env.step calls.
+  bool gate_fires(int gate, int interval) const {
+    interval = std::max(1, interval);
+    if (gate == MUAVTA_GATE_TRAINER) {  // train_pair_cost._should_replan (experiments/train_pair_cost.py:33-43; wps_eval.py:64-74 with 15)
+      bool g = time_steps == 0 || time_steps % interval == 0;
+      for (auto& ev : done_events) g |= (ev.tag == MUAVTA_EV_RESET_ALLOCATION || ev.tag == MUAVTA_EV_NEW_THREAT || ev.tag == MUAVTA_EV_AGENT_FAIL);
+      return g;
+    }
+    if (gate == MUAVTA_GATE_ESCORT) return time_steps == 0 || time_steps % interval == 0 || !done_events.empty();  // escort_eval._should_replan (escort_eval.py:52-58)
+    if (gate == MUAVTA_GATE_ALLOCATOR) return should_replan(done_events, interval);  // force=False: the allocator's own should_replan (:27-41)
+    return true;
+  }
+  // The quiet stretch between two gates: the reference's loops call env.step({}) while their gate does not fire
+  // (experiments/train_pair_cost.py:86-89,139-145; wps_eval.py:248-254,273).  Steps until the gate fires, the episode ends or `max_steps`
+  // steps were taken (0: no bound); `already` = steps the caller took in the same launch (counted against max_steps).  Returns the steps
+  // taken here; *at_gate = stopped because the gate fired; *reward_sum += the rewards of these steps, in order.
+  int run_quiet(int gate, int interval, int max_steps, int already, int* at_gate, double* reward_sum) {
+    int n = 0;
+    *at_gate = 0;
+    for (;;) {
+      if (terminated || truncated) break;
+      if (gate_fires(gate, interval)) { *at_gate = 1; break; }
+      if (max_steps > 0 && already + n >= max_steps) break;
+      step(0, nullptr, nullptr);
+      if (reward_sum) *reward_sum += last_reward;
+      n++;
+    }
+    return n;
+  }
   int allocate(int interval, int use_visibility, int32_t* act_agent, int32_t* act_index, int cap, int mode = 0, const Scored* sc = nullptr) {
     last_actions.clear(); last_pairs.clear();
     lsap_costs.clear(); lsap_shapes.clear(); lsap_rows.clear(); lsap_cols.clear();
@@ -1630,16 +1660,8 @@ struct Env {
     std::vector<int> sc_kept;      // mode 4: token columns -> task id
     if (mode == 4) {
       const bool envvis = !(P.sense_radius == 0 && P.threat_delay == 0);
-      bool gate = true;
-      if (sc->gate == MUAVTA_GATE_TRAINER) {  // train_pair_cost._should_replan (experiments/train_pair_cost.py:33-43; wps_eval.py:64-74 with 15)
-        gate = time_steps == 0 || time_steps % interval == 0;
-        for (auto& ev : done_events) gate |= (ev.tag == MUAVTA_EV_RESET_ALLOCATION || ev.tag == MUAVTA_EV_NEW_THREAT || ev.tag == MUAVTA_EV_AGENT_FAIL);
-      } else if (sc->gate == MUAVTA_GATE_ESCORT) {  // escort_eval._should_replan (experiments/escort_eval.py:52-58)
-        gate = time_steps == 0 || time_steps % interval == 0 || !done_events.empty();
-      } else if (sc->gate == MUAVTA_GATE_ALLOCATOR) {  // force=False: the allocator's own should_replan (:27-41)
-        n_calls++;
-        gate = should_replan(done_events, interval);
-      }
+      if (sc->gate == MUAVTA_GATE_ALLOCATOR) n_calls++;
+      const bool gate = gate_fires(sc->gate, interval);
       if (sc->selected) std::fill(sc->selected, sc->selected + (size_t)sc->max_agents * sc->max_tasks, 0.0f);
       if (!gate) return finish();
       if (sc->gate != MUAVTA_GATE_ALLOCATOR) n_calls++;
@@ -1881,6 +1903,10 @@ int orc_allocate_scored(void* h, int interval, int use_vis, int gate, int kind, 
                         const double* pri, uint64_t reserved, int32_t* act_agent, int32_t* act_index, int cap, float* selected) {
   Env::Scored sc{gate, kind, max_tasks, max_agents, flags, scores, pri, reserved, selected};
   return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap, 4, &sc);
+}
+int orc_gate(void* h, int gate, int interval) { return ((Env*)h)->gate_fires(gate, interval) ? 1 : 0; }
+int orc_run_quiet(void* h, int gate, int interval, int max_steps, int already, int* at_gate, double* reward_sum) {
+  return ((Env*)h)->run_quiet(gate, interval, max_steps, already, at_gate, reward_sum);
 }
 int orc_rollout_mode(void* h, uint64_t seed, int n_steps, int interval, int use_vis, int mode) {
   Env* e = (Env*)h;

@@ -29,6 +29,7 @@ def lib():
         L.orc_norm2.restype = C.c_double
         L.orc_np_sum.restype = C.c_double
         L.orc_get_lsap.restype = C.c_int64
+        L.orc_run_quiet.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         _LIB = L
     return _LIB
 
@@ -87,6 +88,49 @@ class OracleEnv:
                                        None if sc is None else _p(sc), None if pr is None else _p(pr), C.c_uint64(int(reserved)),
                                        _p(aa), _p(ai), self.A, _p(sel))
         return aa[:n].copy(), ai[:n].copy(), sel
+
+    def gate(self, gate, interval):
+        """The callers' replan gate (MUAVTA_GATE_*) on the current state."""
+        return bool(self.L.orc_gate(self.h, int(gate), int(interval)))
+
+    def run_quiet(self, gate, interval, max_steps=0, already=0, reward0=0.0):
+        """env.step({}) until the gate fires / the episode ends / max_steps (counting `already`): (steps taken, at_gate, reward0 + the
+        rewards of these steps, added in step order)."""
+        ag = C.c_int(0)
+        rs = C.c_double(float(reward0))
+        n = self.L.orc_run_quiet(self.h, int(gate), int(interval), int(max_steps), int(already), C.byref(ag), C.byref(rs))
+        return int(n), bool(ag.value), float(rs.value)
+
+    def rl_run(self, interval, use_vis, gate, kind, max_tasks, max_agents, flags=0, scores=None, pri=None, reserved=0, max_steps=0):
+        """One launch of muavta_rl_run_device for this env, composed from the oracle's own pieces: the first step of run_rl_episode's loop body
+        (plan with the caller's scores under the gate -> step -> S_WPS before / after -> next tokens, experiments/train_pair_cost.py:139-152)
+        and then the quiet stretch up to the next gate.  Returns a dict; an env whose episode had ended is left alone."""
+        d = self.dims()
+        out = {"n_stepped": 0, "replanned": False, "selected": np.zeros((max_agents, max_tasks), np.float32), "reward_sum": 0.0}
+        if d["terminated"] or d["truncated"]:
+            s = self.metrics()[4]
+            out.update(s_before=s, s_after=s, done=int(d["terminated"]) | (int(d["truncated"]) << 1), at_gate=False)
+        else:
+            t0 = d["time_steps"]
+            out["s_before"] = self.metrics()[4]
+            oa, oi, sel = self.allocate_scored(interval, use_vis, gate, kind, max_tasks, max_agents, flags, scores=scores, pri=pri, reserved=reserved)
+            out["replanned"] = self.scalars_last_plan() == t0
+            out["selected"] = sel
+            self.step(oa, oi)
+            out["reward_sum"] = float(self.scalars()[1])
+            out["s_after"] = self.metrics()[4]
+            d = self.dims()
+            out["done"] = int(d["terminated"]) | (int(d["truncated"]) << 1)
+            if out["replanned"]:
+                out["next_tok"] = self.tokens(kind, max_tasks, max_agents)
+            n, ag, rs = self.run_quiet(gate, interval, max_steps, 1, out["reward_sum"])  # (same order of additions as the device: first step, then the quiet ones)
+            out["n_stepped"] = 1 + n
+            out["at_gate"] = ag
+            out["reward_sum"] = rs
+        d = self.dims()
+        out["park"] = int(d["terminated"]) | (int(d["truncated"]) << 1) | (4 if out["at_gate"] else 0)
+        out["park_tok"] = self.tokens(kind, max_tasks, max_agents)
+        return out
 
     def rollout_mode(self, seed, n_steps, interval, use_vis, mode):
         return self.L.orc_rollout_mode(self.h, C.c_uint64(seed), int(n_steps), int(interval), int(use_vis), int(mode))

@@ -1870,3 +1870,139 @@ def test_rl_step_by_sub_batches_equals_the_whole_batch_launch():
     b.set_parts(0)
     assert np.array_equal(a.metrics(), b.metrics())
     assert np.array_equal(a.get("AGENT_POS"), b.get("AGENT_POS"))
+
+
+# ---- run to the next replan gate: muavta_rl_run_device / muavta_step_run ----------------------------------------------------------------
+@pytest.mark.parametrize("max_steps", [0, 4], ids=["to-the-gate", "at-most-4-steps"])
+@pytest.mark.parametrize("path", RL_FILES, ids=[os.path.basename(p)[3:-4] for p in RL_FILES])
+def test_rl_run_ahead_policy_consulted_at_gates_vs_reference_and_oracle(path, max_steps):
+    """run_rl_episode with the policy consulted only when _should_replan fires (experiments/train_pair_cost.py:139-145): muavta_amd.il.rl_run_stream /
+    muavta_rl_run_device.  Env 0 replays the reference episode launch by launch — one launch per gate of the reference (tests/golden/rl_*.npz hold
+    every gate step): tok, selected, step reward, next_tok, ep_done, and the quiet stretch ends at the reference's next gate.  The other envs run
+    other seeds (their clocks drift apart: every env advances to ITS next gate) against the oracle's run-to-the-gate, the policy a function of the
+    token tensors on the GPU; final state of every env vs the oracle, field by field."""
+    import torch
+    from muavta_amd.il import rl_run_stream
+
+    g = np.load(path)
+    case = os.path.basename(path)[3:-4]
+    raw = bool(int(g["raw"]))
+    kname, kind = ("pair_raw", 1) if raw else ("pair", 0)
+    n, seed0 = 6, int(g["seed"])
+    env = _env(case, n)
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(seed0 + i)
+    steps, T = g["step"].tolist(), len(g["replanned"])
+    state = {"k": 0, "t0": 0}
+    ref_scores = torch.from_numpy(g["scores"]).cuda()
+
+    def policy(tok):
+        sc = torch.tanh(tok["agent_feats"][:, :, :1] * 3.0 - tok["task_feats"][:, :, 0].unsqueeze(1) * 2.0 + tok["task_feats"][:, :, 1].unsqueeze(1)) * 0.35
+        sc = sc.contiguous()
+        if state["k"] < len(steps) and steps[state["k"]] == state["t0"]:  # env 0 is parked at the reference's gate k: the matrix the reference was given
+            sc[0] = ref_scores[state["k"]]
+        return sc
+
+    launches = 0
+    tot_steps = np.zeros(n, dtype=np.int64)
+    for kk, tr in rl_run_stream(env, np.arange(seed0, seed0 + n), policy, interval=20, kind=kname, max_steps=max_steps):
+        launches += 1
+        sc = tr["scores"].cpu().numpy()
+        sel, rep, rew, dn = tr["selected"].cpu().numpy(), tr["replanned"].cpu().numpy(), tr["step_reward"].cpu().numpy(), tr["done"].cpu().numpy()
+        nst, prk, rsum = tr["n_stepped"].cpu().numpy(), tr["park"].cpu().numpy(), tr["reward_sum"].cpu().numpy()
+        tok = {k_: v.cpu().numpy() for k_, v in tr["tok"].items()}
+        nxt = {k_: v.cpu().numpy() for k_, v in tr["next_tok"].items()}
+        ptk = {k_: v.cpu().numpy() for k_, v in tr["park_tok"].items()}
+        # env 0 vs the reference episode
+        k, t0 = state["k"], state["t0"]
+        if t0 < T:
+            at = k < len(steps) and steps[k] == t0
+            assert bool(rep[0]) == at, f"{case} t={t0}: gate"
+            if at:
+                assert np.array_equal(tok["task_feats"][0], g["tf"][k]) and np.array_equal(tok["agent_feats"][0], g["af"][k]) and np.array_equal(tok["edge_valid"][0], g["ev"][k])
+                assert np.array_equal(tok["task_ids"][0], g["tid"][k]) and np.array_equal(tok["agent_ids"][0], g["aid"][k])
+                assert np.array_equal(sel[0], g["selected"][k]), f"{case} t={t0}: selected"
+                assert rew[0] == g["step_r"][k] and bool(dn[0]) == bool(g["ep_done"][k])
+                assert np.array_equal(nxt["task_feats"][0], g["ntf"][k]) and np.array_equal(nxt["agent_feats"][0], g["naf"][k]) and np.array_equal(nxt["task_ids"][0], g["ntid"][k])
+                state["k"] = k = k + 1
+            else:
+                assert not sel[0].any()
+            assert rew[0] == (g["s_wps"][t0 + 1] - g["s_wps"][t0]) / 20.0
+            nxt_gate = steps[k] if k < len(steps) else T
+            assert int(nst[0]) == (nxt_gate - t0 if max_steps == 0 else min(nxt_gate - t0, max_steps)), f"{case} t={t0}: steps taken, reference's next gate at {nxt_gate}"
+            state["t0"] = t0 + int(nst[0])
+        else:
+            assert int(nst[0]) == 0 and not rep[0]
+        # every env vs the oracle's run-to-the-gate with the same scores
+        for i, o in enumerate(oracles):
+            r = o.rl_run(20, 1, 1, kind, 32, 16, 1, scores=sc[i], max_steps=max_steps)
+            tag = f"{case} seed {seed0 + i} launch {kk}"
+            assert int(nst[i]) == r["n_stepped"] and int(prk[i]) == r["park"] and bool(rep[i]) == r["replanned"], f"{tag}: {nst[i]} {prk[i]} {rep[i]} vs {r['n_stepped']} {r['park']} {r['replanned']}"
+            assert np.array_equal(sel[i], r["selected"]), f"{tag}: selected"
+            assert rew[i] == (r["s_after"] - r["s_before"]) / 20.0 and int(dn[i]) == r["done"], f"{tag}: step reward / done"
+            assert rsum[i] == r["reward_sum"], f"{tag}: reward sum"
+            if r["replanned"]:
+                for key in ("task_feats", "agent_feats", "edge_valid", "task_ids", "agent_ids", "task_mask", "agent_mask"):
+                    assert np.array_equal(nxt[key][i], r["next_tok"][key]), f"{tag}: next_tok {key}"
+                assert int(nxt["n_urgent"][i]) == r["next_tok"]["n_urgent"]
+            for key in ("task_feats", "agent_feats", "edge_valid", "task_ids", "agent_ids", "task_mask", "agent_mask"):
+                assert np.array_equal(ptk[key][i], r["park_tok"][key]), f"{tag}: park_tok {key}"
+            assert int(ptk["n_urgent"][i]) == r["park_tok"]["n_urgent"]
+        tot_steps += nst
+    assert state["k"] == len(steps) and np.all(tot_steps == T) and np.array_equal(env.metrics()[0], g["metrics"])
+    if max_steps == 0:
+        assert launches >= len(steps)  # (the batch needs as many launches as its env with the most gates)
+    env.refresh_observation()
+    snap = Snapshot(env)
+    for i, o in enumerate(oracles):
+        compare(snap, i, o, f"rl_run_stream {case} seed {seed0 + i} final", check_obs=False)
+
+
+@pytest.mark.parametrize("case,interval,gate,n", [("WPS_hard", 20, "trainer", 6), ("WPS_escort", 12, "escort", 5), ("WPS_hard_x2", 20, "allocator", 6), ("WPS_burst64", 15, "trainer", 2)])
+def test_step_run_host_planner_runs_ahead_to_its_gate_vs_oracle(case, interval, gate, n):
+    """muavta_step_run: env.step(actions of a host-side plan) + env.step({}) up to the env's next gate in ONE launch (the loop of
+    experiments/wps_eval.py:248-254,273).  The plan is the device allocator's, fetched to the host and handed back as action rows (odd
+    launches) or left staged (even launches); every field of every env + the observation of the state it stopped in, after every launch."""
+    G = {"force": 0, "trainer": 1, "escort": 2, "allocator": 3}[gate]
+    env = _env(case, n)
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    env.reset(np.arange(n, dtype=np.uint64))
+    for i, o in enumerate(oracles):
+        o.reset(i)
+    launches, total = 0, np.zeros(n, dtype=np.int64)
+    while True:
+        cap = 0 if launches % 3 else 5
+        aa, ai = env.allocate(interval, True)
+        for i, o in enumerate(oracles):
+            oa, oi = o.allocate(interval, 1)
+            k = len(oa)
+            assert np.array_equal(aa[i][:k], oa) and np.all(aa[i][k:] == -1) and np.array_equal(ai[i][:k], oi), f"{case} seed {i} launch {launches}: plan"
+        if launches % 2:
+            nst, prk, rs = env.step_run(aa, ai, gate=gate, replan_interval=interval, max_steps=cap)
+        else:
+            nst, prk, rs = env.step_run(None, None, gate=gate, replan_interval=interval, max_steps=cap)
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            d = o.dims()
+            if d["terminated"] or d["truncated"]:
+                assert nst[i] == 0 and (prk[i] & 3)
+                continue
+            # (the device's plan equals the oracle's, checked above: replay it through step, then the quiet stretch)
+            pa, pi = aa[i][aa[i] >= 0], ai[i][:int((aa[i] >= 0).sum())]
+            o.step(pa, pi)
+            r0 = float(o.scalars()[1])
+            q, ag, rq = o.run_quiet(G, interval, cap, 1, r0)
+            dd = o.dims()
+            want_park = int(dd["terminated"]) | (int(dd["truncated"]) << 1) | (4 if ag else 0)
+            assert int(nst[i]) == 1 + q and int(prk[i]) == want_park and rs[i] == rq, f"{case} seed {i} launch {launches}: {nst[i]} {prk[i]} {rs[i]} vs {1 + q} {want_park} {rq}"
+            compare(snap, i, o, f"step_run {case} seed {i} launch {launches}")
+        total += nst
+        launches += 1
+        if np.all(prk & 3):
+            break
+        assert launches < 400
+    m = env.metrics()
+    for i, o in enumerate(oracles):
+        assert np.array_equal(m[i], o.metrics()), f"{case} seed {i}: final metrics"
+    assert launches < int(total.max())  # fewer launches than env steps: that is the point

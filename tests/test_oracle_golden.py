@@ -510,3 +510,48 @@ def test_escort_scored_plans_vs_reference(path):
         assert np.array_equal(np.stack([aa[order], ai[order]], axis=1).reshape(-1, 2), want_a.reshape(-1, 2)), f"{case} t={t}: actions"
         e.step(aa, ai)
     assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"])
+
+
+# ---- run to the next gate (muavta_rl_run_device's checker): the reference episodes hold every gate step ------------------------------
+@pytest.mark.parametrize("max_steps", [0, 3])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rl_*.npz"))))
+def test_rl_run_to_the_next_gate_vs_reference(path, max_steps):
+    """OracleEnv.rl_run — plan at a gate, step, then env.step({}) up to the next gate (experiments/train_pair_cost.py:139-145) — replays the
+    reference's run_rl_episode launch by launch: one launch per gate of the reference episode (its `step` list), each consuming the score matrix
+    the reference's policy was given there and reproducing the pushed transition (tok, selected, step_r, next_tok, ep_done); the quiet stretch
+    ends exactly at the reference's next gate.  max_steps = 3 cuts the quiet stretches short: the extra launches must plan nothing."""
+    g = np.load(path)
+    case = os.path.basename(path)[3:-4]
+    kind = 1 if int(g["raw"]) else 0
+    e = orc.OracleEnv(params_for_case(case))
+    e.reset(int(g["seed"]))
+    steps, T = g["step"].tolist(), len(g["replanned"])
+    tok = e.tokens(kind, 32, 16)
+    t, k, launches = 0, 0, 0
+    while t < T:
+        at = k < len(steps) and steps[k] == t
+        sc = g["scores"][k] if at else np.full((16, 32), 0.3, np.float32)  # (scores handed to an env that is not at a gate are not read)
+        r = e.rl_run(20, 1, GATE_TRAINER, kind, 32, 16, SC_EDGE_VALID_ONLY, scores=sc, max_steps=max_steps)
+        launches += 1
+        assert r["replanned"] == at, f"{case} t={t}: gate"
+        if at:
+            assert np.array_equal(tok["task_feats"], g["tf"][k]) and np.array_equal(tok["agent_feats"], g["af"][k]) and np.array_equal(tok["edge_valid"], g["ev"][k])
+            assert np.array_equal(r["selected"], g["selected"][k]), f"{case} t={t}: selected"
+            assert (r["s_after"] - r["s_before"]) / 20.0 == g["step_r"][k] and bool(r["done"]) == bool(g["ep_done"][k])
+            nt = r["next_tok"]
+            assert np.array_equal(nt["task_feats"], g["ntf"][k]) and np.array_equal(nt["agent_feats"], g["naf"][k]) and np.array_equal(nt["task_ids"], g["ntid"][k])
+            k += 1
+        else:
+            assert not r["selected"].any()
+        assert r["s_before"] == g["s_wps"][t] and r["s_after"] == g["s_wps"][t + 1]
+        nxt_gate = steps[k] if k < len(steps) else T
+        want_n = nxt_gate - t if max_steps == 0 else min(nxt_gate - t, max_steps)
+        assert r["n_stepped"] == want_n, f"{case} t={t}: {r['n_stepped']} steps, next gate of the reference at {nxt_gate}"
+        t += r["n_stepped"]
+        assert bool(r["park"] & 4) == (t < T and t == nxt_gate) and bool(r["park"] & 3) == (t == T)
+        tok = r["park_tok"]
+    assert k == len(steps) and np.array_equal(e.metrics(), g["metrics"]) and e.dims()["n_replans"] == int(g["n_replans"])
+    if max_steps == 0:
+        assert launches == len(steps)
+    r = e.rl_run(20, 1, GATE_TRAINER, kind, 32, 16, SC_EDGE_VALID_ONLY, scores=None)  # an ended episode is left alone
+    assert r["n_stepped"] == 0 and not r["replanned"] and r["s_before"] == r["s_after"] == g["s_wps"][-1] and np.array_equal(e.metrics(), g["metrics"])
