@@ -18,12 +18,12 @@ kernel keeps the env state in LDS, so this is an algorithmic-equivalent rate, NO
 `roofline.traffic` / `roofline.measured_hbm_GBs` are the PMC-measured bytes (see `roofline.note`).
 `cpu_baseline` = the CPU oracle (oracle/, a restatement of the reference: kind "port") timed on ALL of this
 box's host cores over a bounded sample of the same workload (rank 0, N=1 only).
-`other_tiles` (N=1 only) = the same measurement for BASELINE configs 4 and 5 (24x48 escort, 64x128 burst), each also with two handles
-in flight.  Further N=1 figures (r4): `value_two_in_flight` (the headline loop with launches alternating between two handles),
-`launch_gap_ms` / `ms_per_step_unaccounted` (where ms_per_step goes beyond the kernel), `policy_in_loop_env_steps_per_s`
-(muavta_rl_step_device: the RL trainers' loop with caller-supplied edge scores, one launch per env step).
-`--inflight 2` makes the TIMED loop itself alternate between two handles per rank (composes with --gpus N: each rank owns its handles,
-the metric reduction still runs once).  Progress lines go to stderr.
+`other_tiles` (N=1 only) = the same measurement for BASELINE configs 4 and 5 (24x48 escort, 64x128 burst).  The timed loop queues its
+launches back to back on ONE handle; since round 5 the handle runs them on two state lanes (muavta_set_lanes: launch i+1 starts in the wave
+slots launch i's early finishers free), `--lanes 1` pins it to one lane and `value_one_lane` / `other_tiles.*.one_lane` report that mode.
+Further N=1 figures: `launch_gap_ms` (where ms_per_step goes beyond the kernel), `policy_in_loop_env_steps_per_s` + `policy_calls_per_env_step`
+(muavta_rl_run_device: the RL trainers' loop, the policy consulted once per replan gate), `facade_steps_per_s` (the drop-in PettingZoo facade).
+Progress lines go to stderr.
 """
 from __future__ import annotations
 
@@ -162,13 +162,15 @@ def _cpu_worker(case, interval, seconds, seed0):
     return steps, time.perf_counter() - t0
 
 
-def roofline(case, envs, n_agents_tile, kernel_ms):
-    """SURVEY 8(d) roofline of k_rollout (kept exactly as defined there: algorithmic bytes / kernel time against HBM peak) plus
-    what the counters say actually bounds the kernel: `issue` (instruction issue per env-step and VALU-port occupancy) and
-    `hbm_measured_frac` (PMC traffic / kernel time / peak).  The PMC-derived fields are null unless profiles/pmc_traffic.json
-    holds a collection taken on exactly these kernel sources (source_hash)."""
+def roofline(case, envs, n_agents_tile, kernel_ms, isolated_ms=None, ms_per_step=None, lanes=1, max_tasks=None, n_agents=None):
+    """SURVEY 8(d) roofline block of k_rollout.  `achieved` / `frac` stay exactly as 8(d) defines them (algorithmic bytes per launch / that
+    kernel's mean launch duration, against HBM peak) — but the kernel is not HBM-bound, and the labels say so: `bound` = "issue", with
+    `issue_frac` (VALU-port occupancy), `lane_util` (enabled lanes per VALU instruction / 64) and the measured HBM traffic beside it, and
+    `hbm_floor` = what a state-resident rollout MUST move per env-step (the observation it writes and the actions it reads).  The PMC-derived
+    fields are null unless profiles/pmc_traffic.json holds a collection taken on exactly these kernel sources (source_hash)."""
     B = ALGO_BYTES_PER_ENV_STEP.get(n_agents_tile)
-    achieved = (envs * HORIZON * B) / (kernel_ms * 1e-3) / 1e9 if B else None
+    launch_bytes = envs * HORIZON * B if B else None
+    achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9 if B else None
     e = pmc_entry(case, envs)
     traffic = e.get("bytes_per_launch") if e else None
     measured = (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None
@@ -177,34 +179,65 @@ def roofline(case, envs, n_agents_tile, kernel_ms):
         issue = dict(e["issue"])
         issue["source"] = "profiles/" + str(e.get("profile"))
         issue["source_hash"] = e.get("source_hash")
-    return {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    out = {
+        "bound": "issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
         "kernel": "k_rollout", "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": B,
-        "achieved_is": ("algorithmic bytes (SURVEY 8d: 2*S_state + S_obs + S_act per env-step) / kernel time, not HBM traffic. Values "
-                        "above 1.0 are possible: the fused kernel keeps the env state in LDS for the whole rollout and never moves the "
-                        "2*S_state per step the formula charges; that the timed work is the whole workload is shown by `quality` "
-                        "equalling the CPU oracle (quality.oracle_checked)"),
+        "issue_frac": issue.get("valu_port_busy") if issue else None,
+        "lane_util": (issue.get("mean_enabled_lanes_per_valu") / 64.0) if issue and issue.get("mean_enabled_lanes_per_valu") else None,
+        "achieved_is": ("SURVEY 8d as written: algorithmic bytes (2*S_state + S_obs + S_act per env-step) / the kernel's mean launch duration — an algorithmic-equivalent rate, "
+                        "not HBM traffic, kept for comparability between rounds.  It is NOT what bounds the kernel (`bound`: instruction issue): the fused kernel keeps the env state "
+                        "in LDS for the whole rollout and never moves the 2*S_state per step the formula charges, so values above 1.0 are possible; that the timed work is the whole "
+                        "workload is shown by `quality` equalling the CPU oracle (quality.oracle_checked)"),
         "measured_hbm_GBs": measured, "hbm_measured_frac": (measured / HBM_PEAK_GBS) if measured else None,
         "issue": issue,
         "limiter": ("instruction issue, not memory: the env state is LDS-resident, the order-dependent phases of a step execute with one "
-                    "lane enabled, and the waves sharing a SIMD keep its VALU port busy most of the launch (`issue.valu_port_busy` = "
-                    "waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES from the matching PMC pass)"),
+                    "lane enabled, and the waves sharing a SIMD keep its VALU port busy most of the launch (`issue_frac` = issue.valu_port_busy = "
+                    "waves per SIMD x SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, `lane_util` = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64, from the matching PMC pass)"),
     }
+    if max_tasks and n_agents:
+        # what a state-resident rollout has to move per env-step: S_obs + S_act of SURVEY 8(d) with the env's own max_tasks / fleet
+        # (the observation it writes: T*84 + T + A*(36 + 4*ceil(T/32)) + 30, and the 4A bytes of actions)
+        floor = max_tasks * 84 + max_tasks + n_agents * (36 + 4 * ((max_tasks + 31) // 32)) + 30 + 4 * n_agents
+        fl_rate = envs * HORIZON * floor / (kernel_ms * 1e-3) / 1e9
+        out["hbm_floor_bytes_per_env_step"] = floor
+        out["hbm_floor_frac"] = fl_rate / HBM_PEAK_GBS
+        out["hbm_floor_is"] = "S_obs + S_act: the bytes per env-step a rollout that keeps its state on chip still has to write / read; hbm_floor_frac = that rate / HBM peak"
+    if isolated_ms:
+        iso = launch_bytes / (isolated_ms * 1e-3) / 1e9 if B else None
+        out["isolated"] = {"kernel_ms": isolated_ms, "achieved": iso, "frac": (iso / HBM_PEAK_GBS) if iso else None,
+                           "is": "one launch alone on the GPU (warm-up launches, HIP events): the figure earlier rounds reported as roofline.frac"}
+    if ms_per_step and lanes > 1:
+        dev = launch_bytes / (ms_per_step * 1e-3) / 1e9 if B else None
+        out["launches_in_flight"] = lanes
+        out["device_achieved"] = dev
+        out["device_frac"] = (dev / HBM_PEAK_GBS) if dev else None
+        out["device_is"] = ("with two state lanes the timed launches overlap: each lasts `kernel_ms` but one completes every ms_per_step; device_achieved = algorithmic bytes per launch / ms_per_step")
+    return out
 
 
 def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
-    kernel_ms, seed_ms = [], []
-    for w in range(warmup):
+    """(elapsed s of the timed region, mean k_rollout ms of its launches, mean k_seed ms, mean k_rollout ms of ISOLATED launches).  The warm-up
+    launches run one at a time (isolated kernel / seeding times) except the last two, which are queued back to back like the timed ones: the
+    handle's second state lane (include/muavta.h: a seeded rollout issued while the previous one still runs goes to the other lane) is
+    created there, not inside the timed region."""
+    kernel_ms, seed_ms, iso_ms = [], [], []
+    n_iso = max(1, warmup - 2)
+    for w in range(n_iso):
         env.rollout(seeds, HORIZON, interval, True, write_obs)
         env.sync()
-        if w or warmup == 1:  # (the very first call also allocates the seeding buffers)
+        if w or n_iso == 1:  # (the very first call also allocates the seeding buffers)
             seed_ms.append(env.last_seed_ms())  # k_seed on an idle GPU (in the timed loop it runs next to the previous launch)
+            iso_ms.append(env.last_kernel_ms())
+    for w in range(warmup - n_iso):
+        env.rollout(seeds, HORIZON, interval, True, write_obs)
+    env.sync()
     barrier()
     t0 = time.perf_counter()
-    # launches are queued back to back (the library seeds launch i+1 on its own stream while launch i runs); the per-launch
-    # k_rollout durations come from the handle's ring of 64 HIP event pairs.  Reading them back (an event query per launch, ~0.1 ms
-    # each) is bookkeeping, not work: it happens after the closing barrier, and inside the loop only when the ring would wrap.
+    # launches are queued back to back (the library seeds launch i+1 on its own stream while launch i runs, and with two state lanes launch
+    # i+1 itself starts in the wave slots launch i's early finishers free); the per-launch k_rollout durations come from the handle's ring of
+    # 64 HIP event pairs.  Reading them back (an event query per launch, ~0.1 ms each) is bookkeeping, not work: it happens after the closing
+    # barrier, and inside the loop only when the ring would wrap.
     pending = 0
     for _ in range(steps):
         env.rollout(seeds, HORIZON, interval, True, write_obs)
@@ -220,51 +253,29 @@ def time_rollouts(env, seeds, interval, write_obs, steps, warmup, barrier):
         kernel_ms.extend(env.kernel_ms_history(pending).tolist())
     if not seed_ms:
         seed_ms.append(env.last_seed_ms())
-    time_rollouts.last_gap_ms = float(np.mean(gaps)) if gaps else None   # start(i + 1) - end(i) on the handle's stream, from the same event ring
+    time_rollouts.last_gap_ms = float(np.mean(gaps)) if gaps else None   # start(i + 1) - end(i), from the same event rings (negative: launches overlapped on two lanes)
+    time_rollouts.isolated_kernel_ms = float(np.mean(iso_ms)) if iso_ms else None
     return elapsed, float(np.mean(kernel_ms)), float(np.mean(seed_ms))
 
 
-def time_rollouts_in_flight(envs, seeds, interval, write_obs, steps, warmup, barrier):
-    """The same timed loop with the launches alternating between several handles (each with its own stream, blobs and seeding slots):
-    batch i+1's workgroups take the wave slots that batch i's early finishers free, instead of waiting for its slowest env.  Every
-    launch is still one whole batch; K launches are timed.  Returns (elapsed, mean per-launch kernel ms — overlapping launches, so
-    longer than an isolated one)."""
-    k = len(envs)
-    for w in range(max(warmup, k)):
-        envs[w % k].rollout(seeds, HORIZON, interval, True, write_obs)
-    for e in envs:
-        e.sync()
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        envs[i % k].rollout(seeds, HORIZON, interval, True, write_obs)
-    for e in envs:
-        e.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    per = [e.kernel_ms_history(max(1, min(64, steps // k))) for e in envs if steps // k >= 1]
-    return elapsed, float(np.mean(np.concatenate(per))) if per else float("nan")
-
-
-def in_flight_figure(case, n, interval, seeds, write_obs, steps, warmup, barrier, device, want_metrics, k=2):
-    """`k` handles of the same case / seeds in flight; every handle's last batch must be complete (no capacity flags) and bit-equal to
-    `want_metrics` (the single-handle batch the oracle check covers)."""
+def one_lane_figure(case, n, interval, seeds, write_obs, steps, warmup, barrier, device, want_metrics):
+    """The same timed loop on a handle pinned to ONE state lane (muavta_set_lanes(h, 1): launches in order, none overlapping — the only mode
+    before round 5); its last batch must be complete (no capacity flags) and bit-equal to `want_metrics` (the default handle's batch)."""
     from muavta_amd.batched import BatchedMultiUAVEnv
     from muavta_amd.params import params_for_case
 
-    hs = [BatchedMultiUAVEnv(params_for_case(case), n, device=device) for _ in range(k)]
+    h = BatchedMultiUAVEnv(params_for_case(case), n, device=device)
     try:
-        el, kms = time_rollouts_in_flight(hs, seeds, interval, write_obs, steps, warmup, barrier)
-        for h in hs:
-            if int(np.count_nonzero(h.get("ERROR"))):
-                raise SystemExit(f"bench: capacity-flagged envs in an in-flight batch of {case}")
-            if want_metrics is not None and not np.array_equal(h.rollout_metrics(), want_metrics):
-                raise SystemExit(f"bench: an in-flight batch of {case} differs from the single-handle batch")
-        return {"env_steps_per_s": n * HORIZON * steps / el, "handles": k, "ms_per_step": el / steps * 1e3, "overlapped_kernel_ms": kms,
-                "bit_equal_to_single_handle_batch": want_metrics is not None}
+        h.set_lanes(1)
+        el, kms, _ = time_rollouts(h, seeds, interval, write_obs, steps, warmup, barrier)
+        if int(np.count_nonzero(h.get("ERROR"))):
+            raise SystemExit(f"bench: capacity-flagged envs in the one-lane batch of {case}")
+        if want_metrics is not None and not np.array_equal(h.rollout_metrics(), want_metrics):
+            raise SystemExit(f"bench: the one-lane batch of {case} differs from the two-lane handle's batch")
+        return {"env_steps_per_s": n * HORIZON * steps / el, "ms_per_step": el / steps * 1e3, "kernel_ms": kms, "launch_gap_ms": getattr(time_rollouts, "last_gap_ms", None),
+                "bit_equal_to_default_handle_batch": want_metrics is not None}
     finally:
-        for h in hs:
-            h.close()
+        h.close()
 
 
 def main():
@@ -281,8 +292,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the step-API / other-tile / IL figures (profiling runs)")
     ap.add_argument("--abi-collective", action="store_true", help="reduce the metrics through muavta_allreduce_metrics (RCCL behind the C ABI) instead of torch.distributed")
     ap.add_argument("--seed-base", type=int, default=0, help="first global env index (default 0: seeds = global env index)")
-    ap.add_argument("--inflight", type=int, default=1, help="handles per rank whose launches alternate in the TIMED loop (default 1: one handle, launches in order; "
-                                                           "2: batch i+1 fills the wave slots batch i's early finishers free).  The N=1 line reports value_two_in_flight either way")
+    ap.add_argument("--lanes", type=int, default=0, choices=(0, 1, 2), help="state lanes of the handle (muavta_set_lanes): 0 = library default (a second lane is created when a "
+                                                                           "seeded rollout is queued while the previous one still runs: launches overlap), 1 = one lane, launches in order, 2 = always alternate")
     args = ap.parse_args()
     if args.interval is None:
         args.interval = 12 if "escort" in args.case else 20
@@ -321,15 +332,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.lanes:
+        env.set_lanes(args.lanes)
     elapsed, mean_kernel_ms, mean_seed_ms = time_rollouts(env, seeds, args.interval, write_obs, args.steps, args.warmup, barrier)
     launch_gap_ms = getattr(time_rollouts, "last_gap_ms", None)
-    if args.inflight > 1:  # the timed region again, launches alternating between `inflight` handles of this rank (the first one above gave the isolated kernel time)
-        others = [BatchedMultiUAVEnv(params_for_case(args.case), args.envs, device=local_rank) for _ in range(args.inflight - 1)]
-        elapsed, _ = time_rollouts_in_flight([env] + others, seeds, args.interval, write_obs, args.steps, args.warmup, barrier)
-        for h in others:
-            if int(np.count_nonzero(h.get("ERROR"))) or not np.array_equal(h.rollout_metrics(), env.rollout_metrics()):
-                raise SystemExit("bench: an in-flight batch is incomplete or differs from the first handle's batch")
-            h.close()
+    isolated_kernel_ms = getattr(time_rollouts, "isolated_kernel_ms", None)
+    lanes_mode, lanes_allocated = env.lanes()
 
     # metrics of the last batch: per-rank partials -> the one collective of this path (muavta_amd/dist.py).  Every env has
     # to produce a result: a capacity-flagged env (ERROR != 0) fails the run, on every rank alike (the count is reduced
@@ -366,18 +374,20 @@ def main():
                        "lds_bytes_per_env": int(env.dims.lds_bytes),
                        "horizon": HORIZON, "parallelism": f"env-sharded x{world}, RCCL all-reduce of the metric vector only"
                                       + (" (muavta_allreduce_metrics)" if args.abi_collective else " (torch.distributed nccl backend)" if dist is not None else "")},
-            "roofline": roofline(args.case, args.envs, env.dims.tile_agents, mean_kernel_ms),
+            "roofline": roofline(args.case, args.envs, env.dims.tile_agents, mean_kernel_ms, isolated_kernel_ms, elapsed / args.steps * 1e3, lanes_allocated, env.max_tasks, env.n_agents),
             "seed_kernel_ms": mean_seed_ms,
             # where ms_per_step goes: the k_rollout launch itself (roofline.kernel_ms), the gap to the next launch on the handle's stream
             # (command processing + waiting for the next batch's seeding, from the same HIP event ring), and what is left: the host's
             # closing synchronisation and barrier, amortised over `steps` launches
             "launch_gap_ms": launch_gap_ms,
-            "ms_per_step_unaccounted": (elapsed / args.steps * 1e3 - mean_kernel_ms - launch_gap_ms) if (launch_gap_ms is not None and args.inflight == 1) else None,
+            "ms_per_step_unaccounted": (elapsed / args.steps * 1e3 - mean_kernel_ms - launch_gap_ms) if (launch_gap_ms is not None and lanes_allocated == 1) else None,
             # launches are queued back to back, so launch i+1's seeding (upload + k_seed on a second stream) runs under launch i's
             # tail; an isolated batch pays k_seed in front of the rollout kernel:
             "value_unpipelined": total_envs * HORIZON / ((mean_kernel_ms + mean_seed_ms) * 1e-3),
             "value_unpipelined_is": "whole-job env-steps/s of ONE isolated batch: envs x 150 / (k_rollout ms + k_seed ms on an idle GPU)",
-            "inflight": args.inflight,
+            "lanes": {"mode": lanes_mode, "allocated": lanes_allocated,
+                      "is": "state lanes of the ONE handle the timed loop drives (include/muavta.h: muavta_set_lanes): with 2 allocated, launch i+1 runs on the other lane and starts in the wave "
+                            "slots launch i's early finishers free; roofline.kernel_ms is then the duration of an OVERLAPPED launch, roofline.isolated the launch alone on the GPU"},
             "quality": {"mean_S_WPS": summary["mean_S_WPS"], "std_S_WPS": summary["std_S_WPS"], "on_time_rate": summary["on_time_rate"],
                         "n_envs": summary["n_envs"], "capacity_flagged_envs": 0},
         }
@@ -548,7 +558,8 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
                            next_tok=bufs[(t + 1) & 1], s_wps=sw, done=dn)
             e4.sync()
             dt_rl = time.perf_counter() - t1
-        out["policy_in_loop_env_steps_per_s"] = args.envs * HORIZON / dt_rl
+        out["policy_in_loop_per_step_env_steps_per_s"] = args.envs * HORIZON / dt_rl
+        m_per_step = e4.metrics()
         # the same loop with the batch in two sub-batches on their own streams (MuavtaRlStep.part): what a trainer that runs its network on
         # part A's tokens while the device steps part B gets from the env side
         e4.set_parts(2)
@@ -564,10 +575,73 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
             e4.sync()
             dt_rl2 = time.perf_counter() - t1
         e4.set_parts(0)
-        out["policy_in_loop_2_parts_env_steps_per_s"] = args.envs * HORIZON / dt_rl2
-        out["policy_in_loop_is"] = (f"muavta_rl_step_device, one launch per env step of all {args.envs} envs: plan (Hungarian - caller's f32 edge scores [N,16,32], "
-                                    "trainer gate) -> step -> S_WPS before/after -> next pair tokens 32x16 + edge_valid, + _selected_mask / replanned / done; "
-                                    "the score tensor is fixed and device-resident (times the env side; the reference's run_rl_episode is this loop for one env)")
+        out["policy_in_loop_per_step_2_parts_env_steps_per_s"] = args.envs * HORIZON / dt_rl2
+        # (r5) run to the next gate: the reference consults the policy only when _should_replan fires (train_pair_cost.py:139-145) and steps with
+        # empty actions otherwise — muavta_rl_run_device does that per env inside one launch (first step = the planned one, then quiet steps up
+        # to the env's own next gate), so the policy is called once per GATE.  max_steps bounds the quiet stretch per launch (an env cut short
+        # continues at the next launch without a plan): 0 = to the gate (fewest policy calls), 5 = the best env-side rate measured.
+        nxt = {k: torch.empty(sh, dtype=tdt[dt], device=dev) for k, (sh, dt) in e4.token_shapes("pair", 32, 16).items()}
+        nst = torch.empty((args.envs,), dtype=torch.int32, device=dev)
+        prk = torch.empty((args.envs,), dtype=torch.uint8, device=dev)
+
+        def run_ahead(max_steps, check_every):
+            res = None
+            for rep_i in range(2):
+                e4.reset(seeds)
+                e4.tokens("pair", 32, 16, out=bufs[0])
+                e4.sync()
+                t1 = time.perf_counter()
+                k = 0
+                while True:
+                    e4.rl_run("pair", 32, 16, edge_scores=scores, gate="trainer", replan_interval=args.interval, selected=sel, replanned=rep, next_tok=nxt, s_wps=sw,
+                              done=dn, park_tok=bufs[(k + 1) & 1], n_stepped=nst, park=prk, max_steps=max_steps)
+                    k += 1
+                    if k % check_every == 0:
+                        e4.sync()
+                        if bool(((prk & 3) != 0).all()):
+                            break
+                    if k > 4 * HORIZON:
+                        raise RuntimeError("run-ahead did not finish")
+                res = (args.envs * HORIZON / (time.perf_counter() - t1), k)
+            if not np.array_equal(e4.metrics(), m_per_step):
+                raise SystemExit("bench: the run-ahead policy loop ended in other metrics than the per-step loop")
+            return res
+
+        r5, k5 = run_ahead(5, 4)
+        r0, k0 = run_ahead(0, 1)
+        out["policy_in_loop_env_steps_per_s"] = r5
+        out["policy_calls_per_env_step"] = k5 / HORIZON
+        out["policy_in_loop_to_the_gate"] = {"env_steps_per_s": r0, "policy_calls_per_env_step": k0 / HORIZON, "launches": k0,
+                                             "is": "max_steps 0: every env runs to its own next gate in each launch; the host checks the park flags after every launch (what il.rl_run_stream does)"}
+        out["policy_in_loop_is"] = (f"muavta_rl_run_device, {k5} launches per episode batch of {args.envs} envs (at most 5 env steps per env and launch, done-check every 4 launches): per launch "
+                                    "the envs parked at a gate plan (Hungarian - caller's f32 edge scores [N,16,32], trainer gate) -> step -> S_WPS before/after -> next pair tokens, "
+                                    "then every env steps quietly towards its own next gate and writes the tokens it stops on; the score tensor is fixed and device-resident (times the env "
+                                    "side); final metrics bit-equal to the per-step loop's (policy_in_loop_per_step_env_steps_per_s: muavta_rl_step_device, one launch per env step)")
+        # the same two loops with a NETWORK in them (il.rl_stream / il.rl_run_stream: host syncs + a small torch MLP edge scorer on the token tensors,
+        # hidden 32 — the shape of PairCostHybrid's MLP scorer, random weights): what the policy-call count buys end to end
+        try:
+            from muavta_amd.il import rl_run_stream, rl_stream
+
+            g2 = torch.Generator(device=dev); g2.manual_seed(7)
+            Wa = torch.randn((12, 32), generator=g2, device=dev) * 0.3
+            Wt = torch.randn((13, 32), generator=g2, device=dev) * 0.3
+            Wo = torch.randn((32,), generator=g2, device=dev) * 0.3
+
+            def mlp_policy(tok):
+                h = torch.relu((tok["agent_feats"] @ Wa).unsqueeze(2) + (tok["task_feats"] @ Wt).unsqueeze(1))
+                return (torch.tanh(h @ Wo) * 0.35).contiguous()
+
+            net = {}
+            for name, gen_ in (("per_step", lambda: rl_stream(e4, seeds, mlp_policy, n_steps=HORIZON, interval=args.interval)),
+                               ("run_ahead", lambda: rl_run_stream(e4, seeds, mlp_policy, interval=args.interval))):
+                for rep_i in range(2):
+                    t1 = time.perf_counter()
+                    calls = sum(1 for _ in gen_())
+                    dt_n = time.perf_counter() - t1
+                net[name] = {"env_steps_per_s": args.envs * HORIZON / dt_n, "policy_calls": calls}
+            out["policy_in_loop_with_network"] = net
+        except Exception as exc:
+            out["policy_in_loop_with_network"] = {"error": repr(exc)}
         n_flag = int(np.count_nonzero(e4.get("ERROR")))
         out["policy_in_loop_capacity_flagged_envs"] = n_flag
         out["policy_in_loop_mean_S_WPS"] = float(e4.metrics()[:, 4].mean()) if not n_flag else None
@@ -576,35 +650,34 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     except Exception as exc:
         out["policy_in_loop_env_steps_per_s"] = None
         out["policy_in_loop_error"] = repr(exc)
-    # two handles in flight (each its own stream and blobs, same seeds): launches alternate A, B, A, B, so batch i+1's workgroups start in
-    # the wave slots batch i's early finishers free; both handles' batches are checked bit-equal to the headline batch
-    mark("two handles in flight")
+    # the headline loop again on a handle pinned to ONE state lane (launches in order, nothing overlapping: the only mode before round 5)
+    mark("one lane")
     try:
         env.rollout(seeds, HORIZON, args.interval, True, write_obs)
         env.sync()
-        tf = in_flight_figure(args.case, args.envs, args.interval, seeds, write_obs, max(args.steps, 8), 4, barrier, env.device_index, env.rollout_metrics())
-        out["value_two_in_flight"] = tf["env_steps_per_s"]
-        out["value_two_in_flight_is"] = (f"the headline loop with launches alternating between 2 handles (own streams): {tf['ms_per_step']:.3f} ms per launch of "
-                                         f"{args.envs} envs x {HORIZON} steps; each overlapped launch lasts {tf['overlapped_kernel_ms']:.3f} ms; both handles' batches bit-equal to the headline batch")
+        tf = one_lane_figure(args.case, args.envs, args.interval, seeds, write_obs, max(args.steps, 8), 4, barrier, env.device_index, env.rollout_metrics())
+        out["value_one_lane"] = tf["env_steps_per_s"]
+        out["value_one_lane_is"] = (f"the headline loop on a handle with muavta_set_lanes(h, 1): {tf['ms_per_step']:.3f} ms per launch of {args.envs} envs x {HORIZON} steps, k_rollout "
+                                    f"{tf['kernel_ms']:.3f} ms, gap to the next launch {tf['launch_gap_ms']}; its batch is bit-equal to the default handle's")
     except Exception as exc:
-        out["value_two_in_flight"] = None
-        out["value_two_in_flight_error"] = repr(exc)
+        out["value_one_lane"] = None
+        out["value_one_lane_error"] = repr(exc)
     if args.case == "WPS_hard_x2":
         tiles = {}
         for case, n, interval in OTHER_TILES:
             mark(f"other tile {case}")
             e2 = BatchedMultiUAVEnv(params_for_case(case), n, device=env.device_index)
             s2 = np.arange(n, dtype=np.uint64)
-            el, kms, sms = time_rollouts(e2, s2, interval, True, 5, 2, barrier)
+            el, kms, sms = time_rollouts(e2, s2, interval, True, 8, 4, barrier)
             flagged = int(np.count_nonzero(e2.get("ERROR")))
-            tiles[case] = {"env_steps_per_s": n * HORIZON * 5 / el, "envs": n, "tile": f"{e2.dims.tile_agents}x{e2.dims.tile_tasks}",
-                           "interval": interval, "ms_per_step": el / 5 * 1e3, "lds_bytes_per_env": int(e2.dims.lds_bytes),
-                           "capacity_flagged_envs": flagged, "seed_kernel_ms": sms,
-                           "roofline": roofline(case, n, e2.dims.tile_agents, kms)}
+            tiles[case] = {"env_steps_per_s": n * HORIZON * 8 / el, "envs": n, "tile": f"{e2.dims.tile_agents}x{e2.dims.tile_tasks}",
+                           "interval": interval, "ms_per_step": el / 8 * 1e3, "lds_bytes_per_env": int(e2.dims.lds_bytes),
+                           "capacity_flagged_envs": flagged, "seed_kernel_ms": sms, "lanes_allocated": e2.lanes()[1],
+                           "roofline": roofline(case, n, e2.dims.tile_agents, kms, getattr(time_rollouts, "isolated_kernel_ms", None), el / 8 * 1e3, e2.lanes()[1], e2.max_tasks, e2.n_agents)}
             try:
-                tiles[case]["two_in_flight"] = in_flight_figure(case, n, interval, s2, True, 8, 4, barrier, env.device_index, e2.rollout_metrics())
+                tiles[case]["one_lane"] = one_lane_figure(case, n, interval, s2, True, 8, 4, barrier, env.device_index, e2.rollout_metrics())
             except Exception as exc:
-                tiles[case]["two_in_flight"] = {"env_steps_per_s": None, "error": repr(exc)}
+                tiles[case]["one_lane"] = {"env_steps_per_s": None, "error": repr(exc)}
             e2.close()
         out["other_tiles"] = tiles
     return out

@@ -406,6 +406,26 @@ int muavta_step_run(MuavtaEnv* env, const int32_t* act_agent, const int32_t* act
 int muavta_rollout(MuavtaEnv* env, const uint64_t* seeds, int32_t n_steps, int32_t replan_interval,
                    int32_t use_visibility, int32_t write_obs);
 
+/* State lanes: episode batches in flight inside ONE handle.  A fused rollout launch lasts as long as its slowest env; the wave slots its early
+ * finishers free stay empty until it ends.  The reference's evaluation loop runs episode after episode (experiments/wps_eval.py:528-546: cases x
+ * seeds), so the next batch's work exists before this one has finished: a handle may own a SECOND complete set of per-batch device state (env
+ * records, RNG tapes, observation buffers, metrics, streams, seeding slots), and a seeded muavta_rollout / muavta_rollout_record that is issued
+ * while the handle's previous seeded rollout is still running goes to the other lane — its workgroups start in the free wave slots (+3 % / +17 % /
+ * +37 % env-steps/s on BASELINE configs 2 / 4 / 5).  Results are those of the same calls on one lane, bit for bit (env instances are independent).
+ *   lanes 0 (default)  the second lane is created the first time a seeded rollout finds the previous one still running (a caller that
+ *                      synchronises between rollouts never allocates it);   1  one lane only;   2  create it now, seeded rollouts always alternate
+ * After a flip EVERY entry point of the handle refers to the lane of the latest seeded rollout (state, observations, metrics, step calls, ...),
+ * exactly as if that rollout had overwritten the previous batch — which is what it does on one lane.  What the second lane adds is reach-back:
+ *   muavta_rollout_metrics_back(h, 1, out) / muavta_error_flags_back(h, 1, flags)   the batch BEFORE the latest one (its lane is idle or finishing)
+ * (MUAVTA_E_STATE when that batch ran on the SAME lane and has been overwritten: in mode 0 a rollout that finds its predecessor finished does
+ * not flip — use mode 2 for a pipeline that relies on reach-back), so `rollout(seeds[i + 1]); read batch i` keeps two batches in flight.  muavta_sync waits for both lanes; muavta_device_ptrs returns the current
+ * lane's buffers (they change with every flip: fetch them again after a seeded rollout, or pin the handle to one lane).  Device memory per
+ * handle: lanes x n_envs x (MuavtaDims.state_bytes + 19,968 B of RNG tapes + the observation tensors + 240 B of metrics) + 8 MB. */
+int muavta_set_lanes(MuavtaEnv* env, int32_t lanes);
+int muavta_lanes(const MuavtaEnv* env, int32_t* mode, int32_t* allocated);
+int muavta_rollout_metrics_back(MuavtaEnv* env, int32_t back, double* out);
+int muavta_error_flags_back(MuavtaEnv* env, int32_t back, int32_t* flags /* [N] */);
+
 /* Batched observation of the last reset/step (DroneEnv.py:365-415,468-492), feature-major so that
  * the device writes it with contiguous stores (transpose on the host if a row-major view is wanted):
  *   tasks   f32 [N, 21, max_tasks]  rows of the 21 features: id, x, y, status(-1 pad), current_reqs[6],

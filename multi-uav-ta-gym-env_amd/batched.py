@@ -573,8 +573,29 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_metrics(self.h, _vp(m)))
         return m
 
-    def rollout_metrics(self) -> np.ndarray:
+    def set_lanes(self, lanes: int = 0):
+        """State lanes of the handle (include/muavta.h): 0 = a second lane is created when a seeded rollout is issued while the previous one
+        still runs (default), 1 = one lane only, 2 = create it now and always alternate.  With two lanes `rollout(seeds[i + 1])` can be
+        queued before batch i is read: `rollout_metrics(back=1)` / `error_flags(back=1)` reach the batch before the latest one."""
+        self._ck(self.L.muavta_set_lanes(self.h, int(lanes)))
+
+    def lanes(self):
+        """(mode, lanes allocated)"""
+        m, a = C.c_int32(), C.c_int32()
+        self._ck(self.L.muavta_lanes(self.h, C.byref(m), C.byref(a)))
+        return int(m.value), int(a.value)
+
+    def error_flags(self, back: int = 0) -> np.ndarray:
+        """`get("ERROR")` of the latest seeded batch (back=0) or of the one before it on the other lane (back=1)."""
+        out = np.empty(self.n_envs, dtype=np.int32)
+        self._ck(self.L.muavta_error_flags_back(self.h, int(back), _vp(out)))
+        return out
+
+    def rollout_metrics(self, back: int = 0) -> np.ndarray:
         m = np.empty((self.n_envs, N_METRICS), dtype=np.float64)
+        if back:
+            self._ck(self.L.muavta_rollout_metrics_back(self.h, int(back), _vp(m)))
+            return m
         self._ck(self.L.muavta_rollout_metrics(self.h, _vp(m)))
         if self._esc_rows:  # rollout(escalate=True): rows of the envs that were re-run on a larger tile
             for i, row in self._esc_rows.items():

@@ -404,16 +404,16 @@ struct RunOut {
   double* reward_sum;   // [N] rewards of this launch's steps, added in step order
 };
 enum { RUN_SRC_SCORED = 0, RUN_SRC_STAGED = 1, RUN_SRC_ROWS = 2 };
-// The launch's tensors (~45 pointers) sit in device memory, one slot per stream of the handle, and are read through the scalar cache
-// where they are used — like the ring pointers of the recording rollout: as by-value kernel arguments they stayed live across the whole
-// step loop (first build: 259 SGPR spill stores and 60 spilled VGPRs on the 16-agent tile).
+// The launch's tensors (~45 pointers) are a by-value kernel argument that the body never names: it reads them from the KERNARG SEGMENT
+// (constant memory, through the scalar cache) where they are used, like the context.  Named, the compiler loads every argument in the
+// prologue and keeps them live across the step loop (first build: 259 SGPR spill stores and 60 spilled VGPRs on the 16-agent tile).
 template <class TL> struct RunArgs { ScoredDev sc; typename Sim<TL>::TokPtrs K, KP; RunOut R; };
-struct RunBlob { uint32_t w[128]; };  // 512 B: a RunArgs<TL> by value
-__global__ void k_store_run(RunBlob b, uint32_t* dst) { dst[threadIdx.x] = b.w[threadIdx.x]; }
 template <class TL>
-__global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_run(const DevCtx* __restrict__ ctxp, const RunArgs<TL>* __restrict__ argp, int src, int gate, int interval, int use_vis,
+__global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_run(RunArgs<TL> args_in_kernarg_segment, const DevCtx* __restrict__ ctxp, int src, int gate, int interval, int use_vis,
                                                                 int write_obs, int max_steps, const int32_t* act_agent, const int32_t* act_index, int act_cap, int n_envs,
                                                                 int env_base) {
+  static_assert(alignof(RunArgs<TL>) <= 8, "first kernel argument: offset 0 of the kernarg segment");
+  const uint64_t argp = (uint64_t)(uintptr_t)__builtin_amdgcn_kernarg_segment_ptr();
   const DevCtx& ctx0 = ctx_ref(ctxp);
   const int env = env_base + blockIdx.x;
   __shared__ __align__(16) unsigned char lds_own[Lds<TL>::bytes() + SCORED_EXTRA_LDS];
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_run(const DevCtx* __
   EnvState<TL>* blob = blob_of<TL>(ctx0, env);
   copy16(L.S, blob, sizeof(EnvState<TL>));
   lds_sync();
-  const uint32_t arg_lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)argp), arg_hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)argp >> 32));
+  const uint32_t arg_lo = __builtin_amdgcn_readfirstlane((uint32_t)argp), arg_hi = __builtin_amdgcn_readfirstlane((uint32_t)(argp >> 32));
   int n = 0;
   bool at_gate = false;
   double rsum = 0.0;
@@ -961,8 +961,6 @@ struct MuavtaEnv {
   int32_t *d_act_agent = nullptr, *d_act_index = nullptr, *d_call_out = nullptr;
   int32_t *d_list_agent = nullptr, *d_list_index = nullptr;  // muavta_step_lists rows [N][list_cap] (grown on demand)
   void* d_run = nullptr;  // muavta_step_run's outputs: [N] f64 reward sums | [N] i32 steps taken | [N] u8 park flags
-  enum { RUN_SLOT = 512 };
-  void* d_runargs = nullptr;  // [1 + MAX_PARTS][RUN_SLOT]: the RunArgs of the k_run launch in flight on the main stream / on each part stream
   int list_cap = 0;
   ncclComm_t comm = nullptr;  // muavta_comm_init
   int comm_rank = 0, comm_ranks = 0;
@@ -990,8 +988,28 @@ struct MuavtaEnv {
   std::vector<unsigned char> host_blobs, host_cold;  // cache for muavta_get
   bool host_valid = false;
   std::string err;
+  // ---- state lanes (muavta_set_lanes) -----------------------------------------------------------------------------------------------
+  // Everything above is ONE lane: the env records, tapes, observation buffers, metrics, streams, seeding slots and event rings of a batch.
+  // A handle may own a second one (`hl.twin`, a complete MuavtaEnv of the same configuration that no caller ever sees): a seeded rollout
+  // issued while the previous one is still running goes to the other lane — launch i + 1's workgroups start in the wave slots launch i's
+  // early finishers free instead of waiting for its slowest env.  A flip SWAPS the two objects' contents (everything but `hl` and the
+  // communicator), so every entry point keeps working on `*e` = the lane of the latest seeded rollout, without routing.
+  int lane_id = 0;  // travels with the lane's contents
+  struct HandleLevel {
+    MuavtaEnv* twin = nullptr;
+    int lanes_mode = 0;  // 0 auto (second lane on demand), 1 one lane only, 2 always alternate
+    bool twin_failed = false;
+    enum { RING = 64 };
+    unsigned char ring_lane[RING] = {};         // rollout launch k (mod RING) of the HANDLE ran on this lane ...
+    unsigned long long ring_no[RING] = {};      // ... as that lane's launch number
+    unsigned long long n_launches = 0;
+  } hl;
 };
 static int join_parts(MuavtaEnv* e);  // (sub-batches: defined with the other part helpers in front of the C ABI)
+extern "C" int muavta_set_parts(MuavtaEnv* e, int32_t n_parts);
+extern "C" int muavta_set_release_log(MuavtaEnv* e, int32_t enable);
+extern "C" int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, MuavtaEnv** out);
+extern "C" int muavta_destroy(MuavtaEnv* e);
 
 namespace {
 
@@ -1035,7 +1053,7 @@ static void launch_rl_step(MuavtaEnv* e, const ScoredDev& sc, const MuavtaRlStep
 
 template <class TL>
 static void launch_run(MuavtaEnv* e, int src, const ScoredDev& sc, const MuavtaRlStep* rs, const MuavtaRlRun* rr, const RunOut& R, int gate, int interval, int use_vis,
-                       int write_obs, int max_steps, const int32_t* da, const int32_t* di, int cap, hipStream_t stream, int slot, int first, int count) {
+                       int write_obs, int max_steps, const int32_t* da, const int32_t* di, int cap, hipStream_t stream, int first, int count) {
   RunArgs<TL> G;
   memset(&G, 0, sizeof(G));
   G.sc = sc; G.R = R;
@@ -1049,15 +1067,7 @@ static void launch_run(MuavtaEnv* e, int src, const ScoredDev& sc, const MuavtaR
                                 rr->park_n_urgent, nullptr, nullptr, rs->plan.kind, rs->plan.max_tasks, rs->plan.max_agents};
     G.KP = k;
   }
-  static_assert(sizeof(RunArgs<TL>) <= MuavtaEnv::RUN_SLOT, "run-argument slot too small");
-  // (filled by a kernel that takes the struct BY VALUE, stream-ordered behind the previous launch that read the slot: see launch_rollout)
-  RunBlob blob;
-  memset(&blob, 0, sizeof(blob));
-  memcpy(&blob, &G, sizeof(G));
-  uint32_t* dst = (uint32_t*)((char*)e->d_runargs + (size_t)slot * MuavtaEnv::RUN_SLOT);
-  hipLaunchKernelGGL(k_store_run, dim3(1), dim3(128), 0, stream, blob, dst);
-  hipLaunchKernelGGL(k_run<TL>, dim3(count), dim3(WG), 0, stream, (const DevCtx*)e->d_ctx, (const RunArgs<TL>*)dst, src, gate, interval, use_vis, write_obs, max_steps, da, di, cap,
-                     e->n_envs, first);
+  hipLaunchKernelGGL(k_run<TL>, dim3(count), dim3(WG), 0, stream, G, (const DevCtx*)e->d_ctx, src, gate, interval, use_vis, write_obs, max_steps, da, di, cap, e->n_envs, first);
 }
 
 int fill_dev_params(const MuavtaParams* p, DevParams* d, std::string* err) {
@@ -1378,6 +1388,29 @@ int check_errors(MuavtaEnv* e) {  // scan the per-env error words after a synchr
 
 }  // namespace
 
+// ---- state lanes ----------------------------------------------------------------------------------------------------------------------
+static void flip_lanes(MuavtaEnv* e) {  // the other lane's contents move into *e (and this one's into the twin)
+  MuavtaEnv* t = e->hl.twin;
+  std::swap(*e, *t);
+  std::swap(e->hl, t->hl);  // (handle-level state and the RCCL communicator stay with the handle the caller holds)
+  std::swap(e->comm, t->comm); std::swap(e->comm_rank, t->comm_rank); std::swap(e->comm_ranks, t->comm_ranks); std::swap(e->d_comm, t->d_comm);
+}
+static MuavtaEnv* lane_by_id(MuavtaEnv* e, int id) { return e->lane_id == id ? e : e->hl.twin; }
+static int ensure_twin(MuavtaEnv* e) {  // create the second lane (same configuration, allocator, sub-batches, release log)
+  if (e->hl.twin) return MUAVTA_OK;
+  if (e->hl.twin_failed) return MUAVTA_E_HIP;
+  MuavtaEnv* t = nullptr;
+  int rc = muavta_create(&e->params, e->n_envs, e->device, &t);
+  if (rc == MUAVTA_OK && e->n_parts) rc = muavta_set_parts(t, e->n_parts);
+  if (rc == MUAVTA_OK && e->d_rel) rc = muavta_set_release_log(t, 1);
+  if (rc != MUAVTA_OK) { if (t) muavta_destroy(t); e->hl.twin_failed = true; return rc; }
+  t->alloc_mode = e->alloc_mode;
+  t->lane_id = e->lane_id ^ 1;
+  t->hl.lanes_mode = 1;  // (a twin never grows a twin)
+  e->hl.twin = t;
+  return MUAVTA_OK;
+}
+
 // ---- sub-batches on their own streams (muavta_set_parts) ------------------------------------------------------------------
 // Ordering between the handle's main stream and the part streams: an entry point that works on the main stream first makes it
 // wait for whatever the part streams still hold (join_parts) and flags every part to wait for the main stream before its next
@@ -1528,6 +1561,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
 int muavta_destroy(MuavtaEnv* e) {
   if (!e) return MUAVTA_OK;
   muavta_comm_destroy(e);
+  if (e->hl.twin) { muavta_destroy(e->hl.twin); e->hl.twin = nullptr; }
   DeviceScope scope_(e->device);
   if (e->seed_stream) hipStreamSynchronize(e->seed_stream);
   for (int p = 0; p < MuavtaEnv::MAX_PARTS; p++) {
@@ -1535,7 +1569,7 @@ int muavta_destroy(MuavtaEnv* e) {
     if (e->part_ev[p]) hipEventDestroy(e->part_ev[p]);
   }
   if (e->ev_fork) hipEventDestroy(e->ev_fork);
-  hipFree(e->d_part_agent); hipFree(e->d_part_index); if (e->d_run) hipFree(e->d_run); if (e->d_runargs) hipFree(e->d_runargs);
+  hipFree(e->d_part_agent); hipFree(e->d_part_index); if (e->d_run) hipFree(e->d_run);
   if (e->stream) hipStreamSynchronize(e->stream);
   if (e->d_seedtmp) hipFree(e->d_seedtmp); hipFree(e->blobs); hipFree(e->cold); hipFree(e->tapes); hipFree(e->d_ctx); hipFree(e->d_pace); if (e->d_rec) hipFree(e->d_rec); for (int b = 0; b < 2; b++) { hipFree(e->d_seeds[b]); if (e->d_seedbuf[b]) hipFree(e->d_seedbuf[b]); if (e->h_seeds[b]) hipHostFree(e->h_seeds[b]); } hipFree(e->d_act_agent); hipFree(e->d_act_index); if (e->d_list_agent) hipFree(e->d_list_agent); if (e->d_list_index) hipFree(e->d_list_index); hipFree(e->d_call_out); hipFree(e->d_metrics); if (e->d_tok) hipFree(e->d_tok); if (e->d_rel) hipFree(e->d_rel);
   hipFree(e->O.tasks); hipFree(e->O.legal); hipFree(e->O.pad); hipFree(e->O.agents); hipFree(e->O.flags); hipFree(e->O.reward); hipFree(e->O.done);
@@ -1801,9 +1835,7 @@ int muavta_rl_run_device(MuavtaEnv* e, const MuavtaRlRun* rr) {
     MAIN_OP(e);
   }
   RunOut R{rs->s_wps, rs->done, rr->n_stepped, rr->park, rr->reward_sum};
-  if (!e->d_runargs) HIPCHK(e, hipMalloc(&e->d_runargs, (size_t)(1 + MuavtaEnv::MAX_PARTS) * MuavtaEnv::RUN_SLOT));
-  DISPATCH(e, launch_run<TL>(e, RUN_SRC_SCORED, sc, rs, rr, R, sp->gate, sp->replan_interval, sp->use_visibility, rs->write_obs, rr->max_steps, nullptr, nullptr, 0, stream,
-                             rs->part > 0 ? rs->part : 0, first, count));
+  DISPATCH(e, launch_run<TL>(e, RUN_SRC_SCORED, sc, rs, rr, R, sp->gate, sp->replan_interval, sp->use_visibility, rs->write_obs, rr->max_steps, nullptr, nullptr, 0, stream, first, count));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   return MUAVTA_OK;
@@ -1837,8 +1869,7 @@ int muavta_step_run(MuavtaEnv* e, const int32_t* act_agent, const int32_t* act_i
   }
   ScoredDev sc{};
   RunOut R{nullptr, nullptr, d_n, d_park, d_rsum};
-  if (!e->d_runargs) HIPCHK(e, hipMalloc(&e->d_runargs, (size_t)(1 + MuavtaEnv::MAX_PARTS) * MuavtaEnv::RUN_SLOT));
-  DISPATCH(e, launch_run<TL>(e, act_agent ? RUN_SRC_ROWS : RUN_SRC_STAGED, sc, nullptr, nullptr, R, gate, interval, 0, write_obs, max_steps, da, di, e->A, e->stream, 0, 0, e->n_envs));
+  DISPATCH(e, launch_run<TL>(e, act_agent ? RUN_SRC_ROWS : RUN_SRC_STAGED, sc, nullptr, nullptr, R, gate, interval, 0, write_obs, max_steps, da, di, e->A, e->stream, 0, e->n_envs));
   HIPCHK(e, hipGetLastError());
   e->host_valid = false;
   if (n_stepped) HIPCHK(e, hipMemcpyAsync(n_stepped, d_n, N * 4, hipMemcpyDeviceToHost, e->stream));
@@ -1885,6 +1916,12 @@ static int rollout_impl(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, in
   if (!e || n_steps < 0) return MUAVTA_E_ARG;
   if (!seeds && !e->did_reset) { e->err = "rollout without seeds before reset"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
+  if (seeds && e->hl.lanes_mode != 1) {
+    // a fresh episode batch while this lane's last rollout is still running (or always, in mode 2): it goes to the other lane
+    bool want = e->hl.lanes_mode == 2;
+    if (!want && e->n_rollouts) { want = hipEventQuery(e->ev1[(e->n_rollouts - 1) % MuavtaEnv::EV_RING]) == hipErrorNotReady; (void)hipGetLastError(); }
+    if (want && ensure_twin(e) == MUAVTA_OK) flip_lanes(e);
+  }
   MAIN_OP(e);
   const uint64_t* ds = nullptr;
   const uint32_t* sb = nullptr;
@@ -1897,6 +1934,9 @@ static int rollout_impl(MuavtaEnv* e, const uint64_t* seeds, int32_t n_steps, in
   DISPATCH(e, launch_rollout<TL>(e, ds, n_steps, interval, use_vis, write_obs, sb, extra_lds, rec, e->stream, 0, e->n_envs));
   HIPCHK(e, hipGetLastError());
   HIPCHK(e, hipEventRecord(e->ev1[evi], e->stream));
+  e->hl.ring_lane[e->hl.n_launches % MuavtaEnv::HandleLevel::RING] = (unsigned char)e->lane_id;
+  e->hl.ring_no[e->hl.n_launches % MuavtaEnv::HandleLevel::RING] = e->n_rollouts;
+  e->hl.n_launches++;
   e->n_rollouts++;
   e->timing_stale = false;
   if (slot >= 0) { int rc = seeding_consumed(e, slot); if (rc) return rc; }
@@ -1947,6 +1987,7 @@ int muavta_set_parts(MuavtaEnv* e, int32_t n_parts) {
     HIPCHK(e, hipMalloc((void**)&e->d_part_index, (size_t)e->n_envs * e->A * sizeof(int32_t)));
   }
   e->n_parts = n_parts;
+  if (e->hl.twin) return muavta_set_parts(e->hl.twin, n_parts);
   return MUAVTA_OK;
 }
 int muavta_part_range(const MuavtaEnv* e, int32_t part, int32_t* first, int32_t* count) {
@@ -2063,12 +2104,14 @@ int muavta_prof_read(unsigned long long* out, int reset) {  // diagnostic build 
 int muavta_set_allocator(MuavtaEnv* e, int32_t mode) {
   if (!e || (mode < MUAVTA_ALLOC_HUNGARIAN || mode > MUAVTA_ALLOC_HUNGARIAN_GATED)) { if (e) e->err = "unknown allocator mode"; return MUAVTA_E_ARG; }
   e->alloc_mode = mode;
+  if (e->hl.twin) e->hl.twin->alloc_mode = mode;
   return MUAVTA_OK;
 }
 
 int muavta_sync(MuavtaEnv* e) {
   if (!e) return MUAVTA_E_ARG;
   DeviceScope scope_(e->device);
+  if (e->hl.twin) { int rc = muavta_sync(e->hl.twin); if (rc) { e->err = e->hl.twin->err; return rc; } }  // everything queued on the handle: both lanes
   MAIN_OP(e);
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
@@ -2076,6 +2119,7 @@ int muavta_sync(MuavtaEnv* e) {
 
 int muavta_wait_stream(MuavtaEnv* e, void* other_stream) {  // work queued on the handle from now on starts after what `other_stream` holds now
   if (!e) return MUAVTA_E_ARG;
+  if (e->hl.twin) { int rc = muavta_wait_stream(e->hl.twin, other_stream); if (rc) { e->err = e->hl.twin->err; return rc; } }
   DeviceScope scope_(e->device);
   hipEvent_t ev = nullptr;
   HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -2102,13 +2146,17 @@ int muavta_last_kernel_ms(MuavtaEnv* e, float* ms) {
 
 int muavta_kernel_ms_history(MuavtaEnv* e, float* ms, int32_t n) {  // durations of the last n rollout launches, oldest first
   if (!e || !ms || n < 1 || n > MuavtaEnv::EV_RING) { if (e) e->err = "muavta_kernel_ms_history: 1 <= n <= 64"; return MUAVTA_E_ARG; }
-  if ((unsigned long long)n > e->n_rollouts) { e->err = "fewer rollouts launched than asked for"; return MUAVTA_E_STATE; }
+  if ((unsigned long long)n > e->hl.n_launches) { e->err = "fewer rollouts launched than asked for"; return MUAVTA_E_STATE; }
   if (e->timing_stale) { e->err = "muavta_kernel_ms_history: the last rollout was a muavta_rollout_part launch, which records no event pair"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
-  for (int k = 0; k < n; k++) {
-    const int evi = (int)((e->n_rollouts - (unsigned long long)n + (unsigned long long)k) % MuavtaEnv::EV_RING);
-    HIPCHK(e, hipEventSynchronize(e->ev1[evi]));
-    HIPCHK(e, hipEventElapsedTime(&ms[k], e->ev0[evi], e->ev1[evi]));
+  for (int k = 0; k < n; k++) {  // (with two state lanes consecutive launches alternate between the lanes' event rings and may overlap on the device)
+    const unsigned long long h = e->hl.n_launches - (unsigned long long)n + (unsigned long long)k;
+    MuavtaEnv* L = lane_by_id(e, e->hl.ring_lane[h % MuavtaEnv::HandleLevel::RING]);
+    const unsigned long long no = e->hl.ring_no[h % MuavtaEnv::HandleLevel::RING];
+    if (!L || L->n_rollouts - no > (unsigned long long)MuavtaEnv::EV_RING) { e->err = "muavta_kernel_ms_history: that launch's event pair has been reused"; return MUAVTA_E_STATE; }
+    const int evi = (int)(no % MuavtaEnv::EV_RING);
+    HIPCHK(e, hipEventSynchronize(L->ev1[evi]));
+    HIPCHK(e, hipEventElapsedTime(&ms[k], L->ev0[evi], L->ev1[evi]));
   }
   e->last_ms = ms[n - 1];
   return MUAVTA_OK;
@@ -2116,13 +2164,27 @@ int muavta_kernel_ms_history(MuavtaEnv* e, float* ms, int32_t n) {  // durations
 
 int muavta_launch_gaps_ms(MuavtaEnv* e, float* ms, int32_t n) {  // idle time of the handle's stream between the last n rollout launches: n - 1 gaps, oldest first
   if (!e || !ms || n < 2 || n > MuavtaEnv::EV_RING) { if (e) e->err = "muavta_launch_gaps_ms: 2 <= n <= 64"; return MUAVTA_E_ARG; }
-  if ((unsigned long long)n > e->n_rollouts) { e->err = "fewer rollouts launched than asked for"; return MUAVTA_E_STATE; }
+  if ((unsigned long long)n > e->hl.n_launches) { e->err = "fewer rollouts launched than asked for"; return MUAVTA_E_STATE; }
   if (e->timing_stale) { e->err = "muavta_launch_gaps_ms: the last rollout was a muavta_rollout_part launch, which records no event pair"; return MUAVTA_E_STATE; }
   DeviceScope scope_(e->device);
-  for (int k = 0; k + 1 < n; k++) {
-    const int a = (int)((e->n_rollouts - (unsigned long long)n + (unsigned long long)k) % MuavtaEnv::EV_RING), b = (a + 1) % MuavtaEnv::EV_RING;
-    HIPCHK(e, hipEventSynchronize(e->ev0[b]));
-    HIPCHK(e, hipEventElapsedTime(&ms[k], e->ev1[a], e->ev0[b]));  // end of launch i .. start of launch i + 1
+  for (int k = 0; k + 1 < n; k++) {  // end of launch i .. start of launch i + 1 (NEGATIVE when they ran on different lanes and overlapped)
+    const unsigned long long ha = e->hl.n_launches - (unsigned long long)n + (unsigned long long)k, hb = ha + 1;
+    MuavtaEnv* La = lane_by_id(e, e->hl.ring_lane[ha % MuavtaEnv::HandleLevel::RING]);
+    MuavtaEnv* Lb = lane_by_id(e, e->hl.ring_lane[hb % MuavtaEnv::HandleLevel::RING]);
+    const unsigned long long na = e->hl.ring_no[ha % MuavtaEnv::HandleLevel::RING], nb = e->hl.ring_no[hb % MuavtaEnv::HandleLevel::RING];
+    if (!La || !Lb || La->n_rollouts - na > (unsigned long long)MuavtaEnv::EV_RING || Lb->n_rollouts - nb > (unsigned long long)MuavtaEnv::EV_RING) {
+      e->err = "muavta_launch_gaps_ms: an event pair has been reused"; return MUAVTA_E_STATE;
+    }
+    const int a = (int)(na % MuavtaEnv::EV_RING), b = (int)(nb % MuavtaEnv::EV_RING);
+    HIPCHK(e, hipEventSynchronize(Lb->ev0[b]));
+    HIPCHK(e, hipEventSynchronize(La->ev1[a]));
+    if (La == Lb) HIPCHK(e, hipEventElapsedTime(&ms[k], La->ev1[a], Lb->ev0[b]));
+    else {  // events of two streams: elapsed time in either direction, signed
+      float fwd = 0.f;
+      hipError_t r = hipEventElapsedTime(&fwd, La->ev1[a], Lb->ev0[b]);
+      if (r != hipSuccess) { e->err = std::string("hipEventElapsedTime: ") + hipGetErrorString(r); return MUAVTA_E_HIP; }
+      ms[k] = fwd;
+    }
   }
   return MUAVTA_OK;
 }
@@ -2333,6 +2395,7 @@ int muavta_comm_destroy(MuavtaEnv* e) {
 
 int muavta_set_release_log(MuavtaEnv* e, int32_t enable) {
   if (!e) return MUAVTA_E_ARG;
+  if (e->hl.twin) { int rc = muavta_set_release_log(e->hl.twin, enable); if (rc) { e->err = e->hl.twin->err; return rc; } }
   DeviceScope scope_(e->device);
   MAIN_OP(e);
   HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -2472,6 +2535,50 @@ int muavta_rollout_metrics(MuavtaEnv* e, double* out) {  // metrics written by t
   MAIN_OP(e);
   HIPCHK(e, hipMemcpyAsync(out, e->d_metrics, (size_t)e->n_envs * MUAVTA_N_METRICS * sizeof(double), hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+// the lane that holds the rollout launched just before the latest one, if that launch ran on the OTHER lane (else nullptr: overwritten)
+static MuavtaEnv* prev_batch_lane(MuavtaEnv* e) {
+  if (!e->hl.twin || e->hl.n_launches < 2) return nullptr;
+  const int R = MuavtaEnv::HandleLevel::RING;
+  const int last = e->hl.ring_lane[(e->hl.n_launches - 1) % R], prev = e->hl.ring_lane[(e->hl.n_launches - 2) % R];
+  if (last == prev) return nullptr;
+  MuavtaEnv* t = lane_by_id(e, prev);
+  return (t && t != e && t->n_rollouts == e->hl.ring_no[(e->hl.n_launches - 2) % R] + 1) ? t : nullptr;  // (and nothing else was launched on that lane since)
+}
+int muavta_rollout_metrics_back(MuavtaEnv* e, int32_t back, double* out) {  // back 0: the last seeded batch (= muavta_rollout_metrics); 1: the one before it, on the other lane
+  if (!e || !out || back < 0 || back > 1) return MUAVTA_E_ARG;
+  if (back == 0) return muavta_rollout_metrics(e, out);
+  MuavtaEnv* t = prev_batch_lane(e);
+  if (!t) { e->err = "muavta_rollout_metrics_back: the batch before the latest one is gone — it ran on the same lane (the latest rollout found it finished, or there is one lane only); muavta_set_lanes(h, 2) makes seeded rollouts always alternate"; return MUAVTA_E_STATE; }
+  int rc = muavta_rollout_metrics(t, out);
+  if (rc) e->err = t->err;
+  return rc;
+}
+int muavta_error_flags_back(MuavtaEnv* e, int32_t back, int32_t* out) {  // MUAVTA_F_ERROR of the batch `back` launches ago (0 or 1)
+  if (!e || !out || back < 0 || back > 1) return MUAVTA_E_ARG;
+  MuavtaEnv* L = back == 0 ? e : prev_batch_lane(e);
+  if (!L) { e->err = "muavta_error_flags_back: the batch before the latest one is gone (it ran on the same lane)"; return MUAVTA_E_STATE; }
+  int rc = muavta_get(L, MUAVTA_F_ERROR, out, (size_t)L->n_envs * sizeof(int32_t));
+  if (rc && L != e) e->err = L->err;
+  return rc;
+}
+int muavta_set_lanes(MuavtaEnv* e, int32_t lanes) {
+  if (!e || lanes < 0 || lanes > 2) { if (e) e->err = "muavta_set_lanes: 0 (second lane on demand), 1 (one lane) or 2 (always alternate)"; return MUAVTA_E_ARG; }
+  DeviceScope scope_(e->device);
+  if (lanes == 2) { int rc = ensure_twin(e); if (rc) { e->err = "muavta_set_lanes: the second lane could not be created: " + g_create_error; return rc; } }
+  if (lanes == 1 && e->hl.twin) {  // back to one lane: the second lane's batch completes and its memory is released
+    muavta_destroy(e->hl.twin);
+    e->hl.twin = nullptr;
+  }
+  e->hl.lanes_mode = lanes;
+  return MUAVTA_OK;
+}
+int muavta_lanes(const MuavtaEnv* e, int32_t* mode, int32_t* allocated) {
+  if (!e) return MUAVTA_E_ARG;
+  if (mode) *mode = e->hl.lanes_mode;
+  if (allocated) *allocated = e->hl.twin ? 2 : 1;
   return MUAVTA_OK;
 }
 

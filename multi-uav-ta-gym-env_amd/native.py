@@ -34,7 +34,7 @@ EXPORTS = [
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
     "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_domain_log", "muavta_step_lists",
     "muavta_allocate_scored", "muavta_allocate_scored_device", "muavta_rl_step_device", "muavta_launch_gaps_ms",
-    "muavta_rl_run_device", "muavta_step_run",
+    "muavta_rl_run_device", "muavta_step_run", "muavta_set_lanes", "muavta_lanes", "muavta_rollout_metrics_back", "muavta_error_flags_back",
 ]
 
 
@@ -173,6 +173,10 @@ def lib() -> C.CDLL:
     L.muavta_rl_step_device.argtypes = [vp, C.POINTER(MuavtaRlStep)]
     L.muavta_rl_run_device.argtypes = [vp, C.POINTER(MuavtaRlRun)]
     L.muavta_step_run.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
+    L.muavta_set_lanes.argtypes = [vp, i32]
+    L.muavta_lanes.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.muavta_rollout_metrics_back.argtypes = [vp, i32, vp]
+    L.muavta_error_flags_back.argtypes = [vp, i32, vp]
     L.muavta_abi_sizes.argtypes = [C.POINTER(i32 * 3)]
     for name in EXPORTS:
         if name != "muavta_last_error":

@@ -993,10 +993,11 @@ def test_observation_rings_of_the_fused_rollout_vs_oracle(case, interval):
         env.rollout_record(seeds, steps, interval, True, obs_rings={k: v for k, v in rings.items() if k != "obs_done"})
 
 
-def test_queued_rollouts_overlap_seeding_and_keep_their_event_pairs():
+@pytest.mark.parametrize("lanes", [1, 0], ids=["one-lane", "default-lanes"])
+def test_queued_rollouts_overlap_seeding_and_keep_their_event_pairs(lanes):
     """Rollouts queued back to back (the seeding of launch i+1 runs on the handle's second stream under launch i, through two
-    slots) give the same metrics as synchronised ones, for alternating seed sets; kernel_ms_history returns one duration per
-    launch, the newest equal to last_kernel_ms."""
+    slots — and, with the default lanes, launch i+1 itself on the handle's other state lane) give the same metrics as synchronised
+    ones, for alternating seed sets; kernel_ms_history returns one duration per launch, the newest equal to last_kernel_ms."""
     case, n = "WPS_hard_x2", 64
     env = _env(case, n)
     sets = [np.arange(k * 100, k * 100 + n, dtype=np.uint64) for k in range(5)]
@@ -1006,6 +1007,7 @@ def test_queued_rollouts_overlap_seeding_and_keep_their_event_pairs():
         env.sync()
         want.append(env.rollout_metrics())
     env2 = _env(case, n)
+    env2.set_lanes(lanes)
     got = []
     for sd in sets:
         env2.rollout(sd, 150, 20, True, True)   # no sync in between
@@ -1015,6 +1017,7 @@ def test_queued_rollouts_overlap_seeding_and_keep_their_event_pairs():
     assert np.array_equal(env2.rollout_metrics(), want[-1])
     # interleaved: queue two launches, read the metrics of each through a fresh handle's synchronous run
     env3 = _env(case, n)
+    env3.set_lanes(lanes)
     for k, sd in enumerate(sets):
         env3.rollout(sd, 150, 20, True, True)
         env3.reset(sets[(k + 1) % len(sets)])  # a reset in between takes the other seeding slot
@@ -1298,7 +1301,7 @@ def test_comm_abi_single_rank():
     env.close()
 
 
-@pytest.mark.parametrize("extra", [[], ["--abi-collective"], ["--inflight", "2"]], ids=["torch-nccl", "abi-rccl", "two-handles-in-flight"])
+@pytest.mark.parametrize("extra", [[], ["--abi-collective"], ["--lanes", "1"]], ids=["torch-nccl", "abi-rccl", "one-state-lane"])
 def test_bench_under_torchrun_world_size_1(extra):
     """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, nccl backend = RCCL), at world size 1:
     sharding, barrier-bracketed timing, metric reduction and the single JSON line."""
@@ -1318,7 +1321,7 @@ def test_bench_under_torchrun_world_size_1(extra):
     line = [x for x in p.stdout.splitlines() if x.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["total_envs"] == 512 and out["quality"]["n_envs"] == 512
-    assert out["inflight"] == (2 if "--inflight" in extra else 1)
+    assert out["lanes"]["allocated"] == (1 if "--lanes" in extra else 2)  # (launches queued back to back: the default handle runs them on two state lanes)
     want = orc.parallel_metrics("WPS_hard_x2", np.arange(512), 20)
     assert out["quality"]["mean_S_WPS"] == float(want[:, 4].sum()) / 512
 
@@ -1819,20 +1822,84 @@ def test_incremental_observation_rows_equal_a_full_rewrite(case, interval, n, mo
     assert np.array_equal(a.metrics(), b.metrics())
 
 
-def test_in_flight_rollouts_equal_one_handle_at_a_time():
-    """muavta_amd.pipeline.InFlightRollouts: batches alternating between two handles give the batches a single handle gives"""
+@pytest.mark.parametrize("handles", [1, 2])
+def test_in_flight_rollouts_equal_one_handle_at_a_time(handles):
+    """muavta_amd.pipeline.InFlightRollouts: batches in flight on the two state lanes of one handle (and of two handles) give the
+    batches a single one-lane handle gives, launch by launch"""
     from muavta_amd.pipeline import InFlightRollouts
 
     case, n = "WPS_escort24", 256
-    batches = [np.arange(b * n, (b + 1) * n, dtype=np.uint64) for b in range(5)]
-    pipe = InFlightRollouts(params_for_case(case), n, handles=2)
+    batches = [np.arange(b * n, (b + 1) * n, dtype=np.uint64) for b in range(7)]
+    pipe = InFlightRollouts(params_for_case(case), n, handles=handles)
     got = pipe.run(batches, 150, 12)
+    assert all(e.lanes() == (2, 2) for e in pipe.envs)
     pipe.close()
     one = _env(case, n)
+    one.set_lanes(1)
     for b, seeds in enumerate(batches):
         one.rollout(seeds, 150, 12, True, True)
         assert np.array_equal(got[b], one.rollout_metrics()), f"batch {b}"
+    assert one.lanes() == (1, 1)
     assert np.array_equal(got[0], orc.parallel_metrics(case, batches[0], 12))
+
+
+@pytest.mark.parametrize("case,interval,n", [("WPS_hard_x2", 20, 2048), ("WPS_escort24", 12, 1024), ("WPS_burst64", 20, 256)])
+def test_state_lanes_of_one_handle_every_batch_bit_equal_and_every_entry_point_follows_the_latest_batch(case, interval, n):
+    """muavta_set_lanes (default: the second lane appears when a seeded rollout is queued while the previous one still runs): six
+    batches queued back to back on ONE handle, each read through rollout_metrics(back=1) while the next one runs — all 30 metrics
+    of every env of every batch equal the oracle's; afterwards the handle's state, observation, per-step entry points and the
+    launch-time history all refer to the LATEST batch, exactly as on one lane; a handle that synchronises between rollouts never
+    allocates the second lane."""
+    env = _env(case, n)
+    assert env.lanes() == (0, 1)
+    batches = [np.arange(1000 * b, 1000 * b + n, dtype=np.uint64) for b in range(6)]
+    for seeds in batches[:3]:  # default mode, nothing read in between: the second launch finds the first still running
+        env.rollout(seeds, 150, interval, True, True)
+    assert env.lanes() == (0, 2), "launches queued back to back were expected to find the previous one still running"
+    assert np.array_equal(env.rollout_metrics(), orc.parallel_metrics(case, batches[2], interval))
+    env.set_lanes(2)  # always alternate: the pipeline `launch batch b; read batch b - 1` may rely on reach-back
+    got = []
+    for b, seeds in enumerate(batches):
+        env.rollout(seeds, 150, interval, True, True)
+        if b:
+            got.append(env.rollout_metrics(back=1))  # batch b - 1, on the other lane, while batch b runs
+            assert not np.count_nonzero(env.error_flags(back=1))
+    got.append(env.rollout_metrics())
+    for b, seeds in enumerate(batches):
+        assert np.array_equal(got[b], orc.parallel_metrics(case, seeds, interval)), f"{case} batch {b}"
+    ms = env.kernel_ms_history(6)
+    assert ms.shape == (6,) and np.all(ms > 0)
+    # everything follows the latest batch: continue it stepwise against a one-lane handle that ran only that batch
+    ref = _env(case, n)
+    ref.set_lanes(1)
+    ref.rollout(batches[-1], 150, interval, True, True)
+    assert np.array_equal(env.metrics(), ref.metrics())
+    for name in ("AGENT_POS", "TASK_ID", "TASK_STATUS", "SCALARS", "OPEN_IDS", "KNOWN"):
+        assert np.array_equal(env.get(name), ref.get(name)), name
+    oa, ob = env.observe(), ref.observe()
+    assert all(np.array_equal(oa[k], ob[k]) for k in oa)
+    # a fresh episode, 40 fused steps, then per-step calls: on whichever lane the seeded rollout landed
+    env.rollout(batches[0], 40, interval, True, True); ref.rollout(batches[0], 40, interval, True, True)
+    for _ in range(5):
+        aa, ai = env.allocate(interval, True); ba, bi = ref.allocate(interval, True)
+        assert np.array_equal(aa, ba) and np.array_equal(ai, bi)
+        env.step(aa, ai); ref.step(ba, bi)
+    env.rollout(None, 105, interval, True, True); ref.rollout(None, 105, interval, True, True)
+    assert np.array_equal(env.rollout_metrics(), ref.rollout_metrics()) and np.array_equal(env.rollout_metrics(), got[0])
+    from muavta_amd.native import MuavtaError
+    with pytest.raises(MuavtaError):  # the launch before the latest one (the 40-step one) ran on this same lane: gone, and the call says so
+        env.rollout_metrics(back=1)
+    # a caller that synchronises between its rollouts stays on one lane
+    lone = _env(case, 64)
+    for b in range(3):
+        lone.rollout(batches[b][:64], 150, interval, True, True)
+        lone.sync()
+    assert lone.lanes() == (0, 1)
+    # back to one lane: the second one is released, results unchanged
+    env.set_lanes(1)
+    assert env.lanes() == (1, 1)
+    env.rollout(batches[1], 150, interval, True, True)
+    assert np.array_equal(env.rollout_metrics(), got[1])
 
 
 def test_rl_step_by_sub_batches_equals_the_whole_batch_launch():
