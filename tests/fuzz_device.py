@@ -30,7 +30,16 @@ and are compared with the oracle:
             next tokens in one launch) with a seeded score tensor per step: selected mask, gate, step reward, next tokens, done flags
             and the final metrics.
 
-    python tests/fuzz_device.py [first_k [n_configs [seeds_per_config]]]
+  rlrun     the policy consulted once per GATE (muavta_rl_run_device through il.rl_run_stream: the planned step, then empty-action steps up
+            to the env's next gate, at most max_steps of them — drawn per config — under the trainer / escort / allocator gate): per launch
+            the selected mask, gate bit, step reward, done, steps taken, park flags, reward sum, next and park tokens, against the oracle's
+            run-to-the-gate; final metrics and state;
+  steprun   the same run-ahead for a host-side plan (muavta_step_run: the device allocator's plan handed back as action rows or left
+            staged): plan, steps taken, park flags, reward sum and every field + the observation of the state each env stopped in;
+  lanes     ONE handle with two state lanes (muavta_set_lanes): seeded rollouts queued back to back, every batch read through
+            muavta_rollout_metrics_back while the next one runs; all 30 metrics of every batch.
+
+    python tests/fuzz_device.py [first_k [n_configs [seeds_per_config]]] [--more]
 
 Lives under tests/ because it uses the oracle as its checker."""
 import os
@@ -81,10 +90,8 @@ def reserved_bits(rng, n, A):
 
 
 def params(cfg, tile):
-    c = dict(cfg)
-    c["threats_list"] = [tuple(x) for x in c["threats_list"]]
-    c["escort_agent_types"] = tuple(c["escort_agent_types"])
-    return params_from_config(c, None, tile_agents=tile[0], tile_tasks=tile[1], tile_threats=tile[2])
+    from fuzz_device_params import params_of_wide
+    return params_of_wide(cfg, tile)
 
 
 ESCALATED = [0]  # envs whose metric row came from rollout(escalate=True)
@@ -634,6 +641,166 @@ def rl(k, w, log):
     return "ok"
 
 
+def rlrun(k, w, log):
+    import torch
+    from muavta_amd import il
+
+    cfg, seed = w["cfg"], w["seed"]
+    kind = (0, 1)[k % 2]
+    kname = ("pair", "pair_raw")[kind]
+    mt, ma = ((32, 16), (12, 8), (48, 16))[(k // 2) % 3]
+    tile = tiles_for(cfg)[(k // 7) % len(tiles_for(cfg))]
+    gname, interval = (("trainer", 20), ("escort", 12), ("allocator", 7), ("trainer", 5))[(k // 3) % 4]
+    max_steps = (0, 0, 3, 1, 7)[(k // 5) % 5]
+    p = params(cfg, tile)
+    n = 3
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    env = BatchedMultiUAVEnv(p, n)
+    oracles = [orc.OracleEnv(p) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(int(seeds[i]))
+    rng = np.random.default_rng(5000 + k)
+    dev = torch.device("cuda", 0)
+    cur = {}
+
+    def policy(tok):
+        cur["sc"] = (rng.uniform(-1, 1, (n, ma, mt)) * 0.35).astype(np.float32)
+        return torch.from_numpy(cur["sc"]).to(dev)
+
+    tag = f"k={k} rlrun tile {tile} kind {kname} pads {mt}x{ma} gate {gname}/{interval} max_steps {max_steps}"
+    keys = ("task_feats", "agent_feats", "edge_valid", "task_ids", "agent_ids", "task_mask", "agent_mask")
+    try:
+        launches = 0
+        for kk, tr in il.rl_run_stream(env, seeds, policy, interval=interval, kind=kname, max_tasks=mt, max_agents=ma, gate=gname, max_steps=max_steps,
+                                       max_launches=4 * p.max_time_steps + 8):
+            launches += 1
+            if env.get("ERROR").any():
+                return "overflow"
+            sel, rep = tr["selected"].cpu().numpy(), tr["replanned"].cpu().numpy()
+            rew, dn = tr["step_reward"].cpu().numpy(), tr["done"].cpu().numpy()
+            nst, prk, rsum = tr["n_stepped"].cpu().numpy(), tr["park"].cpu().numpy(), tr["reward_sum"].cpu().numpy()
+            nxt = {key: v.cpu().numpy() for key, v in tr["next_tok"].items()}
+            ptk = {key: v.cpu().numpy() for key, v in tr["park_tok"].items()}
+            for i, o in enumerate(oracles):
+                r = o.rl_run(interval, 1, GATE[gname], kind, mt, ma, 1, scores=cur["sc"][i], max_steps=max_steps)
+                t = f"{tag} seed {seeds[i]} launch {kk}"
+                assert int(nst[i]) == r["n_stepped"] and int(prk[i]) == r["park"] and bool(rep[i]) == r["replanned"], f"{t}: steps / park / gate {nst[i]} {prk[i]} {rep[i]} vs {r['n_stepped']} {r['park']} {r['replanned']}"
+                assert np.array_equal(sel[i], r["selected"]), f"{t}: selected mask"
+                assert rew[i] == (r["s_after"] - r["s_before"]) / 20.0 and int(dn[i]) == r["done"], f"{t}: step reward / done"
+                assert rsum[i] == r["reward_sum"], f"{t}: reward sum {rsum[i]} vs {r['reward_sum']}"
+                for which, got, want in (("next", nxt, r.get("next_tok")), ("park", ptk, r["park_tok"])):
+                    if want is None:
+                        continue
+                    for key in keys:
+                        assert np.array_equal(got[key][i], want[key]), f"{t}: {which} tokens: {key}"
+                    assert int(got["n_urgent"][i]) == want["n_urgent"], f"{t}: {which} tokens: n_urgent"
+        assert all(o.dims()["terminated"] or o.dims()["truncated"] for o in oracles), f"{tag}: the stream ended after {launches} launches with an episode still running"
+        m = env.metrics()
+        env.refresh_observation()
+        snap = Snapshot(env)
+        for i, o in enumerate(oracles):
+            assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: final metrics"
+            compare(snap, i, o, f"{tag} seed {seeds[i]} final state", check_obs=False)
+    except AssertionError as exc:
+        log(f"RLRUN MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
+def steprun(k, w, log):
+    cfg, seed, interval = w["cfg"], w["seed"], w["interval"]
+    tile = tiles_for(cfg)[(k // 11) % len(tiles_for(cfg))]
+    gname = ("trainer", "escort", "allocator")[k % 3]
+    p = params(cfg, tile)
+    n = 3
+    seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
+    env = BatchedMultiUAVEnv(p, n)
+    oracles = [orc.OracleEnv(p) for _ in range(n)]
+    env.reset(seeds)
+    for i, o in enumerate(oracles):
+        o.reset(int(seeds[i]))
+    tag = f"k={k} steprun tile {tile} gate {gname}/{interval}"
+    try:
+        launches = 0
+        while True:
+            cap = (0, 4, 0, 1)[(k + launches) % 4]
+            aa, ai = env.allocate(interval, True)
+            if env.get("ERROR").any():
+                return "overflow"
+            for i, o in enumerate(oracles):
+                oa, oi = o.allocate(interval, 1)
+                kk = len(oa)
+                assert np.array_equal(aa[i][:kk], oa) and np.all(aa[i][kk:] == -1) and np.array_equal(ai[i][:kk], oi), f"{tag} seed {seeds[i]} launch {launches}: plan"
+            nst, prk, rs = env.step_run(aa, ai, gate=gname, replan_interval=interval, max_steps=cap) if launches % 2 else env.step_run(None, None, gate=gname, replan_interval=interval, max_steps=cap)
+            snap = Snapshot(env)
+            if snap.ERROR.any():
+                return "overflow"
+            for i, o in enumerate(oracles):
+                d = o.dims()
+                if d["terminated"] or d["truncated"]:
+                    assert nst[i] == 0 and (prk[i] & 3), f"{tag} seed {seeds[i]} launch {launches}: an ended episode stepped"
+                    continue
+                na = int((aa[i] >= 0).sum())
+                o.step(aa[i][:na], ai[i][:na])
+                q, ag, rq = o.run_quiet(GATE[gname], interval, cap, 1, float(o.scalars()[1]))
+                dd = o.dims()
+                want_park = int(dd["terminated"]) | (int(dd["truncated"]) << 1) | (4 if ag else 0)
+                assert int(nst[i]) == 1 + q and int(prk[i]) == want_park and rs[i] == rq, f"{tag} seed {seeds[i]} launch {launches}: {nst[i]} {prk[i]} {rs[i]} vs {1 + q} {want_park} {rq}"
+                compare(snap, i, o, f"{tag} seed {seeds[i]} launch {launches}")
+            launches += 1
+            if np.all(prk & 3):
+                break
+            assert launches <= 4 * p.max_time_steps + 8, f"{tag}: no end"
+        m = env.metrics()
+        for i, o in enumerate(oracles):
+            assert np.array_equal(m[i], o.metrics()), f"{tag} seed {seeds[i]}: final metrics"
+    except AssertionError as exc:
+        log(f"STEPRUN MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
+def lanes(k, w, log):
+    cfg, interval, seed = w["cfg"], w["interval"], w["seed"]
+    tile = tiles_for(cfg)[(k // 13) % len(tiles_for(cfg))]
+    p = params(cfg, tile)
+    n, steps, rounds = 8, p.max_time_steps, 5
+    mode, name = MODES[(k // 2) % 4]
+    base = min(seed, 2 ** 62)
+    env = BatchedMultiUAVEnv(p, n)
+    tag = f"k={k} lanes tile {tile} mode {name}"
+    try:
+        env.set_allocator(name)
+        env.set_lanes(2)
+        batches = [np.arange(base + 100 * r, base + 100 * r + n, dtype=np.uint64) for r in range(rounds)]
+        got, errs = [], []
+        for r, sd in enumerate(batches):
+            env.rollout(sd, steps, interval, True, bool((k + r) & 1))  # queued: batch r - 1 is read while batch r runs
+            if r:
+                got.append(env.rollout_metrics(back=1)); errs.append(env.error_flags(back=1))
+        got.append(env.rollout_metrics()); errs.append(env.error_flags())
+        o = orc.OracleEnv(p)
+        for r, sd in enumerate(batches):
+            for i in range(n):
+                if errs[r][i]:
+                    continue
+                o.rollout_mode(int(sd[i]), steps, interval, 1, mode)
+                assert np.array_equal(got[r][i], o.metrics()), f"{tag} batch {r} seed {int(sd[i])}: metric columns {np.nonzero(got[r][i] != o.metrics())[0].tolist()}"
+    except AssertionError as exc:
+        log(f"LANES MISMATCH {str(exc)[:600]}")
+        return "bad"
+    finally:
+        env.close()
+    return "ok"
+
+
+LEGS = ("stepwise", "scored", "lists", "rl", "rings", "mutators", "resume", "ilrings", "inflight", "rlrun", "steprun", "lanes")
+
+
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     first = int(args[0]) if len(args) > 0 else 0
@@ -645,7 +812,8 @@ if __name__ == "__main__":
 
     t0 = time.time()
     tot = {"fused_bad": 0, "fused_flagged": 0, "fused_checked": 0, "step_ok": 0, "step_bad": 0, "step_overflow": 0, "scored_ok": 0, "scored_bad": 0,
-           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "resume_overflow": 0, "ilrings_ok": 0, "ilrings_bad": 0, "inflight_ok": 0, "inflight_bad": 0, "errors": 0}
+           "scored_overflow": 0, "lists_ok": 0, "lists_bad": 0, "lists_overflow": 0, "rl_ok": 0, "rl_bad": 0, "rl_overflow": 0, "rings_ok": 0, "rings_bad": 0, "mutators_ok": 0, "mutators_bad": 0, "mutators_overflow": 0, "resume_ok": 0, "resume_bad": 0, "resume_overflow": 0, "ilrings_ok": 0, "ilrings_bad": 0, "inflight_ok": 0, "inflight_bad": 0,
+           "rlrun_ok": 0, "rlrun_bad": 0, "rlrun_overflow": 0, "steprun_ok": 0, "steprun_bad": 0, "steprun_overflow": 0, "lanes_ok": 0, "lanes_bad": 0, "errors": 0}
     for k in range(first, first + n_cfg):
         w = wide_config(k)
         try:
@@ -661,6 +829,9 @@ if __name__ == "__main__":
                 tot["resume_" + resume(k, w, log)] += 1
                 tot["ilrings_" + ilrings(k, w, log)] += 1
                 tot["inflight_" + inflight(k, w, log)] += 1
+                tot["rlrun_" + rlrun(k, w, log)] += 1
+                tot["steprun_" + steprun(k, w, log)] += 1
+                tot["lanes_" + lanes(k, w, log)] += 1
         except Exception as exc:  # a configuration the library rejects (muavta_create's argument checks): reported, not fatal
             if "overflowed a tile" in str(exc):  # (a capacity flag met by a call that refuses flagged batches, e.g. the facade's metrics)
                 tot["capacity_exceptions"] = tot.get("capacity_exceptions", 0) + 1

@@ -106,3 +106,85 @@ def test_four_ranks_with_unequal_shards():
     assert r["n_on_time"] == int(c[0]) and r["n_missed_windows"] == int(c[1]) and r["Kills"] == int(whole[:, 7].sum())
     assert abs(r["sum_S_WPS"] - float(f[0])) <= 1e-9 * max(1.0, abs(float(f[0])))
     assert abs(r["mean_S_WPS"] - whole[:, 4].mean()) < 1e-9
+
+
+def _run_ranks(world, backend, jobs, timeout=600):
+    import dist_workers
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=dist_workers.fuzz_rank, args=(r, world, port, q, backend, jobs)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=timeout) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return results
+
+
+def check_rank_results(results, world, jobs, truth_backend="oracle"):
+    """every rank holds the same summary of every job, and it is the rank-ordered reduction of the single-process truth"""
+    import dist_workers
+    for r in range(1, world):
+        assert results[r] == results[0], f"rank {r} ended with another summary than rank 0"
+    for (k, cfg, tile, shards, interval, steps), (k2, got, flagged) in zip(jobs, results[0]):
+        assert k == k2
+        whole, _ = dist_workers.shard_metrics(truth_backend, cfg, tile, 0, sum(shards), interval, steps)
+        flagged_all = sorted(i for r in range(world) for i in results[r][[j[0] for j in jobs].index(k)][2])
+        parts, lo = [], 0
+        for n in shards:
+            keep = [i for i in range(lo, lo + n) if i not in flagged_all]
+            parts.append(partial_sums(whole[keep].reshape(-1, 30)))
+            lo += n
+        f = parts[0][0].copy()
+        for pf, _ in parts[1:]:
+            f = f + pf                      # rank order, as reduce_metrics adds the gathered partials
+        c = sum(pc for _, pc in parts)
+        assert got["n_envs"] == int(c[-1]) == sum(shards) - len(flagged_all), f"k={k}: env count"
+        assert got["n_on_time"] == int(c[0]) and got["n_missed_windows"] == int(c[1]) and got["Kills"] == int(c[6]), f"k={k}: integer totals"
+        assert got["sum_S_WPS"] == float(f[0]) and got["sum_total_distance"] == float(f[2]), f"k={k}: rank-ordered float sums are bit-stable"
+        if got["n_envs"]:
+            assert got["mean_S_WPS"] == float(f[0] / got["n_envs"])
+
+
+def fuzz_jobs(first_k, n_jobs, world, rng, max_agents=16):
+    from fuzz_reference import wide_config
+    jobs, k = [], first_k
+    while len(jobs) < n_jobs:
+        w = wide_config(k)
+        cfg = w["cfg"]
+        na, nh = sum(cfg["agents"].values()), sum(n for _, n in cfg["threats_list"])
+        tile = (16, 40, 16) if (na <= 16 and nh <= 16) else (24, 48, 24) if (na <= 24 and nh <= 24) else (64, 128, 48)
+        if na <= max_agents:
+            shards = [int(x) for x in rng.integers(0 if world > 2 else 1, 6, world)]
+            if sum(shards) == 0:
+                shards[0] = 1
+            jobs.append((k, cfg, tile, shards, w["interval"], min(int(cfg["max_time_steps"]), 150)))
+        k += 1
+    return jobs
+
+
+def test_random_configurations_unequal_and_empty_shards_2_to_4_ranks():
+    """The N > 1 leg of the wide fuzz (container: oracle stand-in for the device): 2, 3 and 4 gloo ranks, shard sizes drawn per configuration
+    (unequal, some EMPTY — a rank that owns no env of a batch still joins the collective), random wide_config draws with their own replan
+    interval and horizon, through dist.reduce_metrics; every rank ends with the same summary = the rank-ordered reduction of the truth."""
+    rng = np.random.default_rng(77)
+    for world, first in ((2, 50000), (3, 50100), (4, 50200)):
+        jobs = fuzz_jobs(first, 5, world, rng)
+        check_rank_results(_run_ranks(world, "oracle", jobs), world, jobs)
+
+
+def test_comm_abi_argument_paths_without_a_device():
+    """muavta_comm_* / muavta_allreduce_metrics reject bad arguments before they touch a device or RCCL (the same checks the N > 1 path
+    meets on a GPU box): NULL handle, NULL uid, counts beyond 64, missing buffers."""
+    import ctypes as C
+    from muavta_amd import native
+    L = native.lib()
+    assert L.muavta_comm_uid(None) == -1
+    assert L.muavta_comm_init(None, 0, 2, None) == -1
+    assert L.muavta_allreduce_metrics(None, None, 0, None, 0, None, None) == -1
+    assert L.muavta_comm_destroy(None) == -1
+    assert L.muavta_set_lanes(None, 2) == -1 and L.muavta_rollout_metrics_back(None, 1, None) == -1

@@ -1129,7 +1129,8 @@ def test_wide_fuzz_regressions_stepwise_vs_oracle_and_reference_metrics(path):
 
 @pytest.mark.parametrize("leg,k", [("mutators", 12794), ("mutators", 12782), ("mutators", 14016), ("mutators", 14068), ("mutators", 14173),
                                    ("scored", 7178), ("mutators", 1001642), ("stepwise", 992), ("stepwise", 40), ("rl", 12041), ("lists", 12042), ("rings", 12043),
-                                   ("resume", 17001), ("ilrings", 18801), ("inflight", 21001)])
+                                   ("resume", 17001), ("ilrings", 18801), ("inflight", 21001), ("rlrun", 22001), ("rlrun", 1003001), ("steprun", 22002),
+                                   ("steprun", 2002001), ("lanes", 22003)])
 def test_wide_fuzz_legs_on_the_configurations_that_found_bugs(leg, k):
     """One episode of a leg of tests/fuzz_device.py on the configurations that exposed device bugs (the allocator's list after an
     out-of-step _retire_escort / _create_escort_for, the recon-as-escort retire verdicts, rows beyond max_tasks, the expired escort
@@ -2073,3 +2074,60 @@ def test_step_run_host_planner_runs_ahead_to_its_gate_vs_oracle(case, interval, 
     for i, o in enumerate(oracles):
         assert np.array_equal(m[i], o.metrics()), f"{case} seed {i}: final metrics"
     assert launches < int(total.max())  # fewer launches than env steps: that is the point
+
+
+def test_device_fuzz_fresh_slice():
+    """A slice of the wide device fuzz (tests/fuzz_device.py: the fused rollout on every tile that holds the fleet + all twelve legs) on
+    configurations NO earlier run has seen: the first id of each family (small / large-fleet / EDGE of tests/fuzz_reference.py::wide_config)
+    comes from the committed counter file tests/fuzz_counter.json, which the builder bumps every round past everything its own batches
+    covered.  Round 4's seven device bugs were all invisible to the case-based tests and found by this driver; ~150 s of it now run wherever
+    `pytest -m gpu` runs (MUAVTA_FUZZ_SLICE_SECONDS overrides the budget).  A mismatch fails the test with the configuration id and leg."""
+    import json
+    import time
+
+    import fuzz_device as FD
+    from fuzz_reference import wide_config
+
+    budget = float(os.environ.get("MUAVTA_FUZZ_SLICE_SECONDS", "150"))
+    counter = json.load(open(os.path.join(os.path.dirname(__file__), "fuzz_counter.json")))
+    fams = [(f, int(counter[f])) for f in ("small", "large", "edge")]
+    msgs, notes, tot, covered = [], [], {}, {f: 0 for f, _ in fams}
+    t0, i = time.time(), 0
+    while time.time() - t0 < budget:
+        fam, base = fams[i % len(fams)]
+        k = base + i // len(fams)
+        w = wide_config(k)
+        log = lambda m, k=k, fam=fam: (notes if " note: " in m else msgs).append(f"[{fam} k={k}] {m}")  # noqa: E731  ("note": an env beyond the LARGEST tile, flagged and skipped)
+        try:
+            b, f, c = FD.fused(k, w, 3, log)
+            tot["fused_bad"] = tot.get("fused_bad", 0) + b; tot["fused_flagged"] = tot.get("fused_flagged", 0) + f; tot["fused_checked"] = tot.get("fused_checked", 0) + c
+            for leg in FD.LEGS:
+                key = f"{leg}_{getattr(FD, leg)(k, w, log)}"
+                tot[key] = tot.get(key, 0) + 1
+        except Exception as exc:  # (a capacity flag met by a call that refuses flagged batches; a configuration muavta_create rejects)
+            if "overflowed a tile" in str(exc):
+                tot["capacity_exceptions"] = tot.get("capacity_exceptions", 0) + 1
+            else:
+                msgs.append(f"[{fam} k={k}] ERROR {type(exc).__name__}: {str(exc)[:300]}")
+        covered[fam] += 1
+        i += 1
+    summary = {"round": counter.get("round"), "seconds": round(time.time() - t0, 1), "configs": i,
+               "ranges": {f: [b, b + covered[f] - 1] for f, b in fams if covered[f]}, "totals": tot, "mismatches": msgs[:20], "capacity_notes": len(notes)}
+    print("device fuzz, fresh slice:", json.dumps(summary))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+    if os.path.isdir(out_dir):
+        json.dump(summary, open(os.path.join(out_dir, "fuzz_fresh_slice.json"), "w"), indent=1)
+    assert i >= 3, "the slice ran fewer than one configuration per family"
+    assert not msgs and not tot.get("fused_bad"), msgs[:5]
+
+
+def test_n_ranks_with_unequal_shards_on_the_one_gpu_random_configurations():
+    """The N > 1 path with the PRODUCT on hardware: three ranks (spawned processes, one handle each on this box's one GPU, the collective over
+    gloo: RCCL wants a GPU per rank), shard sizes drawn per configuration (unequal, some empty), random wide_config draws on the tile that
+    holds their fleet — dist.reduce_metrics on every rank = the rank-ordered reduction of the ORACLE's metrics of the same global indices."""
+    from test_dist_cpu import _run_ranks, check_rank_results, fuzz_jobs
+
+    rng = np.random.default_rng(78)
+    world = 3
+    jobs = fuzz_jobs(51000, 6, world, rng, max_agents=24) + fuzz_jobs(1011000, 2, world, rng, max_agents=64)
+    check_rank_results(_run_ranks(world, "hip", jobs, timeout=900), world, jobs, truth_backend="oracle")
