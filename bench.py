@@ -278,6 +278,73 @@ def one_lane_figure(case, n, interval, seeds, write_obs, steps, warmup, barrier,
         h.close()
 
 
+def facade_figures(device, case="WPS_hard", seeds=range(8), batch_n=64):
+    from muavta_amd.env import MultiUAVEnv
+    from muavta_amd.scenarios import CASE_SPECS, TILES, WPS_ENV_FLAGS
+
+    ta, tt, th = TILES[case]
+    kw = dict(flags=dict(WPS_ENV_FLAGS), device=device, tile_agents=ta, tile_tasks=tt, tile_threats=th)
+
+    def harness_reads(env):
+        live = env.get_live_agents()
+        open_tasks = [t for t in env.tasks if t.id != 0 and t.status != 2]
+        vis = env.agent_visibility_map()
+        return live, open_tasks, vis
+
+    def plan_to_actions(env, aa, ai):
+        pairs = [(env.agents_obj[int(a)].name, env.last_tasks_info[int(i)]) for a, i in zip(aa[0], ai[0]) if a >= 0]
+        actions = {}
+        for name, task in pairs:  # _apply_assign (experiments/wps_eval.py:55-61)
+            if env.last_tasks_info and task in env.last_tasks_info:
+                actions[name] = env.last_tasks_info.index(task)
+        return actions
+
+    env = MultiUAVEnv(CASE_SPECS[case], **kw)
+    n_steps, t_total = 0, 0.0
+    for k, seed in enumerate([0] + list(seeds)):  # (the first episode warms up)
+        t0 = time.perf_counter()
+        obs, info = env.reset(seed=seed)
+        done, n = False, 0
+        while not done:
+            harness_reads(env)
+            actions = plan_to_actions(env, *env._b.allocate(20, True))
+            obs, rew, term, trunc, info = env.step(actions)
+            n += 1
+            done = all(term.values()) or all(trunc.values())
+        if k:
+            n_steps += n; t_total += time.perf_counter() - t0
+    single = n_steps / t_total
+    s_wps = float(info["metrics"]["S_WPS"])
+    # the vectorised facade: batch_n env objects over ONE handle, the same per-env Python loop
+    batch = MultiUAVEnv.batch(CASE_SPECS[case], batch_n, **kw)
+    rate_b = None
+    for rep in range(2):
+        t0 = time.perf_counter()
+        outs = batch.reset(list(range(batch_n)))
+        n = 0
+        while True:
+            acts = []
+            for v in batch.envs:
+                harness_reads(v)
+                acts.append(plan_to_actions(v, *v._b.allocate(20, True)))
+            outs = batch.step(acts)
+            n += 1
+            if all(all(o[3].values()) or all(o[2].values()) for o in outs):
+                break
+        rate_b = batch_n * n / (time.perf_counter() - t0)
+    batch.close()
+    return {"facade_steps_per_s": single,
+            "facade_is": (f"muavta_amd.env.MultiUAVEnv (HIP backend, 1 env per handle), {case} seeds {list(seeds)[0]}..{list(seeds)[-1]}, the loop of experiments/wps_eval.py:112-133,273 "
+                          "(live agents / open tasks / visibility map read every step, plan as [(name, Task)] -> _apply_assign -> env.step(dict) -> observation dicts); the plan itself is the "
+                          "device allocator's, read back (the reference's Python HungarianAllocator cannot travel to this box: ~4 % of the reference's step time)"),
+            "facade_vs_reference_python": single / 1166.0,
+            "facade_reference_python_steps_per_s": 1166.0,
+            "facade_reference_is": "BASELINE.md: the reference's own loop, WPS_hard, 1 process, measured in the build container (8-vCPU Xeon 2.1 GHz — NOT this box's CPU; the reference cannot travel)",
+            "facade_batch_env_steps_per_s": rate_b, "facade_batch_envs": batch_n,
+            "facade_batch_is": f"MultiUAVEnv.batch({batch_n}): the same per-env Python loop over {batch_n} env objects that share ONE handle (one launch + one state mirror + one observation copy per step for all)",
+            "facade_last_episode_S_WPS": s_wps}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -662,6 +729,16 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     except Exception as exc:
         out["value_one_lane"] = None
         out["value_one_lane_error"] = repr(exc)
+    # the drop-in PettingZoo facade (muavta_amd.env.MultiUAVEnv over the HIP backend) in the loop shape of experiments/wps_eval.py:112-133,273:
+    # per step the harness reads the live agents, the open tasks (env.tasks filtered by status) and the visibility map, gets its plan as
+    # [(agent name, Task)] — here the device allocator's plan read back, in place of the reference's Python HungarianAllocator, which cannot travel
+    # to this box — maps it through env.last_tasks_info like _apply_assign, and calls env.step(actions dict) -> observation dicts.
+    mark("facade")
+    try:
+        out.update(facade_figures(env.device_index))
+    except Exception as exc:
+        out["facade_steps_per_s"] = None
+        out["facade_error"] = repr(exc)
     if args.case == "WPS_hard_x2":
         tiles = {}
         for case, n, interval in OTHER_TILES:

@@ -95,9 +95,9 @@ typedef struct MuavtaParams {
   /* Tile (capacity) of one env instance in device memory; 0 = derive a default. */
   int32_t tile_agents;   /* >= n_agents; 16 / 24 / 64 in BASELINE configs */
   int32_t tile_tasks;    /* live task slots (open + retired-but-referenced); 40 / 48 / 128.  The library picks the smallest built tile
-                            that holds (tile_agents, tile_tasks, tile_threats); a tile_tasks below 40 (the smallest tile's slot count) caps the
-                            slots an env may use at that number (field widths stay the tile's: MuavtaDims.tile_tasks) — an env that needs
-                            more sets MUAVTA_F_ERROR, which is how the capacity path (BatchedMultiUAVEnv.rollout(escalate=True)) is tested */
+                            that holds (tile_agents, tile_tasks, tile_threats): any request up to 40 gets the 40-slot tile (MuavtaDims.tile_tasks
+                            says what was chosen).  (Round 4 briefly read a value below 40 as a cap on the live slots; that test hook is
+                            muavta_set_slot_cap now and this field means what it always meant.) */
   int32_t tile_threats;  /* >= sum(threat_count) */
   int32_t random_init_pos; /* config.random_init_pos (DroneEnv.py:607) */
 } MuavtaParams;
@@ -425,6 +425,11 @@ int muavta_set_lanes(MuavtaEnv* env, int32_t lanes);
 int muavta_lanes(const MuavtaEnv* env, int32_t* mode, int32_t* allocated);
 int muavta_rollout_metrics_back(MuavtaEnv* env, int32_t back, double* out);
 int muavta_error_flags_back(MuavtaEnv* env, int32_t back, int32_t* flags /* [N] */);
+
+/* Test hook for the capacity path (the reference's task list is unbounded, DroneEnv.py:325-328; the tiles are not): an env may use at most
+ * `cap` of its tile's task slots (0 = all); one that needs more sets MUAVTA_F_ERROR exactly as on a full tile, which is how
+ * BatchedMultiUAVEnv.rollout(escalate=True) and the capped-tile fuzz runs are driven.  Field widths stay the tile's.  Synchronises. */
+int muavta_set_slot_cap(MuavtaEnv* env, int32_t cap);
 
 /* Batched observation of the last reset/step (DroneEnv.py:365-415,468-492), feature-major so that
  * the device writes it with contiguous stores (transpose on the host if a row-major view is wanted):

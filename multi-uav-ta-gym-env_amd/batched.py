@@ -143,8 +143,8 @@ class BatchedMultiUAVEnv:
                 if t is None:
                     continue
                 shape, size = shapes[name]
-                if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != size:
-                    raise ValueError(f"allocate_scored: {name} must be a contiguous CUDA tensor of shape {shape} with {size}-byte elements")
+                if tuple(t.shape) != shape or not t.is_cuda or not t.is_contiguous() or t.element_size() != size or t.device.index != self.device_index:
+                    raise ValueError(f"allocate_scored: {name} must be a contiguous tensor of shape {shape} with {size}-byte elements on cuda:{self.device_index}")
                 setattr(spec, name, t.data_ptr())
             self._ck(self.L.muavta_allocate_scored_device(self.h, C.byref(spec)))
             return out
@@ -572,6 +572,12 @@ class BatchedMultiUAVEnv:
         m = np.empty((self.n_envs, N_METRICS), dtype=np.float64)
         self._ck(self.L.muavta_metrics(self.h, _vp(m)))
         return m
+
+    def set_slot_cap(self, cap: int = 0):
+        """Test hook (muavta_set_slot_cap): an env may use at most `cap` of its tile's task slots (0: all) — overflow raises the capacity
+        flag exactly as a full tile does."""
+        self._ck(self.L.muavta_set_slot_cap(self.h, int(cap)))
+        self.slot_cap = int(cap)
 
     def set_lanes(self, lanes: int = 0):
         """State lanes of the handle (include/muavta.h): 0 = a second lane is created when a seeded rollout is issued while the previous one

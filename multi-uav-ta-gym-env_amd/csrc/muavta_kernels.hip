@@ -583,9 +583,18 @@ __global__ __launch_bounds__(WG, TILE_MIN_WAVES(TL)) void k_rollout(const DevCtx
 // (r2, r3) every step's 16-lane read went to the memory side of the fabric (~2 us on this eight-XCD part) and — VMEM loads return in
 // order — the step's first `s_waitcnt vmcnt(0)` waited for it: tools/ablate_probe.py measured the whole pacing block at 0.35 ms of a
 // 1.19 ms quiet launch.  Headline 240 -> 248 M on one box (profiles/r04_ab_pacing.txt); publishing every 2nd / 4th step changes nothing.
+// NOTE on the memory model: the waves that share a row belong to DIFFERENT workgroups (one env per workgroup), and workgroup scope
+// promises nothing across workgroups — it works because they share a CU's L1, and would stop working under tgsplit / another CU mode.
+// Correctness never depends on a loaded value: the row only feeds s_setprio and (MUAVTA_PACE_HOLD builds) a sleep loop whose polls are
+// bounded by MUAVTA_PACE_HOLD_POLLS; a build that holds on these values uses AGENT scope.  -DMUAVTA_PACE_SCOPE overrides.
 #ifndef MUAVTA_PACE_SCOPE
+#if MUAVTA_PACE_HOLD
+#define MUAVTA_PACE_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#else
 #define MUAVTA_PACE_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 #endif
+#endif
+static_assert(MUAVTA_PACE_HOLD_POLLS > 0 && MUAVTA_PACE_HOLD_POLLS <= (1 << 16), "the hold loop of the pacing block must be poll-bounded");
 #ifndef MUAVTA_PACE_EVERY
 #define MUAVTA_PACE_EVERY 1  // publish / read / re-rank every n-th step (a power of two)
 #endif
@@ -1010,6 +1019,7 @@ extern "C" int muavta_set_parts(MuavtaEnv* e, int32_t n_parts);
 extern "C" int muavta_set_release_log(MuavtaEnv* e, int32_t enable);
 extern "C" int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, MuavtaEnv** out);
 extern "C" int muavta_destroy(MuavtaEnv* e);
+extern "C" int muavta_set_slot_cap(MuavtaEnv* e, int32_t cap);
 
 namespace {
 
@@ -1405,6 +1415,7 @@ static int ensure_twin(MuavtaEnv* e) {  // create the second lane (same configur
   if (rc == MUAVTA_OK && e->d_rel) rc = muavta_set_release_log(t, 1);
   if (rc != MUAVTA_OK) { if (t) muavta_destroy(t); e->hl.twin_failed = true; return rc; }
   t->alloc_mode = e->alloc_mode;
+  if (e->P.slot_cap && muavta_set_slot_cap(t, e->P.slot_cap) != MUAVTA_OK) { muavta_destroy(t); e->hl.twin_failed = true; return MUAVTA_E_HIP; }
   t->lane_id = e->lane_id ^ 1;
   t->hl.lanes_mode = 1;  // (a twin never grows a twin)
   e->hl.twin = t;
@@ -1488,7 +1499,7 @@ int muavta_create(const MuavtaParams* params, int32_t n_envs, int32_t device, Mu
   else if (ta <= Tile64::A && tt <= Tile64::T && th <= Tile64::H) e->tile = TK64;
   else { g_create_error = "muavta_create: requested tile exceeds 64 agents x 128 task slots x 48 threats"; delete e; return MUAVTA_E_ARG; }
   size_t scratch_bytes = 0;
-  e->P.slot_cap = (tt > 0 && tt < Tile16::T) ? tt : 0;  // a request below the smallest tile's slot count caps the live slots (0: no cap)
+  e->P.slot_cap = 0;  // (live slots an env may use: the tile's; muavta_set_slot_cap lowers it for capacity tests)
   DISPATCH(e, { e->A = TL::A; e->T = TL::T; e->H = TL::H; e->E = TL::E; e->R = TL::R; e->Q = TL::Q; e->state_bytes = sizeof(EnvState<TL>);
                 e->cold_bytes = sizeof(EnvCold<TL>); scratch_bytes = sizeof(Scratch<TL>); });
   (void)scratch_bytes;
@@ -2563,6 +2574,16 @@ int muavta_error_flags_back(MuavtaEnv* e, int32_t back, int32_t* out) {  // MUAV
   int rc = muavta_get(L, MUAVTA_F_ERROR, out, (size_t)L->n_envs * sizeof(int32_t));
   if (rc && L != e) e->err = L->err;
   return rc;
+}
+int muavta_set_slot_cap(MuavtaEnv* e, int32_t cap) {  // test hook: an env may use at most `cap` of its tile's task slots (0: all of them)
+  if (!e || cap < 0 || cap > e->T) { if (e) e->err = "muavta_set_slot_cap: 0 .. the tile's slot count"; return MUAVTA_E_ARG; }
+  DeviceScope scope_(e->device);
+  if (e->hl.twin) { int rc = muavta_set_slot_cap(e->hl.twin, cap); if (rc) { e->err = e->hl.twin->err; return rc; } }
+  MAIN_OP(e);
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  e->P.slot_cap = (cap > 0 && cap < e->T) ? cap : 0;
+  HIPCHK(e, hipMemcpy((char*)e->d_ctx + offsetof(DevCtx, P) + offsetof(DevParams, slot_cap), &e->P.slot_cap, sizeof(int32_t), hipMemcpyHostToDevice));
+  return MUAVTA_OK;
 }
 int muavta_set_lanes(MuavtaEnv* e, int32_t lanes) {
   if (!e || lanes < 0 || lanes > 2) { if (e) e->err = "muavta_set_lanes: 0 (second lane on demand), 1 (one lane) or 2 (always alternate)"; return MUAVTA_E_ARG; }

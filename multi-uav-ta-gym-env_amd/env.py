@@ -45,6 +45,15 @@ class _Snapshot:
             self.cache[name] = self.b.get(name)[0]
         return self.cache[name]
 
+    @property
+    def slot_map(self) -> Dict[int, int]:
+        """Task.id -> device slot of the tasks resident now (one pass per snapshot: every TaskView field read looks its slot up here)"""
+        m = self.cache.get("_slot_map")
+        if m is None:
+            ids = self["TASK_ID"]
+            m = self.cache["_slot_map"] = {int(t): int(s) for s, t in enumerate(ids) if t >= 0}
+        return m
+
     def clear(self):
         self.cache.clear()
 
@@ -58,9 +67,7 @@ class TaskView:
         self._last: Dict[str, Any] = {}
 
     def _slot(self) -> int:
-        ids = self._env._snap["TASK_ID"]
-        hit = np.nonzero(ids == self.id)[0]
-        return int(hit[0]) if len(hit) else -1
+        return self._env._snap.slot_map.get(self.id, -1)
 
     def _field(self, key: str, name: str, pick):
         s = self._slot()
@@ -410,6 +417,11 @@ class MultiUAVEnv:
         self.observations: Dict[str, dict] = {}
         self.last_tasks_info: Optional[List[TaskView]] = None
 
+    @classmethod
+    def batch(cls, config, n_envs: int, flags=None, backend=None, device: int = 0, **tiles) -> "MultiUAVEnvBatch":
+        """`n_envs` env objects over ONE device handle: one launch per step for all of them (MultiUAVEnvBatch below)."""
+        return MultiUAVEnvBatch(config, n_envs, flags=flags, backend=backend, device=device, **tiles)
+
     # ------------------------------------------------------------------ helpers
     def _task(self, tid: int) -> TaskView:
         t = self._tasks.get(tid)
@@ -427,20 +439,17 @@ class MultiUAVEnv:
             self._task(int(tid))
         for tid in range(1, int(self._scalar(27)) + 1):  # tasks created and retired between two observations
             self._task(tid)
-        # touch the cached fields of resident tasks so they survive slot recycling
-        for t in self._tasks.values():
-            if t.id and t._slot() >= 0:
-                _ = (t.position, t.typeIdx, t.currentReqs, t.allocatedReqs, t.orgReqs, t.created_at, t.required_agents,
-                     t.kind, t._meta(6, -1), t._meta(7, -1), getattr(t, "hard_deadline", None), t.initTime, t.doneTime, t.allocationDetails)
+        # (the fields of a task whose slot a STEP recycles reach its view through the release log below — its final record; slots recycled by an
+        # out-of-step call are captured by _capture_resident() in front of the call.  Round 4 re-read every field of every resident task here,
+        # every step: 6 ms of Python per step, 4x the reference's whole step)
         self.last_tasks_info = [self._task(int(i)) for i in self._snap["OPEN_IDS"] if i >= 0]
         _ = self.threats  # register this step's spawns now, so the order is right even if nobody looks every step
         # agent_known_tasks grows monotonically in the reference; bits of recycled slots are folded in here
         known = self._snap["KNOWN"]
+        bits = (known[:, :, None] >> np.arange(32, dtype=known.dtype)) & 1           # [A, KW, 32] -> slot-major bool rows
+        bits = bits.reshape(known.shape[0], -1)[:, :len(ids)].astype(bool) & (ids >= 0)
         for a in self.agents_obj:
-            s = self._known.setdefault(a.name, set())
-            for slot, tid in enumerate(ids):
-                if tid >= 0 and (known[a.id][slot >> 5] >> (slot & 31)) & 1:
-                    s.add(int(tid))
+            self._known.setdefault(a.name, set()).update(ids[bits[a.id]].tolist())
         # ... ids that left the device during this step, with the agents that knew them then (muavta_set_release_log)
         if self._steps != self._log_step:
             self._log_step = self._steps
@@ -517,6 +526,10 @@ class MultiUAVEnv:
             seed = self._seed_stream.randint(0, MAX_INT)
         self._seed = int(seed)
         self._b.reset(np.array([self._seed], dtype=np.uint64))
+        return self._after_reset()
+
+    def _after_reset(self):
+        """everything reset() does behind the device launch (a MultiUAVEnvBatch launches once for all its views)"""
         self._steps = 0
         self._tasks = {0: self.task_idle}
         self._threats = {}
@@ -536,6 +549,12 @@ class MultiUAVEnv:
         return self.observations, self.infos
 
     def step(self, actions):
+        aa, ai = self._b.pack_actions([self._action_items(actions)])
+        self._b.step(aa, ai)
+        return self._after_step()
+
+    def _action_items(self, actions):
+        """the ORDERED (UAV.id, index) items of an actions dict {agent_name: index | [indices]} (DroneEnv.py:813-825)"""
         if not isinstance(actions, dict):
             raise TypeError("actions must be a dict {agent_name: index | [indices]} (DroneEnv.py:810)")
         items = []
@@ -543,8 +562,10 @@ class MultiUAVEnv:
             a = self.agent_by_name[name]
             for i in (idxs if isinstance(idxs, list) else [idxs]):
                 items.append((a.id, int(i)))
-        aa, ai = self._b.pack_actions([items])
-        self._b.step(aa, ai)
+        return items
+
+    def _after_step(self):
+        """everything step() does behind the device launch"""
         self._steps += 1
         self._refresh()
         self._build_observations()
@@ -653,6 +674,14 @@ class MultiUAVEnv:
         return _spaces()[2](self.max_tasks)
 
     # ------------------------------------------------------------------ out-of-step mutators (muavta_call)
+    def _capture_resident(self):
+        """Read every field of every resident task into its view's cache.  An out-of-step call may recycle a slot on demand, and only
+        env.step writes the release log: called in FRONT of such a call, so the views of the tasks it displaces keep their last values."""
+        for t in self._tasks.values():
+            if t.id and t._slot() >= 0:
+                _ = (t.position, t.typeIdx, t.currentReqs, t.allocatedReqs, t.orgReqs, t.created_at, t.required_agents,
+                     t.kind, t._meta(6, -1), t._meta(7, -1), getattr(t, "hard_deadline", None), t.initTime, t.doneTime, t.allocationDetails)
+
     def _after_call(self):
         """A mutator changed the device state behind the cached views: re-read it (new tasks get their proxies)."""
         self._refresh(new_step=False)
@@ -680,17 +709,20 @@ class MultiUAVEnv:
     def _create_escort_for(self, recon_agent, rec_task):  # :1888-1917
         if not self.escort_enabled or recon_agent is None:
             return None
+        self._capture_resident()
         out = self._b.call("create_escort", [recon_agent.id, int(rec_task.id) if rec_task is not None else 0])
         self._after_call()
         return None if out[0] < 0 else self._task(int(out[0]))
 
     def _sync_escorts(self):  # :1964-2000
+        self._capture_resident()
         self._b.call("sync_escorts")
         self._after_call()
 
     def _retire_escort(self, escort_task, failed: bool = False):  # :1938-1950
         if escort_task is None or escort_task.status == 2:
             return
+        self._capture_resident()
         self._b.call("retire_escort", [int(escort_task.id), int(bool(failed))])
         self._after_call()
 
@@ -727,3 +759,148 @@ def _spaces():
         return GDict, Box, Discrete
     except Exception:
         return _Dict, _Box, _Discrete
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Vectorised facade: n reference-shaped env objects over ONE handle
+# ---------------------------------------------------------------------------------------------------------------------------------------
+class _SharedBatch:
+    """Whole-batch fetches of the one handle behind a MultiUAVEnvBatch, kept until the next launch / mutator call."""
+
+    def __init__(self, backend):
+        self.b = backend
+        self.cache: Dict[Any, Any] = {}
+
+    def invalidate(self):
+        self.cache.clear()
+
+    def fetch(self, key, fn):
+        if key not in self.cache:
+            self.cache[key] = fn()
+        return self.cache[key]
+
+
+class _RowBackend:
+    """Row `i` of the shared handle behind the 1-env backend surface MultiUAVEnv talks to (every array keeps a leading axis of 1)."""
+
+    def __init__(self, shared: _SharedBatch, i: int):
+        self.S, self.i = shared, int(i)
+        b = shared.b
+        self.params, self.n_envs, self.n_agents, self.A_tile, self.T = b.params, 1, b.n_agents, b.A_tile, b.T
+        self.max_tasks, self.possible_agents, self.dims, self.device_index = b.max_tasks, b.possible_agents, b.dims, getattr(b, "device_index", 0)
+
+    def _row(self, x):
+        return x[self.i:self.i + 1]
+
+    def get(self, name):
+        return self._row(self.S.fetch(("get", name), lambda: self.S.b.get(name)))
+
+    def set(self, name, value):
+        full = self.S.b.get(name)
+        full[self.i] = np.asarray(value)[0]
+        self.S.b.set(name, full)
+        self.S.invalidate()
+
+    def observe(self):
+        o = self.S.fetch("observe", self.S.b.observe)
+        return {k: self._row(v) for k, v in o.items()}
+
+    def step_result(self):
+        r, t, u = self.S.fetch("step_result", self.S.b.step_result)
+        return self._row(r), self._row(t), self._row(u)
+
+    def metrics(self):
+        return self._row(self.S.fetch("metrics", self.S.b.metrics))
+
+    def allocate(self, replan_interval: int = 20, use_visibility: bool = True, fetch: bool = True):
+        """the device allocator's plan for this env (one launch for the whole batch, kept until the next step)"""
+        aa, ai = self.S.fetch(("allocate", int(replan_interval), bool(use_visibility)), lambda: self.S.b.allocate(replan_interval, use_visibility))
+        return self._row(aa), self._row(ai)
+
+    def call(self, op, iargs=(), darg: float = -1.0, env_index: int = 0):
+        out = self.S.b.call(op, iargs, darg, env_index=self.i)
+        self.S.invalidate()
+        return out
+
+    def set_release_log(self, enable: bool = True):
+        pass  # (the batch switched it on for the whole handle)
+
+    def pack_actions(self, per_env):
+        return self.S.b.pack_actions(per_env)
+
+    def reset(self, seeds):
+        raise RuntimeError("a view of a MultiUAVEnvBatch is reset through the batch (one launch for all envs): batch.reset(seeds)")
+
+    def step(self, act_agent, act_index):
+        raise RuntimeError("a view of a MultiUAVEnvBatch is stepped through the batch (one launch for all envs): batch.step([actions, ...])")
+
+    def get_state(self):
+        raise NotImplementedError("whole-handle snapshot: use MultiUAVEnvBatch.backend.get_state()")
+
+    get_rng = get_state
+
+
+class MultiUAVEnvBatch:
+    """`n_envs` MultiUAVEnv objects — the reference's env surface, object views included — that share ONE device handle: a Python-side
+    allocator loop written against the reference (experiments/wps_eval.py:112-133,273: `hung.allocate_tasks(env.get_live_agents(),
+    _open_tasks(env), ...)`, `_apply_assign`, `env.step`) runs over `batch.envs[i]` unchanged, and the batch pays one launch, one state
+    mirror and one observation copy per step for ALL of them instead of one each.
+
+        batch = MultiUAVEnv.batch(config, 64, flags=...)
+        outs = batch.reset(seeds)                                  # [(obs, infos)] per env
+        while ...: outs = batch.step([actions_of(env) for env in batch.envs])   # [(obs, rewards, terms, truncs, infos)] per env
+
+    An env whose episode has ended keeps receiving steps like its neighbours (pass {} for it); as with the reference, what a step after the
+    end returns is the caller's to ignore.  `views=[...]` limits the Python-side refresh (object views, observation dicts) of a step to those
+    envs — the others return None and catch up at their next refreshed step."""
+
+    def __init__(self, config, n_envs: int, flags=None, backend=None, device: int = 0, **tiles):
+        from .params import params_from_config as _pfc
+
+        params = _pfc(config, flags, **tiles)
+        if backend is None:
+            from .batched import BatchedMultiUAVEnv
+
+            backend = BatchedMultiUAVEnv(params, int(n_envs), device)
+        if backend.n_envs != int(n_envs):
+            raise ValueError("backend holds another number of envs")
+        self.backend = backend
+        backend.set_release_log(True)
+        self._S = _SharedBatch(backend)
+        self.envs: List[MultiUAVEnv] = [MultiUAVEnv(config, flags=flags, backend=_RowBackend(self._S, i), **tiles) for i in range(int(n_envs))]
+        self.n_envs = int(n_envs)
+
+    def __len__(self):
+        return self.n_envs
+
+    def __getitem__(self, i):
+        return self.envs[i]
+
+    def reset(self, seeds):
+        seeds = np.asarray(seeds, dtype=np.uint64)
+        self.backend.reset(seeds)
+        self._S.invalidate()
+        out = []
+        for e, sd in zip(self.envs, seeds):
+            e._seed = int(sd)
+            out.append(e._after_reset())
+        return out
+
+    def step(self, actions_list, views=None):
+        if len(actions_list) != self.n_envs:
+            raise ValueError(f"one actions dict per env: {self.n_envs}")
+        aa, ai = self.backend.pack_actions([e._action_items(a or {}) for e, a in zip(self.envs, actions_list)])
+        self.backend.step(aa, ai)
+        self._S.invalidate()
+        todo = set(range(self.n_envs) if views is None else views)
+        out = []
+        for i, e in enumerate(self.envs):
+            if i in todo:
+                out.append(e._after_step())
+            else:
+                e._steps += 1   # (its release-log rows of this step are skipped: a view that sits out a step loses the ids released in it)
+                out.append(None)
+        return out
+
+    def close(self):
+        self.backend.close()

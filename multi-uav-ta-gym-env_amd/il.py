@@ -90,7 +90,9 @@ def rl_stream(env: BatchedMultiUAVEnv, seeds, policy, n_steps: int = 150, interv
     ((S_WPS_now - S_WPS_prev) / 20), `next_tok`, `done` (u8: bit 0 terminated, bit 1 truncated).  The token dicts alternate
     between two buffer sets: `tok` of step t is `next_tok` of step t - 1 and is overwritten at step t + 1 — copy what must live
     longer.  `fused=False` runs the same step as four separate launches (tokens / allocate_scored / step / metrics): the
-    cross-check of the fused kernel.  Envs whose episode has ended idle (replanned 0, reward 0); `selected`, `replanned`, `done` and the
+    cross-check of the fused kernel WHILE EVERY ENV IS LIVE — the separate launches keep planning and stepping an env whose episode has
+    ended (as four separate calls on the reference would), the fused kernel leaves it alone; the yielded rows of ended envs are masked the
+    same way in both modes (replanned 0, selected 0, reward 0), their final `env.metrics()` are not comparable between the modes.  Envs whose episode has ended idle (replanned 0, reward 0); `selected`, `replanned`, `done` and the
     reward tensors are the SAME tensors at every yield, overwritten by the next step — clone what must live longer (like the token dicts).
     `run_ahead=True`: the policy is consulted once per GATE instead of once per step (`rl_run_stream` below; `n_steps` then bounds the
     number of launches)."""
@@ -112,6 +114,7 @@ def rl_stream(env: BatchedMultiUAVEnv, seeds, policy, n_steps: int = 150, interv
     twenty = torch.full((N,), 20.0, dtype=torch.float64, device=dev)
     env.reset(np.asarray(seeds, dtype=np.uint64))
     env.tokens(kind, max_tasks, max_agents, out=bufs[0])   # tok of step 0
+    ended = None
     for t in range(n_steps):
         tok, nxt = bufs[t & 1], bufs[(t + 1) & 1]
         env.sync()                                       # the handle's stream wrote `tok`; the policy runs on torch's stream
@@ -132,8 +135,13 @@ def rl_stream(env: BatchedMultiUAVEnv, seeds, policy, n_steps: int = 150, interv
             _, term, trunc = env.step_result()
             env.tokens(kind, max_tasks, max_agents, out=nxt)
             env.sync()
+            if ended is not None and ended.any():  # rows of envs whose episode had ended before this step: as the fused kernel reports them
+                after = np.where(ended, before, after)
+                keep = torch.from_numpy(~ended).to(dev)
+                selected.mul_(keep.to(selected.dtype).view(-1, 1, 1)); replanned.mul_(keep.to(replanned.dtype))
             s_wps.copy_(torch.from_numpy(np.stack([before, after])))
             done.copy_(torch.from_numpy((term.astype(np.uint8) | (trunc.astype(np.uint8) << 1))))
+            ended = term | trunc
         yield t, {"tok": tok, "scores": scores, "selected": selected, "replanned": replanned,
                   "step_reward": torch.div(s_wps[1] - s_wps[0], twenty), "next_tok": nxt, "done": done}
 

@@ -34,7 +34,7 @@ EXPORTS = [
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
     "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_domain_log", "muavta_step_lists",
     "muavta_allocate_scored", "muavta_allocate_scored_device", "muavta_rl_step_device", "muavta_launch_gaps_ms",
-    "muavta_rl_run_device", "muavta_step_run", "muavta_set_lanes", "muavta_lanes", "muavta_rollout_metrics_back", "muavta_error_flags_back",
+    "muavta_rl_run_device", "muavta_step_run", "muavta_set_lanes", "muavta_lanes", "muavta_rollout_metrics_back", "muavta_error_flags_back", "muavta_set_slot_cap",
 ]
 
 
@@ -51,7 +51,9 @@ class MuavtaScored(C.Structure):
 
 
 def sources():
-    return [os.path.join(CSRC, f) for f in ("muavta_kernels.hip", "muavta_device.h", "muavta_state.h")] + [
+    """every file the shipped library is compiled from (muavta_diag.h is not one of them: diagnostic builds only)"""
+    sim = sorted(os.path.join(CSRC, "sim", f) for f in os.listdir(os.path.join(CSRC, "sim")) if f.endswith(".inc"))
+    return [os.path.join(CSRC, f) for f in ("muavta_kernels.hip", "muavta_device.h", "muavta_state.h", "muavta_math.h", "muavta_rng.h")] + sim + [
         os.path.join(os.path.dirname(PKG_DIR), "include", "muavta.h")]
 
 
@@ -174,6 +176,7 @@ def lib() -> C.CDLL:
     L.muavta_rl_run_device.argtypes = [vp, C.POINTER(MuavtaRlRun)]
     L.muavta_step_run.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.muavta_set_lanes.argtypes = [vp, i32]
+    L.muavta_set_slot_cap.argtypes = [vp, i32]
     L.muavta_lanes.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.muavta_rollout_metrics_back.argtypes = [vp, i32, vp]
     L.muavta_error_flags_back.argtypes = [vp, i32, vp]

@@ -94,6 +94,14 @@ def params(cfg, tile):
     return params_of_wide(cfg, tile)
 
 
+def make_env(p, n, tile):
+    """a handle on `tile`; a slot count below the smallest tile's 40 is the CAPPED variant (muavta_set_slot_cap: field widths stay the tile's)"""
+    env = make_env(p, n, tile)
+    if tile[1] < 40:
+        env.set_slot_cap(tile[1])
+    return env
+
+
 ESCALATED = [0]  # envs whose metric row came from rollout(escalate=True)
 
 
@@ -114,7 +122,7 @@ def fused(k, w, n_seeds, log):
     bad = flagged = checked = 0
     n_esc = [0]
     for tile in tiles_for(cfg, k):
-        env = BatchedMultiUAVEnv(params(cfg, tile), n_seeds)
+        env = make_env(params(cfg, tile), n_seeds, tile)
         env.set_allocator(name)
         escalate = (not split) and k % 2 == 0 and tile[0] < 64  # every other config: flagged envs re-run on the next larger tile and spliced in
         if split:
@@ -155,7 +163,7 @@ def stepwise(k, w, log):
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
-    env = BatchedMultiUAVEnv(p, n)
+    env = make_env(p, n, tile)
     env.set_allocator(name)
     oracles = [orc.OracleEnv(p) for _ in range(n)]
     env.reset(seeds)
@@ -215,7 +223,7 @@ def scored(k, w, log):
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
-    env = BatchedMultiUAVEnv(p, n)
+    env = make_env(p, n, tile)
     A = env.n_agents
     oracles = [orc.OracleEnv(p) for _ in range(n)]
     env.reset(seeds)

@@ -1,4 +1,4 @@
-"""Sim::div_small (csrc/muavta_device.h): x / c by q = RN(x * inv), r = fma(-q, c, x), q' = fma(r, inv, q) must equal the IEEE
+"""Sim::div_small (csrc/sim/observe.inc): x / c by q = RN(x * inv), r = fma(-q, c, x), q' = fma(r, inv, q) must equal the IEEE
 quotient bit for bit for the divisors the observation writer uses (1200, 6, max_time_steps, max_tasks).  The FMA is emulated
 exactly with rationals, so this is a check of the algorithm the kernel relies on, run on the CPU."""
 import math

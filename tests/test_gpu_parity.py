@@ -281,7 +281,7 @@ def test_full_size_properties_cfg2():
 
 
 def test_domain_sqrt_div_bit_exact():
-    """fsqrt / fdiv (csrc/muavta_device.h): the compiler's sqrt and division sequences without range scaling and fix-ups must be
+    """fsqrt / fdiv (csrc/muavta_math.h): the compiler's sqrt and division sequences without range scaling and fix-ups must be
     the IEEE-754 correctly rounded results (numpy's) on everything the simulation can feed them: coordinates and their
     differences, squared distances, distances from 1e-12 up, speeds, zero numerators and radicands."""
     from muavta_amd.batched import domain_math
@@ -369,6 +369,21 @@ def test_avoid_obstacles_vs_oracle():
         want[i] = out
     assert np.array_equal(got, want), f"{int((got != want).any(axis=1).sum())} of {len(pos)} differ"
     assert np.array_equal(avoid_obstacles(pos, np.zeros((0, 3)), mov), np.zeros_like(pos))  # K=0: the live configs
+    # (r5) the arbitrary-precision witness of tests/sim_core_witness.py (every IEEE operation in Python floats, ln / atan2 in 300 bits,
+    # rounded once): the device must equal it wherever the host libm's log is correctly rounded for the arguments met
+    import math
+    from sim_core_witness import avoid_cr
+    near = pos[:1500].copy()
+    which = rng.integers(0, 3, len(near)); ang = rng.uniform(0, 2 * math.pi, len(near)); rad = obst[which, 2] + rng.uniform(0.2, 39.9, len(near))
+    near[:, 0] = obst[which, 0] + rad * np.cos(ang); near[:, 1] = obst[which, 1] + rad * np.sin(ang)
+    got_near = avoid_obstacles(near, obst, mov[:1500])
+    n_cr = 0
+    for i in range(len(near)):
+        w, info = avoid_cr(near[i].tolist(), obst.tolist(), mov[i].tolist())
+        if all(r["libm_log_cr"] for r in info) and all(abs(r["angle_between"]) > 1e-9 and abs(abs(r["angle_between"]) - math.pi) > 1e-9 for r in info):
+            assert got_near[i, 0] == w[0] and got_near[i, 1] == w[1], f"pair {i}: device {got_near[i].tolist()} vs arbitrary-precision witness {w}"
+            n_cr += 1
+    assert n_cr > 1400
     from muavta_amd.core_sim import SimCore  # the reference's call shape: lists in, [dx, dy] out (DroneEnv.py:1033)
     sc = SimCore()
     one = sc.avoid_obstacles(list(pos[5]), [list(o) for o in obst], list(mov[5]))
@@ -1705,12 +1720,13 @@ def test_rl_stream_policy_in_the_loop_vs_reference_and_oracle(path, fused):
 
 def test_capacity_flagged_envs_escalate_to_the_next_tile():
     """rollout(escalate=True): the reference's task list is unbounded (DroneEnv.py:325-328); an env that needs more than its
-    tile is re-run from its seed on the next larger tile and its metrics spliced in.  Forced here with tile_tasks = 32 on the
-    16-agent tile (a request below the tile's 40 slots caps the live slots): global index 9649 of WPS_hard_x2 needs 34."""
+    tile is re-run from its seed on the next larger tile and its metrics spliced in.  Forced here with muavta_set_slot_cap(32)
+    on the 16-agent tile (at most 32 of its 40 slots): global index 9649 of WPS_hard_x2 needs 34."""
     case = "WPS_hard_x2"
     seeds = np.array([9649, 6231, 8273, 11430, 11656] + list(range(251)), dtype=np.uint64)
     n = len(seeds)
-    small = _env(case, n, tile_tasks=32)
+    small = _env(case, n)
+    small.set_slot_cap(32)
     assert small.T == 40 and small.A_tile == 16
     small.rollout(seeds, 150, 20, True, True, escalate=True)
     flagged = np.nonzero(small.get("ERROR"))[0]
@@ -2131,3 +2147,57 @@ def test_n_ranks_with_unequal_shards_on_the_one_gpu_random_configurations():
     world = 3
     jobs = fuzz_jobs(51000, 6, world, rng, max_agents=24) + fuzz_jobs(1011000, 2, world, rng, max_agents=64)
     check_rank_results(_run_ranks(world, "hip", jobs, timeout=900), world, jobs, truth_backend="oracle")
+
+
+@pytest.mark.parametrize("case,n,interval", [("WPS_hard", 5, 20), ("WPS_escort", 4, 12)])
+def test_vectorised_facade_views_equal_single_env_facades(case, n, interval):
+    """MultiUAVEnv.batch(n): n reference-shaped env objects over ONE handle (one launch, one state mirror and one observation copy per step for
+    all of them) against n single-env facades stepped side by side with the same actions: observation dicts, rewards, done flags, infos
+    (events, selected, final metrics), last_tasks_info, the Task / UAV views a planner reads and agent_visibility_map(), after every step."""
+    from muavta_amd.env import MultiUAVEnv
+    from muavta_amd.scenarios import CASE_SPECS, TILES, WPS_ENV_FLAGS
+
+    ta, tt, th = TILES[case]
+    kw = dict(flags=dict(WPS_ENV_FLAGS), tile_agents=ta, tile_tasks=tt, tile_threats=th)
+    batch = MultiUAVEnv.batch(CASE_SPECS[case], n, **kw)
+    singles = [MultiUAVEnv(CASE_SPECS[case], **kw) for _ in range(n)]
+    seeds = [3 + 11 * i for i in range(n)]
+    outs = batch.reset(seeds)
+    refs = [s.reset(seed=sd) for s, sd in zip(singles, seeds)]
+
+    def same_obs(a, b):
+        assert a.keys() == b.keys()
+        for name in a:
+            for key in ("agent_position", "agent_caps", "event_flags"):
+                assert np.array_equal(a[name][key], b[name][key])
+            assert a[name]["alloc_task"] == b[name]["alloc_task"] and a[name]["mask"] == b[name]["mask"] and a[name]["legal_mask"] == b[name]["legal_mask"]
+            assert len(a[name]["tasks_info"]) == len(b[name]["tasks_info"])
+            for ra, rb in zip(a[name]["tasks_info"], b[name]["tasks_info"]):
+                assert ra.keys() == rb.keys() and all(np.array_equal(ra[k], rb[k]) for k in ra)
+
+    for i in range(n):
+        same_obs(outs[i][0], refs[i][0])
+    for t in range(150):
+        acts = []
+        for i, (v, s) in enumerate(zip(batch.envs, singles)):
+            aa, ai = v._b.allocate(interval, True)          # the batch: ONE k_allocate launch for all views, fetched once
+            sa, si = s._b.allocate(interval, True)
+            assert np.array_equal(aa, sa) and np.array_equal(ai, si)
+            acts.append({v.agents_obj[int(a)].name: int(j) for a, j in zip(aa[0], ai[0]) if a >= 0})
+        outs = batch.step(acts)
+        for i, (v, s) in enumerate(zip(batch.envs, singles)):
+            o, r, te, tr, info = s.step(acts[i])
+            bo, br, bte, btr, binfo = outs[i]
+            same_obs(bo, o)
+            assert br == r and bte == te and btr == tr and binfo["events"] == info["events"] and binfo["selected"] == info["selected"]
+            assert [x.id for x in v.last_tasks_info] == [x.id for x in s.last_tasks_info] and [x.id for x in v.tasks] == [x.id for x in s.tasks]
+            assert v.agent_visibility_map() == s.agent_visibility_map() and v.time_steps == s.time_steps == t + 1
+            for a, b in zip(v.agents_obj, s.agents_obj):
+                assert a.name == b.name and a.state == b.state and np.array_equal(a.position, b.position) and [x.id for x in a.tasks] == [x.id for x in b.tasks]
+            if t % 25 == 0:
+                for x, y in zip(v.tasks, s.tasks):
+                    assert x.status == y.status and np.array_equal(x.position, y.position) and np.array_equal(x.currentReqs, y.currentReqs) and len(x.allocationDetails) == len(y.allocationDetails)
+            if all(tr.values()):
+                assert binfo["metrics"] == info["metrics"]
+    assert all(all(o[3].values()) for o in outs)
+    batch.close()

@@ -555,3 +555,34 @@ def test_rl_run_to_the_next_gate_vs_reference(path, max_steps):
         assert launches == len(steps)
     r = e.rl_run(20, 1, GATE_TRAINER, kind, 32, 16, SC_EDGE_VALID_ONLY, scores=None)  # an ended episode is left alone
     assert r["n_stepped"] == 0 and not r["replanned"] and r["s_before"] == r["s_after"] == g["s_wps"][-1] and np.array_equal(e.metrics(), g["metrics"])
+
+
+def test_avoid_obstacles_oracle_vs_arbitrary_precision_witness():
+    """a9 with K > 0 obstacles stays "parity unpinned vs the Rust" (core_sim/src/sim_core.rs:25-59 cannot be built here) — what CAN be pinned:
+    a third, independent evaluation of those lines with every IEEE operation in Python floats and `ln` / `atan2` in 300-bit arithmetic rounded
+    once (tests/sim_core_witness.py).  The oracle (host libm) must equal it bit for bit wherever the libm's log is correctly rounded for the
+    argument met; arguments where it is not are the only places a Rust build could differ, by an ulp of the force (tools/a9_witness.py lists them)."""
+    import ctypes as C
+    import math
+    from sim_core_witness import avoid_cr
+
+    rng = np.random.default_rng(11)
+    obst = np.array([[300.0, 300.0, 50.0], [700.0, 200.0, 80.0], [500.0, 500.0, 30.0]])
+    n = 1500
+    pos = rng.uniform(100, 900, (n, 2)); mov = rng.uniform(-1, 1, (n, 2))
+    k = n * 2 // 3   # two thirds of the positions inside a 40-unit zone: the branch is taken
+    which = rng.integers(0, 3, k); ang = rng.uniform(0, 2 * math.pi, k); rad = obst[which, 2] + rng.uniform(0.2, 39.9, k)
+    pos[:k, 0] = obst[which, 0] + rad * np.cos(ang); pos[:k, 1] = obst[which, 1] + rad * np.sin(ang)
+    mov[::7] = 0.0  # atan2(0, 0)
+    L = orc.lib()
+    taken = explained = 0
+    for i in range(n):
+        out = np.zeros(2)
+        L.orc_avoid_obstacles(obst.ctypes.data_as(C.c_void_p), 3, pos[i].ctypes.data_as(C.c_void_p), mov[i].ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        want, info = avoid_cr(pos[i].tolist(), obst.tolist(), mov[i].tolist())
+        taken += len(info)
+        if all(r["libm_log_cr"] for r in info) and all(abs(r["angle_between"]) > 1e-9 and abs(abs(r["angle_between"]) - math.pi) > 1e-9 for r in info):
+            assert out[0] == want[0] and out[1] == want[1], f"pair {i}: oracle {out.tolist()} vs witness {want}"
+        else:
+            explained += 1
+    assert taken > n // 2 and explained < n // 100, (taken, explained)

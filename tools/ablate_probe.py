@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Builder's probe: true cost of the fixed phases of a step.  Runs the QUIET workload (config 2 with nothing happening: the ablated
 phases have nothing to do, so leaving them out does not change what the other phases see) on libraries built with
--DMUAVTA_ABLATE=<1 << bit> (tools/_build/libmuavta_abl<bit>.so) and on the shipped one; prints kernel ms per variant.
+-DMUAVTA_DIAGNOSTIC_BUILD -DMUAVTA_ABLATE=<1 << bit> (tools/_build/libmuavta_abl<bit>.so; csrc/muavta_diag.h) and on the shipped one; prints kernel ms per variant.
     usage: MUAVTA_SO=... python tools/ablate_probe.py   (one process per library: tools/ablate_probe.sh)"""
 import os, sys
 import numpy as np
