@@ -489,6 +489,7 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
         env.step_staged()
     env.sync()
     out["step_api_env_steps_per_s"] = args.envs * HORIZON / (time.perf_counter() - t1)
+    m_step_api = env.metrics()
     env.reset(seeds)
     env.sync()
     t1 = time.perf_counter()
@@ -542,6 +543,32 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
     except Exception as exc:
         out["fused_step_api_wide_env_steps_per_s"] = None
         out["fused_step_api_wide_error"] = repr(exc)
+    # (r5) the per-step path with the run-ahead of a host-side planner: k_allocate stages the plan, muavta_step_run applies it and keeps stepping
+    # every env with empty actions until ITS allocator gate fires again (HungarianAllocator.should_replan: interval or any event), its episode
+    # ends or 5 steps were taken — the loop of wps_eval.py:248-254,273 where the planner is only consulted at a gate
+    mark("step_run")
+    try:
+        for rep in range(2):
+            env.reset(seeds)
+            env.sync()
+            t1 = time.perf_counter()
+            k_launch = 0
+            while True:
+                env.allocate(args.interval, True, fetch=False)
+                _, prk, _ = env.step_run(None, None, gate="allocator", replan_interval=args.interval, max_steps=5, write_obs=write_obs)
+                k_launch += 1
+                if np.all(prk & 3):
+                    break
+            dt_sr = time.perf_counter() - t1
+        out["step_run_env_steps_per_s"] = args.envs * HORIZON / dt_sr
+        out["step_run_launches"] = k_launch
+        out["step_run_is"] = ("k_allocate + muavta_step_run(staged plan, allocator gate, at most 5 steps per launch), the park flags read back after every launch: "
+                              f"{k_launch} launch pairs for {HORIZON} env steps of {args.envs} envs (step_api_env_steps_per_s: one pair per env step)")
+        if not np.array_equal(env.metrics(), m_step_api):
+            raise RuntimeError("step_run ended in other metrics than the per-step path")
+    except Exception as exc:
+        out["step_run_env_steps_per_s"] = None
+        out["step_run_error"] = repr(exc)
     # obs_ring: the fused rollout in launches of K steps whose per-step observations (+ reward, done) land in slot t of device
     # rings [K][N][...] (muavta_rollout_record) instead of overwriting one buffer — every step's observation stays readable by
     # a consumer on the device, at K steps per launch instead of one

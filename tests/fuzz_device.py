@@ -96,7 +96,7 @@ def params(cfg, tile):
 
 def make_env(p, n, tile):
     """a handle on `tile`; a slot count below the smallest tile's 40 is the CAPPED variant (muavta_set_slot_cap: field widths stay the tile's)"""
-    env = make_env(p, n, tile)
+    env = BatchedMultiUAVEnv(p, n)
     if tile[1] < 40:
         env.set_slot_cap(tile[1])
     return env
@@ -270,7 +270,7 @@ def lists(k, w, log):
     p = params(cfg, tile)
     n = 2
     seeds = np.array([seed - i if seed > 2 ** 62 else seed + i for i in range(n)], dtype=np.uint64)
-    env = BatchedMultiUAVEnv(p, n)
+    env = make_env(p, n, tile)
     A = env.n_agents
     oracles = [orc.OracleEnv(p) for _ in range(n)]
     env.reset(seeds)
