@@ -128,7 +128,7 @@ static __device__ __forceinline__ uint32_t lds_zero() { return 0u; }
 // Residency on a CU is bound by LDS bytes per env (160 KiB per CU, 1 KiB granule): 16 envs of the 16-agent tile
 // (BASELINE configs 2 and 3: 4096 envs = 16 per CU, one round) need <= 10 KiB each.
 static_assert(Lds<Tile16>::bytes() <= 10240, "Tile16 no longer fits 16 workgroups per CU");
-static_assert(Lds<Tile24>::bytes() <= 10240, "Tile24 no longer fits 16 workgroups per CU");
+static_assert(!MUAVTA_TILE24_SLIM || Lds<Tile24>::bytes() <= 10240, "Tile24 no longer fits 16 workgroups per CU");
 static_assert(sizeof(EnvState<Tile16>) % 16 == 0 && sizeof(EnvState<Tile24>) % 16 == 0 && sizeof(EnvState<Tile64>) % 16 == 0, "blob copies move 16 B per lane");
 static_assert(sizeof(EnvCold<Tile16>) % 16 == 0 && sizeof(EnvCold<Tile24>) % 16 == 0 && sizeof(EnvCold<Tile64>) % 16 == 0, "cold records are 16 B aligned");
 

@@ -192,7 +192,10 @@ struct alignas(16) EnvState : QueueSide<TL::A, TL::T, !TL::SLIM> {
 // with 32 slots / queue 8 about 1 in 10,000 seeds of WPS_hard_x2 overflowed (34 slots); events <= 16, pending reveals <= 22
 // measured over 4096 seeds.
 typedef Tile<16, 40, 16, 48, 40, 10, true> Tile16;
-typedef Tile<24, 48, 24, 88, 32, 12, true, false, true> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
+#ifndef MUAVTA_TILE24_SLIM  // experiment knob (0: QueueSide in LDS like the other tiles: 11.6 KB per env, 14 envs per CU)
+#define MUAVTA_TILE24_SLIM 1
+#endif
+typedef Tile<24, 48, 24, 88, 32, 12, true, false, MUAVTA_TILE24_SLIM != 0> Tile24;  // escort 24-UAV config: queue <= 10, pending <= 60, events <= 20 measured
 typedef Tile<64, 128, 48, 128, 96, 12, true, true> Tile64;  // register cost columns up to 64 LSAP columns, on-the-fly LDS solver beyond
 
 #define MUAVTA_REL_ROW 29  // doubles per release-log row (include/muavta.h: MUAVTA_F_RELEASE_LOG)
