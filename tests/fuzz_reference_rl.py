@@ -3,7 +3,8 @@
 (fuzz_reference.wide_config; fleets of at most 16 UAVs, the trainers' token pad) are run through the REFERENCE's run_rl_episode loop
 with PairCostHybrid.plan(scores=<seeded matrix>) (tools/gen_golden.py::rl_episode) and checked against the oracle's scored allocator
 with the comparison the committed rl_*.npz traces go through (test_oracle_golden.check_rl): tokens, edge_valid, every scored LSAP
-cost matrix and assignment, _selected_mask, pairs, actions, step rewards, next tokens, done flags, final metrics — bit for bit.
+cost matrix and assignment, _selected_mask, pairs, actions, step rewards, next tokens, done flags, final metrics — bit for bit; (r5) and the
+oracle's run-to-the-next-gate (OracleEnv.rl_run, the checker of muavta_rl_run_device) replays the same reference episode launch by launch.
 
     python tests/fuzz_reference_rl.py [first_k [n_configs [procs]]]
 
@@ -40,6 +41,8 @@ def run_one(k: int):
     try:
         P = params_from_config(dict(cfg), None, tile_agents=64, tile_tasks=128, tile_threats=48)
         TOG.check_rl(tr, f"WIDE{k}", P)
+        if len(tr["replanned"]) and not bool(tr["ep_done"][:-1].any() if len(tr["ep_done"]) else False):
+            TOG.check_rl_run(tr, f"WIDE{k} run-ahead", P, (0, 3, 1)[k % 3])  # (r5) the run-to-the-next-gate checker, launch by launch on the same reference episode
     except AssertionError as exc:
         return k, "MISMATCH", str(exc)[:400]
     except Exception as exc:

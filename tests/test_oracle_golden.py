@@ -513,19 +513,15 @@ def test_escort_scored_plans_vs_reference(path):
 
 
 # ---- run to the next gate (muavta_rl_run_device's checker): the reference episodes hold every gate step ------------------------------
-@pytest.mark.parametrize("max_steps", [0, 3])
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rl_*.npz"))))
-def test_rl_run_to_the_next_gate_vs_reference(path, max_steps):
-    """OracleEnv.rl_run — plan at a gate, step, then env.step({}) up to the next gate (experiments/train_pair_cost.py:139-145) — replays the
-    reference's run_rl_episode launch by launch: one launch per gate of the reference episode (its `step` list), each consuming the score matrix
-    the reference's policy was given there and reproducing the pushed transition (tok, selected, step_r, next_tok, ep_done); the quiet stretch
-    ends exactly at the reference's next gate.  max_steps = 3 cuts the quiet stretches short: the extra launches must plan nothing."""
-    g = np.load(path)
-    case = os.path.basename(path)[3:-4]
+def check_rl_run(g, case, params, max_steps):
+    """OracleEnv.rl_run — plan at a gate, step, then env.step({}) up to the next gate (experiments/train_pair_cost.py:139-145) — replays a reference
+    run_rl_episode trace LAUNCH BY LAUNCH: one launch per gate step of the reference (its `step` list), each consuming the score matrix the reference's
+    policy was given there and reproducing the pushed transition (tok, selected, step_r, next_tok, ep_done); the quiet stretch ends exactly at the
+    reference's next gate.  max_steps > 0 cuts the quiet stretches short: the extra launches must plan nothing."""
     kind = 1 if int(g["raw"]) else 0
-    e = orc.OracleEnv(params_for_case(case))
+    e = orc.OracleEnv(params)
     e.reset(int(g["seed"]))
-    steps, T = g["step"].tolist(), len(g["replanned"])
+    steps, T = list(np.asarray(g["step"]).tolist()), len(g["replanned"])
     tok = e.tokens(kind, 32, 16)
     t, k, launches = 0, 0, 0
     while t < T:
@@ -555,6 +551,14 @@ def test_rl_run_to_the_next_gate_vs_reference(path, max_steps):
         assert launches == len(steps)
     r = e.rl_run(20, 1, GATE_TRAINER, kind, 32, 16, SC_EDGE_VALID_ONLY, scores=None)  # an ended episode is left alone
     assert r["n_stepped"] == 0 and not r["replanned"] and r["s_before"] == r["s_after"] == g["s_wps"][-1] and np.array_equal(e.metrics(), g["metrics"])
+
+
+@pytest.mark.parametrize("max_steps", [0, 3])
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "rl_*.npz"))))
+def test_rl_run_to_the_next_gate_vs_reference(path, max_steps):
+    """muavta_rl_run_device's checker pinned on the reference's own episodes (tests/golden/rl_*.npz hold every gate step): see check_rl_run."""
+    case = os.path.basename(path)[3:-4]
+    check_rl_run(np.load(path), case, params_for_case(case), max_steps)
 
 
 def test_avoid_obstacles_oracle_vs_arbitrary_precision_witness():
