@@ -75,14 +75,14 @@ def test_product_never_imports_the_oracle():
 
 
 def test_binding_structs_match_the_header_field_by_field(tmp_path):
-    """MuavtaParams / MuavtaDims / MuavtaRecord / MuavtaScored / MuavtaRlStep: sizeof and the offset of every field of the ctypes
+    """MuavtaParams / MuavtaDims / MuavtaRecord / MuavtaScored / MuavtaRlStep / MuavtaRlRun: sizeof and the offset of every field of the ctypes
     binding against a C program that includes include/muavta.h (gcc: the header is plain C)."""
     import subprocess
 
-    from muavta_amd.native import MuavtaRlStep, MuavtaScored
+    from muavta_amd.native import MuavtaRlRun, MuavtaRlStep, MuavtaScored
     from muavta_amd.params import MuavtaRecord
 
-    structs = {"MuavtaParams": MuavtaParams, "MuavtaDims": MuavtaDims, "MuavtaRecord": MuavtaRecord, "MuavtaScored": MuavtaScored, "MuavtaRlStep": MuavtaRlStep}
+    structs = {"MuavtaParams": MuavtaParams, "MuavtaDims": MuavtaDims, "MuavtaRecord": MuavtaRecord, "MuavtaScored": MuavtaScored, "MuavtaRlStep": MuavtaRlStep, "MuavtaRlRun": MuavtaRlRun}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "muavta.h"', 'int main(void) {']
     for name, st in structs.items():
         lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')

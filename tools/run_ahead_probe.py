@@ -40,7 +40,7 @@ def per_step():
         dt = time.perf_counter() - t1
     return N * H / dt, e.metrics()
 
-def run_ahead(max_steps, check_every, parts=0):
+def run_ahead(max_steps, check_every, parts=0, with_next=True, with_park=True, with_sel=True):
     e.set_parts(parts)
     res = None
     for _ in range(2):
@@ -50,8 +50,8 @@ def run_ahead(max_steps, check_every, parts=0):
         planned = 0
         while True:
             for p in ([None] if parts <= 1 else range(parts)):
-                e.rl_run("pair", 32, 16, edge_scores=scores, gate="trainer", replan_interval=interval, selected=sel, replanned=rep, next_tok=nxt, s_wps=sw, done=dn,
-                         park_tok=bufs[(k + 1) & 1], n_stepped=nst, park=prk, reward_sum=rs, max_steps=max_steps, part=p)
+                e.rl_run("pair", 32, 16, edge_scores=scores, gate="trainer", replan_interval=interval, selected=sel if with_sel else None, replanned=rep, next_tok=nxt if with_next else None, s_wps=sw, done=dn,
+                         park_tok=bufs[(k + 1) & 1] if with_park else None, n_stepped=nst, park=prk, reward_sum=rs, max_steps=max_steps, part=p)
             k += 1
             if k % check_every == 0:
                 e.sync()
@@ -73,3 +73,9 @@ for parts in (2, 4):
     for ms in (0, 4, 6):
         r, k, m = run_ahead(ms, 4, parts)
         print(f"  run-ahead {parts} parts max_steps={ms:2d} check every 4: {r / 1e6:6.1f} M env-steps/s, {k} launches per part, metrics equal: {bool(np.array_equal(m, m0))}")
+
+print("what the outputs cost (max_steps 5, check every 4):")
+for label, kw in (("all outputs", {}), ("no next_tok", dict(with_next=False)), ("no next_tok, no park_tok", dict(with_next=False, with_park=False)),
+                  ("no tokens, no selected", dict(with_next=False, with_park=False, with_sel=False))):
+    r, k, m = run_ahead(5, 4, **kw)
+    print(f"  {label:28s} {r / 1e6:6.1f} M env-steps/s, {k} launches")
