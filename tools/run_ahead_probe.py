@@ -40,7 +40,7 @@ def per_step():
         dt = time.perf_counter() - t1
     return N * H / dt, e.metrics()
 
-def run_ahead(max_steps, check_every, parts=0, with_next=True, with_park=True, with_sel=True):
+def run_ahead(max_steps, check_every, parts=0, with_next=True, with_park=True, with_sel=True, with_scores=True):
     e.set_parts(parts)
     res = None
     for _ in range(2):
@@ -50,7 +50,7 @@ def run_ahead(max_steps, check_every, parts=0, with_next=True, with_park=True, w
         planned = 0
         while True:
             for p in ([None] if parts <= 1 else range(parts)):
-                e.rl_run("pair", 32, 16, edge_scores=scores, gate="trainer", replan_interval=interval, selected=sel if with_sel else None, replanned=rep, next_tok=nxt if with_next else None, s_wps=sw, done=dn,
+                e.rl_run("pair", 32, 16, edge_scores=scores if with_scores else None, gate="trainer", replan_interval=interval, selected=sel if with_sel else None, replanned=rep, next_tok=nxt if with_next else None, s_wps=sw, done=dn,
                          park_tok=bufs[(k + 1) & 1] if with_park else None, n_stepped=nst, park=prk, reward_sum=rs, max_steps=max_steps, part=p)
             k += 1
             if k % check_every == 0:
@@ -79,3 +79,5 @@ for label, kw in (("all outputs", {}), ("no next_tok", dict(with_next=False)), (
                   ("no tokens, no selected", dict(with_next=False, with_park=False, with_sel=False))):
     r, k, m = run_ahead(5, 4, **kw)
     print(f"  {label:28s} {r / 1e6:6.1f} M env-steps/s, {k} launches")
+r, k, m = run_ahead(5, 4, with_scores=False)
+print(f"  all outputs, NO score tensor (the plan is the plain Hungarian's: other episodes)  {r / 1e6:6.1f} M env-steps/s, {k} launches")
