@@ -299,6 +299,14 @@ int muavta_tokens_device(MuavtaEnv* env, int32_t kind, int32_t max_tasks, int32_
                          int32_t* task_ids, float* agent_feats, uint8_t* agent_mask, int32_t* agent_ids, float* edge_valid, int32_t* n_urgent,
                          float* expert_mask, int32_t* replanned);
 
+/* The context vector of the ContextPair hybrids, batched: build_context_summary(env, build_pair_tokens(env, max_tasks, ...)) of
+ * TaskAllocation/Hybrid/ContextPairHybrid.py:33-78 — kind MUAVTA_TOK_PAIR: f32 [N, 8] = urgent share, min(open / live, 4) / 4, free share, fighter
+ * share, left share, right share, |left - right| share of the kept open tasks, mission clock; kind MUAVTA_TOK_PAIR_RAW: f32 [N, 1] = the clock
+ * (raw=True).  `max_tasks` is the token pad (the summary runs over the first max_tasks underfilled tasks, as tok["open_tasks"] does).
+ * muavta_context fills a HOST buffer and synchronises; muavta_context_device a DEVICE buffer on the handle's stream. */
+int muavta_context(MuavtaEnv* env, int32_t kind, int32_t max_tasks, float* context);
+int muavta_context_device(MuavtaEnv* env, int32_t kind, int32_t max_tasks, float* context);
+
 /* The learned hybrids' planner call: HungarianAllocator.allocate_tasks(live, tok["open_tasks"], time_step, events, force,
  * task_priorities=..., reserved_agent_names=..., agent_known_ids=..., edge_scores=...) with CALLER-COMPUTED inputs
  * (TaskAllocation/OptimizationBased/HungarianAllocator.py:72-92,123-124,170-179), as PairCostHybrid.plan

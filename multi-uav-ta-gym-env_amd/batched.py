@@ -304,6 +304,22 @@ class BatchedMultiUAVEnv:
         self._ck(self.L.muavta_tokens(self.h, k, mt, ma, *[_vp(a) for a in arrs.values()]))
         return arrs
 
+    def context(self, kind: str = "pair", max_tasks: int = 32, out=None):
+        """The ContextPair hybrids' context vector for every env (`build_context_summary`, ContextPairHybrid.py:33-78): f32 [N, 8]
+        ('pair') or [N, 1] ('pair_raw').  `out`: a contiguous CUDA torch tensor to fill on the handle's stream (no sync)."""
+        k = self.TOKEN_KINDS[kind][0]
+        if k == 2:
+            raise ValueError("the context vector is defined for the pair tokens ('pair', 'pair_raw')")
+        shape = (self.n_envs, 1 if k == 1 else 8)
+        if out is not None:
+            if tuple(out.shape) != shape or not out.is_cuda or not out.is_contiguous() or out.element_size() != 4 or out.device.index != self.device_index:
+                raise ValueError(f"context(out=...): a contiguous float32 tensor of shape {shape} on cuda:{self.device_index}")
+            self._ck(self.L.muavta_context_device(self.h, k, int(max_tasks), C.c_void_p(out.data_ptr())))
+            return out
+        a = np.empty(shape, dtype=np.float32)
+        self._ck(self.L.muavta_context(self.h, k, int(max_tasks), _vp(a)))
+        return a
+
     OPS = {"uav_allocate": 0, "create_escort": 1, "sync_escorts": 2, "retire_escort": 3, "escort_fighters_near": 4,
            "action_valid": 5, "set_queue": 6}
 

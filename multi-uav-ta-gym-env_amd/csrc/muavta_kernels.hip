@@ -752,6 +752,17 @@ __global__ __launch_bounds__(WG) void k_tokens(const DevCtx* __restrict__ ctxp, 
   sim.tokens(K, env);
 }
 
+template <class TL>
+__global__ __launch_bounds__(WG) void k_context(const DevCtx* __restrict__ ctxp, int raw, int max_tasks, float* out) {
+  const DevCtx& ctx = ctx_ref(ctxp);
+  const int env = blockIdx.x;
+  Lds<TL> L(smem);
+  copy16(L.S, blob_of<TL>(ctx, env), sizeof(EnvState<TL>));
+  lds_sync();
+  Sim<TL> sim(*L.S, *cold_of<TL>(ctx, env), *L.X, ctx.P, nullptr);
+  sim.context(raw, max_tasks, as_global(out) + (size_t)env * (raw ? 1 : 8));
+}
+
 // muavta_call: one of the reference's out-of-step mutators on ONE env, with the device routines step() itself uses.
 struct CallArgs { int32_t op, env, i[8]; double d; };
 template <class TL>
@@ -1030,7 +1041,7 @@ int launch_attr(MuavtaEnv* e) {
   if (lds > 48 * 1024) {
     const void* ks[] = {reinterpret_cast<const void*>(&k_reset<TL>), reinterpret_cast<const void*>(&k_step<TL>), reinterpret_cast<const void*>(&k_allocate<TL>),
                         reinterpret_cast<const void*>(&k_rollout<TL, false>), reinterpret_cast<const void*>(&k_rollout<TL, true>), reinterpret_cast<const void*>(&k_metrics<TL>), reinterpret_cast<const void*>(&k_observe<TL>),
-                        reinterpret_cast<const void*>(&k_tokens<TL>), reinterpret_cast<const void*>(&k_call<TL>)};
+                        reinterpret_cast<const void*>(&k_tokens<TL>), reinterpret_cast<const void*>(&k_call<TL>), reinterpret_cast<const void*>(&k_context<TL>)};
     for (const void* k : ks) HIPCHK(e, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPCHK(e, hipFuncSetAttribute(reinterpret_cast<const void*>(&k_allocate_scored<TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds + SCORED_EXTRA_LDS));
   }
@@ -2270,6 +2281,34 @@ int muavta_tokens(MuavtaEnv* e, int32_t kind, int32_t max_tasks, int32_t max_age
   void* host[10] = {task_feats, task_mask, task_ids, agent_feats, agent_mask, agent_ids, edge_valid, n_urgent, expert_mask, replanned};
   for (int i = 0; i < 10; i++)
     if (host[i]) HIPCHK(e, hipMemcpyAsync(host[i], b + off[i], sz[i], hipMemcpyDeviceToHost, e->stream));
+  HIPCHK(e, hipStreamSynchronize(e->stream));
+  return MUAVTA_OK;
+}
+
+int muavta_context_device(MuavtaEnv* e, int32_t kind, int32_t max_tasks, float* context) {
+  if (!e || !context || (kind != MUAVTA_TOK_PAIR && kind != MUAVTA_TOK_PAIR_RAW) || max_tasks < 1 || max_tasks > 4096) {
+    if (e) e->err = "muavta_context: kind MUAVTA_TOK_PAIR (8 floats per env) or MUAVTA_TOK_PAIR_RAW (1), max_tasks >= 1"; return MUAVTA_E_ARG;
+  }
+  if (!e->did_reset) { e->err = "context before reset"; return MUAVTA_E_STATE; }
+  DeviceScope scope_(e->device);
+  MAIN_OP(e);
+  DISPATCH(e, hipLaunchKernelGGL(k_context<TL>, dim3(e->n_envs), dim3(WG), Lds<TL>::bytes(), e->stream, (const DevCtx*)e->d_ctx, (int)(kind == MUAVTA_TOK_PAIR_RAW), max_tasks, context));
+  HIPCHK(e, hipGetLastError());
+  return MUAVTA_OK;
+}
+int muavta_context(MuavtaEnv* e, int32_t kind, int32_t max_tasks, float* context) {
+  if (!e || !context) return MUAVTA_E_ARG;
+  DeviceScope scope_(e->device);
+  const size_t bytes = (size_t)e->n_envs * (kind == MUAVTA_TOK_PAIR_RAW ? 1 : 8) * sizeof(float);
+  if (bytes > e->tok_bytes) {  // (shares the staging buffer of muavta_tokens' host variant)
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->d_tok) hipFree(e->d_tok);
+    e->d_tok = nullptr; e->tok_bytes = 0;
+    HIPCHK(e, hipMalloc(&e->d_tok, bytes));
+    e->tok_bytes = bytes;
+  }
+  if (int rc = muavta_context_device(e, kind, max_tasks, (float*)e->d_tok)) return rc;
+  HIPCHK(e, hipMemcpyAsync(context, e->d_tok, bytes, hipMemcpyDeviceToHost, e->stream));
   HIPCHK(e, hipStreamSynchronize(e->stream));
   return MUAVTA_OK;
 }

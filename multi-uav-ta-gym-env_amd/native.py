@@ -34,7 +34,7 @@ EXPORTS = [
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
     "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_domain_log", "muavta_step_lists",
     "muavta_allocate_scored", "muavta_allocate_scored_device", "muavta_rl_step_device", "muavta_launch_gaps_ms",
-    "muavta_rl_run_device", "muavta_step_run", "muavta_set_lanes", "muavta_lanes", "muavta_rollout_metrics_back", "muavta_error_flags_back", "muavta_set_slot_cap",
+    "muavta_rl_run_device", "muavta_step_run", "muavta_set_lanes", "muavta_lanes", "muavta_rollout_metrics_back", "muavta_error_flags_back", "muavta_set_slot_cap", "muavta_context", "muavta_context_device",
 ]
 
 
@@ -177,6 +177,8 @@ def lib() -> C.CDLL:
     L.muavta_step_run.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, vp]
     L.muavta_set_lanes.argtypes = [vp, i32]
     L.muavta_set_slot_cap.argtypes = [vp, i32]
+    L.muavta_context.argtypes = [vp, i32, i32, vp]
+    L.muavta_context_device.argtypes = [vp, i32, i32, vp]
     L.muavta_lanes.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.muavta_rollout_metrics_back.argtypes = [vp, i32, vp]
     L.muavta_error_flags_back.argtypes = [vp, i32, vp]

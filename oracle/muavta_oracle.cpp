@@ -1586,6 +1586,33 @@ struct Env {
   };
   // the token builder's task list: build_att_tokens' open_tasks (kind 0/1, AttentionRAH.py:69-73) or build_escort_tokens' sorted
   // local open list (kind 2, AttentionEscort.py:83-96), untruncated
+  // build_context_summary (TaskAllocation/Hybrid/ContextPairHybrid.py:33-78) over build_pair_tokens' tok["live"] (every live agent) and
+  // tok["open_tasks"] (the first max_tasks underfilled tasks, PairCostHybrid.py:36,62): 8 floats, or the raw variant's mission clock alone.
+  int context(int raw, int max_tasks, float* out) const {
+    const double clock = (double)time_steps / (double)std::max(P.max_time_steps, 1);
+    if (raw) { out[0] = (float)clock; return 1; }
+    std::vector<int> kept = token_task_list(0);
+    if ((int)kept.size() > max_tasks) kept.resize(max_tasks);
+    int n_live = 0, n_free = 0, n_fighters = 0;
+    for (auto& a : agents) if (a.state != -1) {
+      n_live++;
+      n_free += (a.tasks.empty() || a.tasks[0] == 0) ? 1 : 0;
+      n_fighters += !is_recon(a.type) && a.type != MUAVTA_E1 ? 1 : 0;  // type name starts with "F"
+    }
+    const int n_agents = std::max(n_live, 1), n_tasks = std::max((int)kept.size(), 1);
+    const double mid_x = 1200.0 * 0.5;  // area_width * 0.5
+    int n_urgent = 0, left = 0, right = 0;
+    for (int tid : kept) {
+      const Task& t = tasks[tid];
+      if (task_urgency(t) >= (1.0 - 12.0 / 40.0) && t.has_deadline) n_urgent++;
+      if (t.pos.x < mid_x) left++; else right++;
+    }
+    const double imbalance = (double)std::abs(left - right) / (double)n_tasks;
+    const double v[8] = {(double)n_urgent / (double)n_tasks, std::fmin((double)kept.size() / (double)n_agents, 4.0) / 4.0, (double)n_free / (double)n_agents,
+                         (double)n_fighters / (double)n_agents, (double)left / (double)n_tasks, (double)right / (double)n_tasks, imbalance, clock};
+    for (int i = 0; i < 8; i++) out[i] = (float)v[i];
+    return 8;
+  }
   std::vector<int> token_task_list(int kind) const {
     const bool vis = !(P.sense_radius == 0 && P.threat_delay == 0);
     std::vector<int> out;
@@ -1904,6 +1931,7 @@ int orc_allocate_scored(void* h, int interval, int use_vis, int gate, int kind, 
   Env::Scored sc{gate, kind, max_tasks, max_agents, flags, scores, pri, reserved, selected};
   return ((Env*)h)->allocate(interval, use_vis, act_agent, act_index, cap, 4, &sc);
 }
+int orc_context(void* h, int raw, int max_tasks, float* out) { return ((Env*)h)->context(raw, max_tasks, out); }
 int orc_gate(void* h, int gate, int interval) { return ((Env*)h)->gate_fires(gate, interval) ? 1 : 0; }
 int orc_run_quiet(void* h, int gate, int interval, int max_steps, int already, int* at_gate, double* reward_sum) {
   return ((Env*)h)->run_quiet(gate, interval, max_steps, already, at_gate, reward_sum);

@@ -168,6 +168,12 @@ class OracleEnv:
         out["n_urgent"] = int(nu[0])
         return out
 
+    def context(self, kind, max_tasks):
+        """build_context_summary of the ContextPair hybrids: f32 [8] (kind 0) or [1] (kind 1, raw)."""
+        out = np.zeros(8, np.float32)
+        n = self.L.orc_context(self.h, int(kind == 1), int(max_tasks), _p(out))
+        return out[:n].copy()
+
     def scalars_last_plan(self):
         self.L.orc_last_plan_step.restype = C.c_longlong
         return int(self.L.orc_last_plan_step(self.h))

@@ -2201,3 +2201,40 @@ def test_vectorised_facade_views_equal_single_env_facades(case, n, interval):
                 assert binfo["metrics"] == info["metrics"]
     assert all(all(o[3].values()) for o in outs)
     batch.close()
+
+
+CONTEXT_FILES = sorted(glob.glob(os.path.join(GOLDEN, "context_*.npz")))
+
+
+@pytest.mark.parametrize("path", CONTEXT_FILES, ids=[os.path.basename(p)[8:-4] for p in CONTEXT_FILES])
+def test_context_vector_vs_reference_and_oracle(path):
+    """muavta_context: build_context_summary of the ContextPair hybrids for every env (ContextPairHybrid.py:33-78) — env 0 against the
+    reference's own values along its episode (tests/golden/context_*.npz), the other seeds against the oracle; host and device-tensor variants."""
+    import torch
+
+    g = np.load(path)
+    case = os.path.basename(path)[8:-4]
+    seed0, interval, n = int(g["seed"]), int(g["interval"]), 4
+    env = _env(case, n)
+    env.reset(np.arange(seed0, seed0 + n, dtype=np.uint64))
+    oracles = [orc.OracleEnv(params_for_case(case)) for _ in range(n)]
+    for i, o in enumerate(oracles):
+        o.reset(seed0 + i)
+    steps = g["step"].tolist()
+    dev_out = torch.empty((n, 8), dtype=torch.float32, device="cuda")
+    for t in range(150):
+        aa, ai = env.allocate(interval, True)
+        for o in oracles:
+            o.allocate(interval, 1)
+        if t in steps:
+            k = steps.index(t)
+            c32, c12, craw = env.context("pair", 32), env.context("pair", 12), env.context("pair_raw", 32)
+            assert np.array_equal(c32[0], g["ctx"][k]) and np.array_equal(c12[0], g["ctx12"][k]) and np.array_equal(craw[0], g["ctx_raw"][k]), f"{case} t={t} (reference)"
+            for i, o in enumerate(oracles):
+                assert np.array_equal(c32[i], o.context(0, 32)) and np.array_equal(c12[i], o.context(0, 12)) and np.array_equal(craw[i], o.context(1, 32)), f"{case} seed {seed0 + i} t={t}"
+            env.context("pair", 32, out=dev_out); env.sync()
+            assert np.array_equal(dev_out.cpu().numpy(), c32)
+        env.step(aa, ai)
+        for i, o in enumerate(oracles):
+            kk = int(np.sum(aa[i] >= 0))
+            o.step(aa[i][:kk], ai[i][:kk])

@@ -590,3 +590,23 @@ def test_avoid_obstacles_oracle_vs_arbitrary_precision_witness():
         else:
             explained += 1
     assert taken > n // 2 and explained < n // 100, (taken, explained)
+
+
+CONTEXT_FILES = sorted(glob.glob(os.path.join(GOLDEN, "context_*.npz")))
+
+
+@pytest.mark.parametrize("path", CONTEXT_FILES, ids=[os.path.basename(p)[8:-4] for p in CONTEXT_FILES])
+def test_context_vector_vs_reference(path):
+    """build_context_summary of the ContextPair hybrids (TaskAllocation/Hybrid/ContextPairHybrid.py:33-78) sampled along reference episodes
+    (tools/gen_golden.py --context): token pads 32 x 16 and 12 x 6, and the raw variant — bit for bit."""
+    g = np.load(path)
+    case = os.path.basename(path)[8:-4]
+    o = orc.OracleEnv(params_for_case(case))
+    o.reset(int(g["seed"]))
+    steps = g["step"].tolist()
+    for t in range(150):
+        oa, oi = o.allocate(int(g["interval"]), 1)
+        if t in steps:
+            k = steps.index(t)
+            assert np.array_equal(o.context(0, 32), g["ctx"][k]) and np.array_equal(o.context(0, 12), g["ctx12"][k]) and np.array_equal(o.context(1, 32), g["ctx_raw"][k]), f"{case} t={t}"
+        o.step(oa, oi)

@@ -380,7 +380,7 @@ def main():
         print("metrics", case, np.stack(rows)[:, 4].mean())
 
 
-if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens", "--il", "--fuzz", "--lists")):
+if __name__ == "__main__" and not any(f in sys.argv for f in ("--urgency-pair", "--urgency-coalition", "--tokens", "--il", "--fuzz", "--lists", "--context")):
     main()
 
 
@@ -578,6 +578,44 @@ def gen_tokens():
 
 if __name__ == "__main__" and "--tokens" in sys.argv:
     gen_tokens()
+
+
+# ------------------------------------------------------------------------------------------------
+# The context vector of the ContextPair hybrids (TaskAllocation/Hybrid/ContextPairHybrid.py:33-78: build_context_summary over
+# build_pair_tokens' live agents and kept open tasks) sampled along reference episodes, for two token pads and the raw variant.
+# ------------------------------------------------------------------------------------------------
+def gen_context():
+    from TaskAllocation.Hybrid.ContextPairHybrid import build_context_summary
+    from TaskAllocation.Hybrid.PairCostHybrid import build_pair_tokens
+
+    for case, seed, interval in (("WPS_hard", 0, 20), ("WPS_attn", 0, 20), ("WPS_hard_x2", 1, 20), ("WPS_escort", 0, 12), ("WPS_burst64", 0, 20), ("WPS_easy", 2, 20)):
+        env = make_env(case)
+        obs, info = env.reset(seed=seed)
+        hung = HA.HungarianAllocator(replan_interval=interval, max_coord=env.max_coord)
+        done = {a: False for a in env.agents}
+        trunc = {a: False for a in env.agents}
+        rec = {k: [] for k in ("step", "ctx", "ctx12", "ctx_raw")}
+        while not all(done.values()) and not all(trunc.values()):
+            result = hung.allocate_tasks(env.get_live_agents(), _open_tasks(env), time_step=env.time_steps, events=_events(info),
+                                         agent_known_ids=env.agent_visibility_map())
+            actions = {}
+            for name, task in result:
+                if env.last_tasks_info and task in env.last_tasks_info and name not in actions:
+                    actions[name] = env.last_tasks_info.index(task)
+            if env.time_steps % 3 == 0 or env.time_steps in (1, 149):
+                rec["step"].append(env.time_steps)
+                rec["ctx"].append(build_context_summary(env, build_pair_tokens(env, 32, 16)))
+                rec["ctx12"].append(build_context_summary(env, build_pair_tokens(env, 12, 6)))
+                rec["ctx_raw"].append(build_context_summary(env, build_pair_tokens(env, 32, 16, raw=True), raw=True))
+            obs, reward, done, trunc, info = env.step(actions)
+        out = {k: np.stack([np.asarray(x) for x in v]) for k, v in rec.items()}
+        out.update(interval=np.int64(interval), seed=np.int64(seed))
+        np.savez_compressed(os.path.join(OUT, f"context_{case}.npz"), **out)
+        print("context", case, out["ctx"].shape, out["ctx"].dtype, out["ctx"][len(out["ctx"]) // 2])
+
+
+if __name__ == "__main__" and "--context" in sys.argv:
+    gen_context()
 
 
 # ------------------------------------------------------------------------------------------------
