@@ -196,6 +196,10 @@ def stepwise(k, w, log):
                     for key in want:
                         gv = int(got[key][i]) if key == "n_urgent" else got[key][i]
                         assert np.array_equal(np.asarray(gv), np.asarray(want[key])), f"{tag} seed {seeds[i]} t={t}: tokens kind {kind} pads {mt}x{ma}: {key}"
+                if kind != 2:  # ... and the ContextPair hybrids' context vector over the same token pad (muavta_context)
+                    ctx = env.context(("pair", "pair_raw")[kind], mt)
+                    for i, o in enumerate(oracles):
+                        assert np.array_equal(ctx[i], o.context(kind, mt)), f"{tag} seed {seeds[i]} t={t}: context vector kind {kind} pad {mt}: {ctx[i]} vs {o.context(kind, mt)}"
             for i, o in enumerate(oracles):
                 o.step(*plans[i])
             env.step(aa, ai)
