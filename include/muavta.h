@@ -388,6 +388,7 @@ int muavta_rl_step_device(MuavtaEnv* env, const MuavtaRlStep* step);
  * Outputs of `first` for an env that did NOT plan (replanned 0: it was not at a gate, or its episode had ended): selected 0, s_wps / done
  * of its first step, next-token rows untouched.  The launch of a whole batch ends when every env has stopped; envs advance by different
  * numbers of steps (each has its own clock), which is what lets the policy be called once per GATE instead of once per step.
+ * first.write_obs != 0 refreshes the handle's observation buffers ONCE per launch, for the state each env stopped in (not after every quiet step).
  * All pointers are DEVICE pointers; asynchronous on the handle's stream (first.part > 0: on that sub-batch's stream, for its rows). */
 typedef struct MuavtaRlRun {
   MuavtaRlStep first;
