@@ -221,7 +221,10 @@ class UAVView:
 
     @property
     def name(self) -> str:
-        return self._env.possible_agents[int(self._env._snap["AGENT_NAME_IDX"][self.id])]
+        n = self.__dict__.get("_name")  # (fixed by reset's shuffle for the whole episode: the view is rebuilt at every reset)
+        if n is None:
+            n = self._name = self._env.possible_agents[int(self._env._snap["AGENT_NAME_IDX"][self.id])]
+        return n
 
     @property
     def typeIdx(self) -> int:
@@ -495,29 +498,38 @@ class MultiUAVEnv:
     def _build_observations(self):
         o = self._b.observe()
         rows = o["tasks"][0]
+        # bulk conversions once per step (a row dict then holds VIEWS of these arrays, as the reference's rows hold their own arrays)
+        r64 = rows.astype(np.float64)
+        ids, status = rows[:, 0].astype(np.int64).tolist(), rows[:, 3].astype(np.int64).tolist()
+        extra = rows[:, 16:21].tolist()   # init_time, end_time, type_idx, unmet, age as Python floats (float(np.float32))
+        windows, have_open = bool(self._params.include_time_windows), len(self.last_tasks_info) > 0
         tasks_info = []
-        for r in rows:
-            if r[3] == -1.0:
+        for j, st in enumerate(status):
+            if st == -1:
                 tasks_info.append({"status": -1})
                 continue
-            d = {"id": int(r[0]), "position": np.array(r[1:3], dtype=np.float64), "status": int(r[3]),
-                 "current_reqs": np.array(r[4:10], dtype=np.float64), "alloc_reqs": np.array(r[10:16], dtype=np.float64)}
-            if int(r[0]) != 0 or len(self.last_tasks_info) > 0:
-                if self._params.include_time_windows:
-                    d.update(init_time=float(r[16]), end_time=float(r[17]), type_idx=float(r[18]))
-                d.update(unmet=float(r[19]), age=float(r[20]))
+            d = {"id": ids[j], "position": r64[j, 1:3], "status": st, "current_reqs": r64[j, 4:10], "alloc_reqs": r64[j, 10:16]}
+            if ids[j] != 0 or have_open:
+                e = extra[j]
+                if windows:
+                    d.update(init_time=e[0], end_time=e[1], type_idx=e[2])
+                d.update(unmet=e[3], age=e[4])
             tasks_info.append(d)
-        mask = [bool(x) for x in o["mask"][0]]
+        mask = o["mask"][0].astype(bool).tolist()
+        agents64 = o["agents"][0].astype(np.float64)
+        alloc = o["agents"][0, :, 8].astype(np.int64).tolist()
+        legal = o["legal_mask"][0].astype(bool).tolist()
+        flags = np.array(o["event_flags"][0], dtype=np.float32)
         self.observations = {}
         for a in self.agents_obj:
             self.observations[a.name] = {
-                "agent_position": np.array(o["agents"][0, a.id, 0:2], dtype=np.float64),
-                "agent_caps": np.array(o["agents"][0, a.id, 2:8], dtype=np.float64),
-                "alloc_task": int(o["agents"][0, a.id, 8]),
+                "agent_position": agents64[a.id, 0:2],
+                "agent_caps": agents64[a.id, 2:8],
+                "alloc_task": alloc[a.id],
                 "tasks_info": tasks_info,
                 "mask": mask,
-                "legal_mask": [bool(x) for x in o["legal_mask"][0, a.id]],
-                "event_flags": np.array(o["event_flags"][0], dtype=np.float32),
+                "legal_mask": legal[a.id],
+                "event_flags": flags.copy(),
             }
 
     # ------------------------------------------------------------------ PettingZoo surface
