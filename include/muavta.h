@@ -494,6 +494,12 @@ int muavta_domain_math(int32_t device, const double* x, const double* y, int32_t
  * parity tests pin that against the host's log. */
 int muavta_domain_log(int32_t device, const double* x, int32_t n, double* out);
 
+/* Diagnostic: the two-argument arctangent of the obstacle rule's heading test (core_sim/src/sim_core.rs:46-47, f64::atan2 = the host
+ * libm's atan2), evaluated on the device for n (y, x) pairs: libm_atan2 in csrc/muavta_atan2.h restates glibc 2.35's algorithm (which
+ * is not correctly rounded) with that library's node table so that device and host agree bit for bit, special operands included;
+ * the parity tests pin that against the host's atan2. */
+int muavta_domain_atan2(int32_t device, const double* y, const double* x, int32_t n, double* out);
+
 /* core_sim.SimCore.avoid_obstacles (core_sim/src/sim_core.rs:25-59) for n (position, movement)
  * pairs against one obstacle list, evaluated on the device. */
 int muavta_avoid_obstacles(int32_t device, const double* agent_pos, const double* movement, int32_t n,

@@ -728,6 +728,20 @@ def domain_log(x, device: int = 0):
     return out
 
 
+def domain_atan2(y, x, device: int = 0):
+    """The obstacle rule's two-argument arctangent as the device computes it (diagnostic, `muavta_domain_atan2`)."""
+    y = np.ascontiguousarray(y, dtype=np.float64).ravel()
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    if y.shape != x.shape:
+        raise ValueError("domain_atan2: y and x differ in length")
+    out = np.empty_like(x)
+    L = native.lib()
+    rc = L.muavta_domain_atan2(int(device), _vp(y), _vp(x), x.shape[0], _vp(out))
+    if rc != 0:
+        raise MuavtaError(f"muavta_domain_atan2 failed ({rc}): {L.muavta_last_error(None).decode()}")
+    return out
+
+
 def domain_math(x, y, device: int = 0):
     """The kernels' range-restricted sqrt / division on the device (diagnostic, `muavta_domain_math`):
     returns (sqrt(x), x / y, -x / y) as the device computes them."""

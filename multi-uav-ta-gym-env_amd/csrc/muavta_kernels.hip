@@ -893,6 +893,11 @@ __global__ void k_libm_log(const double* x, int n, double* out) {
   if (i < n) out[i] = libm_log(x[i]);
 }
 
+__global__ void k_libm_atan2(const double* y, const double* x, int n, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = libm_atan2(y[i], x[i]);
+}
+
 __global__ void k_avoid(const double* pos, const double* mov, int n, const double* obst, int n_obs, double* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -907,7 +912,7 @@ __global__ void k_avoid(const double* pos, const double* mov, int n, const doubl
       double nx = dx / d_zone, ny = dy / d_zone;
       double force = libm_log(fmax(1.05, d_zone));
       force = 0.5 / (1.0 - force);
-      double ang = atan2(my, mx) - atan2(dy, dx);
+      double ang = libm_atan2(my, mx) - libm_atan2(dy, dx);
       ang = fmod(ang + PI, 2.0 * PI) - PI;
       double rx, ry;
       if (ang > 0.0) { rx = ny; ry = -nx; } else { rx = -ny; ry = nx; }
@@ -2723,6 +2728,25 @@ int muavta_domain_log(int32_t device, const double* x, int32_t n, double* out) {
   hipLaunchKernelGGL(k_libm_log, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], n, d[1]);
   CK(hipGetLastError());
   CK(hipMemcpy(out, d[1], bytes, hipMemcpyDeviceToHost));
+#undef CK
+  for (double* q : d) hipFree(q);
+  return MUAVTA_OK;
+}
+
+int muavta_domain_atan2(int32_t device, const double* y, const double* x, int32_t n, double* out) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { g_create_error = "muavta_domain_atan2: no HIP device"; return MUAVTA_E_NO_DEVICE; }
+  if (!x || !y || !out || n < 1) return MUAVTA_E_ARG;
+  double* d[3] = {nullptr, nullptr, nullptr};
+#define CK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { g_create_error = std::string(#expr) + ": " + hipGetErrorString(e_); for (double* q : d) hipFree(q); return MUAVTA_E_HIP; } } while (0)
+  DeviceScope scope_(device);
+  const size_t bytes = (size_t)n * sizeof(double);
+  for (double*& q : d) CK(hipMalloc(&q, bytes));
+  CK(hipMemcpy(d[0], y, bytes, hipMemcpyHostToDevice));
+  CK(hipMemcpy(d[1], x, bytes, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_libm_atan2, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], d[1], n, d[2]);
+  CK(hipGetLastError());
+  CK(hipMemcpy(out, d[2], bytes, hipMemcpyDeviceToHost));
 #undef CK
   for (double* q : d) hipFree(q);
   return MUAVTA_OK;

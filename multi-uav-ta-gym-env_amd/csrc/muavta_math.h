@@ -171,5 +171,6 @@ DEV double libm_log(double x) {
   q = __builtin_fma(q, r2, p);
   return __builtin_fma(rr2, q, lo) + hi;
 }
+#include "muavta_atan2.h"
 DEV bool is_recon(int t) { return t == MUAVTA_R1 || t == MUAVTA_R2; }
 DEV bool is_fighter(int t) { return t == MUAVTA_F1 || t == MUAVTA_F2; }

@@ -32,7 +32,7 @@ EXPORTS = [
     "muavta_set_allocator", "muavta_tokens", "muavta_tokens_device", "muavta_set_release_log", "muavta_lsap_impl",
     "muavta_last_seed_ms", "muavta_call", "muavta_rollout_record", "muavta_comm_uid", "muavta_comm_init", "muavta_allreduce_metrics", "muavta_comm_destroy",
     "muavta_kernel_ms_history", "muavta_wait_stream", "muavta_set_parts", "muavta_part_range", "muavta_rollout_part", "muavta_allocate_part",
-    "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_domain_log", "muavta_step_lists",
+    "muavta_step_part", "muavta_observe_part", "muavta_wait_part", "muavta_domain_math", "muavta_domain_log", "muavta_domain_atan2", "muavta_step_lists",
     "muavta_allocate_scored", "muavta_allocate_scored_device", "muavta_rl_step_device", "muavta_launch_gaps_ms",
     "muavta_rl_run_device", "muavta_step_run", "muavta_set_lanes", "muavta_lanes", "muavta_rollout_metrics_back", "muavta_error_flags_back", "muavta_set_slot_cap", "muavta_context", "muavta_context_device",
 ]
@@ -53,7 +53,7 @@ class MuavtaScored(C.Structure):
 def sources():
     """every file the shipped library is compiled from (muavta_diag.h is not one of them: diagnostic builds only)"""
     sim = sorted(os.path.join(CSRC, "sim", f) for f in os.listdir(os.path.join(CSRC, "sim")) if f.endswith(".inc"))
-    return [os.path.join(CSRC, f) for f in ("muavta_kernels.hip", "muavta_device.h", "muavta_state.h", "muavta_math.h", "muavta_rng.h")] + sim + [
+    return [os.path.join(CSRC, f) for f in ("muavta_kernels.hip", "muavta_device.h", "muavta_state.h", "muavta_math.h", "muavta_atan2.h", "muavta_atan2_tab.inc", "muavta_rng.h")] + sim + [
         os.path.join(os.path.dirname(PKG_DIR), "include", "muavta.h")]
 
 
@@ -145,6 +145,7 @@ def lib() -> C.CDLL:
     L.muavta_avoid_obstacles.argtypes = [i32, vp, vp, i32, vp, i32, vp]
     L.muavta_domain_math.argtypes = [i32, vp, vp, i32, vp, vp, vp]
     L.muavta_domain_log.argtypes = [i32, vp, i32, vp]
+    L.muavta_domain_atan2.argtypes = [i32, vp, vp, i32, vp]
     L.muavta_device_ptrs.argtypes = [vp] + [C.POINTER(vp)] * 6
     L.muavta_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     L.muavta_kernel_ms_history.argtypes = [vp, vp, C.c_int32]

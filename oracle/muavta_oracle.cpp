@@ -2011,6 +2011,11 @@ void orc_get_known(void* h, uint8_t* out) {  // [A, NT]
   size_t nt = e->tasks.size();
   for (int a = 0; a < e->n_agents; a++) for (size_t k = 0; k < nt; k++) out[a * nt + k] = e->known[a][k];
 }
+int orc_get_obstacles(void* h, double* out) {  // [K, 3] (x, y, size); returns K
+  Env* e = (Env*)h;
+  for (size_t o = 0; o < e->obstacles.size(); o++) for (int c = 0; c < 3; c++) out[3 * o + c] = e->obstacles[o][c];
+  return (int)e->obstacles.size();
+}
 // threats by id: f64 [H, 8]: status(-9 not spawned), x, y, target, mission target, attackCap, task id, type
 void orc_get_threats(void* h, double* rows) {
   Env* e = (Env*)h;

@@ -201,6 +201,10 @@ class OracleEnv:
         self.L.orc_get_known(self.h, _p(k))
         return k.astype(bool)
 
+    def obstacles(self):
+        out = np.zeros((8, 3))
+        return out[:self.L.orc_get_obstacles(self.h, _p(out))]
+
     def threats(self):
         rows = np.zeros((self.dims()["n_threats"], 10))
         self.L.orc_get_threats(self.h, _p(rows))

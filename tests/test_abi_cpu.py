@@ -98,3 +98,49 @@ def test_binding_structs_match_the_header_field_by_field(tmp_path):
         assert int(got[name]) == C.sizeof(st), f"sizeof({name}): header {got[name]}, binding {C.sizeof(st)}"
         for field, *_ in st._fields_:
             assert int(got[f"{name}.{field}"]) == getattr(st, field).offset, f"{name}.{field}: header offset {got[f'{name}.{field}']}, binding {getattr(st, field).offset}"
+
+
+def test_atan2_restatement_vs_host_libm(tmp_path):
+    """csrc/muavta_atan2.h (glibc 2.35's atan2 restated for the device: the obstacle rule's heading test, sim_core.rs:46-47) compiled for
+    the HOST with the contraction switched off, as the device library is, against the host libm's atan2: bit for bit over every branch —
+    quadrants, both quotient forms, |x| == |y|, the polynomial / table boundary, the 2^+-500 rescaling, quotients beyond 2^+-57,
+    subnormal results, zeros, infinities, NaN.  (The device function itself is checked on the GPU, test_libm_atan2_bit_exact.)"""
+    import math
+    import subprocess
+
+    so = str(tmp_path / "atan2_host_check.so")
+    here = os.path.dirname(os.path.abspath(__file__))
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-shared", "-fPIC", os.path.join(here, "atan2_host_check.c"), "-o", so, "-lm"], check=True)
+    L = C.CDLL(so)
+    L.atan2_count_diff.restype = C.c_int64
+    if math.atan2(float.fromhex("-0x1.19994659f1a50p-4"), float.fromhex("0x1.1fdb7b56bf584p-1")).hex() != "-0x1.f264cb39e91d6p-4":
+        pytest.skip("this host's libm is not the glibc the restatement follows (its atan2 rounds this argument the other way)")
+    rng = np.random.default_rng(1)
+    n = 1_000_000
+    a, r = rng.uniform(-math.pi, math.pi, n), 10.0 ** rng.uniform(-3, 3, n)
+    d = rng.uniform(-5, 5, n)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e308, -1e308, 2.0 ** -500, 2.0 ** 500, 2.2250738585072014e-308])
+    sy, sx = np.meshgrid(sp, sp)
+    u16 = rng.uniform(0.0615, 0.0635, n)
+    cases = {"unit square": (rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)), "coordinates": (rng.uniform(-800, 800, n), rng.uniform(-800, 800, n)),
+             "wide": (rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-8, 8, n), rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-8, 8, n)),
+             "polar": (r * np.sin(a), r * np.cos(a)), "diagonal": (d * rng.choice([1.0, -1.0], n), d),
+             "extreme exponents": (rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-1070, 1020, n), rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-1070, 1020, n)),
+             "around 1/16": (np.concatenate([u16, -u16]), np.concatenate([np.ones(n), -np.ones(n)])), "specials": (sy.ravel(), sx.ravel())}
+    for tag, (y, x) in cases.items():
+        y, x = np.ascontiguousarray(y, dtype=np.float64), np.ascontiguousarray(x, dtype=np.float64)
+        first = C.c_int64(-1)
+        bad = L.atan2_count_diff(y.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p), C.c_int64(len(y)), C.byref(first))
+        assert bad == 0, f"{tag}: {bad} of {len(y)} differ, e.g. y={y[first.value].hex()} x={x[first.value].hex()}"
+
+
+def test_atan2_table_is_the_image_libm_table():
+    """the committed node table is the one tools/gen_atan2_table.py reads out of this image's libm.so.6 (skipped on another libm build)"""
+    import subprocess
+    import sys
+
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gen_atan2_table.py")
+    res = subprocess.run([sys.executable, tool, "--check"], capture_output=True, text=True)
+    if "not the build" in res.stderr:
+        pytest.skip(res.stderr.strip())
+    assert res.returncode == 0, res.stderr

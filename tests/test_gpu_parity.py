@@ -350,6 +350,37 @@ def test_libm_log_bit_exact():
     assert len(bad) == 0, f"{len(bad)} of {len(x)} differ, e.g. x={x[bad[0]].hex()} device {got[bad[0]].hex()} host {want[bad[0]].hex()}"
 
 
+@pytest.mark.gpu
+def test_libm_atan2_bit_exact():
+    """(r5) The obstacle rule's heading test (sim_core.rs:46-47, f64::atan2 = the host libm's atan2, which glibc 2.35 does NOT round
+    correctly): the device's restatement of that library's algorithm (csrc/muavta_atan2.h) against the HOST's atan2, bit for bit — unit
+    vectors against coordinate differences (the rule's operands), every quadrant and both u = min / max forms, |x| == |y|, the
+    polynomial / table boundary at u = 1/16, extreme exponents and the special operands."""
+    import math
+    from muavta_amd.batched import domain_atan2
+    rng = np.random.default_rng(23)
+    n = 400_000
+    a = rng.uniform(-math.pi, math.pi, n)
+    d = rng.uniform(-5.0, 5.0, n)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e308, -1e308, 2.0 ** -500, 2.0 ** 500, 2.2250738585072014e-308])
+    sy, sx = np.meshgrid(sp, sp)
+    u16 = rng.uniform(0.0615, 0.0635, n)
+    y = np.concatenate([np.sin(a), rng.uniform(-800, 800, n), rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-8, 8, n), d * rng.choice([1.0, -1.0], n), u16, -u16,
+                        rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-1070, 1020, n), sy.ravel()])
+    x = np.concatenate([np.cos(a), rng.uniform(-800, 800, n), rng.uniform(-1, 1, n) * 10.0 ** rng.uniform(-8, 8, n), d, np.ones(n), -np.ones(n),
+                        rng.uniform(-1, 1, n) * 2.0 ** rng.integers(-1070, 1020, n), sx.ravel()])
+    got = domain_atan2(y, x)
+    want = np.fromiter(map(math.atan2, y.tolist(), x.tolist()), dtype=np.float64, count=len(x))  # (math.atan2 is libm's)
+    bad = np.nonzero(got.view(np.uint64) != want.view(np.uint64))[0]
+    bad = bad[~(np.isnan(got[bad]) & np.isnan(want[bad]))]
+    assert len(bad) == 0, f"{len(bad)} of {len(x)} differ, e.g. y={y[bad[0]].hex()} x={x[bad[0]].hex()} device {got[bad[0]].hex()} host {want[bad[0]].hex()}"
+    # the pair the device fuzz found (config 32517): an agent on the axis of an obstacle, the two headings one ulp apart
+    f = float.fromhex
+    px, py = f("0x1.e1186bb3bf6abp+8"), f("0x1.c51c9fc28c1a9p+7")
+    pair = domain_atan2([f("-0x1.ffe26cf27704ap-1"), f("0x1.2d0c686c71993p+7") - py], [f("-0x1.5c070de57194ep-6"), f("0x1.df7adf58ae2f0p+8") - px])
+    assert [v.hex() for v in pair.tolist()] == ["-0x1.978fec4a46805p+0", "-0x1.978fec4a46806p+0"]
+
+
 def test_avoid_obstacles_vs_oracle():
     """K > 0 obstacles: no reference test pins this (parity unpinned: sim_core.rs cannot be compiled here); device vs the CPU
     restatement of core_sim/src/sim_core.rs:25-59.  (r4) Bit for bit: the logarithm is the host libm's on both sides
@@ -1143,13 +1174,13 @@ def test_wide_fuzz_regressions_stepwise_vs_oracle_and_reference_metrics(path):
 
 
 @pytest.mark.parametrize("leg,k", [("mutators", 12794), ("mutators", 12782), ("mutators", 14016), ("mutators", 14068), ("mutators", 14173),
-                                   ("scored", 7178), ("mutators", 1001642), ("stepwise", 992), ("stepwise", 40), ("rl", 12041), ("lists", 12042), ("rings", 12043),
+                                   ("scored", 7178), ("scored", 32517), ("mutators", 1001642), ("stepwise", 992), ("stepwise", 40), ("rl", 12041), ("lists", 12042), ("rings", 12043),
                                    ("resume", 17001), ("ilrings", 18801), ("inflight", 21001), ("rlrun", 22001), ("rlrun", 1003001), ("steprun", 22002),
                                    ("steprun", 2002001), ("lanes", 22003)])
 def test_wide_fuzz_legs_on_the_configurations_that_found_bugs(leg, k):
     """One episode of a leg of tests/fuzz_device.py on the configurations that exposed device bugs (the allocator's list after an
     out-of-step _retire_escort / _create_escort_for, the recon-as-escort retire verdicts, rows beyond max_tasks, the expired escort
-    that follows its UAV) plus one plain configuration per remaining leg, so that the fuzz driver itself stays runnable."""
+    that follows its UAV, the agent steered onto an obstacle's axis where the last bit of atan2 picks the side — 32517) plus one plain configuration per remaining leg, so that the fuzz driver itself stays runnable."""
     import fuzz_device as FD
     from fuzz_reference import wide_config
 
