@@ -14,7 +14,10 @@
  * captured by RUNNING the reference in the build container (tools/gen_golden.py ->
  * tests/golden/*.npz; checked by tests/test_oracle_golden.py): bit-exact per-step state for 17 traced
  * episodes and final metrics for 240 more.  Exception: avoid_obstacles with K>0 obstacles is pinned by
- * no reference test or live configuration ("parity unpinned" for K>0; K=0 is the identity).
+ * no reference test or live configuration ("parity unpinned" for K>0; K=0 is the identity).  Its f64::ln
+ * and f64::atan2 are the platform libm's log / atan2 (std::log / std::atan2 here): the DEVICE restates this
+ * image's glibc 2.35 algorithms for both (csrc/muavta_math.h, csrc/muavta_atan2.h) because the last bit of
+ * either can decide an episode (an agent on an obstacle's axis passes on the side the last bit of atan2 picks).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.  The
  * product (multi-uav-ta-gym-env_amd/csrc) never includes, links or calls it.
