@@ -27,6 +27,12 @@ def _vp(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def _fp(a: np.ndarray):
+    """pointer of an array the CALLER keeps alive in a local for the duration of the (synchronous) library call — a third of data_as's
+    cost, which holds a reference for the pointer's lifetime; the per-step calls of the facade (get / observe / step / allocate) use it"""
+    return C.c_void_p(a.ctypes.data)
+
+
 class BatchedMultiUAVEnv:
     def __init__(self, config, n_envs: int, device: int = 0, flags=None, **tiles):
         self.params = config if isinstance(config, MuavtaParams) else params_from_config(config, flags, **tiles)
@@ -83,7 +89,7 @@ class BatchedMultiUAVEnv:
         if aa.ndim != 2 or aa.shape != ai.shape or aa.shape[0] != self.n_envs or aa.shape[1] < 1:
             raise ValueError(f"actions must have shape ({self.n_envs}, cap), cap >= 1")
         if aa.shape[1] == self.A_tile:
-            self._ck(self.L.muavta_step(self.h, _vp(aa), _vp(ai)))
+            self._ck(self.L.muavta_step(self.h, _fp(aa), _fp(ai)))
         else:
             self._ck(self.L.muavta_step_lists(self.h, _vp(aa), _vp(ai), aa.shape[1]))
 
@@ -103,7 +109,7 @@ class BatchedMultiUAVEnv:
             return None
         aa = np.empty((self.n_envs, self.A_tile), dtype=np.int32)
         ai = np.empty((self.n_envs, self.A_tile), dtype=np.int32)
-        self._ck(self.L.muavta_allocate(self.h, int(replan_interval), int(use_visibility), _vp(aa), _vp(ai)))
+        self._ck(self.L.muavta_allocate(self.h, int(replan_interval), int(use_visibility), _fp(aa), _fp(ai)))
         return aa, ai
 
     def set_allocator(self, name: str = "hungarian"):
@@ -572,7 +578,7 @@ class BatchedMultiUAVEnv:
         pad = np.empty((N, MT), dtype=np.uint8)
         agents = np.empty((N, A, 9), dtype=np.float32)
         flags = np.empty((N, 5), dtype=np.float32)
-        self._ck(self.L.muavta_observe(self.h, _vp(tasks), _vp(legal), _vp(pad), _vp(agents), _vp(flags)))
+        self._ck(self.L.muavta_observe(self.h, _fp(tasks), _fp(legal), _fp(pad), _fp(agents), _fp(flags)))
         tasks = np.ascontiguousarray(tasks.transpose(0, 2, 1))    # -> [N, max_tasks, 21] like the reference's rows
         bits = (legal[..., :, None] >> np.arange(64, dtype=np.uint64)) & np.uint64(1)
         legal = bits.reshape(N, A, -1)[:, :, :MT]
@@ -581,7 +587,7 @@ class BatchedMultiUAVEnv:
     def step_result(self):
         r = np.empty(self.n_envs, dtype=np.float64)
         d = np.empty(self.n_envs, dtype=np.uint8)
-        self._ck(self.L.muavta_step_result(self.h, _vp(r), _vp(d)))
+        self._ck(self.L.muavta_step_result(self.h, _fp(r), _fp(d)))
         return r, (d & 1).astype(bool), (d & 2).astype(bool)
 
     def metrics(self) -> np.ndarray:
@@ -632,9 +638,12 @@ class BatchedMultiUAVEnv:
 
     # ------------------------------------------------------------------ state access
     def _shape(self, name):
+        shapes = self.__dict__.get("_shapes")
+        if shapes is not None:
+            return shapes[name]
         N, A, T, H, Q, E = self.n_envs, self.n_agents, self.T, self.H, self.Q, self.E
         f64, i32, u32 = np.float64, np.int32, np.uint32
-        return {
+        self._shapes = {
             "AGENT_POS": ((N, A, 2), f64), "AGENT_STATE": ((N, A), i32), "AGENT_HEAD": ((N, A), i32),
             "AGENT_QUEUE": ((N, A, Q), i32), "AGENT_NFT": ((N, A), f64), "AGENT_NFP": ((N, A, 2), f64),
             "AGENT_CAPS": ((N, A, 6), f64), "AGENT_ATTACK_CAP": ((N, A), i32), "AGENT_TYPE": ((N, A), i32),
@@ -646,12 +655,13 @@ class BatchedMultiUAVEnv:
             "OPEN_IDS": ((N, T), i32), "EVENTS": ((N, E, 2), i32), "EVENT_LIST": ((N, E, 2), i32),
             "STAGED_ACTIONS": ((N, self.A_tile, 3), i32), "ERROR": ((N,), i32),
             "RELEASE_LOG": ((N, 1 + 29 * T), f64), "KNOWN_COUNT": ((N, A), i32), "ESCORTS": ((N, self.A_tile, 2), i32),
-        }[name]
+        }
+        return self._shapes[name]
 
     def get(self, name: str) -> np.ndarray:
         shape, dt = self._shape(name)
         out = np.empty(shape, dtype=dt)
-        self._ck(self.L.muavta_get(self.h, F[name], _vp(out), out.nbytes))
+        self._ck(self.L.muavta_get(self.h, F[name], _fp(out), out.nbytes))
         return out
 
     def set(self, name: str, value: np.ndarray):
