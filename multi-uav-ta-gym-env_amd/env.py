@@ -415,6 +415,7 @@ class MultiUAVEnv:
         self.agent_by_name: Dict[str, UAVView] = {}
         self._threats: Dict[int, ThreatView] = {}
         self._known: Dict[str, set] = {}
+        self._views_upto, self._known_sig = 0, None
         self._seed_stream = random.Random()
         self._steps = 0
         self.observations: Dict[str, dict] = {}
@@ -438,10 +439,13 @@ class MultiUAVEnv:
     def _refresh(self, new_step: bool = True):
         self._snap.clear()
         ids = self._snap["TASK_ID"]
-        for tid in ids[ids >= 0]:
-            self._task(int(tid))
-        for tid in range(1, int(self._scalar(27)) + 1):  # tasks created and retired between two observations
+        n_ids = int(self._scalar(27))
+        for tid in range(self._views_upto + 1, n_ids + 1):  # every id handed out so far has a view (incl. tasks created and retired between two observations)
             self._task(tid)
+        self._views_upto = max(self._views_upto, n_ids)
+        if ids.max(initial=-1) > n_ids:  # (a resident id beyond the counter: not produced by the device, kept for safety)
+            for tid in ids[ids > n_ids]:
+                self._task(int(tid))
         # (the fields of a task whose slot a STEP recycles reach its view through the release log below — its final record; slots recycled by an
         # out-of-step call are captured by _capture_resident() in front of the call.  Round 4 re-read every field of every resident task here,
         # every step: 6 ms of Python per step, 4x the reference's whole step)
@@ -449,10 +453,13 @@ class MultiUAVEnv:
         _ = self.threats  # register this step's spawns now, so the order is right even if nobody looks every step
         # agent_known_tasks grows monotonically in the reference; bits of recycled slots are folded in here
         known = self._snap["KNOWN"]
-        bits = (known[:, :, None] >> np.arange(32, dtype=known.dtype)) & 1           # [A, KW, 32] -> slot-major bool rows
-        bits = bits.reshape(known.shape[0], -1)[:, :len(ids)].astype(bool) & (ids >= 0)
-        for a in self.agents_obj:
-            self._known.setdefault(a.name, set()).update(ids[bits[a.id]].tolist())
+        sig = (ids.tobytes(), known.tobytes())
+        if sig != self._known_sig:  # (same residents and same bits as at the last refresh: the sets already hold them)
+            self._known_sig = sig
+            bits = (known[:, :, None] >> np.arange(32, dtype=known.dtype)) & 1           # [A, KW, 32] -> slot-major bool rows
+            bits = bits.reshape(known.shape[0], -1)[:, :len(ids)].astype(bool) & (ids >= 0)
+            for a in self.agents_obj:
+                self._known.setdefault(a.name, set()).update(ids[bits[a.id]].tolist())
         # ... ids that left the device during this step, with the agents that knew them then (muavta_set_release_log)
         if self._steps != self._log_step:
             self._log_step = self._steps
@@ -473,9 +480,9 @@ class MultiUAVEnv:
                             cur=np.array(r[17:23]), alloc=np.array(r[23:29]),
                             details={("stale", k): (None, None) for k in range(int(r[8]))})
         # a threat drags its Int task along even after that task was retired (update_threats, DroneEnv.py:1725-1744)
-        tmeta, tpos = self._snap["THREAT_META"], self._snap["THREAT_POS"]
-        for h in range(tmeta.shape[0]):
-            t = self._tasks.get(int(tmeta[h][4])) if tmeta[h][0] != -9 and tmeta[h][4] > 0 else None
+        tpos = self._snap["THREAT_POS"]
+        for h, row in enumerate(self._snap["THREAT_META"].tolist()):
+            t = self._tasks.get(row[4]) if row[0] != -9 and row[4] > 0 else None
             if t is not None and t._slot() < 0:
                 t._last["position"] = np.array(tpos[h], dtype=np.float64)
         # ... and the team-wide reveal of a task whose slot was released before it came due (_register_dynamic_task /
@@ -547,6 +554,7 @@ class MultiUAVEnv:
         self._threats = {}
         self._known = {}
         self._born, self._revealed = {}, set()
+        self._views_upto, self._known_sig = 0, None
         self._log_step = 0  # the reset itself releases nothing
         self._snap.clear()
         self.agents_obj = [UAVView(self, a) for a in range(self.n_agents)]
@@ -607,9 +615,8 @@ class MultiUAVEnv:
     def threats(self) -> List[ThreatView]:
         # env.threats is in spawn order (DroneEnv.py:1601-1643): groups in config order, ascending ids inside a step,
         # so appending the newly spawned ids of each step in ascending order reproduces it (dict keeps insertion order)
-        meta = self._snap["THREAT_META"]
-        for h in range(meta.shape[0]):
-            if meta[h][0] != -9 and h not in self._threats:
+        for h, status in enumerate(self._snap["THREAT_META"][:, 0].tolist()):
+            if status != -9 and h not in self._threats:
                 self._threats[h] = ThreatView(self, h)
         return list(self._threats.values())
 
