@@ -50,8 +50,15 @@ class _Snapshot:
         """Task.id -> device slot of the tasks resident now (one pass per snapshot: every TaskView field read looks its slot up here)"""
         m = self.cache.get("_slot_map")
         if m is None:
-            ids = self["TASK_ID"]
-            m = self.cache["_slot_map"] = {int(t): int(s) for s, t in enumerate(ids) if t >= 0}
+            m = self.cache["_slot_map"] = {t: s for s, t in enumerate(self["TASK_ID"].tolist()) if t >= 0}
+        return m
+
+    @property
+    def status_map(self) -> Dict[int, int]:
+        """Task.id -> status of the resident tasks (an id that is not resident is a retired task: status 2)"""
+        m = self.cache.get("_status_map")
+        if m is None:
+            m = self.cache["_status_map"] = {t: s for t, s in zip(self["TASK_ID"].tolist(), self["TASK_STATUS"].tolist()) if t >= 0}
         return m
 
     def clear(self):
@@ -95,10 +102,7 @@ class TaskView:
     def status(self) -> int:
         if self.id == 0:
             return 0
-        s = self._slot()
-        if s < 0:
-            return 2  # freed slots are retired tasks
-        return int(self._env._snap["TASK_STATUS"][s])
+        return self._env._snap.status_map.get(self.id, 2)  # freed slots are retired tasks
 
     def _meta(self, col: int, default=0):
         v = self._field(f"meta{col}", "TASK_META", lambda r: int(r[col]))
