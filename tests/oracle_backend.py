@@ -177,3 +177,91 @@ class OracleBackend:
             return out[None]
         raise KeyError(name)
 
+
+
+class OracleBatchBackend:
+    """n OracleBackends behind the surface of an n-env BatchedMultiUAVEnv — the test stand-in for the VECTORISED facade (MultiUAVEnv.batch):
+    every array stacked on axis 0; the task- / event-indexed axes, whose length is per env here (slot == task id), padded to the widest env
+    (pad rows of TASK_ID / OPEN_IDS / EVENTS are -1, i.e. free slots)."""
+    PAD_MINUS_ONE = ("TASK_ID", "OPEN_IDS", "EVENTS")
+
+    def __init__(self, params, n_envs):
+        self.backs = [OracleBackend(params) for _ in range(int(n_envs))]
+        b = self.backs[0]
+        self.params, self.n_envs, self.n_agents, self.A_tile = params, int(n_envs), b.n_agents, b.A_tile
+        self.max_tasks, self.possible_agents = b.max_tasks, b.possible_agents
+        self.T, self.dims, self.device_index = None, None, 0
+        self.launches = {"reset": 0, "step": 0, "allocate": 0, "observe": 0, "get": 0}  # whole-batch calls: the batch pays ONE per step
+
+    def reset(self, seeds):
+        self.launches["reset"] += 1
+        for b, s in zip(self.backs, np.asarray(seeds).tolist()):
+            b.reset([s])
+
+    def pack_actions(self, per_env):
+        cap = max([self.A_tile] + [len(acts) for acts in per_env])
+        aa = np.full((self.n_envs, cap), -1, dtype=np.int32)
+        ai = np.zeros((self.n_envs, cap), dtype=np.int32)
+        for n, acts in enumerate(per_env):
+            for k, (a, i) in enumerate(acts):
+                aa[n, k], ai[n, k] = a, i
+        return aa, ai
+
+    def step(self, aa, ai):
+        self.launches["step"] += 1
+        for i, b in enumerate(self.backs):
+            b.step(aa[i:i + 1], ai[i:i + 1])
+
+    def set_allocator(self, name="hungarian"):
+        for b in self.backs:
+            b.set_allocator(name)
+
+    @staticmethod
+    def _stack(rows, fill=0):
+        """[1, ...] arrays whose trailing axes may differ in length -> one [n, ...] array, the short ones padded with `fill`"""
+        shape = tuple(max(r.shape[d] for r in rows) for d in range(1, rows[0].ndim))
+        out = np.full((len(rows),) + shape, fill, dtype=rows[0].dtype)
+        for i, r in enumerate(rows):
+            out[(i,) + tuple(slice(0, k) for k in r.shape[1:])] = r[0]
+        return out
+
+    def allocate(self, interval=20, use_visibility=True, fetch=True):
+        self.launches["allocate"] += 1
+        plans = [b.allocate(interval, use_visibility) for b in self.backs]
+        return self._stack([p[0] for p in plans], -1), self._stack([p[1] for p in plans], 0)
+
+    def step_result(self):
+        r = [b.step_result() for b in self.backs]
+        return tuple(np.concatenate([x[k] for x in r]) for k in range(3))
+
+    def metrics(self):
+        return np.concatenate([b.metrics() for b in self.backs])
+
+    def observe(self):
+        self.launches["observe"] += 1
+        o = [b.observe() for b in self.backs]
+        return {k: np.concatenate([x[k] for x in o]) for k in o[0]}
+
+    def call(self, op, iargs=(), darg=-1.0, env_index=0):
+        return self.backs[env_index].call(op, iargs, darg)
+
+    def get(self, name):
+        self.launches["get"] += 1
+        return self._stack([b.get(name) for b in self.backs], -1 if name in self.PAD_MINUS_ONE else 0)
+
+    def set(self, name, value):
+        v = np.asarray(value)
+        for i, b in enumerate(self.backs):
+            own = b.get(name)  # (this env's own extent: the rows beyond it are padding)
+            b.set(name, v[(slice(i, i + 1),) + tuple(slice(0, k) for k in own.shape[1:])])
+
+    def set_release_log(self, enable=True):
+        pass
+
+    def get_state(self):
+        raise NotImplementedError
+
+    get_rng = get_state
+
+    def close(self):
+        pass

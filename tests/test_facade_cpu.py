@@ -185,3 +185,76 @@ def test_replay_document_equals_reference_generator(tmp_path):
         for key in ("time", "agents", "threats", "events", "decision", "metrics", "tasks"):
             assert a[key] == b[key], f"frame {k} {key}: " + str([(x, y) for x, y in zip(a[key], b[key]) if x != y][:2] if isinstance(a[key], list) else (a[key], b[key]))
     assert got["events"] == want["events"] and got["final_metrics"] == want["final_metrics"]
+
+
+@pytest.mark.parametrize("case,n,interval", [("WPS_hard", 4, 20), ("WPS_escort", 3, 12)])
+def test_vectorised_facade_views_equal_single_env_facades(case, n, interval):
+    """MultiUAVEnv.batch(n) — n reference-shaped env objects over ONE handle (env.py: _SharedBatch / _RowBackend / MultiUAVEnvBatch) — over the
+    oracle stand-in of an n-env handle, against n single-env facades stepped side by side with the same actions: observation dicts, rewards,
+    done flags, infos, last_tasks_info, the Task / UAV views and agent_visibility_map() after every step; an out-of-step mutator through ONE
+    view (UAV.allocate, then a state write) leaves its neighbours untouched; and the batch pays one whole-handle call per step, not n.
+    (The same comparison runs on the HIP backend under -m gpu.)"""
+    from oracle_backend import OracleBatchBackend
+
+    p = params_for_case(case)
+    backend = OracleBatchBackend(p, n)
+    batch = MultiUAVEnv.batch(CASE_SPECS[case], n, flags=dict(WPS_ENV_FLAGS), backend=backend)
+    singles = [MultiUAVEnv(CASE_SPECS[case], backend=OracleBackend(p), flags=dict(WPS_ENV_FLAGS)) for _ in range(n)]
+    seeds = [3 + 11 * i for i in range(n)]
+    outs = batch.reset(seeds)
+    refs = [s.reset(seed=sd) for s, sd in zip(singles, seeds)]
+
+    def same_obs(a, b):
+        assert a.keys() == b.keys()
+        for name in a:
+            for key in ("agent_position", "agent_caps", "event_flags"):
+                assert np.array_equal(a[name][key], b[name][key])
+            assert a[name]["alloc_task"] == b[name]["alloc_task"] and a[name]["mask"] == b[name]["mask"] and a[name]["legal_mask"] == b[name]["legal_mask"]
+            assert len(a[name]["tasks_info"]) == len(b[name]["tasks_info"])
+            for ra, rb in zip(a[name]["tasks_info"], b[name]["tasks_info"]):
+                assert ra.keys() == rb.keys() and all(np.array_equal(ra[k], rb[k]) for k in ra)
+
+    for i in range(n):
+        same_obs(outs[i][0], refs[i][0])
+    done_at, mutated = None, False
+    for t in range(p.max_time_steps):
+        acts = []
+        for v, s in zip(batch.envs, singles):
+            aa, ai = v._b.allocate(interval, True)
+            sa, si = s._b.allocate(interval, True)
+            k = sa.shape[1]
+            assert np.array_equal(aa[:, :k], sa) and np.all(aa[:, k:] == -1) and np.array_equal(ai[:, :k], si)
+            acts.append({v.agents_obj[int(a)].name: int(j) for a, j in zip(aa[0], ai[0]) if a >= 0})
+        if t == 7:  # an out-of-step mutator through view 1 only (and the same on its single-env twin)
+            rets = []
+            for e in (batch.envs[1], singles[1]):
+                uav = e.get_live_agents()[0]
+                open_tasks = [x for x in e.tasks if x.status != 2]
+                assert open_tasks
+                rets.append((uav.allocate(open_tasks[-1], e.time_steps), [x.id for x in uav.tasks]))
+            assert rets[0] == rets[1]
+            mutated = True
+        before = dict(backend.launches)
+        outs = batch.step(acts)
+        assert backend.launches["step"] == before["step"] + 1 and backend.launches["observe"] <= before["observe"] + 1
+        for i, (v, s) in enumerate(zip(batch.envs, singles)):
+            o, r, te, tr, info = s.step(acts[i])
+            bo, br, bte, btr, binfo = outs[i]
+            same_obs(bo, o)
+            assert br == r and bte == te and btr == tr and binfo["events"] == info["events"] and binfo["selected"] == info["selected"]
+            assert [x.id for x in v.last_tasks_info] == [x.id for x in s.last_tasks_info] and [x.id for x in v.tasks] == [x.id for x in s.tasks]
+            assert v.agent_visibility_map() == s.agent_visibility_map() and v.time_steps == s.time_steps == t + 1
+            for a, b in zip(v.agents_obj, s.agents_obj):
+                assert a.name == b.name and a.state == b.state and np.array_equal(a.position, b.position) and [x.id for x in a.tasks] == [x.id for x in b.tasks]
+            if t % 25 == 0:
+                for x, y in zip(v.tasks, s.tasks):
+                    assert x.status == y.status and np.array_equal(x.position, y.position) and np.array_equal(x.currentReqs, y.currentReqs)
+            if all(tr.values()) or all(te.values()):
+                assert binfo["metrics"] == info["metrics"]
+        if all(all(o[3].values()) or all(o[2].values()) for o in outs):
+            done_at = t
+            break
+    assert done_at is not None and mutated
+    # whole-handle fetches per step stay O(fields), not O(fields x envs): the n views share them
+    assert backend.launches["get"] <= 16 * (done_at + 2) + 16 * n
+    batch.close()
