@@ -416,6 +416,7 @@ class MultiUAVEnv:
         self.task_idle = TaskView(self, 0)
         self._tasks: Dict[int, TaskView] = {0: self.task_idle}
         self.agents_obj: List[UAVView] = []
+        self._agent_names: List[str] = []
         self.agent_by_name: Dict[str, UAVView] = {}
         self._threats: Dict[int, ThreatView] = {}
         self._known: Dict[str, set] = {}
@@ -453,7 +454,7 @@ class MultiUAVEnv:
         # (the fields of a task whose slot a STEP recycles reach its view through the release log below — its final record; slots recycled by an
         # out-of-step call are captured by _capture_resident() in front of the call.  Round 4 re-read every field of every resident task here,
         # every step: 6 ms of Python per step, 4x the reference's whole step)
-        self.last_tasks_info = [self._task(int(i)) for i in self._snap["OPEN_IDS"] if i >= 0]
+        self.last_tasks_info = [self._task(i) for i in self._snap["OPEN_IDS"].tolist() if i >= 0]
         _ = self.threats  # register this step's spawns now, so the order is right even if nobody looks every step
         # agent_known_tasks grows monotonically in the reference; bits of recycled slots are folded in here
         known = self._snap["KNOWN"]
@@ -462,8 +463,8 @@ class MultiUAVEnv:
             self._known_sig = sig
             bits = (known[:, :, None] >> np.arange(32, dtype=known.dtype)) & 1           # [A, KW, 32] -> slot-major bool rows
             bits = bits.reshape(known.shape[0], -1)[:, :len(ids)].astype(bool) & (ids >= 0)
-            for a in self.agents_obj:
-                self._known.setdefault(a.name, set()).update(ids[bits[a.id]].tolist())
+            for i, name in enumerate(self._agent_names):
+                self._known.setdefault(name, set()).update(ids[bits[i]].tolist())
         # ... ids that left the device during this step, with the agents that knew them then (muavta_set_release_log)
         if self._steps != self._log_step:
             self._log_step = self._steps
@@ -532,14 +533,14 @@ class MultiUAVEnv:
         legal = o["legal_mask"][0].astype(bool).tolist()
         flags = np.array(o["event_flags"][0], dtype=np.float32)
         self.observations = {}
-        for a in self.agents_obj:
-            self.observations[a.name] = {
-                "agent_position": agents64[a.id, 0:2],
-                "agent_caps": agents64[a.id, 2:8],
-                "alloc_task": alloc[a.id],
+        for i, name in enumerate(self._agent_names):  # (agents_obj[i].id == i)
+            self.observations[name] = {
+                "agent_position": agents64[i, 0:2],
+                "agent_caps": agents64[i, 2:8],
+                "alloc_task": alloc[i],
                 "tasks_info": tasks_info,
                 "mask": mask,
-                "legal_mask": legal[a.id],
+                "legal_mask": legal[i],
                 "event_flags": flags.copy(),
             }
 
@@ -562,14 +563,15 @@ class MultiUAVEnv:
         self._log_step = 0  # the reset itself releases nothing
         self._snap.clear()
         self.agents_obj = [UAVView(self, a) for a in range(self.n_agents)]
-        self.agent_by_name = {a.name: a for a in self.agents_obj}
+        self._agent_names = [a.name for a in self.agents_obj]  # (fixed for the episode: reset's shuffle)
+        self.agent_by_name = dict(zip(self._agent_names, self.agents_obj))
         self.agents = list(self.possible_agents)
         self._refresh()
         self._build_observations()
-        self.rewards = {a.name: 0 for a in self.agents_obj}
-        self.terminations = {a.name: False for a in self.agents_obj}
-        self.truncations = {a.name: False for a in self.agents_obj}
-        self.infos = {a.name: {} for a in self.agents_obj}
+        self.rewards = dict.fromkeys(self._agent_names, 0)
+        self.terminations = dict.fromkeys(self._agent_names, False)
+        self.truncations = dict.fromkeys(self._agent_names, False)
+        self.infos = {n: {} for n in self._agent_names}
         return self.observations, self.infos
 
     def step(self, actions):
@@ -594,10 +596,10 @@ class MultiUAVEnv:
         self._refresh()
         self._build_observations()
         reward, term, trunc = self._b.step_result()
-        self.rewards = {a.name: float(reward[0]) for a in self.agents_obj}
-        self.terminations = {a.name: bool(term[0]) for a in self.agents_obj}
-        self.truncations = {a.name: bool(trunc[0]) for a in self.agents_obj}
-        self.infos = {a.name: {} for a in self.agents_obj}
+        self.rewards = dict.fromkeys(self._agent_names, float(reward[0]))
+        self.terminations = dict.fromkeys(self._agent_names, bool(term[0]))
+        self.truncations = dict.fromkeys(self._agent_names, bool(trunc[0]))
+        self.infos = {n: {} for n in self._agent_names}
         self.infos["selected"] = self.possible_agents[self._steps % len(self.possible_agents)]  # agent_selector.next()
         ev = self._snap["EVENTS"]
         self.infos["events"] = [[EVENT_TAGS[int(t)], int(arg)] for t, arg in ev if t >= 0]
@@ -648,7 +650,7 @@ class MultiUAVEnv:
     current_agent = property(lambda self: self.possible_agents[self._steps % len(self.possible_agents)])
 
     def get_live_agents(self):  # DroneEnv.py:1484-1486
-        return [a for a in self.agents_obj if a.state != -1]
+        return [a for a, st in zip(self.agents_obj, self._snap["AGENT_STATE"].tolist()) if st != -1]
 
     def agent_visibility_map(self):  # :1595-1599
         if not self.sense_radius and not self.threat_delay:
