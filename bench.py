@@ -736,6 +736,47 @@ def secondary_figures(env, seeds, args, write_obs, barrier):
             out["policy_in_loop_with_network"] = net
         except Exception as exc:
             out["policy_in_loop_with_network"] = {"error": repr(exc)}
+        # the same gate loop (max_steps 5) over FOUR times the envs on one handle: a launch of 4096 one-wave workgroups fits the chip at once, so every
+        # launch ends on its slowest env with the early finishers' slots idle; with more workgroups than slots the early finishers are back-filled.  Extra
+        # figure only (the line's policy_in_loop_env_steps_per_s stays at --envs); its first --envs rows must equal the per-step loop's metrics.
+        try:
+            wide_n = 4 * args.envs
+            e5 = BatchedMultiUAVEnv(params_for_case(args.case), wide_n, device=env.device_index)
+            seeds_w = np.concatenate([seeds, np.arange(int(seeds[-1]) + 1, int(seeds[-1]) + 1 + wide_n - args.envs, dtype=np.uint64)]).astype(np.uint64)
+            sc_w = scores.repeat(4, 1, 1).contiguous()
+            shp = e5.token_shapes("pair", 32, 16)
+            tok_w = [{k: torch.empty(sh, dtype=tdt[dt], device=dev) for k, (sh, dt) in shp.items()} for _ in range(3)]
+            sel_w = torch.empty((wide_n, 16, 32), dtype=torch.float32, device=dev)
+            rep_w = torch.empty((wide_n,), dtype=torch.int32, device=dev)
+            sw_w = torch.empty((2, wide_n), dtype=torch.float64, device=dev)
+            dn_w = torch.empty((wide_n,), dtype=torch.uint8, device=dev)
+            nst_w = torch.empty((wide_n,), dtype=torch.int32, device=dev)
+            prk_w = torch.empty((wide_n,), dtype=torch.uint8, device=dev)
+            for rep_i in range(2):
+                e5.reset(seeds_w)
+                e5.tokens("pair", 32, 16, out=tok_w[0])
+                e5.sync()
+                t1 = time.perf_counter()
+                k = 0
+                while True:
+                    e5.rl_run("pair", 32, 16, edge_scores=sc_w, gate="trainer", replan_interval=args.interval, selected=sel_w, replanned=rep_w, next_tok=tok_w[2],
+                              s_wps=sw_w, done=dn_w, park_tok=tok_w[(k + 1) & 1], n_stepped=nst_w, park=prk_w, max_steps=5)
+                    k += 1
+                    if k % 4 == 0:
+                        e5.sync()
+                        if bool(((prk_w & 3) != 0).all()):
+                            break
+                    if k > 4 * HORIZON:
+                        raise RuntimeError("run-ahead did not finish")
+                dt_w = time.perf_counter() - t1
+            same = bool(np.array_equal(e5.metrics()[:args.envs], m_per_step))
+            out["policy_in_loop_wide"] = {"env_steps_per_s": wide_n * HORIZON / dt_w if same else None, "envs": wide_n, "policy_calls_per_env_step": k / HORIZON,
+                                          "first_rows_equal_per_step_loop": same,
+                                          "is": "policy_in_loop_env_steps_per_s's loop over 4x the envs on one handle (more workgroups than the chip holds at once: envs that park early are back-filled)"}
+            e5.close()
+            del tok_w, sel_w, sc_w
+        except Exception as exc:
+            out["policy_in_loop_wide"] = {"error": repr(exc)}
         n_flag = int(np.count_nonzero(e4.get("ERROR")))
         out["policy_in_loop_capacity_flagged_envs"] = n_flag
         out["policy_in_loop_mean_S_WPS"] = float(e4.metrics()[:, 4].mean()) if not n_flag else None
