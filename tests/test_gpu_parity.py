@@ -2130,7 +2130,7 @@ def test_device_fuzz_fresh_slice():
     """A slice of the wide device fuzz (tests/fuzz_device.py: the fused rollout on every tile that holds the fleet + all twelve legs) on
     configurations NO earlier run has seen: the first id of each family (small / large-fleet / EDGE of tests/fuzz_reference.py::wide_config)
     comes from the committed counter file tests/fuzz_counter.json, which the builder bumps every round past everything its own batches
-    covered.  Round 4's seven device bugs were all invisible to the case-based tests and found by this driver, and round 5's one (the last bit of atan2) too; ~300 s of it — ≈400 configurations — now run wherever
+    covered.  Round 4's seven device bugs were all invisible to the case-based tests and found by this driver, and round 5's one (the last bit of atan2) too; ~240 s of it — ≈300 configurations — now run wherever
     `pytest -m gpu` runs (MUAVTA_FUZZ_SLICE_SECONDS overrides the budget).  A mismatch fails the test with the configuration id and leg."""
     import json
     import time
@@ -2138,7 +2138,7 @@ def test_device_fuzz_fresh_slice():
     import fuzz_device as FD
     from fuzz_reference import wide_config
 
-    budget = float(os.environ.get("MUAVTA_FUZZ_SLICE_SECONDS", "300"))
+    budget = float(os.environ.get("MUAVTA_FUZZ_SLICE_SECONDS", "240"))
     counter = json.load(open(os.path.join(os.path.dirname(__file__), "fuzz_counter.json")))
     fams = [(f, int(counter[f])) for f in ("small", "large", "edge")]
     msgs, notes, tot, covered = [], [], {}, {f: 0 for f, _ in fams}
