@@ -561,6 +561,29 @@ def test_rl_run_to_the_next_gate_vs_reference(path, max_steps):
     check_rl_run(np.load(path), case, params_for_case(case), max_steps)
 
 
+def test_avoid_obstacles_on_an_obstacle_axis_is_decided_by_the_last_bit_of_atan2():
+    """The pair the device fuzz found (tests/fuzz_device.py configuration 32517, scored leg, step 182): an agent whose task lies inside an
+    obstacle's keep-out zone is steered onto the line through the obstacle's centre, where the two headings of sim_core.rs:46-47 are one ulp
+    apart and the side it passes on is the last bit of each atan2.  Pins what the oracle (the host libm) does there — the value the device's
+    restated atan2 (csrc/muavta_atan2.h) must reproduce, and does under -m gpu."""
+    import ctypes as C
+    import math
+    from conftest import host_libm_note
+
+    if host_libm_note():
+        pytest.skip(host_libm_note())
+    f = float.fromhex
+    pos = np.array([f("0x1.e1186bb3bf6abp+8"), f("0x1.c51c9fc28c1a9p+7")])
+    mov = np.array([f("-0x1.5c070de57194ep-6"), f("-0x1.ffe26cf27704ap-1")])
+    obst = np.array([[f("0x1.027ff88080afap+8"), f("0x1.41d8385dcd497p+8"), f("0x1.3p+5")], [f("0x1.df7adf58ae2f0p+8"), f("0x1.2d0c686c71993p+7"), f("0x1.04p+6")],
+                     [f("0x1.c2bf3701aaba9p+9"), f("0x1.66a2e1dda60d5p+7"), f("0x1.08p+5")]])
+    a_mov, a_obs = math.atan2(mov[1], mov[0]), math.atan2(obst[1, 1] - pos[1], obst[1, 0] - pos[0])
+    assert (a_mov.hex(), a_obs.hex()) == ("-0x1.978fec4a46805p+0", "-0x1.978fec4a46806p+0")  # one ulp apart: ang + PI rounds to PI, the wrapped angle is 0.0, not > 0
+    out = np.zeros(2)
+    orc.lib().orc_avoid_obstacles(obst.ctypes.data_as(C.c_void_p), 3, pos.ctypes.data_as(C.c_void_p), mov.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    assert [v.hex() for v in out.tolist()] == ["-0x1.3a0ecc607185ep+1", "0x1.ab0d70316c8b9p-5"]
+
+
 def test_avoid_obstacles_oracle_vs_arbitrary_precision_witness():
     """a9 with K > 0 obstacles stays "parity unpinned vs the Rust" (core_sim/src/sim_core.rs:25-59 cannot be built here) — what CAN be pinned:
     a third, independent evaluation of those lines with every IEEE operation in Python floats and `ln` / `atan2` in 300-bit arithmetic rounded
