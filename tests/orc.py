@@ -15,9 +15,9 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        so = os.environ.get("MUAVTA_ORACLE_SO") or os.path.join(ORACLE_DIR, "liboracle.so")  # (override: the sanitizer build, `make -C oracle asan`)
         src = os.path.join(ORACLE_DIR, "muavta_oracle.cpp")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        if "MUAVTA_ORACLE_SO" not in os.environ and (not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
         L = C.CDLL(so)
         L.orc_create.restype = C.c_void_p
