@@ -7,6 +7,11 @@ cost matrix and assignment, _selected_mask, pairs, actions, step rewards, next t
 oracle's run-to-the-next-gate (OracleEnv.rl_run, the checker of muavta_rl_run_device) replays the same reference episode launch by launch.
 
     python tests/fuzz_reference_rl.py [first_k [n_configs [procs]]]
+    python tests/fuzz_reference_rl.py --pin k [k ...]     # commit the reference's RL episode of those configurations as fixtures
+
+--pin writes tests/golden/rlterm_WIDE<k>.npz (the format of rl_<case>.npz) and the configuration into tests/golden/rlterm_configs.json:
+episodes that END EARLY (every task done before max_time_steps; about 4 % of the draws) — the registry cases' rl_*.npz all run to
+their truncation step.  test_oracle_golden.py replays them through the oracle's per-step and run-to-the-gate checkers.
 
 Lives under tests/ because it uses the oracle as its checker."""
 import os
@@ -49,6 +54,33 @@ def run_one(k: int):
         return k, "ERROR", "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))[-700:]
     return k, "ok", f"plans {len(tr['step'])} S_WPS {tr['metrics'][4]:.3f}"
 
+
+def pin(ks):
+    import json
+
+    import numpy as np
+    import gen_golden as G
+    from mUAV_TA.MultiDroneEnvUtils import agentEnvOptions
+
+    path = os.path.join(HERE, "golden", "rlterm_configs.json")
+    configs = json.load(open(path)) if os.path.exists(path) else {}
+    for k in ks:
+        w = wide_config(k)
+        env = G.MultiUAVEnv(agentEnvOptions(render_speed=-1, action_mode="TaskAssign", multiple_agents_per_task=True, fixed_seed=-1, **w["cfg"]))
+        tr = G.rl_episode(env, w["seed"], bool(k & 1))
+        del tr["interval"]
+        out = os.path.join(HERE, "golden", f"rlterm_WIDE{k}.npz")
+        np.savez_compressed(out, **tr)
+        configs[f"WIDE{k}"] = w["cfg"]
+        print(out, os.path.getsize(out) // 1024, "KiB", "steps", len(tr["replanned"]), "of", w["cfg"]["max_time_steps"], "plans", len(tr["step"]),
+              "ep_done", tr["ep_done"].tolist()[-3:], "S_WPS", tr["metrics"][4])
+    with open(path, "w") as f:
+        json.dump(configs, f, indent=1)  # key order is semantic: groups are created in dict order
+
+
+if __name__ == "__main__" and "--pin" in sys.argv:
+    pin([int(a) for a in sys.argv[1:] if not a.startswith("--")])
+    sys.exit(0)
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if not a.startswith("--")]

@@ -561,6 +561,82 @@ def test_rl_run_to_the_next_gate_vs_reference(path, max_steps):
     check_rl_run(np.load(path), case, params_for_case(case), max_steps)
 
 
+# ---- RL episodes that END EARLY (every task done before max_time_steps): tests/fuzz_reference_rl.py --pin ---------------------------
+RLTERM_FILES = sorted(glob.glob(os.path.join(GOLDEN, "rlterm_WIDE*.npz")))
+
+
+def _rlterm_params(path):
+    """The configuration of a pinned early-ending episode (tests/golden/rlterm_configs.json; not in wide_configs.json: that table feeds device
+    tests of its own) on the largest tile, as tests/fuzz_reference_rl.py checks it."""
+    import json
+
+    from muavta_amd.params import params_from_config
+
+    case = os.path.basename(path)[len("rlterm_"):-4]
+    cfg = dict(json.load(open(os.path.join(GOLDEN, "rlterm_configs.json")))[case])
+    cfg["threats_list"] = [tuple(x) for x in cfg["threats_list"]]
+    cfg["escort_agent_types"] = tuple(cfg["escort_agent_types"])
+    return case, cfg, params_from_config(cfg, None, tile_agents=64, tile_tasks=128, tile_threats=48)
+
+
+@pytest.mark.parametrize("path", RLTERM_FILES)
+def test_rl_loop_on_episodes_that_end_early_vs_reference(path):
+    """run_rl_episode (experiments/train_pair_cost.py:132-156) on configurations whose episode TERMINATES before max_time_steps — the registry
+    cases' rl_*.npz all run to their truncation step (round-4 advisor note on rl_stream).  The reference's loop stops with the episode; the
+    oracle's scored allocator + step reproduce every plan up to it, the done flag of the last pushed transition and the final metrics."""
+    g = np.load(path)
+    case, cfg, P = _rlterm_params(path)
+    assert len(g["replanned"]) < int(cfg["max_time_steps"]), "fixture no longer ends early"
+    check_rl(g, case, P)
+
+
+@pytest.mark.parametrize("max_steps", [0, 1, 4])
+@pytest.mark.parametrize("path", RLTERM_FILES)
+def test_rl_run_to_the_next_gate_on_episodes_that_end_early(path, max_steps):
+    """muavta_rl_run_device's checker on the same episodes: the last launch's quiet stretch ends with the EPISODE (park bit 0), not at a gate,
+    and a further launch leaves the ended env alone (check_rl_run's closing assertions)."""
+    g = np.load(path)
+    case, cfg, P = _rlterm_params(path)
+    check_rl_run(g, case, P, max_steps)
+
+
+def test_rl_run_batch_with_envs_that_end_at_different_steps():
+    """What a batched caller of muavta_rl_run_device sees when its envs end at different steps (the loop of muavta_amd/il.py::rl_run_stream over
+    the oracle): every env keeps being launched until ALL have ended, the ended ones must report n_stepped 0 / no plan / unchanged S_WPS and
+    metrics at every further launch, and the others must be unaffected by them — each env's launches equal the reference episode's gates."""
+    if len(RLTERM_FILES) < 2:
+        pytest.skip("needs two pinned early-ending episodes")
+    eps = []
+    for path in RLTERM_FILES:
+        g = np.load(path)
+        case, cfg, P = _rlterm_params(path)
+        e = orc.OracleEnv(P)
+        e.reset(int(g["seed"]))
+        eps.append(dict(g=g, case=case, e=e, kind=1 if int(g["raw"]) else 0, t=0, k=0, T=len(g["replanned"]), steps=np.asarray(g["step"]).tolist(), launches_after_end=0))
+    assert len({ep["T"] for ep in eps}) > 1
+    while any(ep["t"] < ep["T"] for ep in eps):
+        for ep in eps:  # one "launch" of the whole batch
+            g, e = ep["g"], ep["e"]
+            over = ep["t"] >= ep["T"]
+            at = (not over) and ep["k"] < len(ep["steps"]) and ep["steps"][ep["k"]] == ep["t"]
+            sc = g["scores"][ep["k"]] if at else np.full((16, 32), -0.2, np.float32)
+            r = e.rl_run(20, 1, GATE_TRAINER, ep["kind"], 32, 16, SC_EDGE_VALID_ONLY, scores=sc)
+            if over:
+                ep["launches_after_end"] += 1
+                assert r["n_stepped"] == 0 and not r["replanned"] and not r["selected"].any() and r["s_before"] == r["s_after"] == g["s_wps"][-1], ep["case"]
+                assert bool(r["park"] & 3) and np.array_equal(e.metrics(), g["metrics"]), ep["case"]
+                continue
+            assert r["replanned"] == at, f"{ep['case']} t={ep['t']}"
+            if at:
+                assert np.array_equal(r["selected"], g["selected"][ep["k"]]) and bool(r["done"]) == bool(g["ep_done"][ep["k"]])
+                ep["k"] += 1
+            ep["t"] += r["n_stepped"]
+            assert ep["t"] == (ep["steps"][ep["k"]] if ep["k"] < len(ep["steps"]) else ep["T"]), f"{ep['case']}: stopped at {ep['t']}"
+    for ep in eps:
+        assert ep["k"] == len(ep["steps"]) and np.array_equal(ep["e"].metrics(), ep["g"]["metrics"]), ep["case"]
+    assert any(ep["launches_after_end"] > 0 for ep in eps)
+
+
 def test_avoid_obstacles_on_an_obstacle_axis_is_decided_by_the_last_bit_of_atan2():
     """The pair the device fuzz found (tests/fuzz_device.py configuration 32517, scored leg, step 182): an agent whose task lies inside an
     obstacle's keep-out zone is steered onto the line through the obstacle's centre, where the two headings of sim_core.rs:46-47 are one ulp
