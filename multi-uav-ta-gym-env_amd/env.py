@@ -25,7 +25,7 @@ from typing import Any, Dict, List, Optional
 
 import numpy as np
 
-from .params import EVENT_TAGS, METRIC_KEYS, INT_METRICS, TASK_TYPES, UAV_TYPES, params_from_config
+from .params import EVENT_TAGS, METRIC_KEYS, INT_METRICS, REWARD_KEYS, TASK_TYPES, UAV_TYPES, _Cfg, params_from_config
 
 MAX_INT = sys.maxsize
 _TASK_DURATION = {"Hold": 1, "Rec": 10, "Att": 5, "Def": 5, "Int": 0, "Det": 1}   # MultiDroneEnvData.py:72-85
@@ -413,6 +413,27 @@ class MultiUAVEnv:
         self.reassign_penalty = p.reassign_penalty
         self.sense_radius, self.threat_delay = p.sense_radius, p.threat_delay
         self.escort_enabled = bool(p.escort_enabled)
+        # the configuration as the reference env echoes it on itself (DroneEnv.py:101-201): planners and state builders read some of these
+        # through getattr(env, ...) with a default, so a missing one is a silently different input (build_rah_state: `burst_mode`)
+        c = _Cfg(config, flags)
+        self.simulation_frame_rate, self.info = p.simulation_frame_rate, c.get("info", "No Info")
+        self.render_speed, self.render_enabled, self.render_mode = -1, False, c.get("render_mode", "human")   # (nothing is rendered on this path)
+        self.action_mode = "TaskAssign"
+        self.agents_config, self.tasks_config = dict(c.get("agents")), dict(c.get("tasks"))
+        self.threats_list = list(c.get("threats_list") or [])
+        self.random_init_pos, self.num_obstacles, self.hidden_obstacles = bool(p.random_init_pos), p.num_obstacles, False
+        self.multiple_tasks_per_agent, self.multiple_agents_per_task = bool(p.multiple_tasks_per_agent), True
+        self.fail_rate = p.fail_rate
+        self.early_terminate, self.capability_mask, self.saturate_mask = bool(p.early_terminate), bool(p.capability_mask), bool(p.saturate_mask)
+        self.reward_weights = dict(zip(REWARD_KEYS, (float(w) for w in p.reward_weights)))
+        self.arrival_rate, self.include_time_windows, self.dynamic_idle_penalty = p.arrival_rate, bool(p.include_time_windows), p.dynamic_idle_penalty
+        self.hard_windows, self.window_length = bool(p.hard_windows), p.window_length
+        self.burst_mode, self.burst_size, self.dual_region_bursts = bool(p.burst_mode), p.burst_size, bool(p.dual_region_bursts)
+        self.miss_penalty, self.on_time_bonus = p.miss_penalty, p.on_time_bonus
+        self.share_knowledge = bool(p.share_knowledge)
+        self.escort_radius, self.escort_requirement = p.escort_radius, p.escort_requirement
+        self.escort_intercept_radius, self.mutual_support_radius = p.escort_intercept_radius, p.mutual_support_radius
+        self.escort_agent_types = tuple(c.get("escort_agent_types", ("F1", "F2")) or ("F1", "F2"))
         self.task_idle = TaskView(self, 0)
         self._tasks: Dict[int, TaskView] = {0: self.task_idle}
         self.agents_obj: List[UAVView] = []
@@ -421,7 +442,8 @@ class MultiUAVEnv:
         self._threats: Dict[int, ThreatView] = {}
         self._known: Dict[str, set] = {}
         self._views_upto, self._known_sig = 0, None
-        self._seed_stream = random.Random()
+        fs = _Cfg(config, flags).get("fixed_seed", -1)
+        self.fixed_seed = -1 if fs is None else int(fs)                            # DroneEnv.py:530-531: overrides every reset's seed
         self._steps = 0
         self.observations: Dict[str, dict] = {}
         self.last_tasks_info: Optional[List[TaskView]] = None
@@ -545,9 +567,14 @@ class MultiUAVEnv:
             }
 
     # ------------------------------------------------------------------ PettingZoo surface
+    def seed(self, seed):
+        self.reset(seed=seed)                                                       # DroneEnv.py:518-519
+
     def reset(self, seed=None, return_info=True, options=None):
-        if seed is None:  # the reference draws from the global `random` module (DroneEnv.py:525-526)
-            seed = self._seed_stream.randint(0, MAX_INT)
+        if seed is None:  # the reference draws from the GLOBAL `random` module (DroneEnv.py:525-526): random.seed(s) in front of an unseeded
+            seed = random.randint(0, MAX_INT)  # reset() gives the episode it gives there
+        if self.fixed_seed != -1:
+            seed = self.fixed_seed
         self._seed = int(seed)
         self._b.reset(np.array([self._seed], dtype=np.uint64))
         return self._after_reset()

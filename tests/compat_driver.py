@@ -5,6 +5,9 @@ the read-only checkout and runs them.  Prints one JSON document on the last line
 
     compat_driver.py episodes <ref_copy>          run_wps_episode / run_escort_episode for a few (algorithm, case, seed)
     compat_driver.py test_escort <ref_copy>       experiments/test_escort.py, all seven tests, as `python test_escort.py` would
+    compat_driver.py trainers <ref_copy>          experiments/train_pair_cost.py::main() (IL, then RL from the IL checkpoint; MLP and attention+context
+                                                  scorers) — per-episode losses / returns, the evaluation scores and a hash of every trained tensor
+    compat_driver.py trainers_native <ref_copy>   the same WITHOUT the aliases: the reference's own env (what the line above has to reproduce)
 """
 import json
 import os
@@ -24,8 +27,11 @@ refshim.install()
 from oracle_backend import OracleBackend  # noqa: E402
 import muavta_amd.compat as compat  # noqa: E402
 
-compat.install(backend_factory=OracleBackend)  # mUAV_TA.* and core_sim now resolve to this repository
-assert sys.modules["mUAV_TA.DroneEnv"].MultiUAVEnv is compat.MultiUAVEnv
+if mode == "trainers_native":
+    sys.path.append("/root/reference")  # mUAV_TA itself: the read-only checkout (nothing is written there: PYTHONDONTWRITEBYTECODE)
+else:
+    compat.install(backend_factory=OracleBackend)  # mUAV_TA.* and core_sim now resolve to this repository
+    assert sys.modules["mUAV_TA.DroneEnv"].MultiUAVEnv is compat.MultiUAVEnv
 
 if mode == "episodes":
     from experiments.wps_eval import run_wps_episode
@@ -47,3 +53,71 @@ if mode == "episodes":
 elif mode == "test_escort":
     runpy.run_path(os.path.join(ref, "experiments", "test_escort.py"), run_name="__main__")
     print(json.dumps({"ok": True}))
+elif mode in ("trainers", "trainers_native"):
+    import contextlib
+    import hashlib
+    import importlib
+    import io
+    import random
+    import types
+
+    import torch
+
+    torch.set_num_threads(1)
+    rec = {}
+
+    def recording(fn, key):
+        def wrapped(*a, **k):
+            r = fn(*a, **k)
+            rec.setdefault(key, []).append(repr(r))  # (floats: repr round-trips every bit)
+            return r
+        return wrapped
+
+    def tensor_hash(obj, h):
+        if isinstance(obj, torch.Tensor):
+            h.update(obj.detach().cpu().contiguous().numpy().tobytes())
+        elif isinstance(obj, dict):
+            for k in sorted(obj, key=str):
+                h.update(str(k).encode()); tensor_hash(obj[k], h)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                tensor_hash(v, h)
+        elif isinstance(obj, (int, float, str, bool)) or obj is None:
+            h.update(repr(obj).encode())
+
+    pair = ["--case", "WPS_hard", "--d-model", "16", "--nhead", "2", "--n-layers", "1", "--il-warmup", "2", "--il-batch", "4", "--eval-eps", "2"]
+    runs = (  # (name, the reference's trainer file, its command line, checkpoint to start from)
+        ("pair_il_mlp", "train_pair_cost", ["--phase", "il", "--mlp", "--episodes", "3", "--eval-every", "3"] + pair, None),
+        ("pair_rl_mlp", "train_pair_cost", ["--phase", "rl", "--mlp", "--episodes", "2", "--eval-every", "2"] + pair, "pair_il_mlp"),
+        ("pair_il_att_context", "train_pair_cost", ["--phase", "il", "--context", "--episodes", "2", "--eval-every", "2"] + pair, None),
+        ("escort_att", "train_escort", ["--case", "WPS_escort", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--d-model", "16", "--nhead", "2", "--n-layers", "1"], None),
+        ("att_rah", "train_att_rah", ["--case", "WPS_hard", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1"], None),
+        ("att_commit", "train_att_commit", ["--case", "WPS_commit", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1"], None),
+        ("rah", "train_rah", ["--case", "WPS_hard", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1"], None),
+        ("hybrid_rg_dqn", "train_hybrid", ["--algo", "RG-DQN", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1"], None),
+        ("hybrid_ra_dqn", "train_hybrid", ["--algo", "RA-DQN", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1"], None),
+    )
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+    out, ckpts = {}, {}
+    for n_run, (name, modname, argv, init) in enumerate(runs):
+        if only and name not in only:
+            continue
+        T = importlib.import_module(f"experiments.{modname}")
+        assert (T.MultiUAVEnv is compat.MultiUAVEnv) == (mode == "trainers")
+        for attr, fn in list(vars(T).items()):  # the episode runners and evaluation loops of the file, recorded (not changed)
+            if isinstance(fn, types.FunctionType) and fn.__module__ == T.__name__ and (attr.startswith("run_") or attr.startswith("eval")) and not hasattr(fn, "_rec"):
+                w = recording(fn, attr); w._rec = True
+                setattr(T, attr, w)
+        rec.clear()
+        random.seed(20240 + n_run)  # an unseeded env.reset() draws its seed from the GLOBAL random module (DroneEnv.py:525-526); main() seeds numpy and torch only
+        torch.manual_seed(777 + n_run)  # (train_hybrid.py seeds numpy only: its networks' initial weights come from torch's global generator)
+        ckpts[name] = os.path.join(ref, f"ckpt_{mode}_{name}.pth")
+        sys.argv = [modname + ".py"] + argv + ["--seed", "3", "--out", ckpts[name]] + (["--init", ckpts[init]] if init else [])
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            ret = T.main()
+        h = hashlib.sha256()
+        tensor_hash(torch.load(ckpts[name], map_location="cpu", weights_only=True), h)  # (a file this process wrote a moment ago)
+        out[name] = dict(rec, main_returned=repr(ret).replace(ckpts[name], "<ckpt>"), checkpoint_sha256=h.hexdigest(),
+                         printed=[ln.replace(ckpts[name], "<ckpt>") for ln in buf.getvalue().splitlines() if "EVAL" in ln.upper() or "Done" in ln][:6])
+    print(json.dumps(out))

@@ -29,9 +29,9 @@ def ref_copy(tmp_path_factory):
     shutil.rmtree(dst, ignore_errors=True)
 
 
-def _drive(mode, ref_copy):
+def _drive(mode, ref_copy, *more):
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "compat_driver.py"), mode, ref_copy], capture_output=True, text=True, timeout=1500, env=env, cwd=ref_copy)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "compat_driver.py"), mode, ref_copy, *more], capture_output=True, text=True, timeout=1500, env=env, cwd=ref_copy)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     return json.loads(p.stdout.strip().splitlines()[-1]), p.stdout
 
@@ -69,3 +69,22 @@ def test_reference_test_escort_passes_7_of_7(ref_copy):
                  "pi_schedule_impact", "att_coalition_v2"):
         assert f"OK {name}" in stdout, stdout[-2000:]
     assert "ALL PASSED" in stdout
+
+
+def test_reference_trainers_run_unchanged_and_train_the_same_checkpoints(ref_copy):
+    """SURVEY §8 f3 at the reference's own boundary: every trainer file of the reference that drives the env directly — experiments/
+    train_pair_cost.py (IL, RL from the IL checkpoint, MLP and attention + context scorers), train_escort.py, train_att_rah.py,
+    train_att_commit.py, train_rah.py, train_hybrid.py (RG-DQN, RA-DQN on D3_combined: agent failures, arrivals, the TBTA flags) — has its
+    main() called UNCHANGED twice in fresh interpreters: over the reference's env, and over `muavta_amd.compat` (facade + oracle backend).
+    Same global seeds in front of both; episodes are reset UNSEEDED, as the trainers do (the env draws its seed from the global `random`
+    module, DroneEnv.py:525-526).  Every episode's return / loss tuple, every evaluation score, main()'s return value and the SHA-256 over
+    every tensor of the checkpoint it saved must be equal: the planners' state builders and token builders read the facade's object views
+    and echoed configuration (`burst_mode`, ... — DroneEnv.py:101-201) exactly as they read the reference env's."""
+    native, _ = _drive("trainers_native", ref_copy)
+    facade, _ = _drive("trainers", ref_copy)
+    assert set(native) == set(facade) and len(native) == 9
+    for name in native:
+        for key in native[name]:
+            assert native[name][key] == facade[name][key], (name, key, native[name][key], facade[name][key])
+        assert len(native[name]["checkpoint_sha256"]) == 64 and native[name]["printed"], name
+    assert len({r["checkpoint_sha256"] for r in native.values()}) == 9  # (nine different trainings, not one constant)
