@@ -8,6 +8,9 @@ the read-only checkout and runs them.  Prints one JSON document on the last line
     compat_driver.py trainers <ref_copy>          experiments/train_pair_cost.py::main() (IL, then RL from the IL checkpoint; MLP and attention+context
                                                   scorers) — per-episode losses / returns, the evaluation scores and a hash of every trained tensor
     compat_driver.py trainers_native <ref_copy>   the same WITHOUT the aliases: the reference's own env (what the line above has to reproduce)
+    compat_driver.py sweep[_native] <ref_copy>    experiments/wps_eval.py::run_wps_episode for EVERY algorithm it knows (19: Hungarian variants, CBBA, PI, capability
+                                                  greedy, the RAH / commit / pair / context-pair hybrids with randomly initialised networks) and
+                                                  escort_eval.py::run_escort_episode for every algorithm it knows — all result keys but the timings
 """
 import json
 import os
@@ -27,7 +30,7 @@ refshim.install()
 from oracle_backend import OracleBackend  # noqa: E402
 import muavta_amd.compat as compat  # noqa: E402
 
-if mode == "trainers_native":
+if mode.endswith("_native"):
     sys.path.append("/root/reference")  # mUAV_TA itself: the read-only checkout (nothing is written there: PYTHONDONTWRITEBYTECODE)
 else:
     compat.install(backend_factory=OracleBackend)  # mUAV_TA.* and core_sim now resolve to this repository
@@ -120,4 +123,49 @@ elif mode in ("trainers", "trainers_native"):
         tensor_hash(torch.load(ckpts[name], map_location="cpu", weights_only=True), h)  # (a file this process wrote a moment ago)
         out[name] = dict(rec, main_returned=repr(ret).replace(ckpts[name], "<ckpt>"), checkpoint_sha256=h.hexdigest(),
                          printed=[ln.replace(ckpts[name], "<ckpt>") for ln in buf.getvalue().splitlines() if "EVAL" in ln.upper() or "Done" in ln][:6])
+    print(json.dumps(out))
+elif mode in ("sweep", "sweep_native"):
+    import inspect
+    import random
+
+    import numpy as np
+    import torch
+
+    import experiments.escort_eval as E
+    import experiments.wps_eval as W
+
+    assert (W.MultiUAVEnv is compat.MultiUAVEnv) == (mode == "sweep") and (E.MultiUAVEnv is compat.MultiUAVEnv) == (mode == "sweep")
+    torch.set_num_threads(1)
+    torch.manual_seed(11); np.random.seed(11); random.seed(11)
+    pol = dict(rah=W.ReserveAwareHybrid(), att_rah=W.AttentionRAH(), att_commit=W.AttentionCommit(use_attention=True), mlp_commit=W.AttentionCommit(use_attention=False),
+               urg_commit=W.UrgencyCommit(), att_pair=W.PairCostHybrid(use_attention=True), mlp_pair=W.PairCostHybrid(use_attention=False), urg_pair=W.UrgencyPair(max_tasks=32, max_agents=16),
+               att_ctx=W.ContextPairHybrid(use_attention=True), mlp_ctx=W.ContextPairHybrid(use_attention=False), gnn_ctx=W.GNNContextPairHybrid())
+    for v in pol.values():  # (as wps_eval.main() sets them after loading a checkpoint)
+        if hasattr(v, "eps"):
+            v.eps = 0.0
+    src = inspect.getsource(W.run_wps_episode)
+    import re
+    algos = sorted(set(re.findall(r'"([A-Za-z]+(?:-[A-Za-z]+)+)"', src)) - {"Reset-Allocation"})
+    timing = lambda k: "ms" in k.lower() or "time_s" in k.lower() or k.lower().endswith("_sec")  # noqa: E731
+    out = {"wps": {}, "escort": {}}
+    cases = (("WPS_hard", 5), ("WPS_attn", 2), ("WPS_burst", 1), ("WPS_commit", 4), ("WPS_attn_L", 0))
+    for i, algo in enumerate(algos):
+        case, seed = cases[i % len(cases)]
+        torch.manual_seed(100 + i); np.random.seed(100 + i); random.seed(100 + i)
+        r = W.run_wps_episode(algo, case, seed, **pol)
+        out["wps"][f"{algo}|{case}|{seed}"] = {k: (v if isinstance(v, str) else repr(float(v))) for k, v in r.items() if not timing(k)}
+    esrc = inspect.getsource(E.run_escort_episode)
+    ealgos = sorted(set(re.findall(r'"([A-Za-z]+(?:-[A-Za-z0-9]+)+)"', esrc)))
+    torch.manual_seed(12)
+    epol = dict(att=E.AttentionEscort(use_attention=True), mlp=E.AttentionEscort(use_attention=False), urg=E.UrgencyCoalition())
+    for v in epol.values():
+        if hasattr(v, "eps"):
+            v.eps = 0.0
+    ecases = (("WPS_escort", 1, 12), ("WPS_escort", 2, 12), ("WPS_escort", 3, 8))
+    for i, algo in enumerate(ealgos):
+        case, seed, interval = ecases[i % len(ecases)]
+        torch.manual_seed(200 + i); np.random.seed(200 + i); random.seed(200 + i)
+        r = E.run_escort_episode(algo, case, seed, replan_interval=interval, **epol)
+        out["escort"][f"{algo}|{case}|{seed}|{interval}"] = {k: (v if isinstance(v, str) else repr(float(v))) for k, v in r.items() if not timing(k)}
+    out["escort_algorithms"], out["wps_algorithms"] = ealgos, algos
     print(json.dumps(out))

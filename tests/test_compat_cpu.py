@@ -30,7 +30,8 @@ def ref_copy(tmp_path_factory):
 
 
 def _drive(mode, ref_copy, *more):
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2", PYTHONHASHSEED="0")  # (hash seed: the reference's CBBA iterates over sets of names - its
+    # results move from run to run on the reference env itself unless string hashing is pinned)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "compat_driver.py"), mode, ref_copy, *more], capture_output=True, text=True, timeout=1500, env=env, cwd=ref_copy)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     return json.loads(p.stdout.strip().splitlines()[-1]), p.stdout
@@ -88,3 +89,22 @@ def test_reference_trainers_run_unchanged_and_train_the_same_checkpoints(ref_cop
             assert native[name][key] == facade[name][key], (name, key, native[name][key], facade[name][key])
         assert len(native[name]["checkpoint_sha256"]) == 64 and native[name]["printed"], name
     assert len({r["checkpoint_sha256"] for r in native.values()}) == 9  # (nine different trainings, not one constant)
+
+
+def test_every_algorithm_of_the_reference_eval_harnesses_gives_the_reference_result(ref_copy):
+    """experiments/wps_eval.py::run_wps_episode for each of the 19 algorithms it knows (Global / Local Hungarian, CBBA-replan, PI, capability greedy,
+    the RAH / Att-RAH ablations, Att / MLP / Urgency commit, Att / MLP / Urgency pair, Att / MLP / GNN context-pair — the learned ones with
+    randomly initialised networks of the same torch seed) over WPS_hard / WPS_attn / WPS_burst / WPS_commit / WPS_attn_L, and escort_eval.py::
+    run_escort_episode for each of its 7 (Global-Coalition, Coalition-Hungarian, CBBA / PI coalition, Urgency / MLP / Att coalition) at two
+    replan intervals: every result key but the wall-clock ones must equal what the same call returns over the reference's own env.  The
+    allocators other than the Hungarian (not accelerated) read the facade's Task / UAV / threat views and mutate nothing the
+    device does not know about — this is the test that they keep working when a user switches the env import."""
+    native, _ = _drive("sweep_native", ref_copy)
+    facade, _ = _drive("sweep", ref_copy)
+    assert len(native["wps_algorithms"]) == 19 and len(native["escort_algorithms"]) == 7
+    assert len(native["wps"]) == 19 and len(native["escort"]) == 7
+    for grp in ("wps", "escort"):
+        assert set(native[grp]) == set(facade[grp])
+        for k, want in native[grp].items():
+            assert len(want) >= 12 and facade[grp][k] == want, (k, {kk: (want[kk], facade[grp][k].get(kk)) for kk in want if want[kk] != facade[grp][k].get(kk)})
+    assert len({r["S_WPS"] for r in native["wps"].values()}) >= 15  # (different planners, different episodes)
