@@ -30,6 +30,7 @@ from .params import EVENT_TAGS, METRIC_KEYS, INT_METRICS, REWARD_KEYS, TASK_TYPE
 MAX_INT = sys.maxsize
 _TASK_DURATION = {"Hold": 1, "Rec": 10, "Att": 5, "Def": 5, "Int": 0, "Det": 1}   # MultiDroneEnvData.py:72-85
 _MAX_SPEED = {"F1": 20.0, "F2": 15.0, "R1": 5.0, "R2": 8.0, "E1": 5.0, "T1": 14.0, "T2": 12.0}
+_FAIL_MULTIPLIER = {"F1": 1.5, "F2": 0.8, "R1": 1.2, "R2": 0.8, "E1": 1.5, "T1": 1.8, "T2": 1.0}                  # MultiDroneEnvData.py:60-66
 _ENGAGE = {"F1": 40.0, "F2": 30.0, "R1": 0.0, "R2": 0.0, "E1": 0.0, "T1": 35.0, "T2": 25.0}
 
 
@@ -69,9 +70,15 @@ class TaskView:
     """Task (mUAV_TA/DroneEnvComponents.py:223-263).  ``hard_deadline`` is an attribute only on windowed
     tasks, exactly like the reference (callers use ``getattr(task, 'hard_deadline', None)``)."""
 
+    info = None              # DroneEnvComponents.py:228 (no task on this path is created with one)
+
     def __init__(self, env, task_id: int):
         self._env, self.id = env, int(task_id)
         self._last: Dict[str, Any] = {}
+
+    @property
+    def max_time_steps(self) -> int:
+        return self._env.max_time_steps   # :246
 
     def _slot(self) -> int:
         return self._env._snap.slot_map.get(self.id, -1)
@@ -220,8 +227,20 @@ class TaskView:
 class UAVView:
     """UAV (mUAV_TA/DroneEnvComponents.py:7-52)."""
 
+    altitude = 1000          # DroneEnvComponents.py:9,16
+    task_finished = -1       # :21 (never written again)
+    has_capability = True    # :52 (never written again; swarm_gap.py:104 reads it)
+
     def __init__(self, env, agent_id: int):
         self._env, self.id = env, int(agent_id)
+
+    @property
+    def env(self):
+        return self._env     # :11
+
+    @property
+    def fail_multiplier(self) -> float:
+        return _FAIL_MULTIPLIER[self.type]   # :39, MultiDroneEnvData.py:60-66
 
     @property
     def name(self) -> str:

@@ -11,6 +11,8 @@ the read-only checkout and runs them.  Prints one JSON document on the last line
     compat_driver.py sweep[_native] <ref_copy>    experiments/wps_eval.py::run_wps_episode for EVERY algorithm it knows (19: Hungarian variants, CBBA, PI, capability
                                                   greedy, the RAH / commit / pair / context-pair hybrids with randomly initialised networks) and
                                                   escort_eval.py::run_escort_episode for every algorithm it knows — all result keys but the timings
+    compat_driver.py scripts[_native] <ref_copy>  whole command lines, main() to CSV: train_escort.py (Att + MLP) -> escort_eval.py with those checkpoints;
+                                                  wps_eval.py (default suite, six algorithms, per-episode CSV); run_scaling.py (8 generated cases x 4 algorithms)
 """
 import json
 import os
@@ -167,5 +169,68 @@ elif mode in ("sweep", "sweep_native"):
         torch.manual_seed(200 + i); np.random.seed(200 + i); random.seed(200 + i)
         r = E.run_escort_episode(algo, case, seed, replan_interval=interval, **epol)
         out["escort"][f"{algo}|{case}|{seed}|{interval}"] = {k: (v if isinstance(v, str) else repr(float(v))) for k, v in r.items() if not timing(k)}
+    # the paper's static / dynamic table: experiments/paper_eval.py::run_episode, every algorithm but TBTA (a tianshou policy: out of scope) and the ILP oracle
+    import experiments.paper_eval as PE
+    from TaskAllocation.Hybrid.ReplanGate import ReplanGateAgent, ResidualAssignmentAgent
+
+    assert (PE.MultiUAVEnv is compat.MultiUAVEnv) == (mode == "sweep")
+    psrc = inspect.getsource(PE.run_episode)
+    palgos = sorted(set(re.findall(r'algorithm == "([A-Za-z-]+)"', psrc)) - {"TBTA", "ILP-Oracle"})  # (ILP-Oracle needs `pulp`, which this image lacks)
+    torch.manual_seed(13)
+    hyb = {"RG-DQN": ReplanGateAgent(), "RA-DQN": ResidualAssignmentAgent()}
+    for v in hyb.values():
+        v.eps = 0.0
+    pcases = (("static_strike", 2, PE.DEFAULT_ENV_FLAGS), ("D3_combined", 1, PE.TBTA_E3_FLAGS), ("recon_strike_mix", 0, PE.TBTA_E3_FLAGS), ("D1_attrition", 3, PE.DEFAULT_ENV_FLAGS),
+              ("D2_popup_threats", 4, PE.TBTA_E3_FLAGS), ("agent_scaling_mid", 5, PE.DEFAULT_ENV_FLAGS))
+    out["paper"] = {}
+    for i, algo in enumerate(palgos):
+        for j in range(2):
+            case, seed, fl = pcases[(2 * i + j) % len(pcases)]
+            torch.manual_seed(300 + i); np.random.seed(300 + i); random.seed(300 + i)
+            r = PE.run_episode(algo, case, seed, dict(fl), hybrid_agent=hyb.get(algo))
+            out["paper"][f"{algo}|{case}|{seed}"] = {k: (v if isinstance(v, str) else repr(float(v))) for k, v in r.items() if not timing(k)}
+    out["paper_algorithms"] = palgos
     out["escort_algorithms"], out["wps_algorithms"] = ealgos, algos
+    print(json.dumps(out))
+elif mode in ("scripts", "scripts_native"):
+    import contextlib
+    import csv
+    import importlib
+    import io
+    import random
+
+    import numpy as np
+    import torch
+
+    torch.set_num_threads(1)
+    work = os.path.join(ref, f"out_{mode}")
+    os.makedirs(work, exist_ok=True)
+    timing = lambda k: "ms" in k.lower() or "time_s" in k.lower() or k.lower().endswith("_sec") or "wall" in k.lower()  # noqa: E731
+
+    def run_main(modname, argv, seed):
+        M = importlib.import_module(f"experiments.{modname}")
+        assert (M.MultiUAVEnv is compat.MultiUAVEnv) == (mode == "scripts") if hasattr(M, "MultiUAVEnv") else True
+        random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+        sys.argv = [modname + ".py"] + argv
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            M.main()
+        return M, buf.getvalue()
+
+    def rows_of(path):
+        with open(path, newline="", encoding="utf-8") as f:
+            return [{k: v for k, v in r.items() if not timing(k)} for r in csv.DictReader(f)]
+
+    out = {}
+    att, mlp = os.path.join(work, "att.pth"), os.path.join(work, "mlp.pth")
+    run_main("train_escort", ["--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--out", att], 41)
+    run_main("train_escort", ["--mlp", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--out", mlp], 42)
+    E, printed = run_main("escort_eval", ["--episodes", "2", "--seed0", "5", "--att-ckpt", att, "--mlp-ckpt", mlp, "--tag", mode], 43)
+    out["escort_eval_csv"] = rows_of(os.path.join(E.RESULTS, f"WPS_escort_escort_eval_{mode}.csv"))
+    wcsv, wep = os.path.join(work, "wps.csv"), os.path.join(work, "wps_episodes.csv")
+    run_main("wps_eval", ["--episodes", "2", "--algorithms", "Local-Cap-Greedy,Local-Hungarian,Local-PI,Global-Hungarian,Urgency-Pair,Urgency-Commit", "--out", wcsv, "--episodes-out", wep], 44)
+    out["wps_eval_csv"], out["wps_eval_episodes_csv"] = rows_of(wcsv), rows_of(wep)
+    scsv = os.path.join(work, "scaling.csv")
+    run_main("run_scaling", ["--episodes", "1", "--out", scsv], 45)
+    out["run_scaling_csv"] = rows_of(scsv)
     print(json.dumps(out))

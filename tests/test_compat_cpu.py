@@ -96,15 +96,18 @@ def test_every_algorithm_of_the_reference_eval_harnesses_gives_the_reference_res
     the RAH / Att-RAH ablations, Att / MLP / Urgency commit, Att / MLP / Urgency pair, Att / MLP / GNN context-pair — the learned ones with
     randomly initialised networks of the same torch seed) over WPS_hard / WPS_attn / WPS_burst / WPS_commit / WPS_attn_L, and escort_eval.py::
     run_escort_episode for each of its 7 (Global-Coalition, Coalition-Hungarian, CBBA / PI coalition, Urgency / MLP / Att coalition) at two
-    replan intervals: every result key but the wall-clock ones must equal what the same call returns over the reference's own env.  The
+    replan intervals, and paper_eval.py::run_episode — the paper's static / dynamic table — for 9 of its 11 (Random, Greedy, Cap-Greedy, Swarm-GAP,
+    CBBA, CBBA-Replan, Hungarian, RG-DQN, RA-DQN; not tianshou's TBTA, not the ILP oracle: `pulp` is absent) on two of static_strike / recon_strike_mix /
+    agent_scaling_mid / D1_attrition / D2_popup_threats / D3_combined each (agent failures, pop-up threats, arrivals; S_Reward sums every step's reward
+    dict): every result key but the wall-clock ones must equal what the same call returns over the reference's own env.  The
     allocators other than the Hungarian (not accelerated) read the facade's Task / UAV / threat views and mutate nothing the
     device does not know about — this is the test that they keep working when a user switches the env import."""
     native, _ = _drive("sweep_native", ref_copy)
     facade, _ = _drive("sweep", ref_copy)
     assert len(native["wps_algorithms"]) == 19 and len(native["escort_algorithms"]) == 7
-    assert len(native["wps"]) == 19 and len(native["escort"]) == 7
-    for grp in ("wps", "escort"):
+    assert len(native["wps"]) == 19 and len(native["escort"]) == 7 and len(native["paper_algorithms"]) == 9 and len(native["paper"]) == 18
+    for grp in ("wps", "escort", "paper"):
         assert set(native[grp]) == set(facade[grp])
         for k, want in native[grp].items():
-            assert len(want) >= 12 and facade[grp][k] == want, (k, {kk: (want[kk], facade[grp][k].get(kk)) for kk in want if want[kk] != facade[grp][k].get(kk)})
+            assert len(want) >= 11 and facade[grp][k] == want, (k, {kk: (want[kk], facade[grp][k].get(kk)) for kk in want if want[kk] != facade[grp][k].get(kk)})
     assert len({r["S_WPS"] for r in native["wps"].values()}) >= 15  # (different planners, different episodes)

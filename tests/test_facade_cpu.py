@@ -343,3 +343,12 @@ def test_every_env_attribute_the_reference_callers_read_exists_and_echoes_the_co
                   "n_agents", "max_agents", "n_tasks", "max_tasks", "max_coord", "area_width", "area_height", "possible_agents", "render_enabled", "render_speed"):
             r, f = getattr(ref, n), getattr(fac, n)
             assert r == f and type(r) is type(f), (case, n, r, f)
+
+    # the object views: every attribute the reference's planners read on an agent / task exists (swarm_gap.py:104 reads `has_capability`)
+    a_ref, a_fac = ref.agents_obj[0], fac.agents_obj[0]
+    for n in ("has_capability", "altitude", "task_finished", "fail_multiplier", "max_speed", "engage_range", "attackCap", "type", "typeIdx", "name", "id", "state", "commit_until"):
+        assert getattr(a_ref, n) == getattr(a_fac, n), n
+    assert a_fac.env is fac
+    t_ref, t_fac = ref.tasks[1], fac.tasks[1]
+    for n in ("info", "max_time_steps", "type", "typeIdx", "status", "id", "task_duration"):
+        assert getattr(t_ref, n) == getattr(t_fac, n), n
