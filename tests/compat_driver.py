@@ -205,7 +205,7 @@ elif mode in ("scripts", "scripts_native"):
     torch.set_num_threads(1)
     work = os.path.join(ref, f"out_{mode}")
     os.makedirs(work, exist_ok=True)
-    timing = lambda k: "ms" in k.lower() or "time_s" in k.lower() or k.lower().endswith("_sec") or "wall" in k.lower()  # noqa: E731
+    timing = lambda k: "ms" in k.lower() or k.lower() in ("seconds", "time_s") or "wall" in k.lower()  # noqa: E731  (wall-clock columns)
 
     def run_main(modname, argv, seed):
         M = importlib.import_module(f"experiments.{modname}")
@@ -225,7 +225,7 @@ elif mode in ("scripts", "scripts_native"):
     att, mlp = os.path.join(work, "att.pth"), os.path.join(work, "mlp.pth")
     run_main("train_escort", ["--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--out", att], 41)
     run_main("train_escort", ["--mlp", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--out", mlp], 42)
-    E, printed = run_main("escort_eval", ["--episodes", "2", "--seed0", "5", "--att-ckpt", att, "--mlp-ckpt", mlp, "--tag", mode], 43)
+    E, printed = run_main("escort_eval", ["--episodes", "1", "--seed0", "5", "--att-ckpt", att, "--mlp-ckpt", mlp, "--tag", mode], 43)
     out["escort_eval_csv"] = rows_of(os.path.join(E.RESULTS, f"WPS_escort_escort_eval_{mode}.csv"))
     wcsv, wep = os.path.join(work, "wps.csv"), os.path.join(work, "wps_episodes.csv")
     run_main("wps_eval", ["--episodes", "2", "--algorithms", "Local-Cap-Greedy,Local-Hungarian,Local-PI,Global-Hungarian,Urgency-Pair,Urgency-Commit", "--out", wcsv, "--episodes-out", wep], 44)

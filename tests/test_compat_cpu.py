@@ -29,12 +29,27 @@ def ref_copy(tmp_path_factory):
     shutil.rmtree(dst, ignore_errors=True)
 
 
+def _env():
+    return dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2", PYTHONHASHSEED="0")  # (hash seed: the reference's CBBA iterates over sets of names -
+    # its results move from run to run on the reference env itself unless string hashing is pinned)
+
+
 def _drive(mode, ref_copy, *more):
-    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", OMP_NUM_THREADS="2", PYTHONHASHSEED="0")  # (hash seed: the reference's CBBA iterates over sets of names - its
-    # results move from run to run on the reference env itself unless string hashing is pinned)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "compat_driver.py"), mode, ref_copy, *more], capture_output=True, text=True, timeout=1500, env=env, cwd=ref_copy)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "compat_driver.py"), mode, ref_copy, *more], capture_output=True, text=True, timeout=1500, env=_env(), cwd=ref_copy)
     assert p.returncode == 0, p.stdout[-3000:] + "\n" + p.stderr[-3000:]
     return json.loads(p.stdout.strip().splitlines()[-1]), p.stdout
+
+
+def _drive_pair(mode, ref_copy):
+    """`mode`_native (the reference's own env) and `mode` (the aliases installed) side by side in two fresh interpreters -> their JSON documents"""
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "compat_driver.py"), m, ref_copy], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=_env(), cwd=ref_copy)
+             for m in (mode + "_native", mode)]
+    docs = []
+    for pr in procs:
+        so, se = pr.communicate(timeout=1500)
+        assert pr.returncode == 0, so[-3000:] + "\n" + se[-3000:]
+        docs.append(json.loads(so.strip().splitlines()[-1]))
+    return docs
 
 
 def test_reference_episode_runners_run_unchanged_and_reproduce_the_reference_metrics(ref_copy):
@@ -81,8 +96,7 @@ def test_reference_trainers_run_unchanged_and_train_the_same_checkpoints(ref_cop
     module, DroneEnv.py:525-526).  Every episode's return / loss tuple, every evaluation score, main()'s return value and the SHA-256 over
     every tensor of the checkpoint it saved must be equal: the planners' state builders and token builders read the facade's object views
     and echoed configuration (`burst_mode`, ... — DroneEnv.py:101-201) exactly as they read the reference env's."""
-    native, _ = _drive("trainers_native", ref_copy)
-    facade, _ = _drive("trainers", ref_copy)
+    native, facade = _drive_pair("trainers", ref_copy)
     assert set(native) == set(facade) and len(native) == 9
     for name in native:
         for key in native[name]:
@@ -102,8 +116,7 @@ def test_every_algorithm_of_the_reference_eval_harnesses_gives_the_reference_res
     dict): every result key but the wall-clock ones must equal what the same call returns over the reference's own env.  The
     allocators other than the Hungarian (not accelerated) read the facade's Task / UAV / threat views and mutate nothing the
     device does not know about — this is the test that they keep working when a user switches the env import."""
-    native, _ = _drive("sweep_native", ref_copy)
-    facade, _ = _drive("sweep", ref_copy)
+    native, facade = _drive_pair("sweep", ref_copy)
     assert len(native["wps_algorithms"]) == 19 and len(native["escort_algorithms"]) == 7
     assert len(native["wps"]) == 19 and len(native["escort"]) == 7 and len(native["paper_algorithms"]) == 9 and len(native["paper"]) == 18
     for grp in ("wps", "escort", "paper"):
@@ -111,3 +124,17 @@ def test_every_algorithm_of_the_reference_eval_harnesses_gives_the_reference_res
         for k, want in native[grp].items():
             assert len(want) >= 11 and facade[grp][k] == want, (k, {kk: (want[kk], facade[grp][k].get(kk)) for kk in want if want[kk] != facade[grp][k].get(kk)})
     assert len({r["S_WPS"] for r in native["wps"].values()}) >= 15  # (different planners, different episodes)
+
+
+def test_reference_command_lines_write_the_same_csv_files(ref_copy):
+    """Whole command lines of the reference, main() to CSV, unchanged: train_escort.py (Att-Coalition, then --mlp) -> escort_eval.py with the two
+    checkpoints just trained (7 algorithms); wps_eval.py on its default suite (WPS_easy, WPS_hard) with six algorithms incl. the summary's bootstrap
+    confidence intervals and the per-episode CSV; run_scaling.py (8 generated fleet / task scaling cases x Cap-Greedy, CBBA, CBBA-Replan, Hungarian
+    through paper_eval.evaluate_case).  Every cell of every CSV but the wall-clock columns must equal the file the same command writes over the
+    reference's own env."""
+    native, facade = _drive_pair("scripts", ref_copy)
+    assert {k: len(v) for k, v in native.items()} == {"escort_eval_csv": 7, "wps_eval_csv": 12, "wps_eval_episodes_csv": 24, "run_scaling_csv": 32}
+    for name, rows in native.items():
+        assert len(facade[name]) == len(rows)
+        for i, (want, got) in enumerate(zip(rows, facade[name])):
+            assert got == want, (name, i, {k: (want[k], got.get(k)) for k in want if want[k] != got.get(k)})
