@@ -224,6 +224,31 @@ class TaskView:
         return f"<Task {self.id} {self.type} status={self.status}>"
 
 
+class TaskSnapshot:
+    """What `copy.deepcopy(task)` gives in the reference (DroneEnv.py:768): the public fields of a Task frozen at the moment of the copy
+    (`protected_agent` by name: the copy must not follow the live agent)."""
+
+    FIELDS = ("id", "info", "type", "typeIdx", "status", "max_time_steps", "task_duration", "initTime", "doneTime", "created_at", "final_quality",
+              "kind", "required_agents")
+
+    def __init__(self, task: "TaskView"):
+        for f in self.FIELDS:
+            setattr(self, f, getattr(task, f))
+        self.position = np.array(task.position, dtype=np.float64)
+        self.orgReqs, self.currentReqs, self.allocatedReqs = (np.array(x, dtype=np.float64) for x in (task.orgReqs, task.currentReqs, task.allocatedReqs))
+        self.allocationDetails = dict(task.allocationDetails)
+        e = task.eligible_agent_types
+        self.eligible_agent_types = None if e is None else set(e)
+        p = task.protected_agent
+        self.protected_agent = None if p is None else p.name
+        d = getattr(task, "hard_deadline", None)
+        if d is not None:
+            self.hard_deadline = d
+
+    def __repr__(self):
+        return f"<Task copy {self.id} {self.type} status={self.status}>"
+
+
 class UAVView:
     """UAV (mUAV_TA/DroneEnvComponents.py:7-52)."""
 
@@ -441,7 +466,7 @@ class MultiUAVEnv:
         self.agents_config, self.tasks_config = dict(c.get("agents")), dict(c.get("tasks"))
         self.threats_list = list(c.get("threats_list") or [])
         self.random_init_pos, self.num_obstacles, self.hidden_obstacles = bool(p.random_init_pos), p.num_obstacles, False
-        self.multiple_tasks_per_agent, self.multiple_agents_per_task = bool(p.multiple_tasks_per_agent), True
+        self._multi_tasks, self._multi_agents = bool(p.multiple_tasks_per_agent), True   # (read through the two properties below)
         self.fail_rate = p.fail_rate
         self.early_terminate, self.capability_mask, self.saturate_mask = bool(p.early_terminate), bool(p.capability_mask), bool(p.saturate_mask)
         self.reward_weights = dict(zip(REWARD_KEYS, (float(w) for w in p.reward_weights)))
@@ -695,6 +720,20 @@ class MultiUAVEnv:
     protected_rec_completed = property(lambda self: int(self._scalar(22)))
     current_agent = property(lambda self: self.possible_agents[self._steps % len(self.possible_agents)])
 
+    # The two action-mode switches (DroneEnv.py:156-157; read by step at :842,877-882) are parameters of the device handle, fixed when it is created.
+    # The reference's main.py:130-141 flips them on the env object after reset: here such a write must not pass silently with the old behaviour, so a
+    # write that would CHANGE the value raises (put the value into the configuration); writing the value the handle already has is accepted.
+    def _fixed_switch(name, slot):
+        def setter(self, value):
+            if bool(value) != getattr(self, slot):
+                raise ValueError(f"{name} is fixed when the env is created (it is a parameter of the device handle): construct the env with {name}={bool(value)} "
+                                 "in its configuration instead of assigning it afterwards")
+        return property(lambda self: getattr(self, slot), setter)
+
+    multiple_tasks_per_agent = _fixed_switch("multiple_tasks_per_agent", "_multi_tasks")
+    multiple_agents_per_task = _fixed_switch("multiple_agents_per_task", "_multi_agents")
+    del _fixed_switch
+
     def get_live_agents(self):  # DroneEnv.py:1484-1486
         return [a for a, st in zip(self.agents_obj, self._snap["AGENT_STATE"].tolist()) if st != -1]
 
@@ -722,8 +761,19 @@ class MultiUAVEnv:
     def compute_s_esc(self) -> float:  # :2002-2011
         return float(self._b.metrics()[0][METRIC_KEYS.index("S_ESC")])
 
+    def close(self):
+        """pettingzoo's ParallelEnv.close() (main.py:273 calls it when a case is done): frees the device handle"""
+        c = getattr(self._b, "close", None)
+        if c is not None:
+            c()
+
+    backend = property(lambda self: self._b)  # the handle behind the facade (BatchedMultiUAVEnv on the GPU): get_state() / get_rng() checkpoint it
+
     def get_initial_state(self):
-        return {"state": self._b.get_state().copy(), "rng": self._b.get_rng().copy()}
+        """DroneEnv.py:764-771: deep copies of the agent names and of every Task as they stand now, `quality_table` (None on every path: :249) and an
+        empty event list.  The copies are detached `TaskSnapshot`s: they keep the values of this moment while the env moves on, as a deep copy does.
+        (The device-side checkpoint of a whole handle is `backend.get_state()` / `get_rng()`: INTEGRATION.md section 2.)"""
+        return {"agents": list(self.agents), "tasks": [TaskSnapshot(t) for t in self.tasks], "quality_table": None, "events": []}
 
     # ------------------------------------------------------------------ spaces (DroneEnv.py:298-308, 310-323)
     def observation_space(self, agent):

@@ -12,7 +12,8 @@ the read-only checkout and runs them.  Prints one JSON document on the last line
                                                   greedy, the RAH / commit / pair / context-pair hybrids with randomly initialised networks) and
                                                   escort_eval.py::run_escort_episode for every algorithm it knows — all result keys but the timings
     compat_driver.py scripts[_native] <ref_copy>  whole command lines, main() to CSV: train_escort.py (Att + MLP) -> escort_eval.py with those checkpoints;
-                                                  wps_eval.py (default suite, six algorithms, per-episode CSV); run_scaling.py (8 generated cases x 4 algorithms)
+                                                  wps_eval.py (default suite, six algorithms, per-episode CSV); run_scaling.py (8 generated cases x 4 algorithms);
+                                                  benchmark.py of the checkout's root (Random / Greedy / CBBA); a third argument picks steps (escort,wps,scaling,benchmark)
 """
 import json
 import os
@@ -222,15 +223,41 @@ elif mode in ("scripts", "scripts_native"):
             return [{k: v for k, v in r.items() if not timing(k)} for r in csv.DictReader(f)]
 
     out = {}
-    att, mlp = os.path.join(work, "att.pth"), os.path.join(work, "mlp.pth")
-    run_main("train_escort", ["--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--out", att], 41)
-    run_main("train_escort", ["--mlp", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--out", mlp], 42)
-    E, printed = run_main("escort_eval", ["--episodes", "1", "--seed0", "5", "--att-ckpt", att, "--mlp-ckpt", mlp, "--tag", mode], 43)
-    out["escort_eval_csv"] = rows_of(os.path.join(E.RESULTS, f"WPS_escort_escort_eval_{mode}.csv"))
-    wcsv, wep = os.path.join(work, "wps.csv"), os.path.join(work, "wps_episodes.csv")
-    run_main("wps_eval", ["--episodes", "2", "--algorithms", "Local-Cap-Greedy,Local-Hungarian,Local-PI,Global-Hungarian,Urgency-Pair,Urgency-Commit", "--out", wcsv, "--episodes-out", wep], 44)
-    out["wps_eval_csv"], out["wps_eval_episodes_csv"] = rows_of(wcsv), rows_of(wep)
-    scsv = os.path.join(work, "scaling.csv")
-    run_main("run_scaling", ["--episodes", "1", "--out", scsv], 45)
-    out["run_scaling_csv"] = rows_of(scsv)
+    only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+    want = lambda step: only is None or step in only  # noqa: E731
+    if want("escort"):
+        att, mlp = os.path.join(work, "att.pth"), os.path.join(work, "mlp.pth")
+        run_main("train_escort", ["--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--out", att], 41)
+        run_main("train_escort", ["--mlp", "--episodes", "2", "--eval-every", "2", "--eval-eps", "1", "--out", mlp], 42)
+        E, printed = run_main("escort_eval", ["--episodes", "1", "--seed0", "5", "--att-ckpt", att, "--mlp-ckpt", mlp, "--tag", mode], 43)
+        out["escort_eval_csv"] = rows_of(os.path.join(E.RESULTS, f"WPS_escort_escort_eval_{mode}.csv"))
+    if want("wps"):
+        wcsv, wep = os.path.join(work, "wps.csv"), os.path.join(work, "wps_episodes.csv")
+        run_main("wps_eval", ["--episodes", "2", "--algorithms", "Local-Cap-Greedy,Local-Hungarian,Local-PI,Global-Hungarian,Urgency-Pair,Urgency-Commit", "--out", wcsv, "--episodes-out", wep], 44)
+        out["wps_eval_csv"], out["wps_eval_episodes_csv"] = rows_of(wcsv), rows_of(wep)
+    if want("scaling"):
+        scsv = os.path.join(work, "scaling.csv")
+        run_main("run_scaling", ["--episodes", "1", "--out", scsv], 45)
+        out["run_scaling_csv"] = rows_of(scsv)
+    if want("benchmark"):
+        # the reference's own throughput script (benchmark.py at the root of the checkout: Random / Greedy / CBBA, list-valued actions, fixed_seed = 42,
+        # get_initial_state, current_agent): run by path, its per-episode reward / completion printout kept, its SPS and timing dropped
+        import re
+        import runpy
+
+        os.environ["MPLBACKEND"] = "Agg"
+        os.chdir(work)  # (it saves benchmark_results.png into the working directory)
+        random.seed(46); np.random.seed(46)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            runpy.run_path("/root/reference/benchmark.py", run_name="__main__")
+        algo, rows = None, []
+        for ln in buf.getvalue().splitlines():
+            m = re.match(r"Running (\S+) Benchmark", ln)
+            if m:
+                algo = m.group(1)
+            m = re.match(r"Ep (\d+)/(\d+) \| Time: .* \| SPS: .* \| Reward: (\S+) \| Completed: (\S+)", ln)
+            if m:
+                rows.append({"algorithm": algo, "episode": m.group(1), "reward": m.group(3), "completed": m.group(4)})
+        out["benchmark_py"] = rows
     print(json.dumps(out))

@@ -130,10 +130,11 @@ def test_reference_command_lines_write_the_same_csv_files(ref_copy):
     """Whole command lines of the reference, main() to CSV, unchanged: train_escort.py (Att-Coalition, then --mlp) -> escort_eval.py with the two
     checkpoints just trained (7 algorithms); wps_eval.py on its default suite (WPS_easy, WPS_hard) with six algorithms incl. the summary's bootstrap
     confidence intervals and the per-episode CSV; run_scaling.py (8 generated fleet / task scaling cases x Cap-Greedy, CBBA, CBBA-Replan, Hungarian
-    through paper_eval.evaluate_case).  Every cell of every CSV but the wall-clock columns must equal the file the same command writes over the
-    reference's own env."""
+    through paper_eval.evaluate_case); benchmark.py at the root of the checkout (Random / Greedy / CBBA x 5 episodes, list-valued actions,
+    `fixed_seed`, `get_initial_state`, `current_agent`: its per-episode reward / completion printout).  Every cell of every CSV but the wall-clock
+    columns must equal the file the same command writes over the reference's own env."""
     native, facade = _drive_pair("scripts", ref_copy)
-    assert {k: len(v) for k, v in native.items()} == {"escort_eval_csv": 7, "wps_eval_csv": 12, "wps_eval_episodes_csv": 24, "run_scaling_csv": 32}
+    assert {k: len(v) for k, v in native.items()} == {"escort_eval_csv": 7, "wps_eval_csv": 12, "wps_eval_episodes_csv": 24, "run_scaling_csv": 32, "benchmark_py": 15}
     for name, rows in native.items():
         assert len(facade[name]) == len(rows)
         for i, (want, got) in enumerate(zip(rows, facade[name])):

@@ -352,3 +352,34 @@ def test_every_env_attribute_the_reference_callers_read_exists_and_echoes_the_co
     t_ref, t_fac = ref.tasks[1], fac.tasks[1]
     for n in ("info", "max_time_steps", "type", "typeIdx", "status", "id", "task_duration"):
         assert getattr(t_ref, n) == getattr(t_fac, n), n
+
+    # get_initial_state (DroneEnv.py:764-771; benchmark.py:49 and main.py:89 call it after every reset): the same keys, the tasks as detached copies
+    # that keep the values of the moment while the env moves on, as the reference's deep copies do
+    i_ref, i_fac = ref.get_initial_state(), fac.get_initial_state()
+    assert list(i_ref) == list(i_fac) and i_fac["agents"] == i_ref["agents"] and i_fac["agents"] is not fac.agents
+    assert i_fac["quality_table"] is None and i_ref["quality_table"] is None and i_fac["events"] == [] == i_ref["events"]
+    assert len(i_fac["tasks"]) == len(i_ref["tasks"])
+
+    def frozen(tasks):
+        return [(t.id, t.type, t.typeIdx, t.status, tuple(np.asarray(t.position, dtype=float)), tuple(t.orgReqs), tuple(t.currentReqs), tuple(t.allocatedReqs),
+                 t.initTime, t.doneTime, t.created_at, t.task_duration, t.required_agents, t.kind, getattr(t, "hard_deadline", None)) for t in tasks]
+
+    at_reset = frozen(i_ref["tasks"])
+    assert frozen(i_fac["tasks"]) == at_reset
+    for _ in range(30):
+        acts = {a.name: 1 + (k % (len(ref.last_tasks_info) - 1)) for k, a in enumerate(ref.get_live_agents()[:3])}
+        ref.step(dict(acts)); fac.step(dict(acts))
+    assert frozen(i_fac["tasks"]) == at_reset == frozen(i_ref["tasks"])          # the copies did not move ...
+    assert frozen(fac.tasks) == frozen(ref.tasks) and frozen(fac.tasks) != at_reset  # ... the env did
+
+    # the two action-mode switches are parameters of the device handle: main.py:130-141 assigns them on the env after reset — a write that keeps the
+    # value passes, one that would change it raises instead of silently keeping the old behaviour
+    cur = fac.multiple_tasks_per_agent
+    fac.multiple_tasks_per_agent = cur
+    fac.multiple_agents_per_task = True
+    with pytest.raises(ValueError, match="fixed when the env is created"):
+        fac.multiple_tasks_per_agent = not cur
+    with pytest.raises(ValueError, match="fixed when the env is created"):
+        fac.multiple_agents_per_task = False
+    assert fac.multiple_tasks_per_agent == cur and fac.multiple_agents_per_task is True
+
