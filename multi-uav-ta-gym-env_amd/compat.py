@@ -67,12 +67,7 @@ class MultiUAVEnv(_env.MultiUAVEnv):
     def __init__(self, config=None):
         if config is None:
             config = agentEnvOptions()
-        backend = None
-        if _BACKEND_FACTORY is not None:
-            from .params import params_from_config
-
-            backend = _BACKEND_FACTORY(params_from_config(config))
-        super().__init__(config, backend=backend)
+        super().__init__(config, backend_factory=_BACKEND_FACTORY)  # (None: the HIP library)
 
 
 class SceneData:
@@ -101,6 +96,10 @@ def install(backend_factory: Optional[Callable] = None, with_core_sim: bool = Tr
     pkg.__path__ = []  # a package: `from mUAV_TA.DroneEnv import ...` resolves through sys.modules
     drone = types.ModuleType("mUAV_TA.DroneEnv")
     drone.MultiUAVEnv = MultiUAVEnv
+    # the module-level names callers import beside the class (DroneEnv.py:35-68; main.py:11-12): the two factory functions hand out the parallel
+    # env itself — pettingzoo's order-enforcing / AEC wrappers belong to the turn-based TBTA path (out of scope)
+    drone.MAX_INT, drone.EPS = sys.maxsize, 1e-12
+    drone.env = drone.raw_env = lambda config=None: MultiUAVEnv(config)
     utils = types.ModuleType("mUAV_TA.MultiDroneEnvUtils")
     utils.agentEnvOptions = agentEnvOptions
     data = types.ModuleType("mUAV_TA.MultiDroneEnvData")

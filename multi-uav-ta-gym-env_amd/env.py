@@ -431,16 +431,24 @@ class ThreatView:
 class MultiUAVEnv:
     metadata = {"render_modes": ["human"], "name": "multi_agent_env_v0"}
 
-    def __init__(self, config=None, backend=None, device: int = 0, flags: Optional[dict] = None, **tiles):
+    def __init__(self, config=None, backend=None, device: int = 0, flags: Optional[dict] = None, backend_factory=None, **tiles):
         if config is None:
             config = {"agents": {"F1": 0, "F2": 0, "R1": 1, "R2": 1}, "tasks": {"Att": 0, "Rec": 2, "Hold": 0},
                       "threats_list": [("T1", 4), ("T2", 2)]}
         self.config = config
         self._params = params_from_config(config, flags, **tiles)
+        # `backend_factory(params) -> backend`: how a handle for this env is made (kept: a write to `multiple_tasks_per_agent` re-creates it, see the
+        # property below).  The default is the HIP library; an injected `backend` INSTANCE has no factory, and such an env refuses that write.
+        self._backend_factory = backend_factory
         if backend is None:
-            from .batched import BatchedMultiUAVEnv  # HIP library; raises MuavtaError when unavailable
+            if backend_factory is None:
+                def backend_factory(params, _device=device):
+                    from .batched import BatchedMultiUAVEnv  # HIP library; raises MuavtaError when unavailable
 
-            backend = BatchedMultiUAVEnv(self._params, 1, device)
+                    return BatchedMultiUAVEnv(params, 1, _device)
+                self._backend_factory = backend_factory
+            backend = backend_factory(self._params)
+        self._seed = None
         self._b = backend
         self._b.set_release_log(True)  # keeps agent_visibility_map() exact for ids whose slot was recycled
         self._snap = _Snapshot(backend)
@@ -721,18 +729,57 @@ class MultiUAVEnv:
     current_agent = property(lambda self: self.possible_agents[self._steps % len(self.possible_agents)])
 
     # The two action-mode switches (DroneEnv.py:156-157; read by step at :842,877-882) are parameters of the device handle, fixed when it is created.
-    # The reference's main.py:130-141 flips them on the env object after reset: here such a write must not pass silently with the old behaviour, so a
-    # write that would CHANGE the value raises (put the value into the configuration); writing the value the handle already has is accepted.
-    def _fixed_switch(name, slot):
-        def setter(self, value):
-            if bool(value) != getattr(self, slot):
-                raise ValueError(f"{name} is fixed when the env is created (it is a parameter of the device handle): construct the env with {name}={bool(value)} "
-                                 "in its configuration instead of assigning it afterwards")
-        return property(lambda self: getattr(self, slot), setter)
+    # The reference's main.py:130-141 assigns them on the env object right after reset().  `multiple_agents_per_task` has one live value (False is dead
+    # code in the reference, :935): True is accepted, False raises.  A write that CHANGES `multiple_tasks_per_agent` re-creates the handle with the new
+    # parameter and resets it with the episode's seed — reset never reads the switch, so the new handle stands exactly where the old one stood — which is
+    # only right while nothing has happened since reset(): the new handle's state is compared with the old one's, field by field, and the write raises if
+    # they differ (the env was stepped or mutated: the reference would change behaviour mid-episode there, this path does not offer that).
+    _SWAP_FIELDS = ("SCALARS", "AGENT_POS", "AGENT_STATE", "AGENT_QUEUE", "AGENT_NFT", "AGENT_NFP", "AGENT_CAPS", "AGENT_MISC", "TASK_ID", "TASK_STATUS", "TASK_POS",
+                    "TASK_META", "TASK_TIMES", "TASK_CUR", "TASK_ALLOC", "KNOWN", "THREAT_META", "THREAT_POS", "OPEN_IDS", "ESCORTS")
 
-    multiple_tasks_per_agent = _fixed_switch("multiple_tasks_per_agent", "_multi_tasks")
-    multiple_agents_per_task = _fixed_switch("multiple_agents_per_task", "_multi_agents")
-    del _fixed_switch
+    @property
+    def multiple_agents_per_task(self) -> bool:
+        return True
+
+    @multiple_agents_per_task.setter
+    def multiple_agents_per_task(self, value):
+        if not value:
+            raise ValueError("multiple_agents_per_task=False is dead code in the reference (DroneEnv.py:935) and not a mode of the device handle")
+
+    @property
+    def multiple_tasks_per_agent(self) -> bool:
+        return self._multi_tasks
+
+    @multiple_tasks_per_agent.setter
+    def multiple_tasks_per_agent(self, value):
+        value = bool(value)
+        if value == self._multi_tasks:
+            return
+        why = None
+        if self._backend_factory is None:
+            why = "this env was given a backend instance, not a way to make one (backend_factory)"
+        elif self._steps != 0:
+            why = "the env has been stepped since reset()"
+        if why is None:
+            import copy
+
+            params = copy.copy(self._params)
+            params.multiple_tasks_per_agent = int(value)
+            new = self._backend_factory(params)
+            new.set_release_log(True)
+            if self._seed is not None:
+                new.reset(np.array([self._seed], dtype=np.uint64))
+                differs = [f for f in self._SWAP_FIELDS if not np.array_equal(np.asarray(self._b.get(f)), np.asarray(new.get(f)))]
+                if differs:
+                    getattr(new, "close", lambda: None)()
+                    why = f"the env was changed since reset() ({', '.join(differs)})"
+        if why is not None:
+            raise ValueError(f"multiple_tasks_per_agent is a parameter of the device handle and can be changed right after reset() only: {why}.  "
+                             f"Construct the env with multiple_tasks_per_agent={value} in its configuration instead")
+        old, self._b, self._params, self._multi_tasks = self._b, new, params, value
+        self._snap.b = new
+        self._snap.clear()
+        getattr(old, "close", lambda: None)()
 
     def get_live_agents(self):  # DroneEnv.py:1484-1486
         return [a for a, st in zip(self.agents_obj, self._snap["AGENT_STATE"].tolist()) if st != -1]

@@ -13,7 +13,8 @@ the read-only checkout and runs them.  Prints one JSON document on the last line
                                                   escort_eval.py::run_escort_episode for every algorithm it knows — all result keys but the timings
     compat_driver.py scripts[_native] <ref_copy>  whole command lines, main() to CSV: train_escort.py (Att + MLP) -> escort_eval.py with those checkpoints;
                                                   wps_eval.py (default suite, six algorithms, per-episode CSV); run_scaling.py (8 generated cases x 4 algorithms);
-                                                  benchmark.py of the checkout's root (Random / Greedy / CBBA); a third argument picks steps (escort,wps,scaling,benchmark)
+                                                  benchmark.py of the checkout's root (Random / Greedy / CBBA); main.py's run_case_algorithm (Random / Greedy / Swarm-GAP / CBBA); a third
+                                                  argument picks steps (escort,wps,scaling,benchmark,main)
 """
 import json
 import os
@@ -260,4 +261,24 @@ elif mode in ("scripts", "scripts_native"):
             if m:
                 rows.append({"algorithm": algo, "episode": m.group(1), "reward": m.group(3), "completed": m.group(4)})
         out["benchmark_py"] = rows
+    if want("main"):
+        # main.py at the root of the checkout (the legacy entry point): run_case_algorithm for the four allocators that need no tianshou policy — Random,
+        # Greedy, Swarm-GAP, CBBA — on one of its own fleet-scaling cases.  It builds the env with multiple_tasks_per_agent=False and assigns True on the env
+        # object after every reset (main.py:130-141), calls get_initial_state() and close(); imported as a module, so its process pool does not start
+        import importlib.util
+
+        os.environ["MPLBACKEND"] = "Agg"
+        spec = importlib.util.spec_from_file_location("reference_main", "/root/reference/main.py")
+        M = importlib.util.module_from_spec(spec)
+        with contextlib.redirect_stdout(io.StringIO()):
+            spec.loader.exec_module(M)
+        assert (M.MultiUAVEnv is compat.MultiUAVEnv) == (mode == "scripts")
+        case = {"case": 3, "F1": 1, "R1": 3, "F2": 0, "R2": 0, "Att": 6, "Rec": 24}  # (main.py:328-332, i = 3)
+        keep = ("n_agents", "n_tasks", "mean_S_reward", "mean_R_reward", "time_reward", "distance_reward", "quality_reward", "losses", "kills", "process_runs")
+        out["main_py"] = {}
+        for algo in ("Random", "Greedy", "Swarm-GAP", "CBBA"):
+            random.seed(47); np.random.seed(47)
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = M.run_case_algorithm(case, algo, 2, 1, 0.0, -1, False, "Agents")
+            out["main_py"][algo] = {k: r[k] for k in keep}
     print(json.dumps(out))

@@ -376,14 +376,60 @@ def test_every_env_attribute_the_reference_callers_read_exists_and_echoes_the_co
     assert frozen(i_fac["tasks"]) == at_reset == frozen(i_ref["tasks"])          # the copies did not move ...
     assert frozen(fac.tasks) == frozen(ref.tasks) and frozen(fac.tasks) != at_reset  # ... the env did
 
-    # the two action-mode switches are parameters of the device handle: main.py:130-141 assigns them on the env after reset — a write that keeps the
-    # value passes, one that would change it raises instead of silently keeping the old behaviour
-    cur = fac.multiple_tasks_per_agent
-    fac.multiple_tasks_per_agent = cur
-    fac.multiple_agents_per_task = True
-    with pytest.raises(ValueError, match="fixed when the env is created"):
-        fac.multiple_tasks_per_agent = not cur
-    with pytest.raises(ValueError, match="fixed when the env is created"):
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mUAV_TA"), reason="reference checkout not present (GPU box)")
+def test_writing_multiple_tasks_per_agent_after_reset_as_main_py_does_gives_the_reference_episode():
+    """The reference's main.py:130-141 builds its env with multiple_tasks_per_agent=False and assigns True on the env object right after every reset()
+    (Greedy / Swarm-GAP / CBBA hand whole task LISTS to an agent).  On the device the switch is a parameter of the handle: the write re-creates the handle and
+    resets it with the episode's seed (reset never reads the switch), after checking field by field that nothing happened since reset.  The episode that
+    follows must be the reference's, list-valued actions queued in full; the same write after a step, or on an env that was given a backend instance, raises
+    instead of passing silently with the old behaviour; multiple_agents_per_task=False (dead code in the reference) raises."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import refshim
+    refshim.install()
+    from mUAV_TA.DroneEnv import MultiUAVEnv as RefEnv
+    from experiments.paper_eval import make_config
+
+    spec = dict(CASE_SPECS["static_strike"])
+    cfg = make_config(spec, {})
+    cfg.multiple_tasks_per_agent = False
+    ref, fac = RefEnv(cfg), MultiUAVEnv(cfg, backend_factory=OracleBackend)
+    assert ref.multiple_tasks_per_agent is False and fac.multiple_tasks_per_agent is False
+    made = [fac.backend]
+    for seed in (5, 6):
+        ref.reset(seed=seed); fac.reset(seed=seed)
+        views = (fac.agents_obj[0], fac.tasks[1], fac.last_tasks_info)
+        ref.multiple_tasks_per_agent = True; ref.multiple_agents_per_task = True   # main.py:131-132
+        fac.multiple_tasks_per_agent = True; fac.multiple_agents_per_task = True
+        assert fac.multiple_tasks_per_agent is True
+        if fac.backend is not made[-1]:
+            made.append(fac.backend)
+        assert (fac.agents_obj[0], fac.tasks[1], fac.last_tasks_info) == views and fac.agents_obj[0] is views[0]  # (the views a planner holds stay the env's views)
+        rng = np.random.default_rng(seed)
+        multi = 0
+        for t in range(60):
+            n_open = len(ref.last_tasks_info)
+            acts = {a.name: [int(x) for x in rng.integers(1, n_open, size=int(rng.integers(1, 4)))] for a in ref.get_live_agents()[: 1 + t % 3]} if n_open > 1 and t % 4 == 0 else {}
+            r_ref, r_fac = ref.step({k: list(v) for k, v in acts.items()}), fac.step({k: list(v) for k, v in acts.items()})
+            assert r_ref[1] == r_fac[1] and r_ref[2] == r_fac[2] and r_ref[3] == r_fac[3], (seed, t)
+            assert [[x.id for x in a.tasks] for a in ref.agents_obj] == [[x.id for x in a.tasks] for a in fac.agents_obj], (seed, t)
+            assert np.array_equal(np.array([a.position for a in ref.agents_obj]), np.array([a.position for a in fac.agents_obj])), (seed, t)
+            multi += sum(len(a.tasks) > 1 for a in fac.agents_obj)
+        assert multi > 0  # (queues longer than one task: the switch is on)
+    assert len(made) == 2  # one re-creation, at the first write; the later writes keep the value
+
+    with pytest.raises(ValueError, match="right after reset"):  # stepped since reset
+        fac.multiple_tasks_per_agent = False
+    fac.reset(seed=9)
+    fac.agents_obj[0].position = np.array([10.0, 20.0])         # mutated since reset
+    with pytest.raises(ValueError, match="changed since reset"):
+        fac.multiple_tasks_per_agent = False
+    assert fac.multiple_tasks_per_agent is True
+    with pytest.raises(ValueError, match="dead code in the reference"):
         fac.multiple_agents_per_task = False
-    assert fac.multiple_tasks_per_agent == cur and fac.multiple_agents_per_task is True
+    inst = MultiUAVEnv(cfg, backend=OracleBackend(params_from_config(cfg, None)))
+    inst.reset(seed=1)
+    inst.multiple_tasks_per_agent = False                       # (keeps the value)
+    with pytest.raises(ValueError, match="backend instance"):
+        inst.multiple_tasks_per_agent = True
 

@@ -35,6 +35,9 @@ class _ParallelEnv:
     def __init__(self, *a, **k):
         pass
 
+    def close(self):  # pettingzoo.ParallelEnv.close is a no-op the env inherits (main.py:273 calls it)
+        pass
+
 
 class _AgentSelector:
     """Cyclic iterator used by DroneEnv.py:142-143,597-598,754,787."""
