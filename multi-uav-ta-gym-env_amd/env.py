@@ -734,8 +734,35 @@ class MultiUAVEnv:
     # parameter and resets it with the episode's seed — reset never reads the switch, so the new handle stands exactly where the old one stood — which is
     # only right while nothing has happened since reset(): the new handle's state is compared with the old one's, field by field, and the write raises if
     # they differ (the env was stepped or mutated: the reference would change behaviour mid-episode there, this path does not offer that).
-    _SWAP_FIELDS = ("SCALARS", "AGENT_POS", "AGENT_STATE", "AGENT_QUEUE", "AGENT_NFT", "AGENT_NFP", "AGENT_CAPS", "AGENT_MISC", "TASK_ID", "TASK_STATUS", "TASK_POS",
-                    "TASK_META", "TASK_TIMES", "TASK_CUR", "TASK_ALLOC", "KNOWN", "THREAT_META", "THREAT_POS", "OPEN_IDS", "ESCORTS")
+    @staticmethod
+    def _fields_that_differ(old, new) -> List[str]:
+        """names of the device fields in which two handles differ — the resident part of each: task rows of slots that hold a task, threat rows of spawned
+        threats, known-bits of resident slots (what a free slot or an unspawned threat's row holds is not part of the env's state)"""
+        out = []
+        g = lambda b, f: np.asarray(b.get(f))[0]  # noqa: E731
+        for f in ("SCALARS", "AGENT_POS", "AGENT_STATE", "AGENT_QUEUE", "AGENT_NFT", "AGENT_NFP", "AGENT_CAPS", "AGENT_MISC", "TASK_ID", "OPEN_IDS", "ESCORTS"):
+            if not np.array_equal(g(old, f), g(new, f)):
+                out.append(f)
+        ids = g(old, "TASK_ID")
+        if "TASK_ID" not in out:
+            live = ids >= 0
+            for f in ("TASK_STATUS", "TASK_POS", "TASK_META", "TASK_TIMES", "TASK_CUR", "TASK_ALLOC"):
+                if not np.array_equal(g(old, f)[live], g(new, f)[live]):
+                    out.append(f)
+            ka, kb = g(old, "KNOWN"), g(new, "KNOWN")
+            bits = lambda k: ((k[:, :, None] >> np.arange(32, dtype=k.dtype)) & 1).reshape(k.shape[0], -1)[:, :len(ids)][:, live]  # noqa: E731
+            if ka.shape != kb.shape or not np.array_equal(bits(ka), bits(kb)):
+                out.append("KNOWN")
+        ta, tb = g(old, "THREAT_META"), g(new, "THREAT_META")
+        if ta.shape != tb.shape or not np.array_equal(ta[:, 0], tb[:, 0]):
+            out.append("THREAT_META")
+        else:
+            act = ta[:, 0] != -9
+            if not np.array_equal(ta[act], tb[act]):
+                out.append("THREAT_META")
+            if not np.array_equal(g(old, "THREAT_POS")[act], g(new, "THREAT_POS")[act]):
+                out.append("THREAT_POS")
+        return out
 
     @property
     def multiple_agents_per_task(self) -> bool:
@@ -769,7 +796,7 @@ class MultiUAVEnv:
             new.set_release_log(True)
             if self._seed is not None:
                 new.reset(np.array([self._seed], dtype=np.uint64))
-                differs = [f for f in self._SWAP_FIELDS if not np.array_equal(np.asarray(self._b.get(f)), np.asarray(new.get(f)))]
+                differs = self._fields_that_differ(self._b, new)
                 if differs:
                     getattr(new, "close", lambda: None)()
                     why = f"the env was changed since reset() ({', '.join(differs)})"
