@@ -2272,3 +2272,42 @@ def test_context_vector_vs_reference_and_oracle(path):
         for i, o in enumerate(oracles):
             kk = int(np.sum(aa[i] >= 0))
             o.step(aa[i][:kk], ai[i][:kk])
+
+
+@pytest.mark.skipif(os.environ.get("MUAVTA_UNVERIFIED_GPU_TESTS") != "1",
+                    reason="written after round 5's GPU minutes were spent and never run on a device: MUAVTA_UNVERIFIED_GPU_TESTS=1 enables it; verify, then drop the guard")
+def test_facade_switch_write_after_reset_recreates_the_handle_on_the_gpu():
+    """main.py:130-141 assigns `multiple_tasks_per_agent = True` on the env object right after reset().  The facade re-creates the device handle with the new
+    parameter and the episode's seed and swaps it in after comparing the resident state of the two handles (env.py: the property's setter).  Over the HIP
+    backend the episode that follows must equal, call by call, the one the same facade gives over the oracle backend (which the CPU suite compares with the
+    reference env: tests/test_facade_cpu.py), and a write after a step must raise."""
+    from oracle_backend import OracleBackend
+    from muavta_amd.env import MultiUAVEnv
+    from muavta_amd.scenarios import CASE_SPECS
+
+    flags = {"multiple_tasks_per_agent": False}
+    hip, cpu = MultiUAVEnv(CASE_SPECS["static_strike"], flags=dict(flags)), MultiUAVEnv(CASE_SPECS["static_strike"], flags=dict(flags), backend_factory=OracleBackend)
+    assert type(hip.backend).__name__ == "BatchedMultiUAVEnv" and hip.multiple_tasks_per_agent is False
+    first = hip.backend
+    for seed in (5, 6):
+        o_hip, _ = hip.reset(seed=seed)
+        o_cpu, _ = cpu.reset(seed=seed)
+        hip.multiple_tasks_per_agent = True
+        cpu.multiple_tasks_per_agent = True
+        assert hip.multiple_tasks_per_agent is True and hip.backend is not first
+        rng = np.random.default_rng(seed)
+        for t in range(60):
+            n_open = len(cpu.last_tasks_info)
+            assert [x.id for x in hip.last_tasks_info] == [x.id for x in cpu.last_tasks_info], (seed, t)
+            acts = {a.name: [int(x) for x in rng.integers(1, n_open, size=int(rng.integers(1, 4)))] for a in cpu.get_live_agents()[: 1 + t % 3]} if n_open > 1 and t % 4 == 0 else {}
+            r_hip, r_cpu = hip.step({k: list(v) for k, v in acts.items()}), cpu.step({k: list(v) for k, v in acts.items()})
+            assert r_hip[1] == r_cpu[1] and r_hip[2] == r_cpu[2] and r_hip[3] == r_cpu[3], (seed, t)
+            for name in r_cpu[0]:
+                for key in ("agent_position", "agent_caps", "alloc_task", "mask", "legal_mask", "event_flags"):
+                    assert np.array_equal(np.asarray(r_hip[0][name][key]), np.asarray(r_cpu[0][name][key])), (seed, t, name, key)
+            assert [[x.id for x in a.tasks] for a in hip.agents_obj] == [[x.id for x in a.tasks] for a in cpu.agents_obj], (seed, t)
+            assert np.array_equal(np.array([a.position for a in hip.agents_obj]), np.array([a.position for a in cpu.agents_obj])), (seed, t)
+    with pytest.raises(ValueError, match="right after reset"):
+        hip.multiple_tasks_per_agent = False
+    assert int(np.count_nonzero(hip.backend.get("ERROR"))) == 0
+    hip.close(); cpu.close()
