@@ -14,7 +14,7 @@ the read-only checkout and runs them.  Prints one JSON document on the last line
     compat_driver.py scripts[_native] <ref_copy>  whole command lines, main() to CSV: train_escort.py (Att + MLP) -> escort_eval.py with those checkpoints;
                                                   wps_eval.py (default suite, six algorithms, per-episode CSV); run_scaling.py (8 generated cases x 4 algorithms);
                                                   benchmark.py of the checkout's root (Random / Greedy / CBBA); main.py's run_case_algorithm (Random / Greedy / Swarm-GAP / CBBA); a third
-                                                  argument picks steps (escort,wps,scaling,benchmark,main)
+                                                  argument picks steps (escort,wps,scaling,paper,benchmark,main); paper_eval.py --suite dynamic --env-flags d3
 """
 import json
 import os
@@ -240,6 +240,12 @@ elif mode in ("scripts", "scripts_native"):
         scsv = os.path.join(work, "scaling.csv")
         run_main("run_scaling", ["--episodes", "1", "--out", scsv], 45)
         out["run_scaling_csv"] = rows_of(scsv)
+    if want("paper"):
+        # the paper's table generator as a command line: the dynamic suite (D1_attrition, D2_popup_threats, D3_combined) under its `d3` flag preset
+        # (time windows in the observation, the dynamic idle penalty, its own reward weights) x five allocators
+        pcsv = os.path.join(work, "paper.csv")
+        run_main("paper_eval", ["--suite", "dynamic", "--episodes", "2", "--env-flags", "d3", "--algorithms", "Random,Greedy,Cap-Greedy,CBBA-Replan,Hungarian", "--out", pcsv], 48)
+        out["paper_eval_csv"] = rows_of(pcsv)
     if want("benchmark"):
         # the reference's own throughput script (benchmark.py at the root of the checkout: Random / Greedy / CBBA, list-valued actions, fixed_seed = 42,
         # get_initial_state, current_agent): run by path, its per-episode reward / completion printout kept, its SPS and timing dropped
