@@ -14,7 +14,7 @@ the read-only checkout and runs them.  Prints one JSON document on the last line
     compat_driver.py scripts[_native] <ref_copy>  whole command lines, main() to CSV: train_escort.py (Att + MLP) -> escort_eval.py with those checkpoints;
                                                   wps_eval.py (default suite, six algorithms, per-episode CSV); run_scaling.py (8 generated cases x 4 algorithms);
                                                   benchmark.py of the checkout's root (Random / Greedy / CBBA); main.py's run_case_algorithm (Random / Greedy / Swarm-GAP / CBBA); a third
-                                                  argument picks steps (escort,wps,scaling,paper,benchmark,main); paper_eval.py --suite dynamic --env-flags d3
+                                                  argument picks steps (escort,wps,scaling,paper,replay,benchmark,main); paper_eval.py --suite dynamic --env-flags d3
 """
 import json
 import os
@@ -246,6 +246,18 @@ elif mode in ("scripts", "scripts_native"):
         pcsv = os.path.join(work, "paper.csv")
         run_main("paper_eval", ["--suite", "dynamic", "--episodes", "2", "--env-flags", "d3", "--algorithms", "Random,Greedy,Cap-Greedy,CBBA-Replan,Hungarian", "--out", pcsv], 48)
         out["paper_eval_csv"] = rows_of(pcsv)
+    if want("replay"):
+        # the reference's dashboard exporter ITSELF (not muavta_amd/replay.py, its restatement) over the env: every frame's agents / tasks / threats / escort
+        # links / metrics and the event list of two scenarios, as the JSON document it writes
+        import hashlib
+
+        out["replay_json"] = {}
+        for scen, seed in (("WPS_escort", 0), ("WPS_commit", 1)):
+            rp = os.path.join(work, f"{scen}_replay.json")
+            run_main("generate_simulation_replay", ["--seed", str(seed), "--scenario", scen, "--out", rp], 49)
+            doc = json.load(open(rp, encoding="utf-8"))
+            out["replay_json"][scen] = {"frames": len(doc["frames"]), "events": len(doc["events"]), "event_types": sorted({e["type"] for e in doc["events"]}),
+                                        "sha256": hashlib.sha256(json.dumps(doc, sort_keys=True).encode()).hexdigest(), "last_frame": doc["frames"][-1]}
     if want("benchmark"):
         # the reference's own throughput script (benchmark.py at the root of the checkout: Random / Greedy / CBBA, list-valued actions, fixed_seed = 42,
         # get_initial_state, current_agent): run by path, its per-episode reward / completion printout kept, its SPS and timing dropped

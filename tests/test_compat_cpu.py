@@ -131,13 +131,18 @@ def test_reference_command_lines_write_the_same_csv_files(ref_copy):
     checkpoints just trained (7 algorithms); wps_eval.py on its default suite (WPS_easy, WPS_hard) with six algorithms incl. the summary's bootstrap
     confidence intervals and the per-episode CSV; run_scaling.py (8 generated fleet / task scaling cases x Cap-Greedy, CBBA, CBBA-Replan, Hungarian
     through paper_eval.evaluate_case); paper_eval.py itself on its dynamic suite (D1_attrition, D2_popup_threats, D3_combined: agent failures, pop-up threats,
-    arrivals) under its `d3` flag preset x Random, Greedy, Cap-Greedy, CBBA-Replan, Hungarian; benchmark.py at the root of the checkout (Random / Greedy / CBBA x 5 episodes, list-valued actions,
+    arrivals) under its `d3` flag preset x Random, Greedy, Cap-Greedy, CBBA-Replan, Hungarian; generate_simulation_replay.py — the reference's dashboard exporter
+    itself, not this repository's restatement of it — on WPS_escort and WPS_commit (the whole JSON document: 151 frames of agents / tasks / threats / escort links /
+    metrics and the event list, compared through its SHA-256 and its last frame); benchmark.py at the root of the checkout (Random / Greedy / CBBA x 5 episodes, list-valued actions,
     `fixed_seed`, `get_initial_state`, `current_agent`: its per-episode reward / completion printout) and `run_case_algorithm` of main.py (the legacy entry
     point: Random / Greedy / Swarm-GAP / CBBA on one of its fleet-scaling cases; it assigns `multiple_tasks_per_agent = True` on the env after every reset and
     calls `close()`): every per-episode reward list it returns.  Every cell of every CSV but the wall-clock
     columns must equal the file the same command writes over the reference's own env."""
     native, facade = _drive_pair("scripts", ref_copy)
-    assert {k: len(v) for k, v in native.items()} == {"escort_eval_csv": 7, "wps_eval_csv": 12, "wps_eval_episodes_csv": 24, "run_scaling_csv": 32, "paper_eval_csv": 15, "benchmark_py": 15, "main_py": 4}
+    assert {k: len(v) for k, v in native.items()} == {"escort_eval_csv": 7, "wps_eval_csv": 12, "wps_eval_episodes_csv": 24, "run_scaling_csv": 32, "paper_eval_csv": 15, "replay_json": 2, "benchmark_py": 15, "main_py": 4}
+    rep_native, rep_facade = native.pop("replay_json"), facade.pop("replay_json")
+    assert rep_facade == rep_native and all(r["frames"] == 151 and r["events"] > 100 and len(r["sha256"]) == 64 for r in rep_native.values())
+    assert "Escort_Created" in rep_native["WPS_escort"]["event_types"] and rep_native["WPS_escort"]["sha256"] != rep_native["WPS_commit"]["sha256"]
     main_native, main_facade = native.pop("main_py"), facade.pop("main_py")
     assert set(main_native) == {"Random", "Greedy", "Swarm-GAP", "CBBA"} and main_facade == main_native
     assert len({repr(r["mean_S_reward"]) for r in main_native.values()}) == 4 and all(len(r["mean_S_reward"]) == 2 for r in main_native.values())
