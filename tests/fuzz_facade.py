@@ -8,7 +8,7 @@ and after every step everything a caller can see is compared: the observation di
 f32), rewards, done flags, infos['events' / 'selected' / 'metrics'], last_tasks_info, the object views the allocators read
 (positions, states, queues, next_free_*, caps, task reqs / status / deadlines / kinds, threats) and the visibility map.
 
-    python tests/fuzz_facade.py [first_k [n_configs [procs]]]
+    python tests/fuzz_facade.py [first_k [n_configs [procs]]] [--mutators] [--lists]
 
 Lives under tests/ because it uses the oracle (through tests/oracle_backend.py) as the facade's backend."""
 import os
@@ -136,7 +136,7 @@ def run_one(k: int):
         assert F.max_tasks == T and F.possible_agents == R.possible_agents and F.max_agents == R.max_agents
         same_obs(robs, fobs, T, f"{tag} reset")
         same_world(R, F, f"{tag} reset")
-        mut = "--mutators" in sys.argv
+        mut, lists = "--mutators" in sys.argv, "--lists" in sys.argv
         rng = np.random.default_rng(4000 + k)
         hr = HungarianAllocator(replan_interval=interval, max_coord=R.max_coord)
         hf = HungarianAllocator(replan_interval=interval, max_coord=F.max_coord)
@@ -187,14 +187,25 @@ def run_one(k: int):
                     outs.append(r)
                 assert outs[0] == outs[1], f"{tag} t={t} op {op}: returned {outs[0]} vs {outs[1]}"
                 same_world(R, F, f"{tag} t={t} after op {op}")
-            try:
-                ra = _apply_assign(R, hr.allocate_tasks(R.get_live_agents(), _open_tasks(R), time_step=R.time_steps, events=_events(rinfo),
-                                                         agent_known_ids=R.agent_visibility_map()))
-            except Exception as exc:
-                return k, "skip", f"reference raised at t={t}: {type(exc).__name__}: {exc}"
-            fa = _apply_assign(F, hf.allocate_tasks(F.get_live_agents(), _open_tasks(F), time_step=F.time_steps, events=_events(finfo),
-                                                     agent_known_ids=F.agent_visibility_map()))
-            assert ra == fa, f"{tag} t={t}: actions {ra} vs {fa}"
+            if lists:  # no allocator: random scalar / LIST-valued actions keyed by agent name (repeated tasks, indices beyond the open list, dead agents) —
+                # the action dict of tests/fuzz_reference.py --lists, here through the facade's own action packing
+                names = [a.name for a in R.agents_obj]
+                ra = {}
+                for j in rng.permutation(len(names))[:int(rng.integers(0, len(names) + 1))]:
+                    idxs = [int(rng.integers(0, 6)) if rng.random() < 0.9 else int(rng.integers(20, 140)) for _ in range(int(rng.integers(1, 7)))]
+                    ra[names[j]] = idxs if (len(idxs) > 1 or rng.random() < 0.5) else idxs[0]
+                fa = {n: (list(v) if isinstance(v, list) else v) for n, v in ra.items()}
+                if t >= 100:
+                    break
+            else:
+                try:
+                    ra = _apply_assign(R, hr.allocate_tasks(R.get_live_agents(), _open_tasks(R), time_step=R.time_steps, events=_events(rinfo),
+                                                             agent_known_ids=R.agent_visibility_map()))
+                except Exception as exc:
+                    return k, "skip", f"reference raised at t={t}: {type(exc).__name__}: {exc}"
+                fa = _apply_assign(F, hf.allocate_tasks(F.get_live_agents(), _open_tasks(F), time_step=F.time_steps, events=_events(finfo),
+                                                         agent_known_ids=F.agent_visibility_map()))
+                assert ra == fa, f"{tag} t={t}: actions {ra} vs {fa}"
             try:
                 robs, rrew, rdone, rtrunc, rinfo = R.step(ra)
             except Exception as exc:
@@ -209,9 +220,10 @@ def run_one(k: int):
             same_obs(robs, fobs, T, st)
             same_world(R, F, st)
             assert ("metrics" in rinfo) == ("metrics" in finfo), f"{st}: metrics presence"
-        assert list(rinfo["metrics"].keys()) == METRIC_KEYS == list(finfo["metrics"].keys())
-        for key in METRIC_KEYS:
-            assert float(rinfo["metrics"][key]) == float(finfo["metrics"][key]), f"{tag}: metric {key}"
+        if "metrics" in rinfo:  # (a --lists episode is cut at 100 steps: no final info then)
+            assert list(rinfo["metrics"].keys()) == METRIC_KEYS == list(finfo["metrics"].keys())
+            for key in METRIC_KEYS:
+                assert float(rinfo["metrics"][key]) == float(finfo["metrics"][key]), f"{tag}: metric {key}"
         assert R.compute_s_wps() == F.compute_s_wps() and R.compute_s_esc() == F.compute_s_esc()
     except QueueTooDeep as exc:
         return k, "skip", str(exc)
