@@ -474,7 +474,7 @@ class MultiUAVEnv:
         self.agents_config, self.tasks_config = dict(c.get("agents")), dict(c.get("tasks"))
         self.threats_list = list(c.get("threats_list") or [])
         self.random_init_pos, self.num_obstacles, self.hidden_obstacles = bool(p.random_init_pos), p.num_obstacles, False
-        self._multi_tasks, self._multi_agents = bool(p.multiple_tasks_per_agent), True   # (read through the two properties below)
+        self._multi_tasks = bool(p.multiple_tasks_per_agent)   # (read through the property below; multiple_agents_per_task has one live value)
         self.fail_rate = p.fail_rate
         self.early_terminate, self.capability_mask, self.saturate_mask = bool(p.early_terminate), bool(p.capability_mask), bool(p.saturate_mask)
         self.reward_weights = dict(zip(REWARD_KEYS, (float(w) for w in p.reward_weights)))
@@ -803,6 +803,7 @@ class MultiUAVEnv:
         if why is not None:
             raise ValueError(f"multiple_tasks_per_agent is a parameter of the device handle and can be changed right after reset() only: {why}.  "
                              f"Construct the env with multiple_tasks_per_agent={value} in its configuration instead")
+        # (settings made on the old handle through `env.backend` — an allocator mode, lanes — are not carried over: the facade itself makes none)
         old, self._b, self._params, self._multi_tasks = self._b, new, params, value
         self._snap.b = new
         self._snap.clear()
